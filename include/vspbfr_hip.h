@@ -1,0 +1,230 @@
+/*
+ * vspbfr_hip.h -- C ABI of libvspbfr_hip.so: the MI355X (gfx950) device kernels behind the VSPBFR
+ * restoration inference path.
+ *
+ * Boundary contract
+ * -----------------
+ *  - plain C: device pointers, sizes, scalars and an opaque stream handle (a hipStream_t); no torch types.
+ *  - every entry point ENQUEUES work on `stream` and returns immediately (no host sync), exactly like the
+ *    reference's two native ops which launch on at::cuda::getCurrentCUDAStream()
+ *    (reference op/fused_bias_act_kernel.cu:73, op/upfirdn2d_kernel.cu:215).
+ *  - tensors are dense, row-major, fp32 (VSP_F32).  Pointers are borrowed; outputs are caller-allocated
+ *    (the reference allocates with torch::empty_like / at::empty inside the op -- the Python mirror in
+ *    vspbfr_amd/op does that allocation so that the ABI stays torch-free).
+ *  - return value: 0 on success, a negative VSP_E* code otherwise; vsp_last_error() returns a
+ *    thread-local human-readable message.  The Python mirror raises RuntimeError (what TORCH_CHECK raises
+ *    in the reference: op/fused_bias_act.cpp:10-16, op/upfirdn2d.cpp:9-15).
+ *
+ * What each entry point replaces in the reference is cited on the declaration.
+ */
+#ifndef VSPBFR_HIP_H
+#define VSPBFR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSP_ABI_VERSION 1
+
+#define VSP_OK 0
+#define VSP_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported combination) */
+#define VSP_ELAUNCH (-2)  /* hipLaunchKernel / HIP runtime failure */
+#define VSP_ENOTSUP (-3)  /* valid request that this build has no kernel for */
+
+typedef void* vsp_stream_t; /* hipStream_t; NULL = the default stream */
+
+int vsp_abi_version(void);
+const char* vsp_last_error(void);
+/* number of HIP devices visible, or a negative VSP_E* code (used by the loader's self-check). */
+int vsp_device_count(void);
+/* sizeof of an ABI struct (0 = vsp_fir_epilogue, 1 = vsp_conv_params, 2 = vsp_gemm_params): lets a binding in
+ * another language check its own struct layout when it loads the library. */
+int vsp_struct_size(int which);
+
+/* ------------------------------------------------------------------------------------------------
+ * fused bias + activation  -- replaces `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)`
+ * (reference op/fused_bias_act.cpp:18-31, kernel op/fused_bias_act_kernel.cu:19-65).
+ *   out[i] = f(x[i] + bias[(i / step_b) % size_b]) * scale
+ *   act*10+grad: 10,11 -> f = identity; 30 -> leaky-relu(alpha); 31 -> (ref[i] > 0 ? v : v*alpha);
+ *   12, 32 -> 0.  bias == NULL means "no bias" (reference: empty tensor), ref likewise.
+ * n = number of elements; step_b = product of dims after dim 1 (1 for 2-D input).
+ * ---------------------------------------------------------------------------------------------- */
+int vsp_fused_bias_act_f32(float* out, const float* x, const float* bias, const float* ref, int64_t n,
+                           int step_b, int size_b, int act, int grad, float alpha, float scale,
+                           vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * upfirdn2d -- replaces `upfirdn2d_op.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up_x, up_y,
+ * down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)` (reference op/upfirdn2d.cpp:17-31, kernels
+ * op/upfirdn2d_kernel.cu:49-207, CPU definition op/upfirdn2d.py:365-406).
+ * out dims: out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y (likewise out_w); the caller
+ * allocates out[major, out_h, out_w, minor].  Negative pads crop, as in the reference.
+ *
+ * The optional epilogue (all pointers may be NULL) fuses what the reference runs as separate ops right
+ * after the blur of an up-sampling StyledConv (models/RestoreNet.py:599-603, e4e stylegan2/model.py:337-341):
+ *   v = fir(x)
+ *   v = v * plane_scale[plane]                 (per (b,c) demodulation coefficient)
+ *   v = v + noise[b, oy, ox] * noise_w[0]      (NoiseInjection; noise is [B,1,out_h,out_w])
+ *   v = lrelu(v + act_bias[c], slope) * gain   (FusedLeakyReLU; only if act != 0)
+ *   v = v + res1[...] + res2[...]              (same layout as out)
+ * `channels` gives c = plane % channels, b = plane / channels (minor must be 1 when an epilogue is used).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vsp_fir_epilogue {
+  const float* plane_scale; /* [major] or NULL */
+  const float* noise;       /* [major/channels, out_h, out_w] or NULL */
+  const float* noise_w;     /* device scalar, required iff noise != NULL */
+  const float* act_bias;    /* [channels] or NULL (treated as 0) */
+  const float* res1;        /* [major, out_h, out_w] or NULL */
+  const float* res2;        /* [major, out_h, out_w] or NULL */
+  int channels;             /* C (>=1) */
+  int act;                  /* 0 none, 1 leaky-relu */
+  float slope;              /* 0.2 */
+  float gain;               /* sqrt(2) */
+} vsp_fir_epilogue;
+
+int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major, int in_h, int in_w,
+                      int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                      int pad_x1, int pad_y0, int pad_y1, const vsp_fir_epilogue* epi /* may be NULL */,
+                      vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * conv2d as an fp32-MFMA implicit GEMM -- replaces the conv2d_gradfix.conv2d / conv_transpose2d / F.conv2d
+ * calls of the path (reference op/conv2d_gradfix.py:22-92, models/RestoreNet.py:125-131,373-416,510-553,
+ * e4e/models/stylegan2/model.py:116,259-274, e4e/models/encoders/helpers.py:98-113) together with the
+ * element-wise work the reference wraps around them (modulation, demodulation, bias, noise, activation,
+ * residual adds, eval-mode BatchNorm, PReLU).
+ *
+ *   acc[b,co,oy,ox] = sum_{ci,ky,kx} Wp[g][ky*KW+kx][ci][co_g] *
+ *                     xin(b, ci, oy*stride_y + ky*dil[g] - pad[g], ox*stride_x + kx*dil[g] - pad[g])
+ *   xin(b,ci,iy,ix) = 0 outside the image, else x[b,ci,iy,ix] * in_scale[b*in_scale_bstride + ci] + in_shift[ci]
+ * with g = co / cout_g (output-channel groups that differ only in dilation/padding: the four dilated
+ * branches of SMART_layer share one launch), then per output element, in this order:
+ *   v = acc * out_scale[b*Cout + co]                     (demodulation, models/RestoreNet.py:376-379)
+ *   v = v * ch_scale[co] + ch_bias[co]                   (conv bias / folded eval BatchNorm)
+ *   act1: v = lrelu(v + bias1[co], slope1) * gain1       (FusedLeakyReLU of `fusion`, RestoreNet.py:1176-1177)
+ *   v = v + noise[b,oy,ox] * noise_w[0]                  (NoiseInjection, RestoreNet.py:564-569)
+ *   act2: 1: v = lrelu(v + bias2[co], slope2) * gain2    (FusedLeakyReLU `activate`)
+ *         2: v = v >= 0 ? v : v * prelu[co]              (nn.PReLU)
+ *   v = v + res1[b,co,oy,ox] + res2[b,co,oy,ox]
+ *   y[b, y_coff + co, oy*osy + ooy, ox*osx + oox] = v    (y has y_ch channels, y_h x y_w pixels)
+ * The output stride/offset (osy, osx, ooy, oox) lets a stride-2 transposed conv run as four sub-pixel phase
+ * convolutions writing one (2H+1)x(2W+1) tensor (same MACs as conv_transpose2d).
+ * Wp is the launch's weight, packed by the host once at model-load time:
+ *   Wp[g][tap][ci][co_g], co_g contiguous (see vspbfr_amd/packing.py).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vsp_conv_params {
+  const float* x;  /* [B, Cin, H, W] */
+  const float* w;  /* packed [G][KH*KW][Cin][cout_g] */
+  float* y;        /* [B, y_ch, y_h, y_w] */
+  int B, Cin, H, W;
+  int G, cout_g;   /* Cout = G * cout_g */
+  int OH, OW;      /* number of output positions computed per image */
+  int KH, KW;
+  int stride_y, stride_x;
+  int dil[4];      /* per group */
+  int pad_y[4];    /* per group */
+  int pad_x[4];    /* per group */
+  int y_ch, y_coff, y_h, y_w;
+  int osy, osx, ooy, oox;
+  /* prologue */
+  const float* in_scale; /* NULL or [.., Cin] */
+  int in_scale_bstride;  /* Cin for per-sample styles, 0 for per-channel constants */
+  const float* in_shift; /* NULL or [Cin] */
+  /* epilogue */
+  const float* out_scale; /* NULL or [B, Cout] */
+  const float* ch_scale;  /* NULL or [Cout] */
+  const float* ch_bias;   /* NULL or [Cout] */
+  int act1;               /* 0 none, 1 lrelu */
+  const float* bias1;     /* NULL or [Cout] */
+  float slope1, gain1;
+  const float* noise;     /* NULL or [B, OH, OW] */
+  const float* noise_w;   /* device scalar */
+  int act2;               /* 0 none, 1 lrelu, 2 prelu */
+  const float* bias2;     /* NULL or [Cout] */
+  const float* prelu;     /* [Cout] when act2 == 2 */
+  float slope2, gain2;
+  const float* res1;      /* NULL or same layout as the y region written (see res_* below) */
+  const float* res2;
+  int res_ch, res_coff;   /* residual tensors are [B, res_ch, y_h, y_w], read at channel res_coff + co */
+  int tile_hint;          /* 0 = let the library choose; otherwise a VSP_CONV_CFG_* id (tests / tuning) */
+} vsp_conv_params;
+
+int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
+/* Number of tile configurations compiled in, and a description of configuration i ("64x256 ..."). */
+int vsp_conv2d_num_configs(void);
+const char* vsp_conv2d_config_name(int i);
+
+/* ------------------------------------------------------------------------------------------------
+ * Strided, batched small GEMM on fp32 MFMA -- replaces F.linear / torch.matmul of the path
+ * (EqualLinear: models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,
+ * 86-116).
+ *   C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][n][k] )
+ *   element addresses: A + z*a_zs + m*a_ms + k*a_ks   (same for B with n), C + z*c_zs + m*c_ms + n
+ *   epi(v): v += bias[n] * bias_scale (bias may be NULL); act==1: v = lrelu(v, slope) * gain;
+ *           act==2: v = sigmoid(v)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vsp_gemm_params {
+  const float* A;
+  const float* Bm;
+  float* C;
+  int Z, M, N, K;
+  int64_t a_zs, a_ms, a_ks;
+  int64_t b_zs, b_ns, b_ks;
+  int64_t c_zs, c_ms;
+  float alpha;
+  const float* bias;
+  float bias_scale;
+  int act;
+  float slope, gain;
+} vsp_gemm_params;
+
+int vsp_gemm_f32(const vsp_gemm_params* p, vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise helpers of Code_diffuser / the style MLPs (reference models/CodeDiffuser.py:7-12,41,101,31,73;
+ * models/RestoreNet.py:24-29).  x and out are [rows, cols] row-major unless stated otherwise.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[z, r, c] = x[z,r,c] * rsqrt(mean_r(x[z,:,c]^2) + eps): PixelNorm over dim=1 of a [Z,R,C] tensor. */
+int vsp_pixelnorm_dim1_f32(float* out, const float* x, int Z, int R, int C, float eps, vsp_stream_t stream);
+/* LayerNorm over the last dim (biased variance, eps inside sqrt); gamma/beta may be NULL;
+ * optional fused pre-add: normalises (x + add).  post: 0 none, 1 lrelu(slope)*gain. */
+int vsp_layernorm_f32(float* out, const float* x, const float* add, const float* gamma, const float* beta,
+                      int rows, int cols, float eps, int post, float slope, float gain, vsp_stream_t stream);
+/* softmax over the last dim of [rows, cols]. */
+int vsp_softmax_lastdim_f32(float* out, const float* x, int rows, int cols, vsp_stream_t stream);
+/* softmax over dim=1 of [Z, R, C] (column-wise within each z). */
+int vsp_softmax_dim1_f32(float* out, const float* x, int Z, int R, int C, vsp_stream_t stream);
+/* out = h * (1 + gamma) + beta (TACC_block tail, models/CodeDiffuser.py:114). */
+int vsp_film_f32(float* out, const float* h, const float* gamma, const float* beta, int64_t n,
+                 vsp_stream_t stream);
+/* out = a * x + b * y with a, b read from device arrays at index idx (DDPM posterior mean,
+ * ldm/ddpm.py:348-352: coef1[t]*x0 + coef2[t]*x_t). */
+int vsp_axpby_idx_f32(float* out, const float* x, const float* y, const float* a, const float* b, int idx,
+                      int64_t n, vsp_stream_t stream);
+/* demodulation coefficients: out[b, co] = rsqrt(wscale^2 * sum_ci style[b,ci]^2 * wsq[co,ci] + eps)
+ * (models/RestoreNet.py:376-379 with the tap sum hoisted: wsq[co,ci] = sum_taps W[co,ci,:,:]^2). */
+int vsp_demod_f32(float* out, const float* style, const float* wsq, int B, int Cin, int Cout, float wscale,
+                  float eps, vsp_stream_t stream);
+/* 2x2 mean pooling of [planes, 2*OH, 2*OW] (F.interpolate bilinear 512->256 with align_corners=False is
+ * exactly this, Loss/e4e_embedding.py:97; AdaptiveAvgPool2d 1024->512, e4e/models/psp.py:246). */
+int vsp_avgpool2x2_f32(float* out, const float* x, int64_t planes, int OH, int OW, vsp_stream_t stream);
+/* bilinear resize, align_corners=True, then add: out = resize(x -> [OH,OW]) + y
+ * (_upsample_add, e4e/models/encoders/helpers.py:123-140). */
+int vsp_upsample_add_f32(float* out, const float* x, const float* y, int64_t planes, int IH, int IW, int OH,
+                         int OW, vsp_stream_t stream);
+/* global average pool: out[plane] = mean(x[plane, :]) (SEModule, helpers.py:57-73). */
+int vsp_plane_mean_f32(float* out, const float* x, int64_t planes, int hw, vsp_stream_t stream);
+/* out = x * gate[plane] + y (SE excitation + shortcut add, helpers.py:72,112). y may be NULL. */
+int vsp_scale_add_f32(float* out, const float* x, const float* gate, const float* y, int64_t planes, int hw,
+                      vsp_stream_t stream);
+/* strided gather of y[b,c,::s,::s] (MaxPool2d(1, stride) shortcut, helpers.py:101). */
+int vsp_subsample_f32(float* out, const float* x, int64_t planes, int IH, int IW, int s, vsp_stream_t stream);
+/* out = a + b + c (c may be NULL). */
+int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSPBFR_HIP_H */

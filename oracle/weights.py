@@ -1,0 +1,99 @@
+"""Name-keyed synthetic checkpoints (TEST INFRASTRUCTURE).
+
+`synth_state_dict(model, spec, seed)` fills every entry of a state-dict spec [(name, shape, dtype), ...] from
+oracle.keyed_rng, choosing the distribution from the entry's role so that activations stay O(1) through all four
+networks (SURVEY.md section 7 "fixture-init recipe"): the same call regenerates identical tensors in the build container
+(fed to the real reference by tools/make_golden.py) and on the GPU box (fed to the oracle and to the HIP modules).
+The specs themselves are data recorded from the reference's modules: tests/golden/state_specs.json.
+"""
+import json
+import math
+import os
+import re
+
+import torch
+
+from . import keyed_rng as R
+from .ops import make_kernel
+
+SPEC_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "state_specs.json")
+
+
+def load_specs():
+    with open(SPEC_PATH) as f:
+        return json.load(f)
+
+
+def _fan_in(shape):
+    n = 1
+    for d in shape[1:]:
+        n *= d
+    return max(n, 1)
+
+
+def synth_tensor(model, name, shape, dtype, seed):
+    key = f"{model}/{name}"
+    shape = tuple(shape)
+    if dtype == "int64":
+        return torch.zeros(shape, dtype=torch.int64)
+    N = lambda s=1.0: R.normal(seed, key, shape) * s          # noqa: E731
+    U = lambda lo, hi: R.uniform(seed, key, shape, lo, hi)    # noqa: E731
+    leaf = name.rsplit(".", 1)[-1]
+
+    # ---- buffers with fixed values
+    if name.endswith("blur.kernel") or name.endswith("upsample.kernel"):
+        k = make_kernel([1, 3, 3, 1])
+        down = "encoder_convs" in name  # StyledConv_down blurs are not gain-compensated (models/RestoreNet.py:451-457)
+        return k if down else k * 4
+    if name.startswith("noises.") or ".noises." in name:
+        return N()
+    if name == "latent_avg":
+        return N(0.1)
+
+    # ---- e4e encoder (plain nn.Conv2d / BatchNorm2d / PReLU)
+    if model == "e4e_encoder":
+        if leaf == "running_mean":
+            return N(0.1)
+        if leaf == "running_var":
+            return U(0.5, 1.5)
+        is_bn = re.search(r"(input_layer\.1|res_layer\.0|res_layer\.4|shortcut_layer\.1)\.(weight|bias)$", name)
+        if is_bn:
+            return U(0.5, 1.5) if leaf == "weight" else N(0.1)
+        if re.search(r"(input_layer\.2|res_layer\.2)\.weight$", name):  # PReLU slopes
+            return U(0.15, 0.35)
+        if name.endswith("linear.weight"):  # EqualLinear(lr_mul=1): N(0,1), scaled by 1/sqrt(in) in forward
+            return N()
+        if leaf == "bias":
+            return N(0.1)
+        return N(1.0 / math.sqrt(_fan_in(shape)))
+
+    # ---- Code_diffuser (nn.Linear / LayerNorm)
+    if model == "diffuser":
+        if re.search(r"(gamma_|beta_)\.1\.(weight|bias)$", name):  # LayerNorm affine
+            return U(0.5, 1.5) if leaf == "weight" else N(0.1)
+        if leaf == "bias":
+            return N(0.1)
+        return N(1.0 / math.sqrt(_fan_in(shape)))
+
+    # ---- StyleGAN2-style networks: Restoration_net, e4e decoder (Equal* layers: N(0,1)/lr_mul)
+    if name.endswith("modulation.bias"):
+        return torch.ones(shape)
+    if name.endswith("noise.weight"):
+        return U(0.05, 0.15)
+    m = re.match(r"(decoder\.)?style\.(\d+)\.(weight|bias)$", name)
+    if m:  # mapping network, lr_mul = 0.01
+        return N(100.0) if leaf == "weight" else N(10.0)
+    if name.endswith("input.input"):
+        return N()
+    if leaf == "bias":
+        return N(0.1)
+    w = N()
+    if name.endswith("fusion.0.weight") and model == "restorenet":
+        w = w * 0.5
+    if re.search(r"to_rgbs?\d*\.(\d+\.)?conv\.weight$", name):
+        w = w * 0.25
+    return w
+
+
+def synth_state_dict(model, spec, seed=0, prefix=""):
+    return {prefix + n: synth_tensor(model, n, s, d, seed) for n, s, d in spec}

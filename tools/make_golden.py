@@ -1,0 +1,254 @@
+"""Generate tests/golden/* by running the REAL reference (/root/reference) on CPU.  BUILD CONTAINER ONLY.
+
+    python tools/make_golden.py [--only ops,layers,diffuser,restorenet64,generator64,encoder,pipeline512]
+
+Inputs and weights come from oracle.keyed_rng / oracle.weights (regenerable anywhere from names), so the fixtures hold
+only the reference's OUTPUTS (plus the state-dict key/shape lists of its modules).  Every random draw of the reference
+is replaced by an explicit tensor: NoiseInjection.forward is monkeypatched in-process (no reference file is edited) to
+consume a queue, because Restoration_net's own `noise=` argument is unusable.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import refshim  # noqa: E402
+
+refshim.install()
+
+from oracle import cases, weights  # noqa: E402
+from oracle import models as omodels  # noqa: E402
+
+import models.RestoreNet as RN  # noqa: E402  (reference)
+from models.CodeDiffuser import Code_diffuser  # noqa: E402
+from ldm.ddpm import My_DDPM  # noqa: E402
+import e4e.models.stylegan2.model as SG  # noqa: E402
+from e4e.models.encoders.psp_encoders import Encoder4Editing  # noqa: E402
+from op import fused_leaky_relu as ref_fused_leaky_relu  # noqa: E402
+sys_upfirdn = sys.modules["op.upfirdn2d"]
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+# ---- explicit-noise hook -------------------------------------------------------------------------------------------
+NOISE_QUEUE = []
+
+
+def _patched_noise_forward(self, image, noise=None):
+    if noise is None:
+        noise = NOISE_QUEUE.pop(0)
+        assert noise.shape == (image.shape[0], 1, image.shape[2], image.shape[3]), (noise.shape, image.shape)
+    return image + self.weight * noise
+
+
+RN.NoiseInjection.forward = _patched_noise_forward
+SG.NoiseInjection.forward = _patched_noise_forward
+
+
+def spec_of(module):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in module.state_dict().items()]
+
+
+def load_synth(module, model_kind, seed):
+    sd = weights.synth_state_dict(model_kind, spec_of(module), seed)
+    module.load_state_dict(sd, strict=True)
+    module.eval()
+    return sd
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+# ---- generators ----------------------------------------------------------------------------------------------------
+def gen_specs():
+    from argparse import Namespace
+    specs = {
+        "restorenet512": spec_of(RN.Restoration_net(512, 512, 8)),
+        "restorenet64": spec_of(RN.Restoration_net(64, 512, 8)),
+        "diffuser": spec_of(Code_diffuser(timesteps=4)),
+        "e4e_encoder": spec_of(Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))),
+        "e4e_decoder1024": spec_of(SG.Generator(1024, 512, 8, channel_multiplier=2)),
+        "e4e_decoder64": spec_of(SG.Generator(64, 512, 8, channel_multiplier=2)),
+    }
+    with open(os.path.join(GOLD, "state_specs.json"), "w") as f:
+        json.dump(specs, f)
+    print("state_specs.json:", {k: len(v) for k, v in specs.items()})
+
+
+def gen_ops():
+    out = {}
+    for name in cases.LRELU_CASES:
+        x, b = cases.lrelu_inputs(name)
+        out[name] = np_(ref_fused_leaky_relu(x, b))
+    for name in cases.FIR_CASES:
+        x, k, up, down, pad = cases.fir_inputs(name)
+        out[name] = np_(sys_upfirdn.upfirdn2d_native(x, k, up[0], up[1], down[0], down[1], *pad))
+    np.savez_compressed(os.path.join(GOLD, "ops.npz"), **out)
+    print("ops.npz:", {k: v.shape for k, v in out.items()})
+
+
+def gen_layers():
+    out = {}
+    for name, (kind, cin, cout, k, sdim, xs, extra) in cases.MODCONV_CASES.items():
+        m = RN.ModulatedConv2d(cin, cout, k, sdim, upsample=(kind == "up"), downsample=(kind == "down"), **extra)
+        named = [(n, tuple(v.shape)) for n, v in m.state_dict().items()]
+        m.load_state_dict(cases.module_weights(name, named))
+        x, style = cases.tensor(name, "x", xs), cases.tensor(name, "style", (xs[0], sdim))
+        out[name] = np_(m(x, style))
+    for name, (cin, cout, xs, d) in cases.DILCONV_CASES.items():
+        m = RN.Dilated_ModulatedConv2d(cin, cout, 3, 16, dilation=d)
+        named = [(n, tuple(v.shape)) for n, v in m.state_dict().items()]
+        m.load_state_dict(cases.module_weights(name, named))
+        x, style = cases.tensor(name, "x", xs), cases.tensor(name, "style", (xs[0], cin)) * 0.5 + 1.0
+        out[name] = np_(m(x, style))
+    for name, (cin, cout, sdim, xs) in cases.SMART_CASES.items():
+        m = RN.SMART_layer(cin, cout, 3, sdim)
+        named = [(n, tuple(v.shape)) for n, v in m.state_dict().items()]
+        m.load_state_dict(cases.module_weights(name, named))
+        x, style = cases.tensor(name, "x", xs), cases.tensor(name, "style", (xs[0], sdim))
+        noise = cases.tensor(name, "noise", (xs[0], 1, xs[2], xs[3]))
+        out[name] = np_(m(x, style, noise=noise))
+    for name, (cin, cout, k, xs) in cases.LARGECONV_CASES.items():
+        m = RN.LargeConvLayer(cin, cout, kernel_size=k)
+        named = [(n, tuple(v.shape)) for n, v in m.state_dict().items()]
+        m.load_state_dict(cases.module_weights(name, named))
+        out[name] = np_(m(cases.tensor(name, "x", xs)))
+    np.savez_compressed(os.path.join(GOLD, "layers.npz"), **out)
+    print("layers.npz:", {k: v.shape for k, v in out.items()})
+
+
+def gen_diffuser():
+    out = {}
+    for name, (B, T, ls, le) in cases.DIFFUSER_CASES.items():
+        net = Code_diffuser(timesteps=T)
+        load_synth(net, "diffuser", cases.SEED)
+        ddpm = My_DDPM(denoise=net, linear_start=ls, linear_end=le, timesteps=T)
+        cond, x_T = cases.diffuser_inputs(name)
+        # one denoiser call (unit check) + the whole sampling loop restated with the public p_sample and our x_T
+        # (My_DDPM.forward draws x_T itself, ldm/ddpm.py:423; the loop body is ldm/ddpm.py:426-428)
+        t = torch.full((B,), T - 1, dtype=torch.long)
+        out[name + "/x0_first"] = np_(net(x_T, cond, t))
+        x = x_T
+        for i in reversed(range(T)):
+            x, _ = ddpm.p_sample(x, torch.full((B,), i, dtype=torch.long), cond, clip_denoised=ddpm.clip_denoised)
+        out[name + "/final"] = np_(x)
+        out[name + "/coef1"] = np_(ddpm.posterior_mean_coef1)
+        out[name + "/coef2"] = np_(ddpm.posterior_mean_coef2)
+    np.savez_compressed(os.path.join(GOLD, "diffuser.npz"), **out)
+    print("diffuser.npz:", {k: v.shape for k, v in out.items()})
+
+
+def run_restorenet(size, B, case, net=None, de_feats=None, pre_styles=None):
+    net = net or RN.Restoration_net(size, 512, 8)
+    load_synth(net, "restorenet", cases.SEED)
+    imgs = cases.image_batch(case, B, size)
+    enc_s, dec_s = omodels.restoration_noise_shapes(size, B)
+    enc_noise, dec_noise = cases.noise_list(case, "enc", enc_s), cases.noise_list(case, "dec", dec_s)
+    log_size = int(np.log2(size))
+    if de_feats is None:
+        chans = net.channels
+        de_feats = [cases.tensor(case, f"de_feat{k}", (B, chans[2 ** (k + 2)], 2 ** (k + 2), 2 ** (k + 2)), 0.5)
+                    for k in range(log_size - 1)]
+        pre_styles = cases.tensor(case, "pre_styles", (B, 18, 512))
+    z = cases.tensor(case, "z", (B, 512))
+    NOISE_QUEUE.clear()
+    NOISE_QUEUE.extend(enc_noise + dec_noise)
+    img = net(imgs, de_feats, pre_styles, [z])
+    assert not NOISE_QUEUE
+    return img
+
+
+def gen_restorenet64():
+    t = time.time()
+    img = run_restorenet(64, 1, "restorenet64")
+    np.savez_compressed(os.path.join(GOLD, "restorenet64.npz"), image=np_(img))
+    print("restorenet64.npz:", tuple(img.shape), "std %.3f absmax %.3f" % (img.std(), img.abs().max()), "%.1fs" % (time.time() - t))
+
+
+def gen_generator64():
+    g = SG.Generator(64, 512, 8, channel_multiplier=2)
+    load_synth(g, "e4e_decoder", cases.SEED)
+    B = 2
+    latent = cases.tensor("generator64", "latent", (B, 10, 512))
+    noise = cases.noise_list("generator64", "n", omodels.generator_noise_shapes(64, B))
+    img, feats = g([latent], input_is_latent=True, noise=noise, return_features=True)
+    out = {"image": np_(img)}
+    for i, f in enumerate(feats):
+        out[f"feat{i}"] = np_(cases.feat_sample(f))
+    np.savez_compressed(os.path.join(GOLD, "generator64.npz"), **out)
+    print("generator64.npz:", {k: v.shape for k, v in out.items()}, "img std %.3f" % img.std())
+
+
+def gen_encoder():
+    from argparse import Namespace
+    enc = Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))
+    load_synth(enc, "e4e_encoder", cases.SEED)
+    x = cases.image_batch("encoder", 1, 256)
+    w = enc(x)
+    np.savez_compressed(os.path.join(GOLD, "encoder.npz"), codes=np_(w))
+    print("encoder.npz:", tuple(w.shape), "std %.3f absmax %.3f" % (w.std(), w.abs().max()))
+
+
+def gen_pipeline512():
+    """A+B+C+D at 512^2, B=1, T=4 (restoration_test.py:125-131) with every draw pinned."""
+    from argparse import Namespace
+    t0 = time.time()
+    case = "pipeline512"
+    B, T = 1, 4
+    enc = Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))
+    load_synth(enc, "e4e_encoder", cases.SEED)
+    dec = SG.Generator(1024, 512, 8, channel_multiplier=2)
+    load_synth(dec, "e4e_decoder", cases.SEED)
+    latent_avg = weights.synth_tensor("e4e_decoder", "latent_avg", (18, 512), "float32", cases.SEED)
+    net = Code_diffuser(timesteps=T)
+    load_synth(net, "diffuser", cases.SEED)
+    ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T)
+    lq = cases.image_batch(case, B, 512)
+    # A: E4e_embedding.get_w_plus (Loss/e4e_embedding.py:91-100) + My_pSp.forward (e4e/models/psp.py:145-165)
+    x256 = torch.nn.functional.interpolate(lq, (256, 256), mode="bilinear")
+    codes = (enc(x256) + latent_avg.repeat(B, 1, 1))[:, :18]
+    # B: My_DDPM.forward(training=False) with x_T supplied
+    x = cases.tensor(case, "x_T", (B, 18, 512))
+    for i in reversed(range(T)):
+        x, _ = ddpm.p_sample(x, torch.full((B,), i, dtype=torch.long), codes, clip_denoised=ddpm.clip_denoised)
+    pre = x
+    # C: My_pSp.stylegan2_feat_forward (e4e/models/psp.py:235-248)
+    gnoise = cases.noise_list(case, "g", omodels.generator_noise_shapes(1024, B))
+    img1024, feats = dec([pre], input_is_latent=True, noise=gnoise, return_features=True)
+    feats = feats[:16]
+    sample = torch.nn.AdaptiveAvgPool2d((512, 512))(img1024)
+    # D
+    restored = run_restorenet(512, B, case, de_feats=feats, pre_styles=pre)
+    out = {
+        "codes": np_(codes), "pre_latent": np_(pre),
+        "sample_sub": np_(sample[:, :, ::8, ::8]), "restored_sub": np_(restored[:, :, ::8, ::8]),
+        "restored_crop": np_(restored[:, :, 200:264, 200:264]),
+        "restored_stats": np.array([restored.mean(), restored.std(), restored.abs().max()], dtype=np.float32),
+        "sample_stats": np.array([sample.mean(), sample.std(), sample.abs().max()], dtype=np.float32),
+    }
+    for i, f in enumerate(feats):
+        out[f"feat{i}_stats"] = np.array([f.mean(), f.std(), f.abs().max()], dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLD, "pipeline512.npz"), **out)
+    print("pipeline512.npz: restored stats", out["restored_stats"], "sample stats", out["sample_stats"], "%.1fs" % (time.time() - t0))
+
+
+ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "restorenet64": gen_restorenet64,
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=",".join(ALL))
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    for k in args.only.split(","):
+        ALL[k]()

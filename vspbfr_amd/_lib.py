@@ -1,0 +1,122 @@
+"""ctypes binding of libvspbfr_hip.so (the C ABI declared in include/vspbfr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or does not export the ABI this module raises at
+import time, and every wrapper raises RuntimeError when the library reports an error (the reference raises
+RuntimeError from TORCH_CHECK, op/fused_bias_act.cpp:10-16).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("VSPBFR_HIP_LIB", os.path.join(_HERE, "lib", "libvspbfr_hip.so"))
+
+c_float_p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
+
+
+class FirEpilogue(C.Structure):
+    _fields_ = [
+        ("plane_scale", C.c_void_p), ("noise", C.c_void_p), ("noise_w", C.c_void_p), ("act_bias", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("channels", C.c_int), ("act", C.c_int), ("slope", C.c_float), ("gain", C.c_float),
+    ]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int), ("Cin", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("G", C.c_int), ("cout_g", C.c_int),
+        ("OH", C.c_int), ("OW", C.c_int),
+        ("KH", C.c_int), ("KW", C.c_int),
+        ("stride_y", C.c_int), ("stride_x", C.c_int),
+        ("dil", C.c_int * 4), ("pad_y", C.c_int * 4), ("pad_x", C.c_int * 4),
+        ("y_ch", C.c_int), ("y_coff", C.c_int), ("y_h", C.c_int), ("y_w", C.c_int),
+        ("osy", C.c_int), ("osx", C.c_int), ("ooy", C.c_int), ("oox", C.c_int),
+        ("in_scale", C.c_void_p), ("in_scale_bstride", C.c_int), ("in_shift", C.c_void_p),
+        ("out_scale", C.c_void_p), ("ch_scale", C.c_void_p), ("ch_bias", C.c_void_p),
+        ("act1", C.c_int), ("bias1", C.c_void_p), ("slope1", C.c_float), ("gain1", C.c_float),
+        ("noise", C.c_void_p), ("noise_w", C.c_void_p),
+        ("act2", C.c_int), ("bias2", C.c_void_p), ("prelu", C.c_void_p), ("slope2", C.c_float), ("gain2", C.c_float),
+        ("res1", C.c_void_p), ("res2", C.c_void_p), ("res_ch", C.c_int), ("res_coff", C.c_int),
+        ("tile_hint", C.c_int),
+    ]
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("Bm", C.c_void_p), ("C", C.c_void_p),
+        ("Z", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_zs", C.c_int64), ("a_ms", C.c_int64), ("a_ks", C.c_int64),
+        ("b_zs", C.c_int64), ("b_ns", C.c_int64), ("b_ks", C.c_int64),
+        ("c_zs", C.c_int64), ("c_ms", C.c_int64),
+        ("alpha", C.c_float), ("bias", C.c_void_p), ("bias_scale", C.c_float),
+        ("act", C.c_int), ("slope", C.c_float), ("gain", C.c_float),
+    ]
+
+
+_i, _i64, _f, _p = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+# name -> argtypes: every symbol include/vspbfr_hip.h declares (tests/test_abi.py cross-checks against the header)
+SIGNATURES = {
+    "vsp_abi_version": [],
+    "vsp_device_count": [],
+    "vsp_struct_size": [_i],
+    "vsp_fused_bias_act_f32": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _f, _p],
+    "vsp_upfirdn2d_f32": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
+    "vsp_conv2d_f32": [C.POINTER(ConvParams), _p],
+    "vsp_conv2d_num_configs": [],
+    "vsp_gemm_f32": [C.POINTER(GemmParams), _p],
+    "vsp_pixelnorm_dim1_f32": [_p, _p, _i, _i, _i, _f, _p],
+    "vsp_layernorm_f32": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _f, _f, _p],
+    "vsp_softmax_lastdim_f32": [_p, _p, _i, _i, _p],
+    "vsp_softmax_dim1_f32": [_p, _p, _i, _i, _i, _p],
+    "vsp_film_f32": [_p, _p, _p, _p, _i64, _p],
+    "vsp_axpby_idx_f32": [_p, _p, _p, _p, _p, _i, _i64, _p],
+    "vsp_demod_f32": [_p, _p, _p, _i, _i, _i, _f, _f, _p],
+    "vsp_avgpool2x2_f32": [_p, _p, _i64, _i, _i, _p],
+    "vsp_upsample_add_f32": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "vsp_plane_mean_f32": [_p, _p, _i64, _i, _p],
+    "vsp_scale_add_f32": [_p, _p, _p, _p, _i64, _i, _p],
+    "vsp_subsample_f32": [_p, _p, _i64, _i, _i, _i, _p],
+    "vsp_add3_f32": [_p, _p, _p, _p, _i64, _p],
+}
+_CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"vspbfr_amd: HIP library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C vspbfr_amd/csrc`; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, args in _CHARP.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p
+    if lib.vsp_abi_version() != 1:
+        raise ImportError(f"vspbfr_amd: ABI version {lib.vsp_abi_version()} != 1")
+    for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams)):
+        if lib.vsp_struct_size(which) != C.sizeof(st):
+            raise ImportError(f"vspbfr_amd: struct layout mismatch for {st.__name__}: "
+                              f"C {lib.vsp_struct_size(which)} vs ctypes {C.sizeof(st)}")
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.vsp_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def exported_symbols():
+    return sorted(list(SIGNATURES) + list(_CHARP))

@@ -1,0 +1,121 @@
+// Strided batched small GEMM ("NT": both operands indexed [row][k]) on fp32 MFMA for gfx950.
+//
+// Used for every F.linear / torch.matmul of the path (EqualLinear style MLPs and modulations:
+// models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,86-116).  These
+// have 8..288 rows (M = batch or batch*18 tokens): far too small to fill 1024 SIMDs with classic tiles, so the
+// kernel goes for many small waves instead: one wave64 owns a 16(m) x 32(n) tile and streams K straight from
+// global/L2 into MFMA fragments (no LDS: nothing is shared between waves).
+//
+// k-permutation trick (VEC path, k contiguous): lane (row = l&15, q = l>>4) loads ONE float4 at [row][k0+4q..4q+3];
+// MFMA j (j=0..3) of the step takes component j of that float4 as its k-slot q, so slot q of MFMA j is k0+4q+j
+// for A and B alike: the products pair up correctly and a 16-wide k-step costs one 16-byte load per operand
+// block (64-byte segments per row instead of the 16-byte segments a scalar fragment load would touch).
+#include "vsp_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct GemmK {
+  const float* A;
+  const float* Bm;
+  float* C;
+  int M, N, K;
+  int64_t a_zs, a_ms, a_ks, b_zs, b_ns, b_ks, c_zs, c_ms;
+  float alpha;
+  const float* bias;
+  float bias_scale;
+  int act;
+  float slope, gain;
+};
+
+constexpr int NBL = 2;  // 16-column blocks per wave
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + wave) * 16 * NBL;
+  const int m0 = blockIdx.y * 16;
+  const int z = blockIdx.z;
+  if (n0 >= p.N) return;  // whole wave exits together
+
+  const int am = min(m0 + lr, p.M - 1);
+  const float* arow = p.A + z * p.a_zs + am * p.a_ms;
+  const float* brow[NBL];
+#pragma unroll
+  for (int j = 0; j < NBL; ++j) brow[j] = p.Bm + z * p.b_zs + (int64_t)min(n0 + j * 16 + lr, p.N - 1) * p.b_ns;
+
+  f32x4 acc[NBL];
+#pragma unroll
+  for (int j = 0; j < NBL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int k0 = 0;
+  if (VEC) {
+    for (; k0 + 16 <= p.K; k0 += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 4 * kq);
+      float4 b[NBL];
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) b[j] = *reinterpret_cast<const float4*>(brow[j] + k0 + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j].x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[j].y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[j].z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[j].w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+  for (; k0 < p.K; k0 += 4) {
+    const int k = k0 + kq;
+    const bool ok = k < p.K;
+    const int kc = ok ? k : 0;
+    const float a = ok ? arow[kc * p.a_ks] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) {
+      const float b = ok ? brow[j][kc * p.b_ks] : 0.f;
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    }
+  }
+
+  // D layout: lane holds column lr, rows kq*4 + r
+#pragma unroll
+  for (int j = 0; j < NBL; ++j) {
+    const int n = n0 + j * 16 + lr;
+    if (n >= p.N) continue;
+    const float bv = p.bias ? p.bias[n] * p.bias_scale : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + kq * 4 + r;
+      if (m >= p.M) continue;
+      float v = acc[j][r] * p.alpha + bv;
+      if (p.act == 1) v = (v > 0.f ? v : v * p.slope) * p.gain;
+      else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
+      p.C[z * p.c_zs + m * p.c_ms + n] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr, "gemm: null params");
+  const vsp_gemm_params& p = *pp;
+  VSP_REQUIRE(p.Z >= 0 && p.M >= 0 && p.N >= 0 && p.K >= 0, "gemm: negative dimension");
+  if (p.Z == 0 || p.M == 0 || p.N == 0) return VSP_OK;
+  VSP_REQUIRE(p.A && p.Bm && p.C, "gemm: null tensor pointer");
+  VSP_REQUIRE(p.act >= 0 && p.act <= 2, "gemm: unknown activation %d", p.act);
+  VSP_REQUIRE(p.Z <= 65535, "gemm: batch too large");
+  GemmK q{p.A, p.Bm, p.C, p.M, p.N, p.K, p.a_zs, p.a_ms, p.a_ks, p.b_zs, p.b_ns, p.b_ks, p.c_zs, p.c_ms,
+          p.alpha, p.bias, p.bias_scale, p.act, p.slope, p.gain};
+  const bool vec = p.a_ks == 1 && p.b_ks == 1 && p.a_ms % 4 == 0 && p.b_ns % 4 == 0 && p.a_zs % 4 == 0 &&
+                   p.b_zs % 4 == 0 && vsp::aligned16(p.A) && vsp::aligned16(p.Bm);
+  dim3 grid((unsigned)((p.N + 64 * NBL - 1) / (64 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);
+  VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");
+  if (vec)
+    gemm_nt_kernel<true><<<grid, 256, 0, vsp::as_stream(stream)>>>(q);
+  else
+    gemm_nt_kernel<false><<<grid, 256, 0, vsp::as_stream(stream)>>>(q);
+  return vsp::check_launch("gemm");
+}

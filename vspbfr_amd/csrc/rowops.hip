@@ -1,0 +1,330 @@
+// Small HBM/L2-bound helpers of the path (normalisations, softmaxes, pooling, resampling, gating) for gfx950.
+// Every kernel here moves O(bytes) once with coalesced accesses along the contiguous dimension; reductions over a
+// row use one wave64 per row with __shfl_xor butterflies (64 lanes, no LDS).  Reference statements are cited on the
+// declarations in include/vspbfr_hip.h.
+#include "vsp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int stream_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > vsp::kMaxStreamBlocks) b = vsp::kMaxStreamBlocks;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// ---- PixelNorm over dim 1 of [Z,R,C]: thread per (z,c), coalesced along c
+__global__ __launch_bounds__(256) void pixelnorm_dim1_kernel(float* out, const float* x, int Z, int R, int C, float eps) {
+  const int64_t total = (int64_t)Z * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i / C), c = (int)(i % C);
+    const float* xp = x + (int64_t)z * R * C + c;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float v = xp[(int64_t)r * C];
+      s = fmaf(v, v, s);
+    }
+    const float inv = rsqrtf(s / (float)R + eps);
+    float* op = out + (int64_t)z * R * C + c;
+    for (int r = 0; r < R; ++r) op[(int64_t)r * C] = xp[(int64_t)r * C] * inv;
+  }
+}
+
+// ---- LayerNorm over the last dim: one wave per row
+__global__ __launch_bounds__(256) void layernorm_kernel(float* out, const float* x, const float* add, const float* gamma,
+                                                         const float* beta, int rows, int cols, float eps, int post,
+                                                         float slope, float gain) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * cols;
+  const float* ar = add ? add + (int64_t)row * cols : nullptr;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += xr[c] + (ar ? ar[c] : 0.f);
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+  for (int c = lane; c < cols; c += 64) {
+    const float d = xr[c] + (ar ? ar[c] : 0.f) - mean;
+    q = fmaf(d, d, q);
+  }
+  const float inv = rsqrtf(wave_sum(q) / (float)cols + eps);
+  float* orow = out + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) {
+    float v = (xr[c] + (ar ? ar[c] : 0.f) - mean) * inv;
+    if (gamma) v = v * gamma[c] + (beta ? beta[c] : 0.f);
+    if (post == 1) v = (v > 0.f ? v : v * slope) * gain;
+    orow[c] = v;
+  }
+}
+
+// ---- softmax over the last dim: one wave per row
+__global__ __launch_bounds__(256) void softmax_last_kernel(float* out, const float* x, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += expf(xr[c] - m);
+  s = wave_sum(s);
+  float* orow = out + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) orow[c] = expf(xr[c] - m) / s;
+}
+
+// ---- softmax over dim 1 of [Z,R,C]: thread per (z,c)
+__global__ __launch_bounds__(256) void softmax_dim1_kernel(float* out, const float* x, int Z, int R, int C) {
+  const int64_t total = (int64_t)Z * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int z = (int)(i / C), c = (int)(i % C);
+    const float* xp = x + (int64_t)z * R * C + c;
+    float m = -INFINITY;
+    for (int r = 0; r < R; ++r) m = fmaxf(m, xp[(int64_t)r * C]);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += expf(xp[(int64_t)r * C] - m);
+    float* op = out + (int64_t)z * R * C + c;
+    for (int r = 0; r < R; ++r) op[(int64_t)r * C] = expf(xp[(int64_t)r * C] - m) / s;
+  }
+}
+
+__global__ __launch_bounds__(256) void film_kernel(float* out, const float* h, const float* gamma, const float* beta, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = h[i] * (1.f + gamma[i]) + beta[i];
+}
+
+__global__ __launch_bounds__(256) void axpby_idx_kernel(float* out, const float* x, const float* y, const float* a, const float* b,
+                                                         int idx, int64_t n) {
+  const float ca = a[idx], cb = b[idx];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = ca * x[i] + cb * y[i];
+}
+
+// ---- demodulation coefficients: one wave per (b, co)
+__global__ __launch_bounds__(256) void demod_kernel(float* out, const float* style, const float* wsq, int B, int Cin, int Cout,
+                                                     float wscale2, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Cout) return;
+  const int b = (int)(row / Cout), co = (int)(row % Cout);
+  const float* sp = style + (int64_t)b * Cin;
+  const float* wp = wsq + (int64_t)co * Cin;
+  float s = 0.f;
+  for (int c = lane; c < Cin; c += 64) {
+    const float st = sp[c];
+    s = fmaf(st * st, wp[c], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = rsqrtf(s * wscale2 + eps);
+}
+
+__global__ __launch_bounds__(256) void avgpool2x2_kernel(float* out, const float* x, int64_t planes, int OH, int OW) {
+  const int64_t total = planes * OH * OW;
+  const int IW = 2 * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t pl = t / OH;
+    const float* xp = x + (pl * 2 * OH + 2 * oy) * IW + 2 * ox;
+    const float2 r0 = *reinterpret_cast<const float2*>(xp);
+    const float2 r1 = *reinterpret_cast<const float2*>(xp + IW);
+    out[i] = ((r0.x + r0.y) + (r1.x + r1.y)) * 0.25f;
+  }
+}
+
+// bilinear, align_corners=True: src = dst * (I-1)/(O-1)
+__global__ __launch_bounds__(256) void upsample_add_kernel(float* out, const float* x, const float* y, int64_t planes, int IH,
+                                                            int IW, int OH, int OW, float ry, float rx) {
+  const int64_t total = planes * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t pl = t / OH;
+    const float fy = ry * (float)oy, fx = rx * (float)ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > IH - 1) y0 = IH - 1;
+    if (x0 > IW - 1) x0 = IW - 1;
+    const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* xp = x + pl * IH * IW;
+    const float v = hy * (hx * xp[y0 * IW + x0] + lx * xp[y0 * IW + x1]) + ly * (hx * xp[y1 * IW + x0] + lx * xp[y1 * IW + x1]);
+    out[i] = v + y[i];
+  }
+}
+
+// one wave per plane
+__global__ __launch_bounds__(256) void plane_mean_kernel(float* out, const float* x, int64_t planes, int hw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pl >= planes) return;
+  const float* xp = x + pl * hw;
+  float s = 0.f;
+  for (int i = lane; i < hw; i += 64) s += xp[i];
+  s = wave_sum(s);
+  if (lane == 0) out[pl] = s / (float)hw;
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(float* out, const float* x, const float* gate, const float* y, int64_t planes,
+                                                         int hw) {
+  const int64_t total = planes * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = gate[i / hw];
+    out[i] = x[i] * g + (y ? y[i] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void subsample_kernel(float* out, const float* x, int64_t planes, int IH, int IW, int OH, int OW,
+                                                         int s) {
+  const int64_t total = planes * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t pl = t / OH;
+    out[i] = x[(pl * IH + (int64_t)oy * s) * IW + (int64_t)ox * s];
+  }
+}
+
+__global__ __launch_bounds__(256) void add3_kernel(float* out, const float* a, const float* b, const float* c, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i] + (c ? c[i] : 0.f);
+}
+
+}  // namespace
+
+#define VSP_LAUNCH_1D(kern, n, s, ...)                                         \
+  do {                                                                         \
+    kern<<<stream_blocks(n), 256, 0, vsp::as_stream(s)>>>(__VA_ARGS__);        \
+  } while (0)
+
+extern "C" {
+
+int vsp_pixelnorm_dim1_f32(float* out, const float* x, int Z, int R, int C, float eps, vsp_stream_t stream) {
+  VSP_REQUIRE(Z >= 0 && R >= 1 && C >= 0, "pixelnorm: bad dims");
+  if ((int64_t)Z * C == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "pixelnorm: null pointer");
+  VSP_LAUNCH_1D(pixelnorm_dim1_kernel, (int64_t)Z * C, stream, out, x, Z, R, C, eps);
+  return vsp::check_launch("pixelnorm_dim1");
+}
+
+int vsp_layernorm_f32(float* out, const float* x, const float* add, const float* gamma, const float* beta, int rows,
+                      int cols, float eps, int post, float slope, float gain, vsp_stream_t stream) {
+  VSP_REQUIRE(rows >= 0 && cols >= 1, "layernorm: bad dims");
+  if (rows == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "layernorm: null pointer");
+  layernorm_kernel<<<(rows + 3) / 4, 256, 0, vsp::as_stream(stream)>>>(out, x, add, gamma, beta, rows, cols, eps, post,
+                                                                        slope, gain);
+  return vsp::check_launch("layernorm");
+}
+
+int vsp_softmax_lastdim_f32(float* out, const float* x, int rows, int cols, vsp_stream_t stream) {
+  VSP_REQUIRE(rows >= 0 && cols >= 1, "softmax: bad dims");
+  if (rows == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "softmax: null pointer");
+  softmax_last_kernel<<<(rows + 3) / 4, 256, 0, vsp::as_stream(stream)>>>(out, x, rows, cols);
+  return vsp::check_launch("softmax_lastdim");
+}
+
+int vsp_softmax_dim1_f32(float* out, const float* x, int Z, int R, int C, vsp_stream_t stream) {
+  VSP_REQUIRE(Z >= 0 && R >= 1 && C >= 0, "softmax_dim1: bad dims");
+  if ((int64_t)Z * C == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "softmax_dim1: null pointer");
+  VSP_LAUNCH_1D(softmax_dim1_kernel, (int64_t)Z * C, stream, out, x, Z, R, C);
+  return vsp::check_launch("softmax_dim1");
+}
+
+int vsp_film_f32(float* out, const float* h, const float* gamma, const float* beta, int64_t n, vsp_stream_t stream) {
+  if (n <= 0) return VSP_OK;
+  VSP_REQUIRE(out && h && gamma && beta, "film: null pointer");
+  VSP_LAUNCH_1D(film_kernel, n, stream, out, h, gamma, beta, n);
+  return vsp::check_launch("film");
+}
+
+int vsp_axpby_idx_f32(float* out, const float* x, const float* y, const float* a, const float* b, int idx, int64_t n,
+                      vsp_stream_t stream) {
+  if (n <= 0) return VSP_OK;
+  VSP_REQUIRE(out && x && y && a && b && idx >= 0, "axpby: bad argument");
+  VSP_LAUNCH_1D(axpby_idx_kernel, n, stream, out, x, y, a, b, idx, n);
+  return vsp::check_launch("axpby_idx");
+}
+
+int vsp_demod_f32(float* out, const float* style, const float* wsq, int B, int Cin, int Cout, float wscale, float eps,
+                  vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1, "demod: bad dims");
+  if (B == 0) return VSP_OK;
+  VSP_REQUIRE(out && style && wsq, "demod: null pointer");
+  const int64_t rows = (int64_t)B * Cout;
+  demod_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, vsp::as_stream(stream)>>>(out, style, wsq, B, Cin, Cout,
+                                                                                wscale * wscale, eps);
+  return vsp::check_launch("demod");
+}
+
+int vsp_avgpool2x2_f32(float* out, const float* x, int64_t planes, int OH, int OW, vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && OH >= 0 && OW >= 0, "avgpool2x2: bad dims");
+  const int64_t n = planes * OH * OW;
+  if (n == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "avgpool2x2: null pointer");
+  VSP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 7u) == 0, "avgpool2x2: input must be 8-byte aligned");
+  VSP_LAUNCH_1D(avgpool2x2_kernel, n, stream, out, x, planes, OH, OW);
+  return vsp::check_launch("avgpool2x2");
+}
+
+int vsp_upsample_add_f32(float* out, const float* x, const float* y, int64_t planes, int IH, int IW, int OH, int OW,
+                         vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1, "upsample_add: bad dims");
+  const int64_t n = planes * OH * OW;
+  if (n == 0) return VSP_OK;
+  VSP_REQUIRE(out && x && y, "upsample_add: null pointer");
+  const float ry = OH > 1 ? (float)(IH - 1) / (float)(OH - 1) : 0.f;
+  const float rx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
+  VSP_LAUNCH_1D(upsample_add_kernel, n, stream, out, x, y, planes, IH, IW, OH, OW, ry, rx);
+  return vsp::check_launch("upsample_add");
+}
+
+int vsp_plane_mean_f32(float* out, const float* x, int64_t planes, int hw, vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && hw >= 1, "plane_mean: bad dims");
+  if (planes == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "plane_mean: null pointer");
+  plane_mean_kernel<<<(unsigned)((planes + 3) / 4), 256, 0, vsp::as_stream(stream)>>>(out, x, planes, hw);
+  return vsp::check_launch("plane_mean");
+}
+
+int vsp_scale_add_f32(float* out, const float* x, const float* gate, const float* y, int64_t planes, int hw,
+                      vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && hw >= 1, "scale_add: bad dims");
+  if (planes == 0) return VSP_OK;
+  VSP_REQUIRE(out && x && gate, "scale_add: null pointer");
+  VSP_LAUNCH_1D(scale_add_kernel, planes * hw, stream, out, x, gate, y, planes, hw);
+  return vsp::check_launch("scale_add");
+}
+
+int vsp_subsample_f32(float* out, const float* x, int64_t planes, int IH, int IW, int s, vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && IH >= 1 && IW >= 1 && s >= 1, "subsample: bad dims");
+  const int OH = (IH - 1) / s + 1, OW = (IW - 1) / s + 1;
+  if (planes == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "subsample: null pointer");
+  VSP_LAUNCH_1D(subsample_kernel, planes * OH * OW, stream, out, x, planes, IH, IW, OH, OW, s);
+  return vsp::check_launch("subsample");
+}
+
+int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream) {
+  if (n <= 0) return VSP_OK;
+  VSP_REQUIRE(out && a && b, "add3: null pointer");
+  VSP_LAUNCH_1D(add3_kernel, n, stream, out, a, b, c, n);
+  return vsp::check_launch("add3");
+}
+
+}  // extern "C"

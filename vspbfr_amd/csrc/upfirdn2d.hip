@@ -1,0 +1,214 @@
+// upfirdn2d (zero-insert upsample -> pad/crop -> 2-D FIR -> decimate) for gfx950, with an optional fused epilogue.
+//
+// Definition (reference CPU statement op/upfirdn2d.py:365-406, CUDA kernels op/upfirdn2d_kernel.cu:49-207):
+//   U[s,t]  = x[s/up_y, t/up_x] when s%up_y==0 && t%up_x==0 && inside, else 0      (zero insertion)
+//   out[oy,ox] = sum_{ky,kx} k[kh-1-ky][kw-1-kx] * U[oy*down_y + ky - pad_y0, ox*down_x + kx - pad_x0]
+// (the taps are flipped: a true convolution; negative pads crop because the index simply shifts).
+//
+// Two kernels:
+//  * fir_tile_kernel<KH,KW>: up=down=1 (the `Blur` of every up/down-sampling StyledConv: the hot case, up to
+//    (B,64,513,513) / (B,32,1025,1025) planes).  One 256-thread block produces a 32x64 output tile of one plane:
+//    the (32+KH-1)x(64+KW-1) input window is staged once in LDS with coalesced row reads and zero fill, the
+//    flipped taps sit in registers (loaded through SGPRs, uniform), and each lane walks 8 rows of one column
+//    with a sliding register window, so every LDS word is read KW times and every HBM byte once.
+//    Roofline: HBM, 4 B read + 4 B written per output element (+ epilogue operands).
+//  * fir_generic_kernel: any up/down/tap count/minor (RGB-skip Upsample: 3 channels, negligible bytes).
+#include "vsp_common.h"
+
+namespace {
+
+struct Epi {
+  const float* plane_scale;
+  const float* noise;
+  const float* noise_w;
+  const float* act_bias;
+  const float* res1;
+  const float* res2;
+  int channels;
+  int act;
+  float slope;
+  float gain;
+  int enabled;
+};
+
+__device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int oy, int ox, int out_h, int out_w) {
+  if (!e.enabled) return v;
+  const int c = plane % e.channels;
+  const int b = plane / e.channels;
+  if (e.plane_scale) v *= e.plane_scale[plane];
+  if (e.noise) v += e.noise[((int64_t)b * out_h + oy) * out_w + ox] * e.noise_w[0];
+  if (e.act) {
+    if (e.act_bias) v += e.act_bias[c];
+    v = (v > 0.f ? v : v * e.slope) * e.gain;
+  }
+  const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
+  if (e.res1) v += e.res1[o];
+  if (e.res2) v += e.res2[o];
+  return v;
+}
+
+constexpr int TOH = 32;  // output tile rows
+constexpr int TOW = 64;  // output tile cols (one wave = one row segment of 64 -> 256 B coalesced stores)
+constexpr int ROWS_PER_THREAD = 8;
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                        const float* __restrict__ kern, int in_h, int in_w,
+                                                        int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
+                                                        int tiles_y, Epi epi) {
+  constexpr int TIH = TOH + KH - 1;
+  constexpr int TIW = TOW + KW - 1;
+  constexpr int LDW = TIW + 1;  // odd-ish pitch; reads are row-contiguous per wave so conflicts are not an issue
+  __shared__ float tile[TIH * LDW];
+
+  const int bid = blockIdx.x;
+  const int tx_i = bid % tiles_x;
+  const int ty_i = (bid / tiles_x) % tiles_y;
+  const int plane = bid / (tiles_x * tiles_y);
+  const int oy0 = ty_i * TOH, ox0 = tx_i * TOW;
+  const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+  const float* xp = x + (int64_t)plane * in_h * in_w;
+
+  // flipped taps -> registers (wave-uniform loads)
+  float taps[KH][KW];
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) taps[ky][kx] = kern[(KH - 1 - ky) * KW + (KW - 1 - kx)];
+
+  for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
+    const int r = i / TIW, c = i - r * TIW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    float v = 0.f;
+    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(int64_t)iy * in_w + ix];
+    tile[r * LDW + c] = v;
+  }
+  __syncthreads();
+
+  const int col = threadIdx.x & 63;
+  const int row0 = (threadIdx.x >> 6) * ROWS_PER_THREAD;
+  const int ox = ox0 + col;
+  float win[KH][KW];
+#pragma unroll
+  for (int ky = 0; ky < KH - 1; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) win[ky + 1][kx] = tile[(row0 + ky) * LDW + col + kx];
+
+#pragma unroll
+  for (int r = 0; r < ROWS_PER_THREAD; ++r) {
+#pragma unroll
+    for (int ky = 0; ky < KH - 1; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) win[ky][kx] = win[ky + 1][kx];
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx) win[KH - 1][kx] = tile[(row0 + r + KH - 1) * LDW + col + kx];
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx) acc = fmaf(taps[ky][kx], win[ky][kx], acc);
+    const int oy = oy0 + row0 + r;
+    if (oy < out_h && ox < out_w) {
+      acc = epi_apply(epi, acc, plane, oy, ox, out_h, out_w);
+      out[((int64_t)plane * out_h + oy) * out_w + ox] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fir_generic_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                           const float* __restrict__ kern, int major, int in_h,
+                                                           int in_w, int minor, int kh, int kw, int up_x, int up_y,
+                                                           int down_x, int down_y, int pad_x0, int pad_y0, int out_h,
+                                                           int out_w, Epi epi) {
+  extern __shared__ float ktaps[];  // flipped taps staged once per block
+  for (int i = threadIdx.x; i < kh * kw; i += blockDim.x) {
+    const int ky = i / kw, kx = i - ky * kw;
+    ktaps[i] = kern[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)major * out_h * out_w * minor;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int uh = in_h * up_y, uw = in_w * up_x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % minor);
+    int64_t t = i / minor;
+    const int ox = (int)(t % out_w);
+    t /= out_w;
+    const int oy = (int)(t % out_h);
+    const int m = (int)(t / out_h);
+    const float* xp = x + (int64_t)m * in_h * in_w * minor + c;
+    float acc = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int s = oy * down_y + ky - pad_y0;
+      if (s < 0 || s >= uh || (s % up_y) != 0) continue;
+      const int iy = s / up_y;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int u = ox * down_x + kx - pad_x0;
+        if (u < 0 || u >= uw || (u % up_x) != 0) continue;
+        const int ix = u / up_x;
+        acc = fmaf(ktaps[ky * kw + kx], xp[((int64_t)iy * in_w + ix) * minor], acc);
+      }
+    }
+    if (epi.enabled) acc = epi_apply(epi, acc, m, oy, ox, out_h, out_w);
+    out[i] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major, int in_h, int in_w,
+                                  int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, const vsp_fir_epilogue* epi_in,
+                                  vsp_stream_t stream) {
+  VSP_REQUIRE(major >= 0 && in_h >= 0 && in_w >= 0 && minor >= 0, "upfirdn2d: negative dimension");
+  VSP_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 1024, "upfirdn2d: unsupported kernel size %dx%d", kh, kw);
+  VSP_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d: up/down factors must be >= 1");
+  const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+  const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+  VSP_REQUIRE(out_h >= 0 && out_w >= 0, "upfirdn2d: negative output size %dx%d", out_h, out_w);
+  const int64_t total = (int64_t)major * out_h * out_w * minor;
+  if (total == 0) return VSP_OK;
+  VSP_REQUIRE(out && x && kernel, "upfirdn2d: null pointer");
+  VSP_REQUIRE((int64_t)major * in_h * in_w * minor < (int64_t)1 << 40, "upfirdn2d: tensor too large");
+
+  Epi e{};
+  if (epi_in) {
+    VSP_REQUIRE(minor == 1, "upfirdn2d: fused epilogue needs minor == 1");
+    VSP_REQUIRE(epi_in->channels >= 1 && major % epi_in->channels == 0,
+                "upfirdn2d: epilogue channels=%d does not divide major=%d", epi_in->channels, major);
+    VSP_REQUIRE(!epi_in->noise || epi_in->noise_w, "upfirdn2d: noise given without noise_w");
+    e.plane_scale = epi_in->plane_scale;
+    e.noise = epi_in->noise;
+    e.noise_w = epi_in->noise_w;
+    e.act_bias = epi_in->act_bias;
+    e.res1 = epi_in->res1;
+    e.res2 = epi_in->res2;
+    e.channels = epi_in->channels;
+    e.act = epi_in->act;
+    e.slope = epi_in->slope;
+    e.gain = epi_in->gain;
+    e.enabled = 1;
+  }
+  hipStream_t s = vsp::as_stream(stream);
+  const bool tile_ok = (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && out_w >= 16);
+  if (tile_ok && ((kh == 4 && kw == 4) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2))) {
+    const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
+    VSP_REQUIRE(blocks < ((int64_t)1 << 31), "upfirdn2d: grid too large");
+    if (kh == 4)
+      fir_tile_kernel<4, 4><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                             pad_y0, tiles_x, tiles_y, e);
+    else if (kh == 3)
+      fir_tile_kernel<3, 3><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                             pad_y0, tiles_x, tiles_y, e);
+    else
+      fir_tile_kernel<2, 2><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                             pad_y0, tiles_x, tiles_y, e);
+    return vsp::check_launch("upfirdn2d(tile)");
+  }
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > vsp::kMaxStreamBlocks) blocks = vsp::kMaxStreamBlocks;
+  fir_generic_kernel<<<(unsigned)blocks, 256, kh * kw * sizeof(float), s>>>(
+      out, x, kernel, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, e);
+  return vsp::check_launch("upfirdn2d(generic)");
+}

@@ -1,0 +1,42 @@
+// Shared host-side helpers for libvspbfr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/vspbfr_hip.h"
+
+namespace vsp {
+
+void set_error(const char* fmt, ...);
+
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  set_error("%s", buf);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(VSP_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return VSP_OK;
+}
+
+inline hipStream_t as_stream(vsp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// MI355X: 256 CUs; memory-bound grids are capped at 8 resident 256-thread blocks per CU and grid-strided.
+constexpr int kNumCU = 256;
+constexpr int kMaxStreamBlocks = kNumCU * 8;
+
+}  // namespace vsp
+
+#define VSP_REQUIRE(cond, ...)                                  \
+  do {                                                          \
+    if (!(cond)) return vsp::fail(VSP_EINVAL, __VA_ARGS__);     \
+  } while (0)

@@ -1,0 +1,378 @@
+"""Tensor-level wrappers over the C ABI (include/vspbfr_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; all arithmetic happens in
+libvspbfr_hip.so.  Every wrapper requires CUDA(HIP) fp32 contiguous tensors and raises RuntimeError otherwise --
+there is no CPU path (the reference's own CPU branch lives in oracle/, test-only).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvParams, FirEpilogue, GemmParams, check, lib
+
+SQRT2 = math.sqrt(2.0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _opt(t, name):
+    return None if t is None else _req(t, name)
+
+
+# ----------------------------------------------------------------------------------------------- fused_bias_act
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
+    """Same signature as the reference's native `fused.fused_bias_act` (op/fused_bias_act.cpp:18-31):
+    empty `bias` / `refer` tensors mean "absent"; returns a new tensor."""
+    x = _req(input, "input")
+    b = _req(bias, "bias") if bias is not None and bias.numel() else None
+    r = _req(refer, "refer") if refer is not None and refer.numel() else None
+    out = torch.empty_like(x)
+    step_b = 1
+    for i in range(2, x.dim()):
+        step_b *= x.size(i)
+    size_b = b.numel() if b is not None else 0
+    if r is not None and r.numel() != x.numel():
+        raise RuntimeError("refer must have the same number of elements as input")
+    check(lib.vsp_fused_bias_act_f32(_ptr(out), _ptr(x), _ptr(b), _ptr(r), x.numel(), step_b, size_b, int(act),
+                                     int(grad), float(alpha), float(scale), _stream()), "fused_bias_act")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- upfirdn2d
+def fir_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, py1):
+    return ((in_h * up_y + py0 + py1 - kh + down_y) // down_y, (in_w * up_x + px0 + px1 - kw + down_x) // down_x)
+
+
+def upfirdn2d_native_layout(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, epilogue=None):
+    """Same contract as the reference's native `upfirdn2d_op.upfirdn2d` (op/upfirdn2d.cpp:17-31):
+    input [major, in_h, in_w, minor] -> new tensor [major, out_h, out_w, minor]."""
+    x = _req(input, "input")
+    k = _req(kernel, "kernel")
+    if x.dim() != 4 or k.dim() != 2:
+        raise RuntimeError("upfirdn2d expects input [major,H,W,minor] and a 2-D kernel")
+    major, in_h, in_w, minor = x.shape
+    kh, kw = k.shape
+    out_h, out_w = fir_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    if out_h < 0 or out_w < 0:
+        raise RuntimeError(f"upfirdn2d: negative output size {out_h}x{out_w}")
+    out = torch.empty((major, out_h, out_w, minor), device=x.device, dtype=x.dtype)
+    epi = C.byref(epilogue) if epilogue is not None else None
+    check(lib.vsp_upfirdn2d_f32(_ptr(out), _ptr(x), _ptr(k), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x,
+                                down_y, pad_x0, pad_x1, pad_y0, pad_y1, epi, _stream()), "upfirdn2d")
+    return out
+
+
+def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_bias=None, act=False, res1=None,
+               res2=None, slope=0.2, gain=SQRT2):
+    """NCHW blur (up=down=1) with the fused demod/noise/bias/leaky-relu/residual epilogue of the C ABI."""
+    x = _req(x, "x")
+    B, Cc, H, W = x.shape
+    epi = FirEpilogue()
+    keep = [_opt(plane_scale, "plane_scale"), _opt(noise, "noise"), _opt(noise_w, "noise_w"), _opt(act_bias, "act_bias"),
+            _opt(res1, "res1"), _opt(res2, "res2")]
+    epi.plane_scale, epi.noise, epi.noise_w, epi.act_bias, epi.res1, epi.res2 = [
+        (t.data_ptr() if t is not None else None) for t in keep]
+    epi.channels, epi.act, epi.slope, epi.gain = Cc, 1 if act else 0, slope, gain
+    out = upfirdn2d_native_layout(x.view(B * Cc, H, W, 1), kernel, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1], epi)
+    return out.view(B, Cc, out.shape[1], out.shape[2])
+
+
+# ----------------------------------------------------------------------------------------------- conv2d
+class PackedConv:
+    """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
+    Built once at model-load time (vspbfr_amd/packing.py)."""
+
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x")
+
+    def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None):
+        self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
+        self.stride = stride
+        self.dil = tuple(dil) + (1,) * (4 - len(dil))
+        self.pad_y = tuple(pad_y) + (0,) * (4 - len(pad_y))
+        pad_x = pad_y if pad_x is None else pad_x
+        self.pad_x = tuple(pad_x) + (0,) * (4 - len(pad_x))
+
+    @property
+    def cout(self):
+        return self.G * self.cout_g
+
+
+def pack_weight(weight, groups=1):
+    """(Cout, Cin, KH, KW) -> [G][KH*KW][Cin][Cout/G] contiguous."""
+    cout, cin, kh, kw = weight.shape
+    assert cout % groups == 0
+    return weight.reshape(groups, cout // groups, cin, kh * kw).permute(0, 3, 2, 1).contiguous()
+
+
+def conv2d_out_size(H, W, pc):
+    d, py, px = pc.dil[0], pc.pad_y[0], pc.pad_x[0]
+    oh = (H + 2 * py - d * (pc.kh - 1) - 1) // pc.stride + 1
+    ow = (W + 2 * px - d * (pc.kw - 1) - 1) // pc.stride + 1
+    return oh, ow
+
+
+def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out_offset=(0, 0), in_scale=None,
+                  in_scale_per_sample=True, in_shift=None, out_scale=None, ch_scale=None, ch_bias=None, act1=False,
+                  bias1=None, noise=None, noise_w=None, act2=0, bias2=None, prelu=None, slope2=0.2, gain2=SQRT2, res1=None,
+                  res2=None, res_coff=0, n_out=None, tile_hint=0):
+    """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
+    compute (defaults to the standard conv output size)."""
+    x = _req(x, "x")
+    B, Cin, H, W = x.shape
+    if Cin != pc.cin:
+        raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {pc.cin}")
+    OH, OW = n_out if n_out is not None else conv2d_out_size(H, W, pc)
+    if out is None:
+        yh, yw = out_hw if out_hw is not None else (OH, OW)
+        out = torch.empty((B, pc.cout, yh, yw), device=x.device, dtype=x.dtype)
+    _req(out, "out")
+    p = ConvParams()
+    keep = [x, pc.w, out, _opt(in_scale, "in_scale"), _opt(in_shift, "in_shift"), _opt(out_scale, "out_scale"),
+            _opt(ch_scale, "ch_scale"), _opt(ch_bias, "ch_bias"), _opt(bias1, "bias1"), _opt(noise, "noise"),
+            _opt(noise_w, "noise_w"), _opt(bias2, "bias2"), _opt(prelu, "prelu"), _opt(res1, "res1"), _opt(res2, "res2")]
+    dp = [(t.data_ptr() if t is not None else None) for t in keep]
+    (p.x, p.w, p.y, p.in_scale, p.in_shift, p.out_scale, p.ch_scale, p.ch_bias, p.bias1, p.noise, p.noise_w, p.bias2,
+     p.prelu, p.res1, p.res2) = dp
+    p.B, p.Cin, p.H, p.W = B, Cin, H, W
+    p.G, p.cout_g, p.OH, p.OW, p.KH, p.KW = pc.G, pc.cout_g, OH, OW, pc.kh, pc.kw
+    p.stride_y = p.stride_x = pc.stride
+    for g in range(4):
+        p.dil[g], p.pad_y[g], p.pad_x[g] = pc.dil[g], pc.pad_y[g], pc.pad_x[g]
+    p.y_ch, p.y_coff, p.y_h, p.y_w = out.shape[1], y_coff, out.shape[2], out.shape[3]
+    p.osy, p.osx = out_stride
+    p.ooy, p.oox = out_offset
+    p.in_scale_bstride = Cin if (in_scale is not None and in_scale_per_sample) else 0
+    p.act1, p.slope1, p.gain1 = (1 if act1 else 0), 0.2, SQRT2
+    p.act2, p.slope2, p.gain2 = int(act2), float(slope2), float(gain2)
+    rt = res1 if res1 is not None else res2
+    p.res_ch = rt.shape[1] if rt is not None else 0
+    p.res_coff = res_coff
+    p.tile_hint = tile_hint
+    if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
+        raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
+    check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
+    return out
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, **epi):
+    """F.conv2d-shaped convenience entry (groups=1): packs the weight on the fly (tests, generic callers)."""
+    weight = _req(weight, "weight")
+    cout, cin, kh, kw = weight.shape
+    pc = PackedConv(pack_weight(weight), 1, cout, cin, kh, kw, stride, (dilation,), (padding,))
+    return conv2d_packed(x, pc, ch_bias=bias, **epi)
+
+
+# transposed conv, stride 2, pad 0, as four sub-pixel phases (include/vspbfr_hip.h, osy/osx/ooy/oox)
+def pack_transposed_s2(weight_oihw):
+    """weight (Cout, Cin, 3, 3) as stored by ModulatedConv2d (reference models/RestoreNet.py:463-465; the reference
+    transposes it to (Cin, Cout, 3, 3) for conv_transpose2d, :527-529).  out[2m+py, 2n+px] only sees taps with
+    ky = py (mod 2): phase 0 is a 2-tap correlation [W[2], W[0]] with pad 1 over m = 0..H, phase 1 the single tap W[1]
+    over m = 0..H-1.  Returns {(py, px): PackedConv}."""
+    cout, cin, kh, kw = weight_oihw.shape
+    assert kh == 3 and kw == 3
+    sel = {0: [2, 0], 1: [1]}
+    phases = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            sub = weight_oihw[:, :, sel[py], :][:, :, :, sel[px]]
+            phases[(py, px)] = PackedConv(pack_weight(sub), 1, cout, cin, len(sel[py]), len(sel[px]), 1, (1,),
+                                          (1 if py == 0 else 0,), (1 if px == 0 else 0,))
+    return phases
+
+
+def conv_transpose2d_s2(x, phases, **kw):
+    """(B, Cin, H, W) -> (B, Cout, 2H+1, 2W+1): conv_transpose2d(stride=2, padding=0) with a 3x3 kernel."""
+    B, _, H, W = x.shape
+    cout = phases[(0, 0)].cout
+    out = torch.empty((B, cout, 2 * H + 1, 2 * W + 1), device=x.device, dtype=x.dtype)
+    for (py, px), pc in phases.items():
+        conv2d_packed(x, pc, out=out, out_stride=(2, 2), out_offset=(py, px),
+                      n_out=(H + 1 if py == 0 else H, W + 1 if px == 0 else W), **kw)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- gemm / linear
+def gemm_nt(a, b, out=None, alpha=1.0, bias=None, bias_scale=1.0, act=0, slope=0.2, gain=SQRT2, a_strides=None,
+            b_strides=None, dims=None):
+    """C[z,m,n] = epi(alpha * sum_k A[z,m,k] B[z,n,k]).  Default: a [Z?,M,K], b [Z?,N,K] contiguous.
+    `a_strides` = (zs, ms, ks), `b_strides` = (zs, ns, ks) and dims = (Z, M, N, K) describe arbitrary views of the
+    storage starting at a.data_ptr()/b.data_ptr()."""
+    if dims is None:
+        if a.dim() == 2:
+            a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
+        else:
+            a3, b3 = a, b
+        Z, M, K = a3.shape
+        N = b3.shape[1]
+        if b3.shape[0] not in (1, Z) or b3.shape[2] != K:
+            raise RuntimeError("gemm_nt: shape mismatch")
+        a_strides = (a3.stride(0), a3.stride(1), a3.stride(2))
+        b_strides = ((b3.stride(0) if b3.shape[0] == Z and Z > 1 else 0), b3.stride(1), b3.stride(2))
+        if Z == 1:
+            a_strides = (0,) + a_strides[1:]
+        out_shape = (M, N) if a.dim() == 2 else (Z, M, N)
+    else:
+        Z, M, N, K = dims
+        out_shape = (Z, M, N)
+    for t, nm in ((a, "a"), (b, "b")):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f"gemm_nt: {nm} must be a CUDA float32 tensor")
+    if out is None:
+        out = torch.empty(out_shape, device=a.device, dtype=a.dtype)
+    _req(out, "out")
+    p = GemmParams()
+    p.A, p.Bm, p.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    p.Z, p.M, p.N, p.K = Z, M, N, K
+    p.a_zs, p.a_ms, p.a_ks = a_strides
+    p.b_zs, p.b_ns, p.b_ks = b_strides
+    p.c_zs, p.c_ms = M * N, N
+    p.alpha = alpha
+    p.bias = _opt(bias, "bias").data_ptr() if bias is not None else None
+    p.bias_scale, p.act, p.slope, p.gain = bias_scale, act, slope, gain
+    check(lib.vsp_gemm_f32(C.byref(p), _stream()), "gemm")
+    return out
+
+
+def linear(x, weight, bias=None, alpha=1.0, bias_scale=1.0, act=0):
+    """F.linear(x, weight*alpha, bias*bias_scale) (+ fused leaky-relu*sqrt2 when act=1, sigmoid when act=2)."""
+    lead = x.shape[:-1]
+    x2 = _req(x, "x").reshape(-1, x.shape[-1])
+    out = gemm_nt(x2, _req(weight, "weight"), alpha=alpha, bias=bias, bias_scale=bias_scale, act=act)
+    return out.view(*lead, weight.shape[0])
+
+
+# ----------------------------------------------------------------------------------------------- row helpers
+def pixelnorm_dim1(x, eps=1e-8):
+    x = _req(x, "x")
+    if x.dim() == 2:
+        Z, R, Cc = 1, x.shape[0], x.shape[1]
+        # PixelNorm on (B, D) normalises over dim 1 = D: that is a [B, D, 1] problem
+        Z, R, Cc = x.shape[0], x.shape[1], 1
+    else:
+        Z, R = x.shape[0], x.shape[1]
+        Cc = x.numel() // (Z * R) if Z * R else 0
+    out = torch.empty_like(x)
+    check(lib.vsp_pixelnorm_dim1_f32(_ptr(out), _ptr(x), Z, R, Cc, eps, _stream()), "pixelnorm_dim1")
+    return out
+
+
+def layernorm(x, add=None, gamma=None, beta=None, eps=1e-5, post_lrelu=False):
+    x = _req(x, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    out = torch.empty_like(x)
+    check(lib.vsp_layernorm_f32(_ptr(out), _ptr(x), _ptr(_opt(add, "add")), _ptr(_opt(gamma, "gamma")),
+                                _ptr(_opt(beta, "beta")), rows, cols, eps, 1 if post_lrelu else 0, 0.2, SQRT2,
+                                _stream()), "layernorm")
+    return out
+
+
+def softmax_lastdim(x):
+    x = _req(x, "x")
+    cols = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib.vsp_softmax_lastdim_f32(_ptr(out), _ptr(x), x.numel() // cols, cols, _stream()), "softmax_lastdim")
+    return out
+
+
+def softmax_dim1(x):
+    x = _req(x, "x")
+    Z, R = x.shape[0], x.shape[1]
+    Cc = x.numel() // (Z * R)
+    out = torch.empty_like(x)
+    check(lib.vsp_softmax_dim1_f32(_ptr(out), _ptr(x), Z, R, Cc, _stream()), "softmax_dim1")
+    return out
+
+
+def film(h, gamma, beta):
+    out = torch.empty_like(_req(h, "h"))
+    check(lib.vsp_film_f32(_ptr(out), _ptr(h), _ptr(_req(gamma, "gamma")), _ptr(_req(beta, "beta")), h.numel(),
+                           _stream()), "film")
+    return out
+
+
+def axpby_idx(x, y, a, b, idx):
+    out = torch.empty_like(_req(x, "x"))
+    check(lib.vsp_axpby_idx_f32(_ptr(out), _ptr(x), _ptr(_req(y, "y")), _ptr(_req(a, "a")), _ptr(_req(b, "b")), int(idx),
+                                x.numel(), _stream()), "axpby_idx")
+    return out
+
+
+def demod_coefs(style, wsq, wscale, eps=1e-8):
+    style, wsq = _req(style, "style"), _req(wsq, "wsq")
+    B, Cin = style.shape
+    Cout = wsq.shape[0]
+    out = torch.empty((B, Cout), device=style.device, dtype=style.dtype)
+    check(lib.vsp_demod_f32(_ptr(out), _ptr(style), _ptr(wsq), B, Cin, Cout, wscale, eps, _stream()), "demod")
+    return out
+
+
+def avgpool2x2(x):
+    x = _req(x, "x")
+    H, W = x.shape[-2:]
+    if H % 2 or W % 2:
+        raise RuntimeError("avgpool2x2 needs even spatial dims")
+    out = torch.empty(x.shape[:-2] + (H // 2, W // 2), device=x.device, dtype=x.dtype)
+    check(lib.vsp_avgpool2x2_f32(_ptr(out), _ptr(x), x.numel() // (H * W), H // 2, W // 2, _stream()), "avgpool2x2")
+    return out
+
+
+def upsample_add(x, y):
+    x, y = _req(x, "x"), _req(y, "y")
+    IH, IW = x.shape[-2:]
+    OH, OW = y.shape[-2:]
+    out = torch.empty_like(y)
+    check(lib.vsp_upsample_add_f32(_ptr(out), _ptr(x), _ptr(y), y.numel() // (OH * OW), IH, IW, OH, OW, _stream()),
+          "upsample_add")
+    return out
+
+
+def plane_mean(x):
+    x = _req(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc), device=x.device, dtype=x.dtype)
+    check(lib.vsp_plane_mean_f32(_ptr(out), _ptr(x), B * Cc, H * W, _stream()), "plane_mean")
+    return out
+
+
+def scale_add(x, gate, y=None):
+    x = _req(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    check(lib.vsp_scale_add_f32(_ptr(out), _ptr(x), _ptr(_req(gate, "gate")), _ptr(_opt(y, "y")), B * Cc, H * W,
+                                _stream()), "scale_add")
+    return out
+
+
+def subsample(x, s):
+    x = _req(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, (H - 1) // s + 1, (W - 1) // s + 1), device=x.device, dtype=x.dtype)
+    check(lib.vsp_subsample_f32(_ptr(out), _ptr(x), B * Cc, H, W, s, _stream()), "subsample")
+    return out
+
+
+def add3(a, b, c=None):
+    out = torch.empty_like(_req(a, "a"))
+    check(lib.vsp_add3_f32(_ptr(out), _ptr(a), _ptr(_req(b, "b")), _ptr(_opt(c, "c")), a.numel(), _stream()), "add3")
+    return out

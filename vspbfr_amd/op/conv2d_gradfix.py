@@ -1,0 +1,56 @@
+"""conv2d_gradfix: signature mirror of reference op/conv2d_gradfix.py:22-92 (which, on every torch other than
+1.7/1.8, is a pass-through to F.conv2d / F.conv_transpose2d, :78-92) routed to the gfx950 implicit-GEMM kernel.
+Forward only.  `groups > 1` is served group by group (the model code in this package never needs it: it uses the
+modulate-input / demodulate-output form, see vspbfr_amd/layers.py)."""
+import contextlib
+
+import torch
+
+from .. import hip_ops
+
+enabled = True
+weight_gradients_disabled = False
+
+
+@contextlib.contextmanager
+def no_weight_gradients():
+    global weight_gradients_disabled
+    old = weight_gradients_disabled
+    weight_gradients_disabled = True
+    yield
+    weight_gradients_disabled = old
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    (sy, sx), (py, px), (dy, dx) = _pair(stride), _pair(padding), _pair(dilation)
+    if sy != sx or py != px or dy != dx:
+        raise RuntimeError("conv2d_gradfix.conv2d: only square stride/padding/dilation are supported")
+    if groups == 1:
+        return hip_ops.conv2d(input.contiguous(), weight.contiguous(), bias, sy, py, dy)
+    B, C, H, W = input.shape
+    cg, og = C // groups, weight.shape[0] // groups
+    outs = []
+    for g in range(groups):
+        outs.append(hip_ops.conv2d(input[:, g * cg:(g + 1) * cg].contiguous(), weight[g * og:(g + 1) * og].contiguous(),
+                                   None if bias is None else bias[g * og:(g + 1) * og].contiguous(), sy, py, dy))
+    return torch.cat(outs, dim=1)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    (sy, sx) = _pair(stride)
+    if (sy, sx) != (2, 2) or _pair(padding) != (0, 0) or _pair(output_padding) != (0, 0) or _pair(dilation) != (1, 1) \
+            or tuple(weight.shape[2:]) != (3, 3) or bias is not None:
+        raise RuntimeError("conv2d_gradfix.conv_transpose2d: the restoration path only uses stride=2, padding=0, 3x3, "
+                           "no bias (models/RestoreNet.py:530-532); other forms are not implemented")
+    B, C, H, W = input.shape
+    cg = C // groups
+    outs = []
+    for g in range(groups):
+        w_io = weight[g * cg:(g + 1) * cg]  # (Cin_g, Cout_g, 3, 3)
+        phases = hip_ops.pack_transposed_s2(w_io.transpose(0, 1).contiguous())
+        outs.append(hip_ops.conv_transpose2d_s2(input[:, g * cg:(g + 1) * cg].contiguous(), phases))
+    return outs[0] if groups == 1 else torch.cat(outs, dim=1)
