@@ -73,7 +73,13 @@ def synth_tensor(model, name, shape, dtype, seed):
             return U(0.5, 1.5) if leaf == "weight" else N(0.1)
         if leaf == "bias":
             return N(0.1)
-        return N(1.0 / math.sqrt(_fan_in(shape)))
+        w = N(1.0 / math.sqrt(_fan_in(shape)))
+        if re.search(r"att_mapper\.\d+\.(q_matrix|k_matrix)\.weight$", name):
+            # token-attention logits K.Q/sqrt(18) sum 512 products: with unit-variance projections they have std ~5 and
+            # the 18-way softmax is one-hot, which makes the T-step chain chaotic in fp32 (the reference's own CPU fp32
+            # run then differs from an fp64 run by O(1) at T=10).  Quarter-scale q/k keeps the logits O(0.3).
+            w = w * 0.25
+        return w
 
     # ---- StyleGAN2-style networks: Restoration_net, e4e decoder (Equal* layers: N(0,1)/lr_mul)
     if name.endswith("modulation.bias"):

@@ -1,0 +1,53 @@
+"""CPU checks of the drop-in boundary: the shared library loads and exports every symbol include/vspbfr_hip.h declares,
+and the ctypes structs have the C layout.  No compute calls (no GPU needed)."""
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "vspbfr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vsp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from vspbfr_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 20
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vsp_[a-z0-9_]+)", out))
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert set(names) == set(_lib.exported_symbols()), sorted(set(names) ^ set(_lib.exported_symbols()))
+
+
+def test_struct_layouts_match():
+    import ctypes as C
+
+    from vspbfr_amd import _lib
+    for which, st in ((0, _lib.FirEpilogue), (1, _lib.ConvParams), (2, _lib.GemmParams)):
+        assert _lib.lib.vsp_struct_size(which) == C.sizeof(st)
+    assert _lib.lib.vsp_abi_version() == 1
+    assert _lib.lib.vsp_conv2d_num_configs() >= 8
+    assert _lib.lib.vsp_conv2d_config_name(0).decode()
+
+
+def test_invalid_arguments_report_errors_without_a_gpu():
+    from vspbfr_amd import _lib
+    assert _lib.lib.vsp_conv2d_f32(None, None) == -1
+    assert "null params" in _lib.last_error()
+    assert _lib.lib.vsp_gemm_f32(None, None) == -1
+
+
+def test_product_does_not_import_oracle():
+    """The product path may not route through the CPU oracle (tier rule): no module under vspbfr_amd/ mentions it."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "vspbfr_amd")):
+        for f in fs:
+            if f.endswith(".py") and f != "smoke.py":  # smoke.py is the driver's self-check and uses the oracle as the checker
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "from oracle" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

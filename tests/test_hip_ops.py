@@ -1,0 +1,304 @@
+"""Parity of the gfx950 kernels (through the C ABI, via vspbfr_amd.hip_ops / vspbfr_amd.op) against the CPU oracle and
+the reference's golden vectors.  Needs a real MI355X: `pytest -m gpu`."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cases, ops as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def dev(t):
+    return t.to(DEV).contiguous()
+
+
+def close(a, b, rtol=1e-5, atol=1e-5, what=""):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), f"{what}: non-finite output"
+    err = np.abs(a - b).max() if a.size else 0.0
+    tol = atol + rtol * (np.abs(b).max() if b.size else 0.0)
+    assert err <= tol, f"{what}: max|d|={err:.3e} tol={tol:.3e}"
+
+
+@pytest.fixture(scope="module")
+def H():
+    from vspbfr_amd import hip_ops
+    return hip_ops
+
+
+# ------------------------------------------------------------------------------------------------ fused_bias_act
+@pytest.mark.parametrize("name", list(cases.LRELU_CASES))
+def test_fused_leaky_relu_golden(golden, name):
+    from vspbfr_amd.op import fused_leaky_relu
+    x, b = cases.lrelu_inputs(name)
+    y = fused_leaky_relu(dev(x), dev(b) if b is not None else None)
+    close(y, golden("ops")[name], 1e-6, 1e-6, name)  # bit-level ops: one add, one select, one multiply
+
+
+@pytest.mark.parametrize("act,grad", [(1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)])
+@pytest.mark.parametrize("shape", [(3, 7, 5, 6), (2, 8, 16, 16), (4, 12)])
+def test_fused_bias_act_modes(H, act, grad, shape):
+    g = torch.Generator().manual_seed(act * 10 + grad)
+    x = torch.randn(shape, generator=g)
+    b = torch.randn(shape[1], generator=g)
+    ref = torch.randn(shape, generator=g)
+    y = H.fused_bias_act(dev(x), dev(b), dev(ref), act, grad, 0.2, math.sqrt(2))
+    close(y, O.fused_bias_act(x, b, ref, act, grad, 0.2, math.sqrt(2)), 1e-6, 1e-6)
+    # no bias / no ref = empty tensors, as in the reference's python wrapper
+    e = torch.empty(0, device=DEV)
+    y = H.fused_bias_act(dev(x), e, e, act, 0, 0.1, 2.0)
+    close(y, O.fused_bias_act(x, None, None, act, 0, 0.1, 2.0), 1e-6, 1e-6)
+
+
+def test_fused_bias_act_large_and_empty(H):
+    x = torch.randn(2, 64, 128, 128)
+    b = torch.randn(64)
+    close(H.fused_bias_act(dev(x), dev(b), torch.empty(0, device=DEV), 3, 0, 0.2, math.sqrt(2)), O.fused_leaky_relu(x, b), 1e-6, 1e-6)
+    z = H.fused_bias_act(torch.empty(0, 4, device=DEV), torch.empty(0, device=DEV), torch.empty(0, device=DEV), 3, 0, 0.2, 1.0)
+    assert z.numel() == 0
+
+
+def test_op_error_behaviour(H):
+    from vspbfr_amd.op import fused_leaky_relu, upfirdn2d
+    with pytest.raises(RuntimeError):
+        fused_leaky_relu(torch.randn(2, 3), torch.randn(3))  # CPU tensor -> RuntimeError (reference: TORCH_CHECK is_cuda)
+    with pytest.raises(RuntimeError):
+        H.fused_bias_act(torch.randn(4, 6, device=DEV).t(), torch.empty(0, device=DEV), torch.empty(0, device=DEV), 3, 0, 0.2, 1.0)
+    with pytest.raises(RuntimeError):
+        upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(2, 2))
+
+
+# ------------------------------------------------------------------------------------------------ upfirdn2d
+@pytest.mark.parametrize("name", list(cases.FIR_CASES))
+def test_upfirdn2d_golden(golden, name):
+    from vspbfr_amd.op import upfirdn2d
+    x, k, up, down, pad = cases.fir_inputs(name)
+    y = upfirdn2d(dev(x), dev(k), up=up, down=down, pad=pad)
+    close(y, golden("ops")[name], 1e-6, 2e-6, name)
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 16, 257, 257), (1, 1)), ((2, 16, 256, 256), (2, 2)), ((1, 3, 65, 31), (1, 1)),
+                                       ((1, 2, 33, 200), (2, 2))])
+def test_upfirdn2d_blur_big(shape, pad):
+    from vspbfr_amd.op import upfirdn2d
+    x = torch.randn(shape)
+    k = O.make_kernel([1, 3, 3, 1]) * 4
+    close(upfirdn2d(dev(x), dev(k), pad=pad), O.upfirdn2d(x, k, pad=pad), 1e-6, 2e-6)
+
+
+def test_blur_fused_epilogue(H):
+    B, C_, Hh, Ww = 2, 6, 33, 37
+    x = torch.randn(B, C_, Hh, Ww)
+    k = O.make_kernel([1, 3, 3, 1]) * 4
+    ps, nz, nw = torch.rand(B, C_) + 0.5, torch.randn(B, 1, Hh - 1, Ww - 1), torch.tensor([0.3])
+    bias, r1, r2 = torch.randn(C_), torch.randn(B, C_, Hh - 1, Ww - 1), torch.randn(B, C_, Hh - 1, Ww - 1)
+    ref = O.upfirdn2d(x, k, pad=(1, 1)) * ps.view(B, C_, 1, 1) + nz * nw
+    ref = O.fused_leaky_relu(ref, bias) + r1 + r2
+    y = H.blur_fused(dev(x), dev(k), (1, 1), plane_scale=dev(ps), noise=dev(nz), noise_w=dev(nw), act_bias=dev(bias), act=True,
+                     res1=dev(r1), res2=dev(r2))
+    close(y, ref, 1e-5, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ conv2d
+CONV_SHAPES = [
+    # B, Cin, Cout, H, W, k, stride, pad, dil
+    (2, 8, 16, 12, 12, 3, 1, 1, 1),
+    (1, 3, 16, 20, 33, 3, 1, 1, 1),      # Cin not a multiple of 4, ragged width
+    (2, 16, 64, 32, 32, 3, 1, 1, 1),
+    (1, 64, 64, 40, 48, 3, 1, 1, 1),
+    (1, 32, 32, 64, 64, 3, 1, 2, 2),
+    (1, 16, 16, 40, 40, 3, 1, 4, 4),
+    (1, 16, 16, 40, 40, 3, 1, 8, 8),
+    (2, 16, 32, 33, 33, 3, 2, 0, 1),     # stride 2, pad 0 (StyledConv_down after blur)
+    (2, 16, 32, 32, 32, 3, 2, 1, 1),     # stride 2, pad 1 (IR-SE, style heads)
+    (2, 24, 3, 16, 16, 1, 1, 0, 1),      # 1x1 to 3 channels (ToRGB)
+    (1, 12, 20, 7, 9, 1, 1, 0, 1),
+    (3, 512, 128, 4, 4, 3, 1, 1, 1),     # tiny maps, deep K
+    (2, 128, 128, 8, 8, 3, 1, 1, 1),
+    (2, 64, 64, 2, 2, 3, 2, 1, 1),       # 2x2 -> 1x1 (last conv of a GradualStyleBlock)
+    (1, 40, 72, 16, 16, 3, 1, 1, 1),     # channel counts that are not multiples of the tile
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv2d_vs_torch(H, shape):
+    B, Cin, Cout, Hh, Ww, k, s, p, d = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, Hh, Ww, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, stride=s, padding=p, dilation=d)
+    y = H.conv2d(dev(x), dev(w), dev(b), s, p, d)
+    close(y, ref, 2e-5, 2e-5, str(shape))
+
+
+def test_conv2d_all_tile_configs(H):
+    from vspbfr_amd._lib import lib
+    B, Cin, Cout, Hh, Ww = 2, 24, 80, 37, 45
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    ref = F.conv2d(x, w, None, padding=1)
+    n = lib.vsp_conv2d_num_configs()
+    assert n >= 8
+    for c in range(1, n + 1):
+        y = H.conv2d(dev(x), dev(w), None, 1, 1, 1, tile_hint=c)
+        close(y, ref, 2e-5, 2e-5, f"cfg {c} {lib.vsp_conv2d_config_name(c - 1)}")
+
+
+def test_conv2d_prologue_epilogue(H):
+    B, Cin, Cout, Hh, Ww = 2, 16, 32, 18, 21
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, shift = torch.rand(B, Cin) + 0.5, torch.randn(Cin) * 0.1
+    demod, cs, cb = torch.rand(B, Cout) + 0.5, torch.rand(Cout) + 0.5, torch.randn(Cout)
+    b1, b2, nz, nw = torch.randn(Cout), torch.randn(Cout), torch.randn(B, 1, Hh, Ww), torch.tensor([0.4])
+    r1, r2 = torch.randn(B, Cout, Hh, Ww), torch.randn(B, Cout, Hh, Ww)
+    xin = x * s_in.view(B, Cin, 1, 1) + shift.view(1, Cin, 1, 1)
+    ref = torch.stack([F.conv2d(xin[i:i + 1], w, padding=1)[0] for i in range(B)])
+    ref = ref * demod.view(B, Cout, 1, 1) * cs.view(1, Cout, 1, 1) + cb.view(1, Cout, 1, 1)
+    ref = O.fused_leaky_relu(ref, b1) + nz * nw
+    ref = O.fused_leaky_relu(ref, b2) + r1 + r2
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), in_shift=dev(shift), out_scale=dev(demod), ch_scale=dev(cs),
+                        ch_bias=dev(cb), act1=True, bias1=dev(b1), noise=dev(nz), noise_w=dev(nw), act2=1, bias2=dev(b2),
+                        res1=dev(r1), res2=dev(r2))
+    close(y, ref, 3e-5, 3e-5)
+    # PReLU flavour + per-channel (batch-independent) input scale, as the IR-SE units use it
+    a = torch.rand(Cout) * 0.3
+    sc = torch.rand(Cin) + 0.5
+    ref2 = F.prelu(F.conv2d(x * sc.view(1, Cin, 1, 1) + shift.view(1, Cin, 1, 1), w, padding=1), a)
+    y2 = H.conv2d_packed(dev(x), pc, in_scale=dev(sc), in_scale_per_sample=False, in_shift=dev(shift), act2=2, prelu=dev(a))
+    close(y2, ref2, 3e-5, 3e-5)
+    # nn.LeakyReLU(0.01) flavour (GradualStyleBlock)
+    ref3 = F.leaky_relu(F.conv2d(x, w, cb, padding=1), 0.01)
+    y3 = H.conv2d_packed(dev(x), pc, ch_bias=dev(cb), act2=1, slope2=0.01, gain2=1.0)
+    close(y3, ref3, 3e-5, 3e-5)
+
+
+def test_conv2d_dilation_groups_into_slices(H):
+    """The four dilated branches of a SMART layer in ONE launch, each writing its channel slice (no torch.cat)."""
+    B, Cin, Cg, Hh, Ww = 2, 16, 8, 24, 24
+    x = torch.randn(B, Cin, Hh, Ww)
+    ws = [torch.randn(Cg, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(4)]
+    ref = torch.cat([F.conv2d(x, w_, padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    close(H.conv2d_packed(dev(x), pc), ref, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 12, 8, 8), (1, 16, 16, 5, 9), (1, 64, 32, 32, 32)])
+def test_conv_transpose_s2_phases(H, B, Cin, Cout, Hh, Ww):
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)  # stored (Cout, Cin, k, k) like ModulatedConv2d.weight[0]
+    ref = F.conv_transpose2d(x, w.transpose(0, 1), stride=2, padding=0)
+    y = H.conv_transpose2d_s2(dev(x), H.pack_transposed_s2(dev(w)))
+    close(y, ref, 2e-5, 2e-5)
+
+
+def test_conv2d_gradfix_mirror():
+    from vspbfr_amd.op import conv2d_gradfix
+    x = torch.randn(1, 12, 10, 10)
+    w = torch.randn(8, 6, 3, 3) * 0.2
+    close(conv2d_gradfix.conv2d(dev(x), dev(w), padding=1, groups=2), F.conv2d(x, w, padding=1, groups=2), 2e-5, 2e-5)
+    wt = torch.randn(12, 5, 3, 3) * 0.2
+    close(conv2d_gradfix.conv_transpose2d(dev(x), dev(wt), stride=2, padding=0), F.conv_transpose2d(x, wt, stride=2), 2e-5, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ modulated conv layers vs golden
+def _modulated(H, x, weight, mod, demodulate, mode, blur, dilation=1):
+    """modulate-input / demodulate-output form of the reference's grouped conv (same algebra as its fused=False
+    branch, models/RestoreNet.py:343-370), on the HIP kernels."""
+    _, Cout, Cin, k, _ = weight.shape
+    scale = 1 / math.sqrt(Cin * k * k)
+    w = weight[0] * scale
+    demod = H.demod_coefs(mod, (weight[0] ** 2).sum((2, 3)).contiguous(), scale) if demodulate else None
+    if mode == "up":
+        y = H.conv_transpose2d_s2(x, H.pack_transposed_s2(w.contiguous()), in_scale=mod, out_scale=demod)
+        return H.blur_fused(y, blur, (1, 1))
+    if mode == "down":
+        xb = H.blur_fused(x, blur, (2, 2))
+        pc = H.PackedConv(H.pack_weight(w.contiguous()), 1, Cout, Cin, k, k, 2, (1,), (0,))
+        return H.conv2d_packed(xb, pc, in_scale=mod, out_scale=demod)
+    pad = ((k - 1) * dilation) // 2
+    pc = H.PackedConv(H.pack_weight(w.contiguous()), 1, Cout, Cin, k, k, 1, (dilation,), (pad,))
+    return H.conv2d_packed(x, pc, in_scale=mod, out_scale=demod)
+
+
+@pytest.mark.parametrize("name", list(cases.MODCONV_CASES))
+def test_modulated_conv_golden(H, golden, name):
+    kind, cin, cout, k, sdim, xs, extra = cases.MODCONV_CASES[name]
+    shapes = [("weight", (1, cout, cin, k, k))] + ([("blur.kernel", (4, 4))] if kind != "same" else [])
+    shapes += [("modulation.weight", (cin, sdim)), ("modulation.bias", (cin,))]
+    sd = {n: dev(t) for n, t in cases.module_weights(name, shapes).items()}
+    x, style = dev(cases.tensor(name, "x", xs)), dev(cases.tensor(name, "style", (xs[0], sdim)))
+    mod = H.linear(style, sd["modulation.weight"], sd["modulation.bias"], alpha=1 / math.sqrt(sdim))
+    y = _modulated(H, x, sd["weight"], mod, extra.get("demodulate", True), kind, sd.get("blur.kernel"))
+    close(y, golden("layers")[name], 3e-5, 3e-5, name)
+
+
+@pytest.mark.parametrize("name", list(cases.DILCONV_CASES))
+def test_dilated_modulated_conv_golden(H, golden, name):
+    cin, cout, xs, d = cases.DILCONV_CASES[name]
+    sd = cases.module_weights(name, [("weight", (1, cout, cin, 3, 3))])
+    x, style = dev(cases.tensor(name, "x", xs)), dev(cases.tensor(name, "style", (xs[0], cin)) * 0.5 + 1.0)
+    y = _modulated(H, x, dev(sd["weight"]), style, True, "same", None, dilation=d)
+    close(y, golden("layers")[name], 3e-5, 3e-5, name)
+
+
+# ------------------------------------------------------------------------------------------------ gemm + row helpers
+@pytest.mark.parametrize("M,N,K", [(8, 512, 2048), (144, 512, 512), (36, 512, 513), (3, 17, 5), (8, 1024, 8192), (1, 16, 16)])
+def test_linear(H, M, N, K):
+    x, w, b = torch.randn(M, K), torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    close(H.linear(dev(x), dev(w), dev(b)), F.linear(x, w, b), 3e-5, 3e-5)
+    close(H.linear(dev(x), dev(w), dev(b), alpha=0.5, bias_scale=0.01, act=1), O.fused_leaky_relu(F.linear(x, w * 0.5), b * 0.01), 3e-5, 3e-5)
+    close(H.linear(dev(x), dev(w), dev(b), act=2), torch.sigmoid(F.linear(x, w, b)), 3e-5, 3e-5)
+
+
+def test_gemm_strided_batched(H):
+    B, T, D = 3, 18, 64
+    Kt, Q, V = torch.randn(B, T, D), torch.randn(B, T, D), torch.randn(B, T, D)
+    # K Q^T (NT), score V (NN via strides), k^T q (TN via strides)
+    s = H.gemm_nt(dev(Kt), dev(Q), alpha=0.25)
+    close(s, torch.matmul(Kt, Q.transpose(1, 2)) * 0.25, 3e-5, 3e-5)
+    sc = torch.softmax(torch.randn(B, T, T), -1)
+    h = H.gemm_nt(dev(sc), dev(V), dims=(B, T, D, T), a_strides=(T * T, T, 1), b_strides=(T * D, 1, D))
+    close(h, torch.matmul(sc, V), 3e-5, 3e-5)
+    a = H.gemm_nt(dev(Kt), dev(Q), dims=(B, D, D, T), a_strides=(T * D, 1, D), b_strides=(T * D, 1, D))
+    close(a, torch.matmul(Kt.transpose(1, 2), Q), 3e-5, 3e-5)
+
+
+def test_row_helpers(H):
+    x = torch.randn(3, 18, 96)
+    close(H.pixelnorm_dim1(dev(x)), O.pixel_norm(x), 1e-5, 1e-5)
+    z = torch.randn(5, 512)
+    close(H.pixelnorm_dim1(dev(z)), O.pixel_norm(z), 1e-5, 1e-5)
+    a = torch.randn(3, 18, 96)
+    g, b = torch.rand(96) + 0.5, torch.randn(96)
+    close(H.layernorm(dev(x)), F.layer_norm(x, (96,)), 2e-5, 2e-5)
+    close(H.layernorm(dev(x), add=dev(a)), F.layer_norm(x + a, (96,)), 2e-5, 2e-5)
+    close(H.layernorm(dev(x), gamma=dev(g), beta=dev(b), post_lrelu=True), F.leaky_relu(F.layer_norm(x, (96,), g, b), 0.2) * math.sqrt(2), 2e-5, 2e-5)
+    close(H.softmax_lastdim(dev(x)), torch.softmax(x, -1), 1e-5, 1e-6)
+    close(H.softmax_dim1(dev(x)), torch.softmax(x, 1), 1e-5, 1e-6)
+    close(H.film(dev(x), dev(a), dev(a * 2)), x * (1 + a) + a * 2, 1e-6, 1e-6)
+    c1, c2 = torch.rand(7), torch.rand(7)
+    close(H.axpby_idx(dev(x), dev(a), dev(c1), dev(c2), 3), c1[3] * x + c2[3] * a, 1e-6, 1e-6)
+    img = torch.randn(2, 5, 12, 16)
+    close(H.avgpool2x2(dev(img)), F.avg_pool2d(img, 2), 1e-6, 1e-6)
+    close(H.avgpool2x2(dev(img)), F.interpolate(img, (6, 8), mode="bilinear"), 1e-6, 1e-6)
+    big = torch.randn(2, 5, 24, 32)
+    close(H.upsample_add(dev(img), dev(big)), F.interpolate(img, (24, 32), mode="bilinear", align_corners=True) + big, 1e-5, 1e-5)
+    close(H.plane_mean(dev(img)), img.mean((2, 3)), 1e-6, 1e-6)
+    gate = torch.rand(2, 5)
+    close(H.scale_add(dev(img), dev(gate), dev(img * 3)), img * gate.view(2, 5, 1, 1) + img * 3, 1e-6, 1e-6)
+    close(H.subsample(dev(img), 2), img[:, :, ::2, ::2], 0, 0)
+    close(H.add3(dev(img), dev(img), dev(img)), img * 3, 1e-6, 1e-6)
+    st, wsq = torch.randn(4, 32), torch.rand(24, 32)
+    close(H.demod_coefs(dev(st), dev(wsq), 0.1), torch.rsqrt(0.01 * (st ** 2) @ wsq.t() + 1e-8), 2e-5, 1e-6)

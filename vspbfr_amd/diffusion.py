@@ -1,0 +1,210 @@
+"""Code_diffuser (4 x TACC_block on W+ latents) and the My_DDPM sampler on gfx950 -- constructor/forward API and
+state-dict keys of the reference's models/CodeDiffuser.py:63-140 and ldm/ddpm.py:253-429.
+
+Execution (MI355X-first): every F.linear / torch.matmul is the strided fp32-MFMA small GEMM of the C ABI; the
+conditioning vector c = [embd, t/T] never materialises as a 513-wide tensor on the hot path: a Linear(513 -> 512) is
+split into its 512-wide part (one GEMM on the step-independent `embd`, hoisted out of the sampling loop by
+`My_DDPM.forward`) plus t/T times its last weight column.  Everything that depends only on (embd, t) -- Q, k, gamma,
+beta of every block -- is therefore computed once per (condition, t) outside the x-dependent chain.
+"""
+import math
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip_ops as H
+
+SQRT2 = math.sqrt(2.0)
+
+
+class spatial_attention(nn.Module):
+    def __init__(self, in_dim=18, latent_dim=512):
+        super().__init__()
+        self.q_matrix = nn.Linear(latent_dim, latent_dim, bias=False)
+        self.k_matrix = nn.Linear(latent_dim + 1, latent_dim, bias=False)
+        self.v_matrix = nn.Linear(latent_dim, latent_dim, bias=False)
+        self.dk = latent_dim
+
+
+class _Head(nn.Sequential):
+    """Linear(D+1, D) -> LayerNorm -> ScaledLeakyReLU -> Linear(D, D) -> Sigmoid | ScaledLeakyReLU (keys .0 .1 .3)."""
+
+    def __init__(self, dim, last):
+        super().__init__(nn.Linear(dim + 1, dim), nn.LayerNorm([dim]), nn.Identity(), nn.Linear(dim, dim), nn.Identity())
+        self.last = last  # 2 = sigmoid, 1 = leaky-relu * sqrt2
+
+
+def _lin513(lin, embd_part, tfrac):
+    """Linear(513 -> 512)(cat[embd, t/T]) given embd_part = embd @ W[:, :512]^T (+bias): adds t/T * W[:, 512]."""
+    return embd_part + tfrac * lin.weight[:, -1]
+
+
+class TACC_block(nn.Module):
+    def __init__(self, latent_dim=512, in_dim=18):
+        super().__init__()
+        d = latent_dim
+        self.dim = d
+        self.q_matrix = nn.Linear(d + 1, d, bias=False)
+        self.k_matrix = nn.Linear(d, d, bias=False)
+        self.v_matrix = nn.Linear(d, d, bias=False)
+        self.gamma_ = _Head(d, 2)
+        self.beta_ = _Head(d, 1)
+        self.attention_layer = spatial_attention(in_dim=in_dim, latent_dim=d)
+        self.dk = 18
+
+    # ---- step-independent part: the four Linear(513) layers applied to embd only
+    def embed(self, embd):
+        d = self.dim
+        rows = embd.reshape(-1, d)
+
+        def proj(lin):
+            wv = lin.weight  # (d, d+1): the GEMM reads its first d columns through the row pitch d+1
+            out = H.gemm_nt(rows, wv, dims=(1, rows.shape[0], d, d), a_strides=(0, d, 1), b_strides=(0, d + 1, 1),
+                            bias=lin.bias)
+            return out.view(*embd.shape[:-1], d)
+        return {"Q": proj(self.q_matrix), "k": proj(self.attention_layer.k_matrix), "g": proj(self.gamma_[0]),
+                "b": proj(self.beta_[0])}
+
+    # ---- (embd, t)-dependent, x-independent part
+    def condition(self, emb, tfrac):
+        Q = _lin513(self.q_matrix, emb["Q"], tfrac)
+        k2 = _lin513(self.attention_layer.k_matrix, emb["k"], tfrac)
+
+        def head(seq, e):
+            g = H.layernorm(_lin513(seq[0], e, tfrac).contiguous(), gamma=seq[1].weight, beta=seq[1].bias, post_lrelu=True)
+            return H.linear(g, seq[3].weight, seq[3].bias, act=seq.last)
+        return {"Q": Q.contiguous(), "k": k2.contiguous(), "gamma": head(self.gamma_, emb["g"]), "beta": head(self.beta_, emb["b"])}
+
+    # ---- x-dependent chain
+    def run(self, x, cond):
+        B, T, d = x.shape
+        xn = H.pixelnorm_dim1(x)                                     # over the 18 tokens (models/CodeDiffuser.py:11-12,92)
+        att = self.attention_layer
+        K = H.linear(xn, self.k_matrix.weight)
+        V = H.linear(xn, self.v_matrix.weight)
+        score = H.softmax_lastdim(H.gemm_nt(K, cond["Q"], alpha=1 / math.sqrt(self.dk)))           # (B,18,18)
+        h = H.gemm_nt(score, V, dims=(B, T, d, T), a_strides=(T * T, T, 1), b_strides=(T * d, 1, d))  # score @ V
+        q2 = H.linear(xn, att.q_matrix.weight)
+        v2 = H.linear(xn, att.v_matrix.weight)
+        # channel attention: A = softmax_dim1(k^T q / sqrt(d)) (d x d per sample), t = LN(v A)
+        A = H.gemm_nt(cond["k"], q2, dims=(B, d, d, T), a_strides=(T * d, 1, d), b_strides=(T * d, 1, d),
+                      alpha=1 / math.sqrt(att.dk))
+        A = H.softmax_dim1(A)
+        t = H.gemm_nt(v2, A, dims=(B, T, d, d), a_strides=(T * d, d, 1), b_strides=(d * d, 1, d))
+        t = H.layernorm(t)
+        h = H.layernorm(h, add=t)
+        return H.film(h, cond["gamma"], cond["beta"])
+
+    def forward(self, x, embd, step):
+        tfrac = step[..., :1] if step.dim() == 3 else step
+        return self.run(x.contiguous(), self.condition(self.embed(embd.contiguous()), tfrac))
+
+
+class Code_diffuser(nn.Module):
+    def __init__(self, timesteps, dim=512):
+        super().__init__()
+        self.max_period = timesteps
+        self.att_mapper = nn.ModuleList([TACC_block(latent_dim=dim) for _ in range(4)])
+
+    def embed(self, embd):
+        return [blk.embed(embd) for blk in self.att_mapper]
+
+    def condition(self, emb, t, n_tokens):
+        tfrac = (t.float() / self.max_period).view(-1, 1, 1).expand(-1, n_tokens, 1)
+        return [blk.condition(e, tfrac) for blk, e in zip(self.att_mapper, emb)]
+
+    def run(self, x, conds):
+        for blk, c in zip(self.att_mapper, conds):
+            x = blk.run(x, c)
+        return x
+
+    @torch.no_grad()
+    def forward(self, x, embd, t):
+        embd = embd.contiguous()
+        return self.run(x.contiguous(), self.condition(self.embed(embd), t, embd.shape[1]))
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """float64 schedule, reference ldm/util2.py:21-43."""
+    if schedule == "linear":
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "cosine":
+        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = torch.cos(ts / (1 + cosine_s) * np.pi / 2).pow(2)
+        alphas = alphas / alphas[0]
+        betas = (1 - alphas[1:] / alphas[:-1]).clamp(0, 0.999)
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+class My_DDPM(nn.Module):
+    """x0-parameterised DDPM over W+ latents; inference = deterministic posterior-mean chain (reference
+    ldm/ddpm.py:400-429: p_sample returns the mean, the drawn noise is unused)."""
+
+    def __init__(self, denoise, timesteps=1000, beta_schedule="linear", clip_denoised=False, linear_start=1e-4,
+                 linear_end=2e-2, cosine_s=8e-3, given_betas=None, v_posterior=0., l_simple_weight=1., parameterization="x0"):
+        super().__init__()
+        assert parameterization in ["eps", "x0"], 'currently only supporting "eps" and "x0"'
+        self.parameterization = parameterization
+        self.clip_denoised = clip_denoised
+        self.model = denoise
+        self.v_posterior, self.l_simple_weight = v_posterior, l_simple_weight
+        self.register_schedule(given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(beta_schedule, timesteps, linear_start,
+                                                                               linear_end, cosine_s)
+        alphas = 1. - betas
+        ac = np.cumprod(alphas, axis=0)
+        ac_prev = np.append(1., ac[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        f32 = partial(torch.tensor, dtype=torch.float32)
+        pv = (1 - self.v_posterior) * betas * (1. - ac_prev) / (1. - ac) + self.v_posterior * betas
+        for name, val in (("betas", betas), ("alphas_cumprod", ac), ("alphas_cumprod_prev", ac_prev),
+                          ("sqrt_alphas_cumprod", np.sqrt(ac)), ("sqrt_one_minus_alphas_cumprod", np.sqrt(1. - ac)),
+                          ("log_one_minus_alphas_cumprod", np.log(1. - ac)), ("sqrt_recip_alphas_cumprod", np.sqrt(1. / ac)),
+                          ("sqrt_recipm1_alphas_cumprod", np.sqrt(1. / ac - 1)), ("posterior_variance", pv),
+                          ("posterior_log_variance_clipped", np.log(np.maximum(pv, 1e-20))),
+                          ("posterior_mean_coef1", betas * np.sqrt(ac_prev) / (1. - ac)),
+                          ("posterior_mean_coef2", (1. - ac_prev) * np.sqrt(alphas) / (1. - ac))):
+            self.register_buffer(name, f32(val))
+
+    # ---- reference-shaped single step (used by callers that drive the loop themselves)
+    @torch.no_grad()
+    def p_sample(self, x, t, c, clip_denoised=True, repeat_noise=False):
+        model_out = self.model(x, c, t)
+        return self._posterior_mean(model_out, x, int(t[0])), model_out
+
+    def _posterior_mean(self, model_out, x, i):
+        if self.parameterization == "eps":
+            x0 = self.sqrt_recip_alphas_cumprod[i] * x - self.sqrt_recipm1_alphas_cumprod[i] * model_out
+        else:
+            x0 = model_out
+        if self.clip_denoised:
+            x0 = x0.clamp(-1., 1.)
+        return H.axpby_idx(x0.contiguous(), x.contiguous(), self.posterior_mean_coef1, self.posterior_mean_coef2, i)
+
+    @torch.no_grad()
+    def forward(self, x=None, condi_in=None, training=False, x_T=None):
+        """training=False: sample from x_T ~ N(0, I) (or the given `x_T`, an extension for parity runs) conditioned on
+        `condi_in`; returns the last denoised latent."""
+        if training:
+            raise RuntimeError("My_DDPM (vspbfr_amd) implements the inference chain only")
+        cond = condi_in.contiguous()
+        B, n_tok = cond.shape[0], cond.shape[1]
+        x = x_T.contiguous() if x_T is not None else torch.randn(cond.shape, device=cond.device)
+        emb = self.model.embed(cond)  # step-independent half of every Linear(513)
+        for i in reversed(range(self.num_timesteps)):
+            t = torch.full((B,), i, device=cond.device, dtype=torch.long)
+            x0 = self.model.run(x, self.model.condition(emb, t, n_tok))
+            x = self._posterior_mean(x0, x, i)
+        return x

@@ -1,0 +1,293 @@
+"""StyleGAN2-style building blocks shared by Restoration_net and the e4e prior decoder, executed on the gfx950 kernels.
+
+Parameter/buffer names and shapes follow the reference's checkpoints so `load_state_dict(strict=True)`
+works on the published files; the forward passes do NOT follow the reference's op sequence.  MI355X-first choices:
+
+* modulate-input / demodulate-output: the per-sample weight tensor (B*Cout, Cin, 3, 3) of the reference's grouped conv
+  (models/RestoreNet.py:373-416) is never built.  The style scales the input while the conv kernel stages its LDS patch,
+  the demodulation coefficient rsqrt(scale^2 * sum_ci s^2 * sum_taps W^2 + 1e-8) is a (B, Cout) vector applied in the
+  conv epilogue (same algebra as the reference's own `fused=False` branch, :343-370).
+* weights are packed ONCE per device into the kernel layout [group][tap][ci][co] with the equalised-lr scale folded in.
+* noise injection, bias, leaky-ReLU, residual adds and channel concatenation run inside the producing kernel's epilogue
+  (conv) or the blur's epilogue (up-sampling convs): no standalone elementwise pass over a (B, C, H, W) tensor.
+* a stride-2 transposed conv is four sub-pixel phase convolutions (same MACs as conv_transpose2d) followed by the FIR blur.
+Inference only (no autograd through the HIP ops).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import hip_ops as H
+
+SQRT2 = math.sqrt(2.0)
+RATES = (1, 2, 4, 8)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    k /= k.sum()
+    return k
+
+
+class _Cached(nn.Module):
+    """Device-side derived tensors (packed weights, folded constants), rebuilt when a source parameter changes."""
+
+    def _derive(self, key, sources, fn):
+        store = self.__dict__.setdefault("_derived", {})
+        stamp = tuple((t.data_ptr(), t._version, t.device) for t in sources)
+        hit = store.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, fn())
+            store[key] = hit
+        return hit[1]
+
+
+class PixelNorm(nn.Module):
+    def forward(self, x):
+        return H.pixelnorm_dim1(x.contiguous())
+
+
+class EqualLinear(_Cached):
+    """weight stored divided by lr_mul; y = x (W * lr_mul/sqrt(in))^T + b * lr_mul, optional fused leaky-ReLU*sqrt2
+    (reference models/RestoreNet.py:142-171)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, x):
+        return H.linear(x.contiguous(), self.weight, self.bias, alpha=self.scale, bias_scale=self.lr_mul,
+                        act=1 if self.activation else 0)
+
+
+class EqualConv2d(nn.Module):
+    """Parameter holder (weight scaled by 1/sqrt(fan_in) at use); executed by its parent block."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True, dilation=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+
+class LeakyBias(nn.Module):
+    """Holds the `bias` of a FusedLeakyReLU; the activation itself is fused into the producer's epilogue."""
+
+    def __init__(self, channel):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def draw(self, noise, like_shape, device):
+        """explicit noise (B,1,H,W) or a fresh N(0,1) draw on the device (reference models/RestoreNet.py:564-569)."""
+        if noise is None:
+            return torch.randn(like_shape, device=device, dtype=torch.float32)
+        return noise.contiguous()
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        kernel = make_kernel(kernel)
+        if upsample_factor > 1:
+            kernel = kernel * (upsample_factor ** 2)
+        self.register_buffer("kernel", kernel)
+        self.pad = pad
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        kernel = make_kernel(kernel) * (factor ** 2)
+        self.register_buffer("kernel", kernel)
+        p = kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, x):
+        from .op import upfirdn2d
+        return upfirdn2d(x.contiguous(), self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class ModulatedConv2d(_Cached):
+    """weight (1, Cout, Cin, k, k) + `modulation` EqualLinear(style_dim -> Cin, bias_init=1) (+ `blur.kernel`)
+    (reference models/RestoreNet.py:421-476, e4e/models/stylegan2/model.py:182-236)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False, downsample=False,
+                 blur_kernel=(1, 3, 3, 1), own_modulation=True, dilation=1):
+        super().__init__()
+        self.in_channel, self.out_channel, self.kernel_size = in_channel, out_channel, kernel_size
+        self.upsample, self.downsample, self.demodulate, self.dilation = upsample, downsample, demodulate, dilation
+        if upsample:
+            self.blur = Blur(list(blur_kernel), pad=(1, 1), upsample_factor=2)
+        if downsample:
+            self.blur = Blur(list(blur_kernel), pad=(2, 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = ((kernel_size - 1) * dilation) // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        if own_modulation:
+            self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+
+    # ---- derived tensors
+    def _w_scaled(self):
+        return (self.weight[0] * self.scale).contiguous()
+
+    def packed(self):
+        def build():
+            w = self._w_scaled()
+            if self.upsample:
+                return H.pack_transposed_s2(w)
+            return H.PackedConv(H.pack_weight(w), 1, self.out_channel, self.in_channel, self.kernel_size, self.kernel_size,
+                                2 if self.downsample else 1, (self.dilation,), (0 if self.downsample else self.padding,))
+        return self._derive("packed", [self.weight], build)
+
+    def wsq(self):
+        return self._derive("wsq", [self.weight], lambda: (self.weight[0] ** 2).sum((2, 3)).contiguous())
+
+    def demod(self, mod):
+        return H.demod_coefs(mod, self.wsq(), self.scale) if self.demodulate else None
+
+    def run(self, x, style, noise=None, noise_w=None, act_bias=None, ch_bias=None, res1=None, res2=None):
+        """conv (+ the caller's fused tail).  `style` is the un-modulated style vector (B, style_dim)."""
+        mod = self.modulation(style)
+        demod = self.demod(mod)
+        x = x.contiguous()
+        act = act_bias is not None
+        if self.upsample:
+            y = H.conv_transpose2d_s2(x, self.packed(), in_scale=mod, out_scale=demod)
+            return H.blur_fused(y, self.blur.kernel, self.blur.pad, noise=noise, noise_w=noise_w, act_bias=act_bias, act=act,
+                                res1=res1, res2=res2)
+        if self.downsample:
+            x = H.blur_fused(x, self.blur.kernel, self.blur.pad)
+        return H.conv2d_packed(x, self.packed(), in_scale=mod, out_scale=demod, ch_bias=ch_bias, noise=noise, noise_w=noise_w,
+                               act2=1 if act else 0, bias2=act_bias, res1=res1, res2=res2)
+
+
+class StyledConv(nn.Module):
+    """conv -> noise -> bias + leaky-ReLU, all in one epilogue (reference models/RestoreNet.py:571-643)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, downsample=False,
+                 blur_kernel=(1, 3, 3, 1), demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample, downsample=downsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = LeakyBias(out_channel)
+
+    def out_hw(self, h, w):
+        if self.conv.upsample:
+            return 2 * h, 2 * w
+        if self.conv.downsample:
+            return h // 2, w // 2
+        return h, w
+
+    def forward(self, x, style, noise=None, res1=None, res2=None):
+        oh, ow = self.out_hw(x.shape[2], x.shape[3])
+        nz = self.noise.draw(noise, (x.shape[0], 1, oh, ow), x.device)
+        return self.conv.run(x, style, noise=nz, noise_w=self.noise.weight, act_bias=self.activate.bias, res1=res1, res2=res2)
+
+
+class ToRGB(nn.Module):
+    """1x1 modulated conv without demodulation + bias + FIR-upsampled skip, skip add fused as the conv's residual
+    (reference models/RestoreNet.py:647-666)."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(list(blur_kernel))
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, x, style, skip=None):
+        res = self.upsample(skip) if skip is not None else None
+        return self.conv.run(x, style, ch_bias=self.bias.view(3), res1=res)
+
+
+class SMARTLayer(_Cached):
+    """SMART_layer (reference models/RestoreNet.py:179-244): shared modulation, four dilated modulated 3x3 branches
+    (one launch, four dilation groups writing channel slices), `fusion` 3x3 conv whose epilogue carries
+    bias+lrelu -> noise -> bias+lrelu."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.in_channel, self.out_channel = in_channel, out_channel
+        self.ModulatedConv2ds = nn.ModuleList(
+            ModulatedConv2d(in_channel, out_channel // len(RATES), kernel_size, style_dim, own_modulation=False, dilation=r)
+            for r in RATES)
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.fusion = nn.Sequential(EqualConv2d(out_channel, out_channel, 3, padding=1, bias=False), LeakyBias(out_channel))
+        self.noise = NoiseInjection()
+        self.activate = LeakyBias(out_channel)
+
+    def _branch_pack(self):
+        ws = [m.weight for m in self.ModulatedConv2ds]
+
+        def build():
+            scale = self.ModulatedConv2ds[0].scale
+            wp = torch.stack([H.pack_weight((w[0] * scale).contiguous())[0] for w in ws]).contiguous()
+            pc = H.PackedConv(wp, len(RATES), self.out_channel // len(RATES), self.in_channel, 3, 3, 1, RATES, RATES)
+            wsq = torch.cat([(w[0] ** 2).sum((2, 3)) for w in ws], 0).contiguous()
+            return pc, wsq
+        return self._derive("branches", ws, build)
+
+    def _fusion_pack(self):
+        conv = self.fusion[0]
+        return self._derive("fusion", [conv.weight], lambda: H.PackedConv(
+            H.pack_weight((conv.weight * conv.scale).contiguous()), 1, self.out_channel, self.out_channel, 3, 3, 1, (1,), (1,)))
+
+    def forward(self, x, style, noise=None):
+        x = x.contiguous()
+        mod = self.modulation(style)
+        pc, wsq = self._branch_pack()
+        demod = H.demod_coefs(mod, wsq, self.ModulatedConv2ds[0].scale)
+        mid = H.conv2d_packed(x, pc, in_scale=mod, out_scale=demod)
+        nz = self.noise.draw(noise, (x.shape[0], 1, x.shape[2], x.shape[3]), x.device)
+        return H.conv2d_packed(mid, self._fusion_pack(), act1=True, bias1=self.fusion[1].bias, noise=nz,
+                               noise_w=self.noise.weight, act2=1, bias2=self.activate.bias)
+
+
+class LargeConvLayer(_Cached):
+    """LargeConvLayer(downsample=False) (reference models/RestoreNet.py:725-787): four dilated EqualConv2d branches in one
+    launch, 1x1 `fusion` conv with both FusedLeakyReLUs in its epilogue."""
+
+    def __init__(self, in_channel, out_channel, kernel_size):
+        super().__init__()
+        self.in_channel, self.out_channel, self.kernel_size = in_channel, out_channel, kernel_size
+        self.dilated_convs = nn.ModuleList(
+            EqualConv2d(in_channel, out_channel // len(RATES), kernel_size, padding=((kernel_size - 1) * r) // 2, bias=False,
+                        dilation=r) for r in RATES)
+        self.fusion = nn.Sequential(EqualConv2d(out_channel, out_channel, 1, bias=False), LeakyBias(out_channel))
+        self.activate = LeakyBias(out_channel)
+
+    def _packs(self):
+        ws = [m.weight for m in self.dilated_convs]
+
+        def build():
+            k = self.kernel_size
+            wp = torch.stack([H.pack_weight((m.weight * m.scale).contiguous())[0] for m in self.dilated_convs]).contiguous()
+            pads = tuple(m.padding for m in self.dilated_convs)
+            pc = H.PackedConv(wp, len(RATES), self.out_channel // len(RATES), self.in_channel, k, k, 1, RATES, pads)
+            f = self.fusion[0]
+            pf = H.PackedConv(H.pack_weight((f.weight * f.scale).contiguous()), 1, self.out_channel, self.out_channel, 1, 1, 1,
+                              (1,), (0,))
+            return pc, pf
+        return self._derive("packs", ws + [self.fusion[0].weight], build)
+
+    def forward(self, x):
+        pc, pf = self._packs()
+        mid = H.conv2d_packed(x.contiguous(), pc)
+        return H.conv2d_packed(mid, pf, act1=True, bias1=self.fusion[1].bias, act2=1, bias2=self.activate.bias)

@@ -1,0 +1,74 @@
+"""The restoration hot path A -> B -> C -> D (reference restoration_test.py:125-131) as one object, plus the
+data-parallel sharding used across the GPUs of a node.
+
+    low_latent     = psp_embedding.get_w_plus(low_imgs)                      # A  e4e encoder
+    pre_dic_latent = diffusion(x=low_latent, condi_in=low_latent)            # B  Code_diffuser DDPM chain
+    sample, feats  = psp_embedding.get_stylegan_feats(pre_dic_latent)        # C  StyleGAN2 prior decoder
+    restored       = generator(low_imgs, feats, pre_dic_latent, noise)       # D  Restoration_net
+
+Every image is independent end to end (eval-mode BatchNorm, per-sample modulated convs), so multi-GPU is a
+contiguous split of the batch with replicated weights and ONE all-gather of the restored images (RCCL over xGMI via
+torch.distributed backend "nccl"); there is no collective inside the path.
+"""
+import torch
+
+from .diffusion import Code_diffuser, My_DDPM
+from .e4e import E4e_embedding
+from .restorenet import Restoration_net, mixing_noise
+
+
+def shard_range(n, rank, world):
+    """Contiguous split of n items: rank r owns [lo, hi); sizes differ by at most one (ragged batches allowed)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def load_ddpm(ddpm_ckpt, device="cuda", timesteps=4, linear_start=0.1, linear_end=0.99):
+    """reference restoration_test.py:31-40 (checkpoint key "att_mapper"); `ddpm_ckpt` may be a path or a state dict."""
+    sd = ddpm_ckpt if isinstance(ddpm_ckpt, dict) else torch.load(ddpm_ckpt, map_location="cpu")
+    if "att_mapper" in sd and not any(k.startswith("att_mapper.") for k in sd):
+        sd = sd["att_mapper"]
+    net = Code_diffuser(timesteps=timesteps).to(device)
+    net.load_state_dict(sd)
+    net.eval()
+    return My_DDPM(denoise=net, linear_start=linear_start, linear_end=linear_end, timesteps=timesteps).to(device)
+
+
+class RestorationPipeline:
+    def __init__(self, generator: Restoration_net, psp_embedding: E4e_embedding, diffusion: My_DDPM, mixing=0.5,
+                 with_sample=True):
+        self.generator, self.psp, self.diffusion = generator.eval(), psp_embedding.eval(), diffusion.eval()
+        self.mixing, self.with_sample = mixing, with_sample
+
+    @torch.no_grad()
+    def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
+        """low_imgs (B,3,512,512) in [-1,1] on the device -> dict(restored, style_sample, latent, pre_latent).
+        All keyword tensors are optional explicit replacements of the reference's RNG draws (parity runs)."""
+        B = low_imgs.shape[0]
+        noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
+        low_latent = self.psp.get_w_plus(low_imgs)
+        pre = self.diffusion(x=low_latent, condi_in=low_latent, training=False, x_T=x_T)
+        sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
+        restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
+                                  dec_noise=dec_noise)
+        return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
+
+
+def gather_restored(local, counts=None):
+    """All-gather the per-rank restored images (B_r,3,H,W) into the full batch on every rank (RCCL all-gather over
+    xGMI; gloo on CPU in tests).  `counts` = per-rank batch sizes when the split is ragged."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    if counts is None or len(set(counts)) == 1:
+        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local.contiguous())
+        return out
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
