@@ -1,0 +1,155 @@
+"""bench.py -- throughput of the restoration hot path on MI355X (contract in the round prompt).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+
+One step = one batch through A (e4e encoder) -> B (Code_diffuser DDPM chain) -> C (StyleGAN2 prior decoder, up to
+1024^2 as the reference does) -> D (Restoration_net), LQ batch resident in HBM, restored batch left in HBM
+(BASELINE.json configs[1]: batch 8 per GPU, 512x512, T = 50, fp32, random-init weights, synthetic inputs).
+N > 1: every rank runs the same per-GPU batch (weak scaling) and the restored images are all-gathered with RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
+ALGO_GFLOP_PER_IMAGE = lambda T: 706.9 + 0.455 * T  # noqa: E731  SURVEY.md section 8(d)
+
+
+def build_pipeline(dev, T, with_sample):
+    from vspbfr_amd.diffusion import Code_diffuser, My_DDPM
+    from vspbfr_amd.e4e import E4e_embedding, Encoder4Editing, Generator
+    from vspbfr_amd.pipeline import RestorationPipeline
+    from vspbfr_amd.restorenet import Restoration_net
+    from argparse import Namespace
+    torch.manual_seed(0)
+    gen = Restoration_net(512, 512, 8, channel_multiplier=2)
+    net = Code_diffuser(timesteps=T)
+    enc = Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))
+    dec = Generator(1024, 512, 8, channel_multiplier=2)
+    sd = {"encoder." + k: v for k, v in enc.state_dict().items()}
+    sd.update({"decoder." + k: v for k, v in dec.state_dict().items()})
+    ckpt = {"state_dict": sd, "latent_avg": 0.1 * torch.randn(18, 512),
+            "opts": {"encoder_type": "Encoder4Editing", "stylegan_size": 1024, "start_from_latent_avg": True}}
+    psp = E4e_embedding(ckpt, out_size=512, size=1024, device=dev, use_generator=True)
+    ddpm = My_DDPM(denoise=net.to(dev).eval(), timesteps=T).to(dev)  # default betas (1e-4, 2e-2), SURVEY 8a row 8
+    return RestorationPipeline(gen.to(dev).eval(), psp, ddpm, mixing=0.0, with_sample=with_sample)
+
+
+def cpu_baseline(T, threads, sample_steps=2):
+    """The CPU restatement of the same step (oracle/, kind = "port": the Python reference cannot travel to the GPU box),
+    timed on the host cores on a BOUNDED sample: one image through A, C, D in full and `sample_steps` steps of the T-step
+    DDPM chain B (every step costs the same: 4 TACC blocks), extrapolated to T steps."""
+    from oracle import pipeline as OP
+    torch.set_num_threads(threads)
+    ck = OP.synth_checkpoints()
+    inp = OP.draw_inputs("bench_cpu", 1)
+    st = {}
+    OP.restore(ck, inp, timesteps=sample_steps, linear_start=1e-4, linear_end=2e-2, timings=st)
+    per_step = st["diffuser"] / sample_steps
+    total = st["encoder"] + st["prior_decoder"] + st["restorenet"] + per_step * T
+    measured = sum(st.values())
+    return {"value": round(1.0 / total, 5), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"1 image 512x512: stages A, C (to 1024^2), D in full + {sample_steps} of {T} DDPM steps ({measured:.1f} s "
+                      f"measured), chain extrapolated linearly to T={T} -> {total:.1f} s/image",
+            "stage_seconds": {"encoder": round(st["encoder"], 2), "diffuser_per_step": round(per_step, 3),
+                              "prior_decoder": round(st["prior_decoder"], 2), "restorenet": round(st["restorenet"], 2)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE configs[1]: 8)")
+    ap.add_argument("--timesteps", type=int, default=50)
+    ap.add_argument("--no-sample", action="store_true", help="skip the 1024^2 tail of the prior (not the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vspbfr_amd import hip_ops
+    from vspbfr_amd.pipeline import gather_restored
+    pipe = build_pipeline(dev, args.timesteps, not args.no_sample)
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(123 + rank)
+    lq = torch.rand(B, 3, 512, 512, device=dev, generator=g) * 2 - 1
+
+    def step():
+        out = pipe(lq)["restored"]
+        return gather_restored(out) if world > 1 else out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        prof = hip_ops.ConvProfiler()
+        hip_ops.PROFILER = prof
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        sync()
+        dt = time.perf_counter() - t0
+        hip_ops.PROFILER = None
+    assert torch.isfinite(res).all(), "non-finite output"
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    conv_flops, conv_ms, conv_launches = prof.summary()
+
+    if rank == 0:
+        imgs = world * B * args.steps
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        line = {
+            "metric": "restored 512x512 faces/sec", "value": round(imgs / dt, 3), "unit": "img/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"restoration_test.py hot path A+B+C+D, batch {B}/GPU, 512x512, {args.timesteps}-step DDPM "
+                                   f"CodeDiffuser + StyleGAN2 prior{'' if not args.no_sample else ' (no 1024^2 tail)'} + RestoreNet "
+                                   "forward, fp32, random-init weights",
+                       "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
+                       "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel (all tile configs)", "launches_per_step": conv_launches // max(args.steps, 1),
+                         "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
+                         "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
+                         "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK_FP32_TFLOPS * world), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(args.timesteps, threads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

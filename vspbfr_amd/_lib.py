@@ -7,6 +7,11 @@ RuntimeError from TORCH_CHECK, op/fused_bias_act.cpp:10-16).
 import ctypes as C
 import os
 
+# Load order matters: the host program's HIP runtime (the libamdhip64.so.7 that PyTorch-ROCm bundles) must be in the
+# process BEFORE this library is dlopen'ed, so that libvspbfr_hip.so binds to it by SONAME and shares its streams and
+# allocations.  Loading this library first would pull /opt/rocm's runtime in and leave two HIP runtimes in one process.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSPBFR_HIP_LIB", os.path.join(_HERE, "lib", "libvspbfr_hip.so"))
 

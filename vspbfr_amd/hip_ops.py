@@ -15,6 +15,33 @@ from ._lib import ConvParams, FirEpilogue, GemmParams, check, lib
 SQRT2 = math.sqrt(2.0)
 
 
+class ConvProfiler:
+    """Optional per-launch timing of vsp_conv2d_f32 with HIP events on the launch stream (bench.py's roofline leg):
+    records (algorithmic FLOPs, start event, end event) for every conv launch while installed as `hip_ops.PROFILER`."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, start, flops, tag):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.append((flops, start, ev, tag))
+
+    def summary(self):
+        """-> (total algorithmic FLOPs, total ms, launches); call after a device synchronize."""
+        fl = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return fl, ms, len(self.records)
+
+
+PROFILER = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -170,7 +197,12 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     p.tile_hint = tile_hint
     if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
         raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
+    prof = PROFILER
+    if prof is not None:
+        start = prof.begin()
     check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
+    if prof is not None:
+        prof.end(start, 2.0 * B * pc.cout * OH * OW * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G))
     return out
 
 
