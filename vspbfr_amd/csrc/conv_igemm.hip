@@ -121,13 +121,84 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
   // exact floor(idx / PW) for idx < 2^16, PW <= 2^8 (host guarantees both)
   const unsigned pw_magic = (unsigned)(((1ull << 32) + PW - 1) / PW);
 
-  for (int ci0 = 0; ci0 < p.Cin; ci0 += CK) {
-    __syncthreads();  // previous chunk's fragment reads are done
-    // ---- stage weights: rows (tap, ci_l) of CO_T floats
+  // ---- staging with a one-chunk register prefetch: the global loads of chunk i+1 are issued right before the MFMA
+  // phase of chunk i and only waited for when they are written to LDS, so HBM/L2 latency hides under ~9k cycles of MFMA
+  // instead of stalling the block 4-6 dependent round trips per chunk.  Everything that does not depend on the chunk
+  // (patch element -> image offset and in-image flag, weight element -> offset) is computed ONCE per lane; per chunk a
+  // staged word costs one load (uniform base + lane offset), one fma/select and one ds_write.
+  constexpr int NW = WM * WN;
+  constexpr int PCH = (CK + NW - 1) / NW;        // patch channels per wave per chunk
+  constexpr int PMAX = 12;                       // prefetched patch words per lane per channel (rest: direct path)
+  constexpr int V = CO_T / 4;
+  constexpr int WMAX = (9 * CK * V + NT - 1) / NT;  // prefetched weight float4 per thread (covers 3x3 taps)
+  float4 wreg[WMAX];
+  float preg[PCH][PMAX];
+  float psc[PCH], psh[PCH];
+  const int wtotal = T * CK * V;
+  const int chw = p.H * p.W;
+
+  auto patch_src = [&](int i, int& off) -> bool {  // element i of the patch plane -> offset inside the channel image
+    const int r = (int)__umulhi((unsigned)i, pw_magic);
+    const int c = i - r * PW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    off = iy * p.W + ix;
+    return iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+  };
+
+  int poff[PMAX];        // image offset of patch word (lane + 64 e); 0 when outside (the word is zeroed at commit)
+  unsigned pin = 0;      // bit e: word e lies inside the image
+#pragma unroll
+  for (int e = 0; e < PMAX; ++e) {
+    const int i = lane + 64 * e;
+    int off;
+    const bool in = (i < plane) && patch_src(i, off);
+    poff[e] = in ? off : 0;
+    pin |= in ? (1u << e) : 0u;
+  }
+  int woff[WMAX];        // weight word offset relative to the chunk's first input channel; -1: zero fill
+  int wdst[WMAX];        // LDS destination (float index), -1: nothing to write
+#pragma unroll
+  for (int w = 0; w < WMAX; ++w) {
+    const int i = tid + w * NT;
+    const int row = i / V, c4 = i - row * V;
+    const int tap = row / CK, cl = row - tap * CK;
+    const bool ok = i < wtotal;
+    wdst[w] = ok ? row * WS + c4 * 4 : -1;
+    woff[w] = (ok && co0 + c4 * 4 < p.cout_g) ? (tap * p.Cin + cl) * p.cout_g + co0 + c4 * 4 : -1;
+  }
+
+  auto issue = [&](int ci0) {
     if (p.w_vec4) {
-      constexpr int V = CO_T / 4;
-#pragma unroll 4
-      for (int i = tid; i < T * CK * V; i += NT) {
+      const float* wc = wg + (int64_t)ci0 * p.cout_g;
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w) {
+        const int row = (tid + w * NT) / V;
+        const int cl = row & (CK - 1);
+        const bool ok = woff[w] >= 0 && ci0 + cl < p.Cin;
+        const float4 v = *reinterpret_cast<const float4*>(wc + (ok ? woff[w] : 0));
+        wreg[w] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int pc = 0; pc < PCH; ++pc) {
+      const int cl = wave + pc * NW;
+      const int ci = ci0 + cl;
+      const bool chok = cl < CK && ci < p.Cin;  // wave-uniform
+      const int cic = chok ? ci : 0;
+      psc[pc] = chok ? (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + cic] : 1.f) : 0.f;
+      psh[pc] = chok ? (p.in_shift ? p.in_shift[cic] : 0.f) : 0.f;
+      const float* xc = xb + (int64_t)cic * chw;
+#pragma unroll
+      for (int e = 0; e < PMAX; ++e) preg[pc][e] = xc[poff[e]];
+    }
+  };
+
+  auto commit = [&](int ci0) {
+    if (p.w_vec4) {
+#pragma unroll
+      for (int w = 0; w < WMAX; ++w)
+        if (wdst[w] >= 0) *reinterpret_cast<float4*>(Wl + wdst[w]) = wreg[w];
+      for (int i = tid + WMAX * NT; i < wtotal; i += NT) {  // only when KH*KW > 9
         const int row = i / V, c4 = i - row * V;
         const int tap = row / CK, cl = row - tap * CK;
         const int ci = ci0 + cl;
@@ -147,28 +218,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         Wl[row * WS + c] = v;
       }
     }
-    // ---- stage the input patch: wave w takes channels w, w+NW, ...
-    for (int cl = wave; cl < CK; cl += WM * WN) {
+#pragma unroll
+    for (int pc = 0; pc < PCH; ++pc) {
+      const int cl = wave + pc * NW;
+      if (cl >= CK) continue;
       const int ci = ci0 + cl;
       float* dst = Pl + cl * PS;
-      if (ci < p.Cin) {
-        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
-        const float sh = p.in_shift ? p.in_shift[ci] : 0.f;
-        const float* xc = xb + (int64_t)ci * p.H * p.W;
+#pragma unroll
+      for (int e = 0; e < PMAX; ++e) {
+        const int i = lane + 64 * e;
+        if (i < plane) dst[i] = ((pin >> e) & 1u) ? fmaf(preg[pc][e], psc[pc], psh[pc]) : 0.f;
+      }
+      if (plane > 64 * PMAX) {  // large halos (dilation 4/8, stride 2): the tail of the plane is loaded directly
+        const bool chok = ci < p.Cin;
+        const float* xc = xb + (int64_t)(chok ? ci : 0) * chw;
 #pragma unroll 4
-        for (int i = lane; i < plane; i += 64) {
-          const int r = (int)__umulhi((unsigned)i, pw_magic);
-          const int c = i - r * PW;
-          const int iy = iy0 + r, ix = ix0 + c;
+        for (int i = lane + 64 * PMAX; i < plane; i += 64) {
+          int off;
           float v = 0.f;
-          if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = fmaf(xc[(int64_t)iy * p.W + ix], sc, sh);
+          if (chok && patch_src(i, off)) v = fmaf(xc[off], psc[pc], psh[pc]);
           dst[i] = v;
         }
-      } else {
-        for (int i = lane; i < plane; i += 64) dst[i] = 0.f;
       }
     }
+  };
+
+  issue(0);
+  for (int ci0 = 0; ci0 < p.Cin; ci0 += CK) {
+    __syncthreads();  // previous chunk's fragment reads are done
+    commit(ci0);
     __syncthreads();
+    if (ci0 + CK < p.Cin) issue(ci0 + CK);
     // ---- MFMA over taps x (CK/4) k-steps
     for (int ky = 0; ky < p.KH; ++ky) {
       for (int kx = 0; kx < p.KW; ++kx) {

@@ -125,6 +125,54 @@ class Code_diffuser(nn.Module):
         embd = embd.contiguous()
         return self.run(x.contiguous(), self.condition(self.embed(embd), t, embd.shape[1]))
 
+    # ---- fused sampler path (all samples share t): 4 launches per block and step, see csrc/tacc.hip
+    def _wcat(self, blk):
+        srcs = [blk.k_matrix.weight, blk.v_matrix.weight, blk.attention_layer.q_matrix.weight, blk.attention_layer.v_matrix.weight]
+        store = self.__dict__.setdefault("_wcat_cache", {})
+        stamp = tuple((w.data_ptr(), w._version) for w in srcs)
+        hit = store.get(id(blk))
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, torch.cat([w.detach() for w in srcs], 0).contiguous())
+            store[id(blk)] = hit
+        return hit[1]
+
+    def chain_supported(self, cond):
+        return cond.dim() == 3 and cond.shape[1] == 18 and cond.shape[2] == 512 and self.att_mapper[0].dim == 512
+
+    def prepare_chain(self, cond, steps):
+        """Everything that depends on (condition, step) only: e-parts of the four Linear(513) layers and the gamma/beta
+        heads of every block for steps 0..steps-1 (two [steps*B*18, 512] GEMMs per block)."""
+        B = cond.shape[0]
+        M = B * 18
+        state = []
+        for blk in self.att_mapper:
+            e = blk.embed(cond)
+            heads = []
+            for seq, key in ((blk.gamma_, "g"), (blk.beta_, "b")):
+                pre = H.tacc_head_pre(e[key].reshape(M, 512), seq[0].weight[:, -1], seq[1].weight, seq[1].bias, steps,
+                                      self.max_period)
+                heads.append(H.linear(pre, seq[3].weight, seq[3].bias, act=seq.last).view(steps, B, 18, 512))
+            state.append({"eQ": e["Q"].reshape(M, 512), "ek": e["k"].reshape(M, 512), "gamma": heads[0], "beta": heads[1],
+                          "wq": blk.q_matrix.weight[:, -1], "wk": blk.attention_layer.k_matrix.weight[:, -1],
+                          "wcat": self._wcat(blk)})
+        return state
+
+    def chain_step(self, x, pn, state, i, c1=None, c2=None):
+        """One denoiser evaluation at step i on (x, pixelnorm(x)); with c1/c2 the posterior mean c1[i]*x0 + c2[i]*x is
+        fused into the last block's tail.  Returns (new x or x0, its pixelnorm)."""
+        B = x.shape[0]
+        tf = float(i) / float(self.max_period)
+        cur, cur_pn = x, pn
+        last = len(self.att_mapper) - 1
+        for bi, st in enumerate(state):
+            P = H.gemm_nt(cur_pn.view(B * 18, 512), st["wcat"])
+            score = H.tacc_scores(P, st["eQ"], st["wq"], tf, B)
+            t = H.tacc_chan_attn(P, st["ek"], st["wk"], tf, B)
+            mix = bi == last and c1 is not None
+            cur, cur_pn = H.tacc_tail(score, P, t, st["gamma"][i], st["beta"][i], B, xold=x if mix else None, c1=c1, c2=c2,
+                                      idx=i)
+        return cur, cur_pn
+
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
     """float64 schedule, reference ldm/util2.py:21-43."""
@@ -202,6 +250,13 @@ class My_DDPM(nn.Module):
         cond = condi_in.contiguous()
         B, n_tok = cond.shape[0], cond.shape[1]
         x = x_T.contiguous() if x_T is not None else torch.randn(cond.shape, device=cond.device)
+        if (self.parameterization == "x0" and not self.clip_denoised and hasattr(self.model, "chain_supported")
+                and self.model.chain_supported(cond) and self.num_timesteps <= self.model.max_period):
+            state = self.model.prepare_chain(cond, self.num_timesteps)
+            pn = H.pixelnorm_dim1(x)
+            for i in reversed(range(self.num_timesteps)):
+                x, pn = self.model.chain_step(x, pn, state, i, self.posterior_mean_coef1, self.posterior_mean_coef2)
+            return x
         emb = self.model.embed(cond)  # step-independent half of every Linear(513)
         for i in reversed(range(self.num_timesteps)):
             t = torch.full((B,), i, device=cond.device, dtype=torch.long)

@@ -408,3 +408,39 @@ def add3(a, b, c=None):
     out = torch.empty_like(_req(a, "a"))
     check(lib.vsp_add3_f32(_ptr(out), _ptr(a), _ptr(_req(b, "b")), _ptr(_opt(c, "c")), a.numel(), _stream()), "add3")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- fused TACC step
+def tacc_scores(P, eQ, wq_col, tfrac, B, k_off=0):
+    score = torch.empty((B, 18, 18), device=P.device, dtype=P.dtype)
+    check(lib.vsp_tacc_scores_f32(_ptr(score), _ptr(_req(P, "P")), P.shape[1], k_off, _ptr(_req(eQ, "eQ")),
+                                  C.c_void_p(wq_col.data_ptr()), wq_col.stride(0), float(tfrac), B, 18, 512, _stream()),
+          "tacc_scores")
+    return score
+
+
+def tacc_chan_attn(P, ek, wk_col, tfrac, B, q2_off=1024, v2_off=1536):
+    t = torch.empty((B, 18, 512), device=P.device, dtype=P.dtype)
+    check(lib.vsp_tacc_chan_attn_f32(_ptr(t), _ptr(_req(P, "P")), P.shape[1], q2_off, v2_off, _ptr(_req(ek, "ek")),
+                                     C.c_void_p(wk_col.data_ptr()), wk_col.stride(0), float(tfrac), B, 18, 512, _stream()),
+          "tacc_chan_attn")
+    return t
+
+
+def tacc_tail(score, P, t, gamma, beta, B, xold=None, c1=None, c2=None, idx=0, v_off=512, want_pn=True):
+    y = torch.empty((B, 18, 512), device=P.device, dtype=P.dtype)
+    pn = torch.empty_like(y) if want_pn else None
+    check(lib.vsp_tacc_tail_f32(_ptr(y), _ptr(pn), _ptr(_req(score, "score")), _ptr(_req(P, "P")), P.shape[1], v_off,
+                                _ptr(_req(t, "t")), _ptr(_req(gamma, "gamma")), _ptr(_req(beta, "beta")),
+                                _ptr(_opt(xold, "xold")), _ptr(_opt(c1, "c1")), _ptr(_opt(c2, "c2")), int(idx), B, 18, 512,
+                                _stream()), "tacc_tail")
+    return y, pn
+
+
+def tacc_head_pre(e, wcol, ln_w, ln_b, steps, t_div):
+    M = e.shape[0]
+    out = torch.empty((steps * M, 512), device=e.device, dtype=e.dtype)
+    check(lib.vsp_tacc_head_pre_f32(_ptr(out), _ptr(_req(e, "e")), C.c_void_p(wcol.data_ptr()), wcol.stride(0),
+                                    _ptr(_req(ln_w, "ln_w")), _ptr(_req(ln_b, "ln_b")), steps, M, 512, float(t_div), _stream()),
+          "tacc_head_pre")
+    return out
