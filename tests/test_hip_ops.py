@@ -148,9 +148,29 @@ def test_conv2d_all_tile_configs(H):
     ref = F.conv2d(x, w, None, padding=1)
     n = lib.vsp_conv2d_num_configs()
     assert n >= 8
+    ran = 0
     for c in range(1, n + 1):
-        y = H.conv2d(dev(x), dev(w), None, 1, 1, 1, tile_hint=c)
+        try:
+            y = H.conv2d(dev(x), dev(w), None, 1, 1, 1, tile_hint=c)
+        except RuntimeError as ex:  # a forced configuration may legitimately not fit (LDS) -- the library says so
+            assert "does not fit" in str(ex), str(ex)
+            continue
         close(y, ref, 2e-5, 2e-5, f"cfg {c} {lib.vsp_conv2d_config_name(c - 1)}")
+        ran += 1
+    assert ran >= 12
+    # K-split configurations on the kind of layer they exist for: deep K, tiny map, ragged channel count
+    x2 = torch.randn(3, 200, 5, 5)
+    w2 = torch.randn(40, 200, 3, 3) / math.sqrt(200 * 9)
+    ref2 = F.conv2d(x2, w2, None, padding=1)
+    for c in range(1, n + 1):
+        if b"k" not in lib.vsp_conv2d_config_name(c - 1):
+            continue
+        try:
+            y2 = H.conv2d(dev(x2), dev(w2), None, 1, 1, 1, tile_hint=c)
+        except RuntimeError as ex:
+            assert "does not fit" in str(ex), str(ex)
+            continue
+        close(y2, ref2, 2e-5, 2e-5, f"ksplit cfg {c}")
 
 
 def test_conv2d_prologue_epilogue(H):

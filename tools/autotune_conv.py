@@ -1,0 +1,78 @@
+"""Autotune the conv tile configuration per layer shape of the restoration path (GPU box).
+
+Runs the pipeline once (batch B, T steps) recording every vsp_conv2d_f32 launch, then times every compiled tile
+configuration on each distinct shape and writes the winners to gpurun_out/conv_tune.json (copy to
+vspbfr_amd/conv_tune.json to ship it).  usage: python tools/autotune_conv.py [B] [T]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+from vspbfr_amd import hip_ops as H
+from vspbfr_amd._lib import lib
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    dev = torch.device("cuda", 0)
+    H.TUNE = {}
+    pipe = bench.build_pipeline(dev, T, True)
+    lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
+    H.RECORDER = []
+    with torch.no_grad():
+        pipe(lq)
+    torch.cuda.synchronize()
+    recs, H.RECORDER = H.RECORDER, None
+    uniq = {}
+    for key, dims, pc in recs:
+        uniq.setdefault(key, [dims, pc, 0])[2] += 1
+    print(f"{len(recs)} conv launches, {len(uniq)} distinct shapes", flush=True)
+    n = lib.vsp_conv2d_num_configs()
+    table, report = {}, []
+    tot_auto = tot_best = 0.0
+    for key, (dims, pc, count) in uniq.items():
+        Bq, Cin, Hh, Ww, OH, OW = dims
+        x = torch.randn(Bq, Cin, Hh, Ww, device=dev)
+        # generous output tensor: phase convs write strided, give them room
+        out = torch.empty(Bq, pc.cout, max(OH, 1) * 2 + 1, max(OW, 1) * 2 + 1, device=dev)
+        flops = 2.0 * Bq * pc.cout * OH * OW * Cin * pc.kh * pc.kw
+        times = {}
+        for c in range(0, n + 1):
+            try:
+                est = timeit(lambda: H.conv2d_packed(x, pc, out=out, n_out=(OH, OW), tile_hint=c), 1)
+                iters = 3 if est > 0.3 else 10
+                times[c] = timeit(lambda: H.conv2d_packed(x, pc, out=out, n_out=(OH, OW), tile_hint=c), iters)
+            except RuntimeError:
+                continue
+        best = min((c for c in times if c > 0), key=lambda c: times[c])
+        table[key] = best
+        tot_auto += times[0] * count
+        tot_best += times[best] * count
+        report.append((times[best] * count, key, count, lib.vsp_conv2d_config_name(best - 1).decode(), round(times[best] * 1e3, 1),
+                       round(times[0] * 1e3, 1), round(flops / times[best] / 1e9, 1)))
+    report.sort(reverse=True)
+    for r in report[:60]:
+        print("%.2f ms total | %s | x%d | best %s %s us (cost-model pick %s us) | %s TF" % r, flush=True)
+    print(f"sum per pipeline pass: cost model {tot_auto:.1f} ms -> tuned {tot_best:.1f} ms")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(table, open("gpurun_out/conv_tune.json", "w"), indent=0, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -67,9 +67,13 @@ __device__ __forceinline__ int round_pitch(int n, int odd) {
   return p >= n ? p : p + 32;
 }
 
-template <int MB, int NB, int WM, int WN, int CK>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p) {
-  constexpr int NT = 64 * WM * WN;
+template <int MB, int NB, int WM, int WN, int CK, int WK, int PMAX>
+__global__ __launch_bounds__(64 * WM * WN * WK) void conv_igemm_kernel(const ConvK p) {
+  // WK > 1: the block's waves are additionally split along K -- wave slice wk runs k-steps wk, wk+WK, ... of every chunk
+  // on the SAME output tile and the partial accumulators are summed through LDS before the epilogue.  With CK = 32 this
+  // cuts the serial chunk count of deep-K / tiny-map layers (4x4 ... 16x16 maps, 512 channels) by 4 while small
+  // 16/32-channel tiles keep >= 256 blocks in flight.
+  constexpr int NT = 64 * WM * WN * WK;
   constexpr int CO_T = 16 * MB * WM;
   constexpr int WS = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -77,7 +81,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN);
+  const int wmn = wave - wk * (WM * WN);
+  const int wm = wmn / WN, wn = wmn % WN;
   const int lr = lane & 15;  // MFMA row (A) / column (B, D) index inside a 16x16 block
   const int kq = lane >> 4;  // MFMA k slot (A, B); D row group
 
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
   for (int nb = 0; nb < NB; ++nb) {
     const int n = (wn * NB + nb) * 16 + lr;
     const int py = n >> p.tw_log2, px = n & (TW - 1);
-    pixoff[nb] = py * p.sy * PW + px * p.sx + kq * PS;
+    pixoff[nb] = py * p.sy * PW + px * p.sx + (kq + 4 * wk) * PS;
   }
-  const int a_lane = kq * WS + wm * MB * 16 + lr;
+  const int a_lane = (kq + 4 * wk) * WS + wm * MB * 16 + lr;
 
   f32x4 acc[MB][NB];
 #pragma unroll
@@ -126,9 +132,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
   // instead of stalling the block 4-6 dependent round trips per chunk.  Everything that does not depend on the chunk
   // (patch element -> image offset and in-image flag, weight element -> offset) is computed ONCE per lane; per chunk a
   // staged word costs one load (uniform base + lane offset), one fma/select and one ds_write.
-  constexpr int NW = WM * WN;
+  constexpr int NW = WM * WN * WK;
   constexpr int PCH = (CK + NW - 1) / NW;        // patch channels per wave per chunk
-  constexpr int PMAX = 12;                       // prefetched patch words per lane per channel (rest: direct path)
+  // PMAX (template): prefetched patch words per lane per channel; the rest of a large plane takes the direct path
   constexpr int V = CO_T / 4;
   constexpr int WMAX = (9 * CK * V + NT - 1) / NT;  // prefetched weight float4 per thread (covers 3x3 taps)
   float4 wreg[WMAX];
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         const int boff = ky * D * PW + kx * D;
         const float* wt = Wl + (ky * p.KW + kx) * CK * WS + a_lane;
 #pragma unroll
-        for (int c4 = 0; c4 < CK / 4; ++c4) {
+        for (int c4 = 0; c4 < CK / 4; c4 += WK) {  // this wave's k-steps: c4 + wk (folded into a_lane / pixoff)
           float a[MB], bv[NB];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) a[mb] = wt[c4 * 4 * WS + mb * 16];
@@ -269,6 +275,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
         }
       }
     }
+  }
+
+  if (WK > 1) {  // sum the K slices: slices 1..WK-1 park their accumulators in LDS, slice 0 adds them and finishes
+    __syncthreads();
+    float* red = smem;  // [(WK-1)][WM*WN][MB*NB*4][64]
+    if (wk > 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            red[((((wk - 1) * (WM * WN) + wmn) * (MB * NB * 4)) + (mb * NB + nb) * 4 + r) * 64 + lane] = acc[mb][nb][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int k2 = 1; k2 < WK; ++k2)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[mb][nb][r] += red[((((k2 - 1) * (WM * WN) + wmn) * (MB * NB * 4)) + (mb * NB + nb) * 4 + r) * 64 + lane];
   }
 
   // ---- epilogue: lane holds pixel column lr of block nb, channel rows kq*4 + r of block mb.
@@ -348,13 +379,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(const ConvK p)
 // host side: tile configuration table and selection
 // ---------------------------------------------------------------------------------------------------------
 struct Cfg {
-  int MB, NB, WM, WN, CK;
+  int MB, NB, WM, WN, CK, WK, PMAX;
   const char* name;
   void (*kern)(const ConvK);
 };
 
 #define VSP_CFG(MB, NB, WM, WN, CK) \
-  { MB, NB, WM, WN, CK, #MB "x" #NB "x" #WM "x" #WN "x" #CK, conv_igemm_kernel<MB, NB, WM, WN, CK> }
+  { MB, NB, WM, WN, CK, 1, 12, #MB "x" #NB "x" #WM "x" #WN "x" #CK, conv_igemm_kernel<MB, NB, WM, WN, CK, 1, 12> }
+#define VSP_CFGK(MB, NB, WM, WN, CK, WK, PMAX) \
+  { MB, NB, WM, WN, CK, WK, PMAX, #MB "x" #NB "x" #WM "x" #WN "x" #CK "k" #WK, conv_igemm_kernel<MB, NB, WM, WN, CK, WK, PMAX> }
 
 static const Cfg kCfgs[] = {
     VSP_CFG(4, 4, 1, 4, 8),  // 0:  64 co x 256 px   (work-horse: C >= 64 at >= 32^2)
@@ -369,8 +402,17 @@ static const Cfg kCfgs[] = {
     VSP_CFG(1, 8, 1, 4, 4),  // 9:  16 co x 512 px, 4-channel chunks
     VSP_CFG(4, 2, 2, 2, 8),  // 10: 128 co x 64 px
     VSP_CFG(1, 1, 4, 1, 8),  // 11:  64 co x 16 px
+    // K-split configurations for deep-K layers on tiny maps (4 wave slices along K, 32-channel chunks)
+    VSP_CFGK(1, 1, 1, 1, 32, 4, 2),  // 12: 16 co x 16 px
+    VSP_CFGK(1, 4, 1, 1, 32, 4, 2),  // 13: 16 co x 64 px
+    VSP_CFGK(2, 4, 1, 1, 32, 4, 2),  // 14: 32 co x 64 px
+    VSP_CFGK(2, 2, 1, 2, 32, 2, 4),  // 15: 32 co x 64 px, 2 slices
+    VSP_CFGK(2, 1, 1, 1, 32, 4, 2),  // 16: 32 co x 16 px
+    VSP_CFGK(1, 2, 1, 2, 32, 2, 4),  // 17: 16 co x 64 px, 2 slices
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+constexpr size_t kMaxLds = 100 * 1024;  // > 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize (set once per kernel)
 
 struct Plan {
   int cfg;
@@ -407,8 +449,10 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const int PW = (TW - 1) * p.stride_x + (p.KW - 1) * dmax + 1;
   if (PW > 256 || PH * PW >= 65536) return false;
   const int PS = host_round_pitch(PH * PW, p.stride_x != 1);
-  const size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)k.CK * PS) * sizeof(float);
-  if (lds > 64 * 1024) return false;
+  size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)k.CK * PS) * sizeof(float);
+  const size_t red = (size_t)(k.WK - 1) * k.WM * k.WN * k.MB * k.NB * 4 * 64 * sizeof(float);
+  if (red > lds) lds = red;
+  if (lds > kMaxLds) return false;
   out->cfg = c;
   out->tw_log2 = twl;
   out->th = TH;
@@ -424,13 +468,13 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
 static double plan_cost(const vsp_conv_params& p, const Plan& pl) {
   const Cfg& k = kCfgs[pl.cfg];
   const int CO_T = 16 * k.MB * k.WM, NPIX = 16 * k.NB * k.WN;
-  const int waves = k.WM * k.WN;
+  const int waves = k.WM * k.WN * k.WK;
   const double blocks = (double)pl.tiles_x * pl.tiles_y * pl.co_tiles * p.G * p.B;
   const int cin_pad = (p.Cin + k.CK - 1) / k.CK * k.CK;
   // cycles one block needs on one SIMD-set: each wave issues MB*NB MFMAs (32 cyc) per k-step
   const double ksteps = (double)p.KH * p.KW * cin_pad / 4.0;
-  const double mfma_cyc = ksteps * k.MB * k.NB * 32.0;  // per wave
-  const double reads = ksteps * (k.MB + k.NB) * 8.0;     // LDS issue cost per wave, overlappable: small weight
+  const double mfma_cyc = ksteps * k.MB * k.NB * 32.0 / k.WK;  // per wave
+  const double reads = ksteps * (k.MB + k.NB) * 8.0 / k.WK;  // LDS issue cost per wave, overlappable: small weight
   const double chunks = (double)cin_pad / k.CK;
   const double stage = chunks * 2500.0;                  // barrier + global latency + LDS writes per chunk
   int per_cu = (int)(160 * 1024 / (pl.lds + 1024));
@@ -591,8 +635,17 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   q.w_vec4 = (p.cout_g % 4 == 0) && (CO_T % 4 == 0) && vsp::aligned16(p.w) ? 1 : 0;
   q.ps_odd = p.stride_x != 1;
 
+  if (best.lds > 64 * 1024) {
+    static bool raised[64] = {};
+    if (!raised[best.cfg]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)kMaxLds);
+      if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
+      raised[best.cfg] = true;
+    }
+  }
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y), (unsigned)gy, (unsigned)p.B);
-  dim3 block(64 * k.WM * k.WN);
+  dim3 block(64 * k.WM * k.WN * k.WK);
   hipLaunchKernelGGL(k.kern, grid, block, best.lds, vsp::as_stream(stream), q);
   return vsp::check_launch("conv2d");
 }

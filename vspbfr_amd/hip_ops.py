@@ -40,6 +40,26 @@ class ConvProfiler:
 
 
 PROFILER = None
+RECORDER = None  # tools/autotune_conv.py: list collecting the shape key of every conv launch
+
+
+def _load_tune_table():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
+
+
+# shape key -> 1-based tile configuration id measured fastest on MI355X (tools/autotune_conv.py); shapes that are not in
+# the table use the library's cost model (tile_hint = 0)
+TUNE = _load_tune_table()
+
+
+def conv_key(B, Cin, H, W, pc, OH, OW):
+    return f"{B},{Cin},{H},{W},{pc.G},{pc.cout_g},{pc.kh},{pc.kw},{pc.stride},{pc.dil[0]},{OH},{OW}"
 
 
 def _stream():
@@ -194,6 +214,12 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     rt = res1 if res1 is not None else res2
     p.res_ch = rt.shape[1] if rt is not None else 0
     p.res_coff = res_coff
+    if tile_hint == 0 and TUNE:
+        tile_hint = TUNE.get(conv_key(B, Cin, H, W, pc, OH, OW), 0)
+        if tile_hint == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
+            tile_hint = TUNE.get(conv_key(8, Cin, H, W, pc, OH, OW), 0)
+    if RECORDER is not None:
+        RECORDER.append((conv_key(B, Cin, H, W, pc, OH, OW), (B, Cin, H, W, OH, OW), pc))
     p.tile_hint = tile_hint
     if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
         raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
