@@ -138,3 +138,17 @@ def test_encoder4editing(golden):
 def test_save_image_quantizer():
     x = torch.tensor([-2.0, -1.0, -0.5, 0.0, 0.5, 1.0, 3.0, 0.999])
     np.testing.assert_array_equal(models.save_image_quantize(x).numpy(), [0, 0, 64, 128, 191, 255, 255, 255])
+
+
+def test_pipeline512(golden):
+    """The whole path A+B+C+D at 512^2 (T=4 as shipped) through oracle/pipeline.py against the reference run."""
+    from oracle import pipeline as OP
+    ck = OP.synth_checkpoints()
+    inp = OP.draw_inputs("pipeline512", 1)
+    out = OP.restore(ck, inp, timesteps=4, linear_start=0.1, linear_end=0.99)
+    g = golden("pipeline512")
+    close(out["latent"], g["codes"], 1e-4, 1e-4)
+    close(out["pre_latent"], g["pre_latent"], 1e-4, 1e-4)
+    close(out["style_sample"][:, :, ::8, ::8], g["sample_sub"], 2e-4, 2e-4)
+    close(out["restored"][:, :, ::8, ::8], g["restored_sub"], 2e-4, 2e-4)
+    close(out["restored"][:, :, 200:264, 200:264], g["restored_crop"], 2e-4, 2e-4)

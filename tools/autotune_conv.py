@@ -61,7 +61,7 @@ def main():
             except RuntimeError:
                 continue
         best = min((c for c in times if c > 0), key=lambda c: times[c])
-        table[key] = best
+        table[key] = lib.vsp_conv2d_config_name(best - 1).decode()
         tot_auto += times[0] * count
         tot_best += times[best] * count
         report.append((times[best] * count, key, count, lib.vsp_conv2d_config_name(best - 1).decode(), round(times[best] * 1e3, 1),

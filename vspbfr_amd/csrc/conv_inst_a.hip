@@ -1,0 +1,25 @@
+// Instantiation unit A of the conv tile configurations (split so that hipcc compiles them in parallel).
+#include "conv_kernel.h"
+namespace vspconv {
+extern const Cfg kCfgsA[] = {
+    VSP_CFG(4, 4, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(4, 4, 1, 4, 4, 1, 12, 1, 1),
+    VSP_CFG(4, 4, 2, 2, 8, 1, 12, 1, 1),
+    VSP_CFG(4, 2, 2, 2, 8, 1, 12, 1, 1),
+    VSP_CFG(2, 8, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(1, 8, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(1, 8, 1, 4, 4, 1, 12, 1, 1),
+    VSP_CFG(4, 1, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(2, 1, 4, 1, 8, 1, 12, 1, 1),
+    VSP_CFG(2, 4, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(1, 4, 1, 4, 8, 1, 12, 1, 1),
+    VSP_CFG(1, 1, 4, 1, 8, 1, 12, 1, 1),
+    VSP_CFG(1, 1, 1, 1, 32, 4, 2, 1, 1),
+    VSP_CFG(1, 4, 1, 1, 32, 4, 2, 1, 1),
+    VSP_CFG(2, 4, 1, 1, 32, 4, 2, 1, 1),
+    VSP_CFG(2, 2, 1, 2, 32, 2, 4, 1, 1),
+    VSP_CFG(2, 1, 1, 1, 32, 4, 2, 1, 1),
+    VSP_CFG(1, 2, 1, 2, 32, 2, 4, 1, 1),
+};
+extern const int kNumA = sizeof(kCfgsA) / sizeof(kCfgsA[0]);
+}  // namespace vspconv

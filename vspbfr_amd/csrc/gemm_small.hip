@@ -1,10 +1,13 @@
 // Strided batched small GEMM ("NT": both operands indexed [row][k]) on fp32 MFMA for gfx950.
 //
 // Used for every F.linear / torch.matmul of the path (EqualLinear style MLPs and modulations:
-// models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,86-116).  These
-// have 8..288 rows (M = batch or batch*18 tokens): far too small to fill 1024 SIMDs with classic tiles, so the
-// kernel goes for many small waves instead: one wave64 owns a 16(m) x 32(n) tile and streams K straight from
-// global/L2 into MFMA fragments (no LDS: nothing is shared between waves).
+// models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,86-116).  These have
+// 8..288 rows (M = batch or batch*18 tokens) and K = 512..8192: far too few rows for classic tiles, and a single wave
+// walking K alone is a chain of dependent L2 round trips.  So: one workgroup (4 wave64s) owns a 16(m) x 32(n) tile and
+// the four waves split K (wave w takes the 16-wide k-steps w, w+4, ...); operands stream straight from global/L2 into
+// MFMA fragments (no LDS staging: nothing is reused across waves) with two k-steps of loads in flight; the four partial
+// accumulators meet in LDS and wave 0 runs the epilogue.  Grids are (N/32) x (M/16) x Z workgroups: 576 for the
+// [144 x 2048 x 512] projection of a TACC block, so all 256 CUs work even at M = 144.
 //
 // k-permutation trick (VEC path, k contiguous): lane (row = l&15, q = l>>4) loads ONE float4 at [row][k0+4q..4q+3];
 // MFMA j (j=0..3) of the step takes component j of that float4 as its k-slot q, so slot q of MFMA j is k0+4q+j
@@ -29,17 +32,18 @@ struct GemmK {
   float slope, gain;
 };
 
-constexpr int NBL = 2;  // 16-column blocks per wave
+constexpr int NBL = 2;  // 16-column blocks per workgroup tile
+constexpr int KW = 4;   // waves splitting K
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
+__global__ __launch_bounds__(64 * KW) void gemm_nt_kernel(const GemmK p) {
+  __shared__ float red[(KW - 1) * NBL * 4 * 64];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-  const int n0 = (blockIdx.x * 4 + wave) * 16 * NBL;
+  const int n0 = blockIdx.x * 16 * NBL;
   const int m0 = blockIdx.y * 16;
   const int z = blockIdx.z;
-  if (n0 >= p.N) return;  // whole wave exits together
 
   const int am = min(m0 + lr, p.M - 1);
   const float* arow = p.A + z * p.a_zs + am * p.a_ms;
@@ -51,13 +55,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
 #pragma unroll
   for (int j = 0; j < NBL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int k0 = 0;
+  int kdone = 0;  // columns [0, kdone) are covered by the vector loop
   if (VEC) {
-    for (; k0 + 16 <= p.K; k0 += 16) {
-      const float4 a = *reinterpret_cast<const float4*>(arow + k0 + 4 * kq);
-      float4 b[NBL];
-#pragma unroll
-      for (int j = 0; j < NBL; ++j) b[j] = *reinterpret_cast<const float4*>(brow[j] + k0 + 4 * kq);
+    kdone = p.K & ~15;
+    auto step = [&](const float4& a, const float4 (&b)[NBL]) {
 #pragma unroll
       for (int j = 0; j < NBL; ++j) {
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j].x, acc[j], 0, 0, 0);
@@ -65,9 +66,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[j].z, acc[j], 0, 0, 0);
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[j].w, acc[j], 0, 0, 0);
       }
+    };
+    int k0 = wave * 16;
+    // two k-steps in flight: the loads of step s+1 are issued before the MFMAs of step s
+    float4 a0, b0[NBL];
+    if (k0 < kdone) {
+      a0 = *reinterpret_cast<const float4*>(arow + k0 + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) b0[j] = *reinterpret_cast<const float4*>(brow[j] + k0 + 4 * kq);
+    }
+    for (; k0 < kdone; k0 += 16 * KW) {
+      const int k1 = k0 + 16 * KW;
+      float4 a1 = a0, b1[NBL];
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) b1[j] = b0[j];
+      if (k1 < kdone) {
+        a1 = *reinterpret_cast<const float4*>(arow + k1 + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) b1[j] = *reinterpret_cast<const float4*>(brow[j] + k1 + 4 * kq);
+      }
+      step(a0, b0);
+      a0 = a1;
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) b0[j] = b1[j];
     }
   }
-  for (; k0 < p.K; k0 += 4) {
+  // scalar k-steps of 4: the K % 16 tail of the vector path, or everything for arbitrary strides
+  for (int k0 = kdone + wave * 4; k0 < p.K; k0 += 4 * KW) {
     const int k = k0 + kq;
     const bool ok = k < p.K;
     const int kc = ok ? k : 0;
@@ -78,6 +103,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
       acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
     }
   }
+
+  // K-slice reduction through LDS
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < NBL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((wave - 1) * NBL + j) * 4 + r) * 64 + lane] = acc[j][r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 1; w < KW; ++w)
+#pragma unroll
+    for (int j = 0; j < NBL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] += red[(((w - 1) * NBL + j) * 4 + r) * 64 + lane];
 
   // D layout: lane holds column lr, rows kq*4 + r
 #pragma unroll
@@ -91,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmK p) {
       if (m >= p.M) continue;
       float v = acc[j][r] * p.alpha + bv;
       if (p.act == 1) v = (v > 0.f ? v : v * p.slope) * p.gain;
-      else if (p.act == 2) v = 1.f / (1.f + __expf(-v));
+      else if (p.act == 2) v = 1.f / (1.f + expf(-v));
       p.C[z * p.c_zs + m * p.c_ms + n] = v;
     }
   }
@@ -111,11 +152,11 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
           p.alpha, p.bias, p.bias_scale, p.act, p.slope, p.gain};
   const bool vec = p.a_ks == 1 && p.b_ks == 1 && p.a_ms % 4 == 0 && p.b_ns % 4 == 0 && p.a_zs % 4 == 0 &&
                    p.b_zs % 4 == 0 && vsp::aligned16(p.A) && vsp::aligned16(p.Bm);
-  dim3 grid((unsigned)((p.N + 64 * NBL - 1) / (64 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);
+  dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);
   VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");
   if (vec)
-    gemm_nt_kernel<true><<<grid, 256, 0, vsp::as_stream(stream)>>>(q);
+    gemm_nt_kernel<true><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
   else
-    gemm_nt_kernel<false><<<grid, 256, 0, vsp::as_stream(stream)>>>(q);
+    gemm_nt_kernel<false><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
   return vsp::check_launch("gemm");
 }

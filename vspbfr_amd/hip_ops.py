@@ -53,9 +53,14 @@ def _load_tune_table():
         return json.load(f)
 
 
-# shape key -> 1-based tile configuration id measured fastest on MI355X (tools/autotune_conv.py); shapes that are not in
-# the table use the library's cost model (tile_hint = 0)
-TUNE = _load_tune_table()
+def _config_ids():
+    return {lib.vsp_conv2d_config_name(i).decode(): i + 1 for i in range(lib.vsp_conv2d_num_configs())}
+
+
+# shape key -> 1-based tile configuration id measured fastest on MI355X (tools/autotune_conv.py stores configuration NAMES,
+# resolved here); shapes that are not in the table use the library's cost model (tile_hint = 0)
+CONFIG_IDS = _config_ids()
+TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_IDS}
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
