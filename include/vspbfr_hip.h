@@ -99,8 +99,9 @@ int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major
  *   acc[b,co,oy,ox] = sum_{ci,ky,kx} Wp[g][ky*KW+kx][ci][co_g] *
  *                     xin(b, ci, oy*stride_y + ky*dil[g] - pad[g], ox*stride_x + kx*dil[g] - pad[g])
  *   xin(b,ci,iy,ix) = 0 outside the image, else x[b,ci,iy,ix] * in_scale[b*in_scale_bstride + ci] + in_shift[ci]
- * with g = co / cout_g (output-channel groups that differ only in dilation/padding: the four dilated
- * branches of SMART_layer share one launch), then per output element, in this order:
+ * with g = co / cout_g (output-channel groups: either groups that differ only in dilation/padding and share the
+ * input -- the four dilated branches of SMART_layer in one launch -- or true convolution groups with their own
+ * input-channel slice, see x_group_stride), then per output element, in this order:
  *   v = acc * out_scale[b*Cout + co]                     (demodulation, models/RestoreNet.py:376-379)
  *   v = v * ch_scale[co] + ch_bias[co]                   (conv bias / folded eval BatchNorm)
  *   act1: v = lrelu(v + bias1[co], slope1) * gain1       (FusedLeakyReLU of `fusion`, RestoreNet.py:1176-1177)
@@ -148,7 +149,12 @@ typedef struct vsp_conv_params {
   const float* res1;      /* NULL or same layout as the y region written (see res_* below) */
   const float* res2;
   int res_ch, res_coff;   /* residual tensors are [B, res_ch, y_h, y_w], read at channel res_coff + co */
-  int tile_hint;          /* 0 = let the library choose; otherwise a VSP_CONV_CFG_* id (tests / tuning) */
+  int tile_hint;          /* 0 = let the library choose; otherwise 1 + configuration index (tests / tuning) */
+  /* grouped input (true grouped convolution, e.g. the 18 map2style heads of the e4e encoder run as one launch per stage):
+   * x has x_ch channels per image (0 = Cin) and group g reads channels [g*x_group_stride, g*x_group_stride + Cin).
+   * x_group_stride = 0: all groups read the same Cin channels (the dilation groups of SMART_layer).  With G > 4 every
+   * group uses dil[0] / pad_y[0] / pad_x[0]. */
+  int x_ch, x_group_stride;
 } vsp_conv_params;
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
@@ -162,7 +168,7 @@ const char* vsp_conv2d_config_name(int i);
  * 86-116).
  *   C[z][m][n] = epi( alpha * sum_k A[z][m][k] * B[z][n][k] )
  *   element addresses: A + z*a_zs + m*a_ms + k*a_ks   (same for B with n), C + z*c_zs + m*c_ms + n
- *   epi(v): v += bias[n] * bias_scale (bias may be NULL); act==1: v = lrelu(v, slope) * gain;
+ *   epi(v): v += bias[z*bias_zs + n] * bias_scale (bias may be NULL); act==1: v = lrelu(v, slope) * gain;
  *           act==2: v = sigmoid(v)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vsp_gemm_params {
@@ -178,6 +184,7 @@ typedef struct vsp_gemm_params {
   float bias_scale;
   int act;
   float slope, gain;
+  int64_t bias_zs; /* bias stride between batches (0 = one bias vector for all z) */
 } vsp_gemm_params;
 
 int vsp_gemm_f32(const vsp_gemm_params* p, vsp_stream_t stream);

@@ -322,3 +322,27 @@ def test_row_helpers(H):
     close(H.add3(dev(img), dev(img), dev(img)), img * 3, 1e-6, 1e-6)
     st, wsq = torch.randn(4, 32), torch.rand(24, 32)
     close(H.demod_coefs(dev(st), dev(wsq), 0.1), torch.rsqrt(0.01 * (st ** 2) @ wsq.t() + 1e-8), 2e-5, 1e-6)
+
+
+def test_conv2d_true_groups_and_batched_head_gemm(H):
+    """Grouped convolution with per-group input slices (the batched map2style heads) + the batched per-head linear."""
+    for G in (3, 5):
+        _grouped_case(H, G)
+
+
+def _grouped_case(H, G):
+    B, C_, Hh = 2, 16, 8
+    x = torch.randn(B, G * C_, Hh, Hh)
+    ws = [torch.randn(C_, C_, 3, 3) / math.sqrt(C_ * 9) for _ in range(G)]
+    bias = torch.randn(G * C_)
+    ref = F.leaky_relu(F.conv2d(x, torch.cat(ws, 0), bias, stride=2, padding=1, groups=G), 0.01)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, G, C_, C_, 3, 3, 2, (1,), (1,), x_group_stride=C_)
+    y = H.conv2d_packed(dev(x), pc, ch_bias=dev(bias), act2=1, slope2=0.01, gain2=1.0)
+    close(y, ref, 2e-5, 2e-5)
+    feat = torch.randn(B, G * C_)
+    lw, lb = torch.randn(G, 24, C_), torch.randn(G, 24)
+    out = H.gemm_nt(dev(feat), dev(lw), dims=(G, B, 24, C_), a_strides=(C_, G * C_, 1), b_strides=(24 * C_, C_, 1), alpha=0.5,
+                    bias=dev(lb), bias_scale=2.0, bias_zs=24)
+    ref2 = torch.stack([F.linear(feat[:, g * C_:(g + 1) * C_], lw[g] * 0.5, lb[g] * 2.0) for g in range(G)])
+    close(out, ref2, 2e-5, 2e-5)

@@ -66,7 +66,7 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   if ((1 << twl) > NPIX) twl = ilog2_ceil(NPIX);
   const int TW = 1 << twl, TH = NPIX / TW;
   int dmax = 1;
-  for (int g = 0; g < p.G; ++g) dmax = p.dil[g] > dmax ? p.dil[g] : dmax;
+  for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g) dmax = p.dil[g] > dmax ? p.dil[g] : dmax;
   const int PH = (TH - 1) * p.stride_y + (p.KH - 1) * dmax + 1;
   const int PW = (TW - 1) * p.stride_x + (p.KW - 1) * dmax + 1;
   if (PW > 256 || PH * PW >= 65536) return false;
@@ -176,21 +176,25 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(p.x && p.w && p.y, "conv2d: null tensor pointer");
   VSP_REQUIRE(p.B >= 0 && p.Cin >= 1 && p.H >= 1 && p.W >= 1, "conv2d: bad input dims B=%d Cin=%d H=%d W=%d", p.B,
               p.Cin, p.H, p.W);
-  VSP_REQUIRE(p.G >= 1 && p.G <= 4 && p.cout_g >= 1, "conv2d: bad group spec G=%d cout_g=%d", p.G, p.cout_g);
+  VSP_REQUIRE(p.G >= 1 && p.G <= 1024 && p.cout_g >= 1, "conv2d: bad group spec G=%d cout_g=%d", p.G, p.cout_g);
+  VSP_REQUIRE(p.x_group_stride >= 0 && p.x_ch >= 0, "conv2d: negative x_ch / x_group_stride");
+  const int x_ch = p.x_ch > 0 ? p.x_ch : p.Cin;
+  VSP_REQUIRE((int64_t)(p.G - 1) * p.x_group_stride + p.Cin <= x_ch, "conv2d: group input channels exceed x_ch=%d", x_ch);
+  VSP_REQUIRE(p.x_group_stride == 0 || !p.in_scale, "conv2d: input scaling is not supported with grouped input");
   VSP_REQUIRE(p.KH >= 1 && p.KW >= 1 && p.KH * p.KW <= 49, "conv2d: unsupported kernel %dx%d", p.KH, p.KW);
   VSP_REQUIRE(p.stride_y >= 1 && p.stride_x >= 1 && p.stride_x <= 2 && p.stride_y <= 2, "conv2d: stride must be 1 or 2");
   VSP_REQUIRE(p.OH >= 0 && p.OW >= 0, "conv2d: negative output size");
   VSP_REQUIRE(p.osy >= 1 && p.osx >= 1 && p.ooy >= 0 && p.oox >= 0, "conv2d: bad output stride/offset");
   VSP_REQUIRE(!p.noise || p.noise_w, "conv2d: noise given without noise_w");
   VSP_REQUIRE(p.act2 != 2 || p.prelu, "conv2d: act2=prelu without slopes");
-  for (int g = 0; g < p.G; ++g) VSP_REQUIRE(p.dil[g] >= 1, "conv2d: dilation must be >= 1");
+  for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g) VSP_REQUIRE(p.dil[g] >= 1, "conv2d: dilation must be >= 1");
   if (p.B == 0 || p.OH == 0 || p.OW == 0) return VSP_OK;
   const int Cout = p.G * p.cout_g;
   VSP_REQUIRE(p.y_coff >= 0 && p.y_coff + Cout <= p.y_ch, "conv2d: output channel window [%d,%d) outside %d", p.y_coff,
               p.y_coff + Cout, p.y_ch);
   VSP_REQUIRE((p.OH - 1) * p.osy + p.ooy < p.y_h && (p.OW - 1) * p.osx + p.oox < p.y_w,
               "conv2d: output positions exceed the %dx%d output tensor", p.y_h, p.y_w);
-  VSP_REQUIRE((int64_t)p.y_ch * p.y_h * p.y_w < ((int64_t)1 << 31) && (int64_t)p.Cin * p.H * p.W < ((int64_t)1 << 31),
+  VSP_REQUIRE((int64_t)p.y_ch * p.y_h * p.y_w < ((int64_t)1 << 31) && (int64_t)x_ch * p.H * p.W < ((int64_t)1 << 31),
               "conv2d: one image must hold fewer than 2^31 elements");
   if (p.res1 || p.res2)
     VSP_REQUIRE(p.res_coff >= 0 && p.res_coff + Cout <= p.res_ch, "conv2d: residual channel window out of range");
@@ -263,6 +267,8 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   q.co_tiles = best.co_tiles;
   q.w_vec4 = (p.cout_g % 4 == 0) && (CO_T % 4 == 0) && vsp::aligned16(p.w) ? 1 : 0;
   q.ps_odd = p.stride_x != 1;
+  q.x_ch = x_ch;
+  q.x_gs = p.x_group_stride;
   {
     static int dbg = -1;
     if (dbg < 0) {

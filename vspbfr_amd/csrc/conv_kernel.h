@@ -56,6 +56,7 @@ struct ConvK {
   int tw_log2, th, tiles_x, tiles_y, co_tiles;  // co_tiles = tiles per group
   int w_vec4;                                    // weight rows may be read as float4
   int ps_odd;                                    // plane pitch parity target (stride-2 reads)
+  int x_ch, x_gs;                                // input channels per image, input-channel stride between groups
   int dbg;                                       // ablation switches for kernel tuning (env VSP_CONV_DBG; 0 in production)
 };
 
@@ -96,13 +97,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int b = blockIdx.z;
 
   const int TW = 1 << p.tw_log2, TH = p.th;
-  const int D = p.dil[g];
+  const int gi = p.G > 4 ? 0 : g;  // more than 4 groups = true grouped conv with uniform geometry
+  const int D = p.dil[gi];
   const int T = p.KH * p.KW;
   const int PH = (TH - 1) * p.sy + (p.KH - 1) * D + 1;
   const int PW = (TW - 1) * p.sx + (p.KW - 1) * D + 1;
   const int PS = round_pitch(PH * PW, p.ps_odd);
   const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-  const int iy0 = oy0 * p.sy - p.pady[g], ix0 = ox0 * p.sx - p.padx[g];
+  const int iy0 = oy0 * p.sy - p.pady[gi], ix0 = ox0 * p.sx - p.padx[gi];
 
   float* Wl = smem;                // [T][CK][WS]
   float* Pl = smem + T * CK * WS;  // [CK][PS]
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* xb = p.x + (int64_t)b * p.Cin * p.H * p.W;
+  const float* xb = p.x + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * p.H * p.W;
   const float* wg = p.w + (int64_t)g * T * p.Cin * p.cout_g;
   const int plane = PH * PW;
   // exact floor(idx / PW) for idx < 2^16, PW <= 2^8 (host guarantees both)

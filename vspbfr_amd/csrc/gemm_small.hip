@@ -30,6 +30,7 @@ struct GemmK {
   float bias_scale;
   int act;
   float slope, gain;
+  int64_t bias_zs;
 };
 
 constexpr int NBL = 2;  // 16-column blocks per workgroup tile
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_nt_kernel(const GemmK p) {
   for (int j = 0; j < NBL; ++j) {
     const int n = n0 + j * 16 + lr;
     if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[n] * p.bias_scale : 0.f;
+    const float bv = p.bias ? p.bias[z * p.bias_zs + n] * p.bias_scale : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + kq * 4 + r;
@@ -149,7 +150,7 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(p.act >= 0 && p.act <= 2, "gemm: unknown activation %d", p.act);
   VSP_REQUIRE(p.Z <= 65535, "gemm: batch too large");
   GemmK q{p.A, p.Bm, p.C, p.M, p.N, p.K, p.a_zs, p.a_ms, p.a_ks, p.b_zs, p.b_ns, p.b_ks, p.c_zs, p.c_ms,
-          p.alpha, p.bias, p.bias_scale, p.act, p.slope, p.gain};
+          p.alpha, p.bias, p.bias_scale, p.act, p.slope, p.gain, p.bias_zs};
   const bool vec = p.a_ks == 1 && p.b_ks == 1 && p.a_ms % 4 == 0 && p.b_ns % 4 == 0 && p.a_zs % 4 == 0 &&
                    p.b_zs % 4 == 0 && vsp::aligned16(p.A) && vsp::aligned16(p.Bm);
   dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);

@@ -230,18 +230,52 @@ class Encoder4Editing(_Cached):
             if i in (6, 20, 23):
                 taps[i] = x
         c1, c2, c3 = taps[6], taps[20], taps[23]
-        codes = [self.styles[0](c3)]
-        feats = c3
-        for i in range(1, self.style_count):
-            if i == self.coarse_ind:
-                p2 = H.upsample_add(c3, H.conv2d_packed(c2, c["l1"], ch_bias=self.latlayer1.bias))
-                feats = p2
-            elif i == self.middle_ind:
-                feats = H.upsample_add(p2, H.conv2d_packed(c1, c["l2"], ch_bias=self.latlayer2.bias))
-            codes.append(self.styles[i](feats))
-        w0 = codes[0]
-        w = torch.stack([w0] + [w0 + d for d in codes[1:]], dim=1)  # w[:, i] = w0 + delta_i
+        p2 = H.upsample_add(c3, H.conv2d_packed(c2, c["l1"], ch_bias=self.latlayer1.bias))
+        p1 = H.upsample_add(p2, H.conv2d_packed(c1, c["l2"], ch_bias=self.latlayer2.bias))
+        B = x.shape[0]
+        outs = [self._heads(lo, hi, f) for (lo, hi), f in zip(self._head_classes(), (c3, p2, p1))]
+        w = torch.cat(outs, 0).permute(1, 0, 2).contiguous()  # (B, 18, 512): [w0, delta_1, ..., delta_17]
+        w[:, 1:] += w[:, :1]                                   # w[:, i] = w0 + delta_i (psp_encoders.py:188-199)
+        assert w.shape == (B, self.style_count, 512)
         return w
+
+    def _head_classes(self):
+        return ((0, self.coarse_ind), (self.coarse_ind, self.middle_ind), (self.middle_ind, self.style_count))
+
+    def _heads(self, lo, hi, feat):
+        """All map2style heads fed by one feature map (same depth) as ONE launch per stage: the first conv is a plain conv
+        with the heads' output channels concatenated, the following ones are true grouped convs (one group per head), the
+        final EqualLinear a batched GEMM.  Returns (hi - lo, B, 512)."""
+        heads = [self.styles[i] for i in range(lo, hi)]
+        nh = len(heads)
+        convs = [[m for m in h.convs if isinstance(m, nn.Conv2d)] for h in heads]
+        n_stage = len(convs[0])
+        src = [m.weight for hc in convs for m in hc] + [m.bias for hc in convs for m in hc] + \
+              [h.linear.weight for h in heads] + [h.linear.bias for h in heads]
+
+        def build():
+            stages = []
+            for s_ in range(n_stage):
+                ws = [hc[s_].weight for hc in convs]
+                bias = torch.cat([hc[s_].bias for hc in convs]).contiguous()
+                if s_ == 0:
+                    wcat = torch.cat(ws, 0).contiguous()
+                    pc = H.PackedConv(H.pack_weight(wcat), 1, nh * 512, wcat.shape[1], 3, 3, 2, (1,), (1,))
+                else:
+                    wp = torch.stack([H.pack_weight(w_.contiguous())[0] for w_ in ws]).contiguous()
+                    pc = H.PackedConv(wp, nh, 512, 512, 3, 3, 2, (1,), (1,), x_group_stride=512 if nh > 1 else 0)
+                stages.append((pc, bias))
+            lw = torch.stack([h.linear.weight for h in heads]).contiguous()
+            lb = torch.stack([h.linear.bias for h in heads]).contiguous()
+            return stages, lw, lb
+        stages, lw, lb = self._derive(f"heads{lo}", src, build)
+        x = feat
+        for pc, bias in stages:
+            x = H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
+        B = x.shape[0]
+        lin = heads[0].linear
+        return H.gemm_nt(x, lw, dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
+                         alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
 
 
 # ------------------------------------------------------------------------------------------------ pSp wrapper

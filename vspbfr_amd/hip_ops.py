@@ -64,7 +64,8 @@ TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_I
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
-    return f"{B},{Cin},{H},{W},{pc.G},{pc.cout_g},{pc.kh},{pc.kw},{pc.stride},{pc.dil[0]},{OH},{OW}"
+    return f"{B},{Cin},{H},{W},{pc.G},{pc.cout_g},{pc.kh},{pc.kw},{pc.stride},{pc.dil[0]},{OH},{OW}" + (
+        f",g{pc.x_group_stride}" if pc.x_group_stride else "")
 
 
 def _stream():
@@ -154,15 +155,16 @@ class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
     Built once at model-load time (vspbfr_amd/packing.py)."""
 
-    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x")
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride")
 
-    def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None):
+    def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
         self.stride = stride
-        self.dil = tuple(dil) + (1,) * (4 - len(dil))
-        self.pad_y = tuple(pad_y) + (0,) * (4 - len(pad_y))
-        pad_x = pad_y if pad_x is None else pad_x
-        self.pad_x = tuple(pad_x) + (0,) * (4 - len(pad_x))
+        self.x_group_stride = x_group_stride  # > 0: true grouped conv, group g reads input channels [g*stride, +cin)
+        rep = lambda t, fill: tuple(t) * 4 if len(t) == 1 else tuple(t) + (fill,) * (4 - len(t))  # noqa: E731
+        self.dil = rep(dil, 1)          # one value = the same geometry for every group
+        self.pad_y = rep(pad_y, 0)
+        self.pad_x = rep(pad_y if pad_x is None else pad_x, 0)
 
     @property
     def cout(self):
@@ -190,9 +192,10 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
     compute (defaults to the standard conv output size)."""
     x = _req(x, "x")
-    B, Cin, H, W = x.shape
-    if Cin != pc.cin:
-        raise RuntimeError(f"conv2d: input has {Cin} channels, weight expects {pc.cin}")
+    B, x_ch, H, W = x.shape
+    Cin = pc.cin
+    if (pc.G - 1) * pc.x_group_stride + Cin != x_ch:
+        raise RuntimeError(f"conv2d: input has {x_ch} channels, weight expects {(pc.G - 1) * pc.x_group_stride + Cin}")
     OH, OW = n_out if n_out is not None else conv2d_out_size(H, W, pc)
     if out is None:
         yh, yw = out_hw if out_hw is not None else (OH, OW)
@@ -226,6 +229,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     if RECORDER is not None:
         RECORDER.append((conv_key(B, Cin, H, W, pc, OH, OW), (B, Cin, H, W, OH, OW), pc))
     p.tile_hint = tile_hint
+    p.x_ch, p.x_group_stride = x_ch, pc.x_group_stride
     if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
         raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
     prof = PROFILER
@@ -276,7 +280,7 @@ def conv_transpose2d_s2(x, phases, **kw):
 
 # ----------------------------------------------------------------------------------------------- gemm / linear
 def gemm_nt(a, b, out=None, alpha=1.0, bias=None, bias_scale=1.0, act=0, slope=0.2, gain=SQRT2, a_strides=None,
-            b_strides=None, dims=None):
+            b_strides=None, dims=None, bias_zs=0):
     """C[z,m,n] = epi(alpha * sum_k A[z,m,k] B[z,n,k]).  Default: a [Z?,M,K], b [Z?,N,K] contiguous.
     `a_strides` = (zs, ms, ks), `b_strides` = (zs, ns, ks) and dims = (Z, M, N, K) describe arbitrary views of the
     storage starting at a.data_ptr()/b.data_ptr()."""
@@ -312,6 +316,7 @@ def gemm_nt(a, b, out=None, alpha=1.0, bias=None, bias_scale=1.0, act=0, slope=0
     p.alpha = alpha
     p.bias = _opt(bias, "bias").data_ptr() if bias is not None else None
     p.bias_scale, p.act, p.slope, p.gain = bias_scale, act, slope, gain
+    p.bias_zs = bias_zs
     check(lib.vsp_gemm_f32(C.byref(p), _stream()), "gemm")
     return out
 
