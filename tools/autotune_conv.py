@@ -48,7 +48,7 @@ def main():
     tot_auto = tot_best = 0.0
     for key, (dims, pc, count) in uniq.items():
         Bq, Cin, Hh, Ww, OH, OW = dims
-        x = torch.randn(Bq, Cin, Hh, Ww, device=dev)
+        x = torch.randn(Bq, (pc.G - 1) * pc.x_group_stride + Cin, Hh, Ww, device=dev)
         # generous output tensor: phase convs write strided, give them room
         out = torch.empty(Bq, pc.cout, max(OH, 1) * 2 + 1, max(OW, 1) * 2 + 1, device=dev)
         flops = 2.0 * Bq * pc.cout * OH * OW * Cin * pc.kh * pc.kw
@@ -60,6 +60,9 @@ def main():
                 times[c] = timeit(lambda: H.conv2d_packed(x, pc, out=out, n_out=(OH, OW), tile_hint=c), iters)
             except RuntimeError:
                 continue
+        if not [c for c in times if c > 0]:
+            print("no configuration ran for", key, flush=True)
+            continue
         best = min((c for c in times if c > 0), key=lambda c: times[c])
         table[key] = lib.vsp_conv2d_config_name(best - 1).decode()
         tot_auto += times[0] * count
