@@ -239,7 +239,8 @@ int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int
  * weight column w* (w*[d * stride]); tfrac = t/T is shared by the batch (the sampler's case).
  *   scores:    score[b,i,j] = softmax_j( K[b,i,:] . (eQ[b,j,:] + tfrac*wq) / sqrt(18) )
  *   chan_attn: A = softmax over rows of ((ek[b] + tfrac*wk)^T q2 / sqrt(512));  t[b] = v2[b] @ A
- *   tail:      y = LN(score @ V + LN(t)) * (1 + gamma) + beta;  if xold: y = c1[idx]*y + c2[idx]*xold (DDPM posterior
+ *   tail:      (token attention folded in: score as above) y = LN(score @ V + LN(t)) * (1 + gamma) + beta;
+ *              if xold: y = c1[idx]*y + c2[idx]*xold (DDPM posterior
  *              mean, ldm/ddpm.py:348-352);  pn = PixelNorm over the 18 tokens of y (may be NULL)
  *   head_pre:  out[s,m,:] = lrelu(LN(e[m,:] + (s/t_div)*wcol) * ln_w + ln_b, 0.2) * sqrt(2) for s = 0..S-1
  *              (first half of the gamma_/beta_ heads for every step of the chain at once)
@@ -249,9 +250,10 @@ int vsp_tacc_scores_f32(float* score, const float* P, int ldp, int k_off, const 
 int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2_off, const float* ek,
                            const float* wk, int wk_stride, float tfrac, int B, int n_tok, int dim,
                            vsp_stream_t stream);
-int vsp_tacc_tail_f32(float* y, float* pn, const float* score, const float* P, int ldp, int v_off, const float* t,
-                      const float* gamma, const float* beta, const float* xold, const float* c1, const float* c2,
-                      int idx, int B, int n_tok, int dim, vsp_stream_t stream);
+int vsp_tacc_tail_f32(float* y, float* pn, const float* P, int ldp, int k_off, int v_off, const float* eQ,
+                      const float* wq /* contiguous [512] */, float tfrac, const float* t, const float* gamma,
+                      const float* beta, const float* xold, const float* c1, const float* c2, int idx, int B, int n_tok,
+                      int dim, vsp_stream_t stream);
 int vsp_tacc_head_pre_f32(float* out, const float* e, const float* wcol, int w_stride, const float* ln_w,
                           const float* ln_b, int S, int M, int dim, float t_div, vsp_stream_t stream);
 

@@ -86,7 +86,7 @@ SIGNATURES = {
     "vsp_add3_f32": [_p, _p, _p, _p, _i64, _p],
     "vsp_tacc_scores_f32": [_p, _p, _i, _i, _p, _p, _i, _f, _i, _i, _i, _p],
     "vsp_tacc_chan_attn_f32": [_p, _p, _i, _i, _i, _p, _p, _i, _f, _i, _i, _i, _p],
-    "vsp_tacc_tail_f32": [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "vsp_tacc_tail_f32": [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}

@@ -177,15 +177,34 @@ __global__ __launch_bounds__(256) void tacc_chan_attn_mfma_kernel(float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
 
-  for (int i = tid; i < 20 * D; i += 256) {
-    const int tok = i / D, r = i - tok * D;
-    float v = 0.f;
-    if (tok < NTOK) v = ek[((int64_t)b * NTOK + tok) * D + r] + tf * wk[(int64_t)r * wk_stride];
-    k2s[tok * CA_KP + r] = v;
-  }
-  for (int i = tid; i < NTOK * D; i += 256) {
-    const int tok = i / D, r = i - tok * D;
-    v2s[tok * CA_VP + r] = P[((int64_t)b * NTOK + tok) * ldp + v2_off + r];
+  if (wk_stride == 1) {  // contiguous condition column (the sampler passes it that way): 16-byte staging loads
+    for (int i = tid; i < 20 * (D / 4); i += 256) {
+      const int tok = i / (D / 4), c4 = i - tok * (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tok < NTOK) {
+        v = *reinterpret_cast<const float4*>(ek + ((int64_t)b * NTOK + tok) * D + c4 * 4);
+        const float4 w = *reinterpret_cast<const float4*>(wk + c4 * 4);
+        v.x = fmaf(tf, w.x, v.x); v.y = fmaf(tf, w.y, v.y); v.z = fmaf(tf, w.z, v.z); v.w = fmaf(tf, w.w, v.w);
+      }
+      *reinterpret_cast<float4*>(k2s + tok * CA_KP + c4 * 4) = v;
+    }
+    for (int i = tid; i < NTOK * (D / 4); i += 256) {
+      const int tok = i / (D / 4), c4 = i - tok * (D / 4);
+      const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)b * NTOK + tok) * ldp + v2_off + c4 * 4);
+      float* d = v2s + tok * CA_VP + c4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int i = tid; i < 20 * D; i += 256) {
+      const int tok = i / D, r = i - tok * D;
+      float v = 0.f;
+      if (tok < NTOK) v = ek[((int64_t)b * NTOK + tok) * D + r] + tf * wk[(int64_t)r * wk_stride];
+      k2s[tok * CA_KP + r] = v;
+    }
+    for (int i = tid; i < NTOK * D; i += 256) {
+      const int tok = i / D, r = i - tok * D;
+      v2s[tok * CA_VP + r] = P[((int64_t)b * NTOK + tok) * ldp + v2_off + r];
+    }
   }
   float qb[5][2];
 #pragma unroll
@@ -296,38 +315,73 @@ __global__ __launch_bounds__(256) void tacc_chan_attn_mfma_kernel(float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Tail.  grid = B, 576 threads (9 waves, 2 token rows each).  Per row i (8 channels per lane):
-//   h = sum_j score[i][j] V[j][:];  tn = LN(t[i]);  hn = LN(h + tn);  y = hn * (1 + gamma) + beta
+// Tail with the token attention folded in.  grid = B, 576 threads (9 waves, 2 token rows each).  V and Q = eQ + tf*wq are
+// staged once per sample in LDS (float4, coalesced); per row i (8 channels per lane):
+//   s = softmax_j(K_i . Q_j / sqrt(18));  h = sum_j s_j V_j;  tn = LN(t_i);  hn = LN(h + tn);  y = hn * (1 + gamma) + beta
 //   mix: y = c1[idx] * y + c2[idx] * xold                       (DDPM posterior mean after the 4th block)
 //   yout = y;  pn = y * rsqrt(mean_i y^2 + 1e-8)                 (PixelNorm over the 18 tokens for the next GEMM)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(576) void tacc_tail_kernel(float* __restrict__ yout, float* __restrict__ pnout,
-                                                         const float* __restrict__ score, const float* __restrict__ P,
-                                                         int ldp, int v_off, const float* __restrict__ t,
+                                                         const float* __restrict__ P, int ldp, int k_off, int v_off,
+                                                         const float* __restrict__ eQ, const float* __restrict__ wq,
+                                                         float tf, float sscale, const float* __restrict__ t,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ xold, const float* __restrict__ c1,
                                                          const float* __restrict__ c2, int idx, float eps) {
-  __shared__ float ys[NTOK * D];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;             // [18][512]
+  float* Qs = Vs + NTOK * D;    // [18][512]
+  float* ys = Qs + NTOK * D;    // [18][512]
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < NTOK * D / 4; i += 576) {
+    const int tok = i / (D / 4), c4 = i - tok * (D / 4);
+    const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)b * NTOK + tok) * ldp + v_off + c4 * 4);
+    float4 q = *reinterpret_cast<const float4*>(eQ + ((int64_t)b * NTOK + tok) * D + c4 * 4);
+    const float4 w = *reinterpret_cast<const float4*>(wq + c4 * 4);
+    q.x = fmaf(tf, w.x, q.x); q.y = fmaf(tf, w.y, q.y); q.z = fmaf(tf, w.z, q.z); q.w = fmaf(tf, w.w, q.w);
+    *reinterpret_cast<float4*>(Vs + tok * D + c4 * 4) = v;
+    *reinterpret_cast<float4*>(Qs + tok * D + c4 * 4) = q;
+  }
+  __syncthreads();
   for (int half = 0; half < 2; ++half) {
     const int i = wave * 2 + half;
     const int64_t row = (int64_t)b * NTOK + i;
-    float h[8], tn[8];
+    float kv[8], h[8], tn[8];
+    const float* kr = P + row * ldp + k_off;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) h[u] = 0.f;
+    for (int u = 0; u < 8; ++u) {
+      kv[u] = kr[lane + 64 * u];
+      tn[u] = t[row * D + lane + 64 * u];
+      h[u] = 0.f;
+    }
+    float s[NTOK];
+#pragma unroll
     for (int j = 0; j < NTOK; ++j) {
-      const float s = score[row * NTOK + j];
-      const float* vr = P + ((int64_t)b * NTOK + j) * ldp + v_off;
+      float acc = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) h[u] = fmaf(s, vr[lane + 64 * u], h[u]);
+      for (int u = 0; u < 8; ++u) acc = fmaf(kv[u], Qs[j * D + lane + 64 * u], acc);
+      s[j] = wsum(acc) * sscale;
+    }
+    float m = s[0];
+#pragma unroll
+    for (int j = 1; j < NTOK; ++j) m = fmaxf(m, s[j]);
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) {
+      s[j] = expf(s[j] - m);
+      den += s[j];
+    }
+    const float rden = 1.f / den;
+#pragma unroll
+    for (int j = 0; j < NTOK; ++j) {
+      const float sj = s[j] * rden;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) h[u] = fmaf(sj, Vs[j * D + lane + 64 * u], h[u]);
     }
     float sm = 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      tn[u] = t[row * D + lane + 64 * u];
-      sm += tn[u];
-    }
+    for (int u = 0; u < 8; ++u) sm += tn[u];
     float mean = wsum(sm) * (1.f / D);
     float var = 0.f;
 #pragma unroll
@@ -363,10 +417,10 @@ __global__ __launch_bounds__(576) void tacc_tail_kernel(float* __restrict__ yout
   __syncthreads();
   if (pnout && threadIdx.x < D) {
     const int ch = threadIdx.x;
-    float s = 0.f;
+    float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < NTOK; ++i) s = fmaf(ys[i * D + ch], ys[i * D + ch], s);
-    const float inv = rsqrtf(s * (1.f / NTOK) + 1e-8f);
+    for (int i = 0; i < NTOK; ++i) sq = fmaf(ys[i * D + ch], ys[i * D + ch], sq);
+    const float inv = rsqrtf(sq * (1.f / NTOK) + 1e-8f);
 #pragma unroll
     for (int i = 0; i < NTOK; ++i) pnout[((int64_t)b * NTOK + i) * D + ch] = ys[i * D + ch] * inv;
   }
@@ -452,15 +506,25 @@ int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2
   return vsp::check_launch("tacc_chan_attn");
 }
 
-int vsp_tacc_tail_f32(float* y, float* pn, const float* score, const float* P, int ldp, int v_off, const float* t,
-                      const float* gamma, const float* beta, const float* xold, const float* c1, const float* c2, int idx,
-                      int B, int n_tok, int dim, vsp_stream_t stream) {
+int vsp_tacc_tail_f32(float* y, float* pn, const float* P, int ldp, int k_off, int v_off, const float* eQ, const float* wq,
+                      float tfrac, const float* t, const float* gamma, const float* beta, const float* xold, const float* c1,
+                      const float* c2, int idx, int B, int n_tok, int dim, vsp_stream_t stream) {
   VSP_REQUIRE(n_tok == NTOK && dim == D, "tacc_tail: built for 18 tokens x 512 channels (got %d x %d)", n_tok, dim);
   if (B <= 0) return VSP_OK;
-  VSP_REQUIRE(y && score && P && t && gamma && beta, "tacc_tail: null pointer");
+  VSP_REQUIRE(y && P && eQ && wq && t && gamma && beta, "tacc_tail: null pointer");
   VSP_REQUIRE(!xold || (c1 && c2 && idx >= 0), "tacc_tail: posterior mix needs c1, c2 and a step index");
-  tacc_tail_kernel<<<B, 576, 0, vsp::as_stream(stream)>>>(y, pn, score, P, ldp, v_off, t, gamma, beta, xold, c1, c2, idx,
-                                                          1e-5f);
+  VSP_REQUIRE(ldp % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && vsp::aligned16(P) && vsp::aligned16(eQ) && vsp::aligned16(wq),
+              "tacc_tail: operands must be 16-byte aligned (contiguous wq column expected)");
+  const size_t lds = (size_t)3 * NTOK * D * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_tail_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_tail: cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  tacc_tail_kernel<<<B, 576, lds, vsp::as_stream(stream)>>>(y, pn, P, ldp, k_off, v_off, eQ, wq, tfrac,
+                                                            1.0f / sqrtf((float)NTOK), t, gamma, beta, xold, c1, c2, idx, 1e-5f);
   return vsp::check_launch("tacc_tail");
 }
 

@@ -153,7 +153,8 @@ class Code_diffuser(nn.Module):
                                       self.max_period)
                 heads.append(H.linear(pre, seq[3].weight, seq[3].bias, act=seq.last).view(steps, B, 18, 512))
             state.append({"eQ": e["Q"].reshape(M, 512), "ek": e["k"].reshape(M, 512), "gamma": heads[0], "beta": heads[1],
-                          "wq": blk.q_matrix.weight[:, -1], "wk": blk.attention_layer.k_matrix.weight[:, -1],
+                          "wq": blk.q_matrix.weight[:, -1].contiguous(),
+                          "wk": blk.attention_layer.k_matrix.weight[:, -1].contiguous(),
                           "wcat": self._wcat(blk)})
         return state
 
@@ -166,11 +167,10 @@ class Code_diffuser(nn.Module):
         last = len(self.att_mapper) - 1
         for bi, st in enumerate(state):
             P = H.gemm_nt(cur_pn.view(B * 18, 512), st["wcat"])
-            score = H.tacc_scores(P, st["eQ"], st["wq"], tf, B)
             t = H.tacc_chan_attn(P, st["ek"], st["wk"], tf, B)
             mix = bi == last and c1 is not None
-            cur, cur_pn = H.tacc_tail(score, P, t, st["gamma"][i], st["beta"][i], B, xold=x if mix else None, c1=c1, c2=c2,
-                                      idx=i)
+            cur, cur_pn = H.tacc_tail(P, st["eQ"], st["wq"], tf, t, st["gamma"][i], st["beta"][i], B, xold=x if mix else None,
+                                      c1=c1, c2=c2, idx=i)
         return cur, cur_pn
 
 

@@ -463,13 +463,14 @@ def tacc_chan_attn(P, ek, wk_col, tfrac, B, q2_off=1024, v2_off=1536):
     return t
 
 
-def tacc_tail(score, P, t, gamma, beta, B, xold=None, c1=None, c2=None, idx=0, v_off=512, want_pn=True):
+def tacc_tail(P, eQ, wq, tfrac, t, gamma, beta, B, xold=None, c1=None, c2=None, idx=0, k_off=0, v_off=512, want_pn=True):
+    """`wq`: the CONTIGUOUS last weight column of the block's q_matrix (512 floats)."""
     y = torch.empty((B, 18, 512), device=P.device, dtype=P.dtype)
     pn = torch.empty_like(y) if want_pn else None
-    check(lib.vsp_tacc_tail_f32(_ptr(y), _ptr(pn), _ptr(_req(score, "score")), _ptr(_req(P, "P")), P.shape[1], v_off,
-                                _ptr(_req(t, "t")), _ptr(_req(gamma, "gamma")), _ptr(_req(beta, "beta")),
-                                _ptr(_opt(xold, "xold")), _ptr(_opt(c1, "c1")), _ptr(_opt(c2, "c2")), int(idx), B, 18, 512,
-                                _stream()), "tacc_tail")
+    check(lib.vsp_tacc_tail_f32(_ptr(y), _ptr(pn), _ptr(_req(P, "P")), P.shape[1], k_off, v_off, _ptr(_req(eQ, "eQ")),
+                                _ptr(_req(wq, "wq")), float(tfrac), _ptr(_req(t, "t")), _ptr(_req(gamma, "gamma")),
+                                _ptr(_req(beta, "beta")), _ptr(_opt(xold, "xold")), _ptr(_opt(c1, "c1")), _ptr(_opt(c2, "c2")),
+                                int(idx), B, 18, 512, _stream()), "tacc_tail")
     return y, pn
 
 
