@@ -63,6 +63,17 @@ def cpu_baseline(T, threads, sample_steps=2):
                               "prior_decoder": round(st["prior_decoder"], 2), "restorenet": round(st["restorenet"], 2)}}
 
 
+def conv_traffic(B, args):
+    """HBM bytes per conv launch from the committed PMC passes (profiles/r01_conv_traffic_pmc.json: FETCH_SIZE x2 per the
+    gfx950 calibration, WRITE_SIZE x1, separate passes, tools/pmc_bench.sh).  PMC collection cannot run inside the timed
+    process, so the figure is only reported for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json")
+    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return round(json.load(f)["conv_hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +82,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE configs[1]: 8)")
     ap.add_argument("--timesteps", type=int, default=50)
     ap.add_argument("--no-sample", action="store_true", help="skip the 1024^2 tail of the prior (not the headline config)")
+    ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm", help="ddim = BASELINE configs[2]'s sampler (fp32 here)")
+    ap.add_argument("--ddim-steps", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -91,6 +104,16 @@ def main():
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
     pipe = build_pipeline(dev, args.timesteps, not args.no_sample)
+    if args.sampler == "ddim":
+        from vspbfr_amd.ddim import DDIMSampler
+        ddpm, S = pipe.diffusion, args.ddim_steps
+        sampler = DDIMSampler(ddpm, device=dev)
+
+        class _DDIM(torch.nn.Module):  # same call shape as My_DDPM.forward for the pipeline
+            def forward(self, x=None, condi_in=None, training=False, x_T=None):
+                return sampler.sample(S=S, batch_size=condi_in.shape[0], shape=18 * 512, conditioning=condi_in, eta=0.0,
+                                      verbose=False, x_T=x_T)[0]
+        pipe.diffusion = _DDIM()
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(123 + rank)
     lq = torch.rand(B, 3, 512, 512, device=dev, generator=g) * 2 - 1
@@ -134,9 +157,10 @@ def main():
                                    f"CodeDiffuser + StyleGAN2 prior{'' if not args.no_sample else ' (no 1024^2 tail)'} + RestoreNet "
                                    "forward, fp32, random-init weights",
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
+                       "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": conv_traffic(B, args),
                          "kernel": "conv_igemm_kernel (all tile configs)", "launches_per_step": conv_launches // max(args.steps, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),

@@ -88,10 +88,11 @@ DIFFUSER_CASES = {
     "ddpm_T4": (2, 4, 0.1, 0.99),          # what restoration_test.py:35-38 runs
     "ddpm_T10": (2, 10, 1e-4, 2e-2),
 }
+DDIM_CASE = ("ddim_T50_S25", 2, 50, 25)  # name, batch, DDPM steps, DDIM steps (BASELINE config 3; default betas)
 
 
 def diffuser_inputs(name):
-    B = DIFFUSER_CASES[name][0]
+    B = DIFFUSER_CASES[name][0] if name in DIFFUSER_CASES else DDIM_CASE[1]
     cond = tensor(name, "cond", (B, 18, 512))
     x_T = tensor(name, "x_T", (B, 18, 512))
     return cond, x_T

@@ -321,3 +321,36 @@ def save_image_quantize(x):
     138-157; torchvision 0.13 utils.py): clamp to [-1,1], map to [0,1], *255 + 0.5, clamp, uint8."""
     y = (x.clamp(-1, 1) + 1) / 2
     return (y * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+
+
+# --------------------------------------------------------------------------------------------- DDIM (BASELINE config 3)
+def ddim_schedule(alphas_cumprod, S, eta=0.0):
+    """make_ddim_timesteps('uniform') + make_ddim_sampling_parameters (reference ldm/util2.py:46-74): steps
+    range(0, T, T // S) + 1; a_t = acp[steps]; a_prev = [acp[0]] + acp[steps[:-1]]; sigma = eta * sqrt(...)."""
+    ac = alphas_cumprod.double().numpy()
+    T = ac.shape[0]
+    steps = np.asarray(list(range(0, T, T // S))) + 1
+    assert steps.max() < T, "the reference indexes alphas_cumprod out of range when S == T (SURVEY section 0)"
+    a = ac[steps]
+    a_prev = np.asarray([ac[0]] + ac[steps[:-1]].tolist())
+    sig = eta * np.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
+    return steps, a, a_prev, sig
+
+
+def ddim_sample(sd, cond, x_T, timesteps, S, linear_start=1e-4, linear_end=2e-2):
+    """DDIMSampler.sample(eta=0) (reference ldm/ddim.py:55-206) on (B, 18, 512) latents with the (x, t, c) ->
+    Code_diffuser(x, c, t) adapter; like the reference's code it treats the network output as e_t."""
+    _, ac, _, _ = ddpm_schedule(timesteps, linear_start, linear_end)
+    steps, a, a_prev, sig = ddim_schedule(ac, S)
+    x = x_T
+    B = cond.shape[0]
+    for index in reversed(range(len(steps))):
+        t = torch.full((B,), int(steps[index]), dtype=torch.long)
+        e_t = code_diffuser(sd, x, cond, t, timesteps)
+        at = torch.tensor(a[index], dtype=torch.float32)
+        ap = torch.tensor(a_prev[index], dtype=torch.float32)
+        st = torch.tensor(sig[index], dtype=torch.float32)
+        som = torch.tensor(np.sqrt(1.0 - a[index]), dtype=torch.float32)
+        pred_x0 = (x - som * e_t) / at.sqrt()
+        x = ap.sqrt() * pred_x0 + (1.0 - ap - st ** 2).sqrt() * e_t  # sigma = 0: the noise term vanishes
+    return x

@@ -93,6 +93,25 @@ def test_diffuser_ddpm_golden(golden, name):
     assert maxerr(final, g[name + "/final"]) <= max(4 * e_ref, 1e-3)
 
 
+def test_ddim_sampler_golden(golden):
+    """DDIM S=25 on T=50, default betas (BASELINE config 3).  This chain is x-dominated (A ~ 1, |B| small), hence well
+    conditioned: tight bound against the reference's DDIMSampler run."""
+    from vspbfr_amd.ddim import DDIMSampler
+    from vspbfr_amd.diffusion import Code_diffuser, My_DDPM
+    name, B, T, S = cases.DDIM_CASE
+    net = load(Code_diffuser(timesteps=T), "diffuser", "diffuser")
+    ddpm = My_DDPM(denoise=net, timesteps=T).to(DEV)
+    cond, x_T = cases.diffuser_inputs(name)
+    g = golden("ddim")
+    sampler = DDIMSampler(ddpm, device=DEV)
+    samples, _ = sampler.sample(S=S, batch_size=B, shape=18 * 512, conditioning=dev(cond), eta=0.0, verbose=False,
+                                x_T=dev(x_T).view(B, -1))
+    np.testing.assert_array_equal(sampler.ddim_timesteps, g["ddim_timesteps"])
+    assert maxerr(samples, g["final"]) < 1e-3
+    with pytest.raises(ValueError):
+        sampler.make_schedule(ddim_num_steps=T)  # S == T is out of range in the reference, refused here
+
+
 def test_restorenet64_golden_and_oracle(golden):
     from vspbfr_amd.restorenet import Restoration_net
     size, B, case = 64, 1, "restorenet64"

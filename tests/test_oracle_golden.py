@@ -152,3 +152,17 @@ def test_pipeline512(golden):
     close(out["style_sample"][:, :, ::8, ::8], g["sample_sub"], 2e-4, 2e-4)
     close(out["restored"][:, :, ::8, ::8], g["restored_sub"], 2e-4, 2e-4)
     close(out["restored"][:, :, 200:264, 200:264], g["restored_crop"], 2e-4, 2e-4)
+
+
+def test_ddim(golden):
+    """DDIM S=25 on T=50 (BASELINE config 3) against the reference's DDIMSampler run (tools/make_golden.py::gen_ddim)."""
+    name, B, T, S = cases.DDIM_CASE
+    sd = weights.synth_state_dict("diffuser", weights.load_specs()["diffuser"], cases.SEED)
+    cond, x_T = cases.diffuser_inputs(name)
+    g = golden("ddim")
+    _, ac, _, _ = models.ddpm_schedule(T)
+    steps, a, a_prev, _ = models.ddim_schedule(ac, S)
+    np.testing.assert_array_equal(steps, g["ddim_timesteps"])
+    np.testing.assert_allclose(a, g["ddim_alphas"], rtol=1e-7)
+    np.testing.assert_allclose(a_prev, g["ddim_alphas_prev"], rtol=1e-7)
+    close(models.ddim_sample(sd, cond, x_T, T, S), g["final"], 1e-5, 1e-5)

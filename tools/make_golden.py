@@ -147,6 +147,32 @@ def gen_diffuser():
     print("diffuser.npz:", {k: v.shape for k, v in out.items()})
 
 
+def gen_ddim():
+    """BASELINE config 3: DDIMSampler (dead code in the reference, ldm/ddim.py) driven the only way it can run on this
+    path: flatten adapter for its (b, L) latents and model.model(x, t, c) argument order,
+    register_buffer patched to plain setattr (it hard-moves buffers to "cuda"), S < T."""
+    from ldm.ddim import DDIMSampler
+    B, T, S = 2, 50, 25
+    net = Code_diffuser(timesteps=T)
+    load_synth(net, "diffuser", cases.SEED)
+    ddpm = My_DDPM(denoise=net, timesteps=T)  # default betas (1e-4, 2e-2)
+    cond, x_T = cases.diffuser_inputs("ddim_T50_S25")
+
+    class Adapter(torch.nn.Module):
+        def forward(self, x, t, c):
+            return net(x.view(B, 18, 512), c, t).reshape(B, -1)
+
+    ddpm.model = Adapter()
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    sampler = DDIMSampler(ddpm, device="cpu")
+    samples, _ = sampler.sample(S=S, batch_size=B, shape=18 * 512, conditioning=cond, eta=0.0, verbose=False,
+                                x_T=x_T.reshape(B, -1))
+    out = {"final": np_(samples.view(B, 18, 512)), "ddim_timesteps": np.asarray(sampler.ddim_timesteps),
+           "ddim_alphas": np.asarray(sampler.ddim_alphas), "ddim_alphas_prev": np.asarray(sampler.ddim_alphas_prev)}
+    np.savez_compressed(os.path.join(GOLD, "ddim.npz"), **out)
+    print("ddim.npz:", out["final"].shape, "absmax %.3f" % np.abs(out["final"]).max(), out["ddim_timesteps"][:4], "...")
+
+
 def run_restorenet(size, B, case, net=None, de_feats=None, pre_styles=None):
     net = net or RN.Restoration_net(size, 512, 8)
     load_synth(net, "restorenet", cases.SEED)
@@ -241,7 +267,7 @@ def gen_pipeline512():
     print("pipeline512.npz: restored stats", out["restored_stats"], "sample stats", out["sample_stats"], "%.1fs" % (time.time() - t0))
 
 
-ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "restorenet64": gen_restorenet64,
+ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
        "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512}
 
 if __name__ == "__main__":

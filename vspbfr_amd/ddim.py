@@ -1,0 +1,97 @@
+"""DDIM sampling over W+ latents on gfx950 (BASELINE config 3) -- the `DDIMSampler(model, device, schedule)` /
+`.make_schedule(...)` / `.sample(S, batch_size, shape, conditioning, eta, x_T, ...)` surface of the reference's
+ldm/ddim.py:11-206.
+
+In the reference this class is dead code that cannot run on the restoration path as written (it calls
+`model.model(x, t, c)`, assumes (b, L) latents and pins its buffers to "cuda": SURVEY.md section 0); what is implemented
+here is what its equations compute when driven through the (x, t, c) -> Code_diffuser(x, c, t) adapter on (B, 18, 512)
+latents -- which is also how the golden vector was produced from the reference (tools/make_golden.py::gen_ddim).  Like the
+reference's code it treats the network output as e_t:
+    pred_x0 = (x - sqrt(1 - a_t) e_t) / sqrt(a_t);   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - s^2) e_t + s * noise
+With eta = 0 a step is the linear combination  x_prev = A x + B e_t, which rides in the epilogue of the last TACC block's
+tail kernel exactly like the DDPM posterior mean (coefficient tables indexed by the DDIM step).
+"""
+import numpy as np
+import torch
+
+from . import hip_ops as H
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
+    """reference ldm/util2.py:46-62."""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ts = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ts = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ts + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
+    """reference ldm/util2.py:65-74 (float64 numpy)."""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+class DDIMSampler(object):
+    def __init__(self, model, device=None, schedule="linear", **kwargs):
+        self.model = model  # a My_DDPM
+        self.device = device if device is not None else model.betas.device
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, torch.Tensor):
+            attr = attr.to(self.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
+        if self.ddim_timesteps.max() >= self.ddpm_num_timesteps:
+            raise ValueError("DDIM needs S < T: with S == T the reference indexes alphas_cumprod out of range "
+                             "(ldm/util2.py:57,65)")
+        ac = self.model.alphas_cumprod.double().cpu().numpy()
+        sig, a, a_prev = make_ddim_sampling_parameters(ac, self.ddim_timesteps, ddim_eta, verbose)
+        f32 = lambda v: torch.tensor(v, dtype=torch.float32)  # noqa: E731
+        self.register_buffer("ddim_sigmas", f32(sig))
+        self.register_buffer("ddim_alphas", f32(a))
+        self.register_buffer("ddim_alphas_prev", f32(a_prev))
+        self.register_buffer("ddim_sqrt_one_minus_alphas", f32(np.sqrt(1. - a)))
+        # x_prev = coef_x * x + coef_e * e_t (+ sigma * noise), fp32 arithmetic in the reference's operation order
+        at, ap, som, st = f32(a), f32(a_prev), f32(np.sqrt(1. - a)), f32(sig)
+        self.register_buffer("coef_x", ap.sqrt() / at.sqrt())
+        self.register_buffer("coef_e", (1. - ap - st ** 2).sqrt() - ap.sqrt() * som / at.sqrt())
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, eta=0., x_T=None, temperature=1., verbose=True, **kwargs):
+        """Returns (samples, intermediates) like the reference; `shape` is accepted for signature compatibility (the
+        latent shape is the conditioning's)."""
+        for k in ("mask", "x0", "score_corrector", "unconditional_conditioning"):
+            if kwargs.get(k) is not None:
+                raise NotImplementedError(f"DDIMSampler.sample: `{k}` is not part of the restoration path")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        cond = conditioning.contiguous()
+        if cond.shape[0] != batch_size:
+            print(f"Warning: Got {cond.shape[0]} conditionings but batch-size is {batch_size}")
+        x = (x_T.view(cond.shape) if x_T is not None else torch.randn(cond.shape, device=cond.device)).contiguous()
+        net = self.model.model
+        total = self.ddim_timesteps.shape[0]
+        fused = eta == 0. and hasattr(net, "chain_supported") and net.chain_supported(cond)
+        if fused:
+            state = net.prepare_chain(cond, self.ddpm_num_timesteps)
+            pn = H.pixelnorm_dim1(x)
+        for index in reversed(range(total)):
+            step = int(self.ddim_timesteps[index])
+            if fused:
+                x, pn = net.chain_step(x, pn, state, step, self.coef_e, self.coef_x, coef_idx=index)
+                continue
+            ts = torch.full((cond.shape[0],), step, device=cond.device, dtype=torch.long)
+            e_t = net(x, cond, ts)
+            x = H.axpby_idx(e_t.contiguous(), x, self.coef_e, self.coef_x, index)
+            if eta != 0.:
+                x = x + self.ddim_sigmas[index] * temperature * torch.randn_like(x)
+        return x, {"x_inter": [x], "pred_x0": []}

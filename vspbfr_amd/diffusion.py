@@ -158,9 +158,10 @@ class Code_diffuser(nn.Module):
                           "wcat": self._wcat(blk)})
         return state
 
-    def chain_step(self, x, pn, state, i, c1=None, c2=None):
-        """One denoiser evaluation at step i on (x, pixelnorm(x)); with c1/c2 the posterior mean c1[i]*x0 + c2[i]*x is
-        fused into the last block's tail.  Returns (new x or x0, its pixelnorm)."""
+    def chain_step(self, x, pn, state, i, c1=None, c2=None, coef_idx=None):
+        """One denoiser evaluation at step i on (x, pixelnorm(x)); with c1/c2 the update c1[k]*f(x) + c2[k]*x (k = coef_idx,
+        default i: DDPM posterior mean; DDIM passes its own tables) is fused into the last block's tail.  Returns
+        (new x or x0, its pixelnorm)."""
         B = x.shape[0]
         tf = float(i) / float(self.max_period)
         cur, cur_pn = x, pn
@@ -170,7 +171,7 @@ class Code_diffuser(nn.Module):
             t = H.tacc_chan_attn(P, st["ek"], st["wk"], tf, B)
             mix = bi == last and c1 is not None
             cur, cur_pn = H.tacc_tail(P, st["eQ"], st["wq"], tf, t, st["gamma"][i], st["beta"][i], B, xold=x if mix else None,
-                                      c1=c1, c2=c2, idx=i)
+                                      c1=c1, c2=c2, idx=i if coef_idx is None else coef_idx)
         return cur, cur_pn
 
 
