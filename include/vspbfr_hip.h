@@ -228,6 +228,11 @@ int vsp_scale_add_f32(float* out, const float* x, const float* gate, const float
                       vsp_stream_t stream);
 /* strided gather of y[b,c,::s,::s] (MaxPool2d(1, stride) shortcut, helpers.py:101). */
 int vsp_subsample_f32(float* out, const float* x, int64_t planes, int IH, int IW, int s, vsp_stream_t stream);
+/* 8-bit image quantiser of torchvision.utils.save_image(normalize=True, value_range=(lo, hi)) fused with the
+ * NCHW -> NHWC transpose a PNG encoder wants (reference restoration_test.py:138-157; torchvision 0.13 utils.py):
+ *   t = (clamp(x, lo, hi) - lo) / max(hi - lo, 1e-5);  out[b,y,x,c] = (uint8) clamp(t * 255 + 0.5, 0, 255) */
+int vsp_quantize_u8_nhwc(uint8_t* out, const float* x, int B, int C, int H, int W, float lo, float hi,
+                         vsp_stream_t stream);
 /* out = a + b + c (c may be NULL). */
 int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream);
 

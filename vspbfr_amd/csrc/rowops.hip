@@ -198,6 +198,24 @@ __global__ __launch_bounds__(256) void subsample_kernel(float* out, const float*
   }
 }
 
+__global__ __launch_bounds__(256) void quantize_u8_nhwc_kernel(uint8_t* out, const float* x, int B, int C, int H, int W, float lo,
+                                                               float hi, float range) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int xw = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float v = x[(((int64_t)b * C + c) * H + y) * W + xw];
+    v = fminf(fmaxf(v, lo), hi);
+    v = (v - lo) / range;
+    v = fminf(fmaxf(v * 255.f + 0.5f, 0.f), 255.f);
+    out[i] = (uint8_t)v;
+  }
+}
+
 __global__ __launch_bounds__(256) void add3_kernel(float* out, const float* a, const float* b, const float* c, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = a[i] + b[i] + (c ? c[i] : 0.f);
@@ -318,6 +336,16 @@ int vsp_subsample_f32(float* out, const float* x, int64_t planes, int IH, int IW
   VSP_REQUIRE(out && x, "subsample: null pointer");
   VSP_LAUNCH_1D(subsample_kernel, planes * OH * OW, stream, out, x, planes, IH, IW, OH, OW, s);
   return vsp::check_launch("subsample");
+}
+
+int vsp_quantize_u8_nhwc(uint8_t* out, const float* x, int B, int C, int H, int W, float lo, float hi, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && C >= 1 && H >= 0 && W >= 0, "quantize_u8: bad dims");
+  const int64_t n = (int64_t)B * C * H * W;
+  if (n == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "quantize_u8: null pointer");
+  const float range = hi - lo > 1e-5f ? hi - lo : 1e-5f;
+  VSP_LAUNCH_1D(quantize_u8_nhwc_kernel, n, stream, out, x, B, C, H, W, lo, hi, range);
+  return vsp::check_launch("quantize_u8_nhwc");
 }
 
 int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream) {

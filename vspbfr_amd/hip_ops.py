@@ -481,3 +481,13 @@ def tacc_head_pre(e, wcol, ln_w, ln_b, steps, t_div):
                                     _ptr(_req(ln_w, "ln_w")), _ptr(_req(ln_b, "ln_b")), steps, M, 512, float(t_div), _stream()),
           "tacc_head_pre")
     return out
+
+
+def quantize_u8_nhwc(x, lo=-1.0, hi=1.0):
+    """(B, C, H, W) fp32 -> (B, H, W, C) uint8 with torchvision's save_image(normalize=True, value_range=(lo, hi)) rounding."""
+    x = _req(x, "x")
+    B, Cc, Hh, Ww = x.shape
+    out = torch.empty((B, Hh, Ww, Cc), device=x.device, dtype=torch.uint8)
+    check(lib.vsp_quantize_u8_nhwc(C.c_void_p(out.data_ptr()), _ptr(x), B, Cc, Hh, Ww, float(lo), float(hi), _stream()),
+          "quantize_u8_nhwc")
+    return out
