@@ -155,6 +155,12 @@ typedef struct vsp_conv_params {
    * x_group_stride = 0: all groups read the same Cin channels (the dilation groups of SMART_layer).  With G > 4 every
    * group uses dil[0] / pad_y[0] / pad_x[0]. */
   int x_ch, x_group_stride;
+  /* transposed = 1: y = conv_transpose2d(xin, W, stride 2, padding 0) for a 3x3 kernel in ONE launch (all four
+   * sub-pixel phases; reference models/RestoreNet.py:530-532, e4e stylegan2/model.py:259).  w is the ordinary packed
+   * [1][9][Cin][Cout] weight (W[co][ci][ky][kx], not flipped); y must be [B, y_ch, 2H+1, 2W+1]; KH = KW = 3, G = 1;
+   * stride / dilation / padding / OH / OW / os* / oo* fields are ignored; prologue scaling and the epilogue's
+   * per-channel terms apply, noise and residuals are not available (they follow the blur in the reference). */
+  int transposed;
 } vsp_conv_params;
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);

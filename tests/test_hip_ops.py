@@ -223,6 +223,31 @@ def test_conv_transpose_s2_phases(H, B, Cin, Cout, Hh, Ww):
     close(y, ref, 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 12, 8, 8), (1, 16, 16, 5, 9), (1, 64, 32, 32, 32), (2, 40, 72, 17, 33), (3, 512, 512, 4, 4)])
+def test_conv_transpose_s2_fused(H, B, Cin, Cout, Hh, Ww):
+    """One-launch transposed conv (all four sub-pixel phases) incl. style scaling and demodulation, every 't' configuration."""
+    from vspbfr_amd._lib import lib
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, demod = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5
+    ref = F.conv_transpose2d(x * s_in.view(B, Cin, 1, 1), w.transpose(0, 1), stride=2, padding=0) * demod.view(B, Cout, 1, 1)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    y = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod))
+    close(y, ref, 2e-5, 2e-5)
+    ran = 0
+    for c in range(1, lib.vsp_conv2d_num_configs() + 1):
+        if not lib.vsp_conv2d_config_name(c - 1).endswith(b"t"):
+            continue
+        try:
+            yc = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), tile_hint=c)
+        except RuntimeError as ex:
+            assert "does not fit" in str(ex), str(ex)
+            continue
+        close(yc, ref, 2e-5, 2e-5, f"cfg {c}")
+        ran += 1
+    assert ran >= 4
+
+
 def test_conv2d_gradfix_mirror():
     from vspbfr_amd.op import conv2d_gradfix
     x = torch.randn(1, 12, 10, 10)

@@ -40,24 +40,25 @@ def main():
     torch.cuda.synchronize()
     recs, H.RECORDER = H.RECORDER, None
     uniq = {}
-    for key, dims, pc in recs:
-        uniq.setdefault(key, [dims, pc, 0])[2] += 1
+    for key, dims, pc, tr in recs:
+        uniq.setdefault(key, [dims, pc, 0, tr])[2] += 1
     print(f"{len(recs)} conv launches, {len(uniq)} distinct shapes", flush=True)
     n = lib.vsp_conv2d_num_configs()
     table, report = {}, []
     tot_auto = tot_best = 0.0
-    for key, (dims, pc, count) in uniq.items():
+    for key, (dims, pc, count, tr) in uniq.items():
         Bq, Cin, Hh, Ww, OH, OW = dims
         x = torch.randn(Bq, (pc.G - 1) * pc.x_group_stride + Cin, Hh, Ww, device=dev)
         # generous output tensor: phase convs write strided, give them room
         out = torch.empty(Bq, pc.cout, max(OH, 1) * 2 + 1, max(OW, 1) * 2 + 1, device=dev)
-        flops = 2.0 * Bq * pc.cout * OH * OW * Cin * pc.kh * pc.kw
+        flops = 2.0 * Bq * pc.cout * (Hh * Ww if tr else OH * OW) * Cin * pc.kh * pc.kw
         times = {}
         for c in range(0, n + 1):
             try:
-                est = timeit(lambda: H.conv2d_packed(x, pc, out=out, n_out=(OH, OW), tile_hint=c), 1)
+                kw = dict(transposed=True) if tr else dict(out=out, n_out=(OH, OW))
+                est = timeit(lambda: H.conv2d_packed(x, pc, tile_hint=c, **kw), 1)
                 iters = 3 if est > 0.3 else 10
-                times[c] = timeit(lambda: H.conv2d_packed(x, pc, out=out, n_out=(OH, OW), tile_hint=c), iters)
+                times[c] = timeit(lambda: H.conv2d_packed(x, pc, tile_hint=c, **kw), iters)
             except RuntimeError:
                 continue
         if not [c for c in times if c > 0]:

@@ -5,7 +5,8 @@ import torch
 from vspbfr_amd import hip_ops as H
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_conv import SHAPES
-name, cfg = sys.argv[1], int(sys.argv[2])
+name, cfg = sys.argv[1], sys.argv[2]
+cfg = H.CONFIG_IDS[cfg] if not cfg.isdigit() else int(cfg)
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 (_, B, Cin, Cout, Hh, Ww, k, s, p, d, G) = [r for r in SHAPES if r[0] == name][0]
 x = torch.randn(B, Cin, Hh, Ww, device="cuda")

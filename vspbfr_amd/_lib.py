@@ -43,7 +43,7 @@ class ConvParams(C.Structure):
         ("noise", C.c_void_p), ("noise_w", C.c_void_p),
         ("act2", C.c_int), ("bias2", C.c_void_p), ("prelu", C.c_void_p), ("slope2", C.c_float), ("gain2", C.c_float),
         ("res1", C.c_void_p), ("res2", C.c_void_p), ("res_ch", C.c_int), ("res_coff", C.c_int),
-        ("tile_hint", C.c_int), ("x_ch", C.c_int), ("x_group_stride", C.c_int),
+        ("tile_hint", C.c_int), ("x_ch", C.c_int), ("x_group_stride", C.c_int), ("transposed", C.c_int),
     ]
 
 

@@ -11,6 +11,8 @@ extern const Cfg kCfgsB[];
 extern const int kNumB;
 extern const Cfg kCfgsC[];
 extern const int kNumC;
+extern const Cfg kCfgsD[];
+extern const int kNumD;
 }  // namespace vspconv
 
 namespace {
@@ -31,6 +33,7 @@ static void build_table() {
   for (int i = 0; i < vspconv::kNumA && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsA[i];
   for (int i = 0; i < vspconv::kNumB && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsB[i];
   for (int i = 0; i < vspconv::kNumC && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsC[i];
+  for (int i = 0; i < vspconv::kNumD && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsD[i];
   kNumCfgs = n;
 }
 
@@ -55,9 +58,13 @@ static int host_round_pitch(int n, int odd) {
 }
 
 // Fill the geometry of configuration c for problem p; returns false if it does not fit (LDS / index limits).
+static bool is_tc(const Cfg& k) { return k.name[strlen(k.name) - 1] == 't'; }
+
 static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const Cfg& k = kCfgs[c];
-  const int CO_T = 16 * k.MB * k.WM, NPIX = 16 * k.NB * k.WN;
+  const bool tc = is_tc(k);
+  if (tc != (p.transposed != 0)) return false;
+  const int CO_T = 16 * k.MB * k.WM, NPIX = tc ? 16 * k.WN : 16 * k.NB * k.WN;
   const int WS = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
   int twl = ilog2_ceil(p.OW);
   // cap the tile width: 16-pixel MFMA column blocks want >= 16 contiguous pixels; wider tiles cut halo re-reads
@@ -67,10 +74,10 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const int TW = 1 << twl, TH = NPIX / TW;
   int dmax = 1;
   for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g) dmax = p.dil[g] > dmax ? p.dil[g] : dmax;
-  const int PH = (TH - 1) * p.stride_y + (p.KH - 1) * dmax + 1;
-  const int PW = (TW - 1) * p.stride_x + (p.KW - 1) * dmax + 1;
+  const int PH = tc ? TH + 1 : (TH - 1) * p.stride_y + (p.KH - 1) * dmax + 1;
+  const int PW = tc ? TW + 1 : (TW - 1) * p.stride_x + (p.KW - 1) * dmax + 1;
   if (PW > 256 || PH * PW >= 65536) return false;
-  const int PS = host_round_pitch(PH * PW, p.stride_x != 1);
+  const int PS = host_round_pitch(PH * PW, !tc && p.stride_x != 1);
   size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)k.CK * PS) * sizeof(float);
   const size_t red = (size_t)(k.WK - 1) * k.WM * k.WN * k.MB * k.NB * 4 * 64 * sizeof(float);
   if (red > lds) lds = red;
@@ -172,7 +179,20 @@ extern "C" const char* vsp_conv2d_config_name(int i) {
 extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d: null params");
   build_table();
-  const vsp_conv_params& p = *pp;
+  vsp_conv_params pcopy = *pp;
+  if (pcopy.transposed) {  // normalise the ignored fields: the launch grid runs over input positions m = 0..H, n = 0..W
+    VSP_REQUIRE(pcopy.KH == 3 && pcopy.KW == 3 && pcopy.G == 1, "conv2d: transposed mode needs a 3x3 kernel and G = 1");
+    VSP_REQUIRE(!pcopy.noise && !pcopy.res1 && !pcopy.res2, "conv2d: transposed mode has no noise / residual epilogue");
+    VSP_REQUIRE(pcopy.y_h == 2 * pcopy.H + 1 && pcopy.y_w == 2 * pcopy.W + 1, "conv2d: transposed output must be (2H+1)x(2W+1)");
+    pcopy.stride_y = pcopy.stride_x = 1;
+    pcopy.dil[0] = 1;
+    pcopy.pad_y[0] = pcopy.pad_x[0] = 1;
+    pcopy.OH = pcopy.H + 1;
+    pcopy.OW = pcopy.W + 1;
+    pcopy.osy = pcopy.osx = 2;
+    pcopy.ooy = pcopy.oox = 0;
+  }
+  const vsp_conv_params& p = pcopy;
   VSP_REQUIRE(p.x && p.w && p.y, "conv2d: null tensor pointer");
   VSP_REQUIRE(p.B >= 0 && p.Cin >= 1 && p.H >= 1 && p.W >= 1, "conv2d: bad input dims B=%d Cin=%d H=%d W=%d", p.B,
               p.Cin, p.H, p.W);
@@ -266,7 +286,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   q.tw_log2 = best.tw_log2; q.th = best.th; q.tiles_x = best.tiles_x; q.tiles_y = best.tiles_y;
   q.co_tiles = best.co_tiles;
   q.w_vec4 = (p.cout_g % 4 == 0) && (CO_T % 4 == 0) && vsp::aligned16(p.w) ? 1 : 0;
-  q.ps_odd = p.stride_x != 1;
+  q.ps_odd = !p.transposed && p.stride_x != 1;
   q.x_ch = x_ch;
   q.x_gs = p.x_group_stride;
   {

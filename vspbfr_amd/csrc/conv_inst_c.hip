@@ -2,11 +2,11 @@
 #include "conv_kernel.h"
 namespace vspconv {
 extern const Cfg kCfgsC[] = {
-    VSP_CFG(4, 4, 1, 4, 8, 1, 12, 0, 4),
-    VSP_CFG(4, 4, 1, 4, 4, 1, 12, 0, 4),
-    VSP_CFG(4, 4, 2, 2, 8, 1, 12, 0, 4),
+    VSP_CFG(4, 4, 1, 4, 8, 1, 6, 0, 4),
+    VSP_CFG(4, 4, 1, 4, 4, 1, 6, 0, 4),
+    VSP_CFG(4, 4, 2, 2, 8, 1, 6, 0, 4),
     VSP_CFG(4, 2, 2, 2, 8, 1, 12, 0, 2),
-    VSP_CFG(2, 8, 1, 4, 8, 1, 12, 0, 4),
+    VSP_CFG(2, 8, 1, 4, 8, 1, 6, 0, 4),
     VSP_CFG(1, 8, 1, 4, 8, 1, 12, 0, 2),
     VSP_CFG(1, 8, 1, 4, 4, 1, 12, 0, 2),
     VSP_CFG(4, 1, 1, 4, 8, 1, 12, 0, 2),

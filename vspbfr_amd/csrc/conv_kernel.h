@@ -67,8 +67,14 @@ __device__ __forceinline__ int round_pitch(int n, int odd) {
   return p >= n ? p : p + 32;
 }
 
-template <int MB, int NB, int WM, int WN, int CK, int WK, int PMAX, int PF, int OCC>
+template <int MB, int NB, int WM, int WN, int CK, int WK, int PMAX, int PF, int OCC, bool TC = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(const ConvK p) {
+  // TC = true: stride-2 transposed 3x3 convolution (conv_transpose2d, padding 0) in ONE pass.  Output (2m+py, 2n+px) only
+  // sees taps with ky = py, kx = px (mod 2), so every tap belongs to exactly one of the four sub-pixel phases: the wave's
+  // four N-blocks are the four phases of ONE group of 16 input positions, tap (ky, kx) multiplies the staged input shifted
+  // by (-(ky>>1), -(kx>>1)) into phase (ky&1, kx&1).  The staged patch (halo 1 up/left) feeds all 9 taps like a 3x3 conv,
+  // instead of four launches that each re-stage the input for 4, 2, 2 and 1 taps.
+  static_assert(!TC || (NB == 4 && WK == 1), "transposed mode: the four N-blocks are the four sub-pixel phases");
   // PF = 1: one-chunk register prefetch (ILP hides global latency, ~250 VGPRs, 2 waves/SIMD);
   // PF = 0: loads are consumed in the staging phase itself, the register budget (OCC = min waves/SIMD) buys occupancy and
   //         other blocks' MFMAs hide the latency (TLP).
@@ -100,11 +106,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int gi = p.G > 4 ? 0 : g;  // more than 4 groups = true grouped conv with uniform geometry
   const int D = p.dil[gi];
   const int T = p.KH * p.KW;
-  const int PH = (TH - 1) * p.sy + (p.KH - 1) * D + 1;
-  const int PW = (TW - 1) * p.sx + (p.KW - 1) * D + 1;
+  const int PH = TC ? TH + 1 : (TH - 1) * p.sy + (p.KH - 1) * D + 1;
+  const int PW = TC ? TW + 1 : (TW - 1) * p.sx + (p.KW - 1) * D + 1;
   const int PS = round_pitch(PH * PW, p.ps_odd);
   const int oy0 = ty_i * TH, ox0 = tx_i * TW;
-  const int iy0 = oy0 * p.sy - p.pady[gi], ix0 = ox0 * p.sx - p.padx[gi];
+  const int iy0 = TC ? oy0 - 1 : oy0 * p.sy - p.pady[gi], ix0 = TC ? ox0 - 1 : ox0 * p.sx - p.padx[gi];
 
   float* Wl = smem;                // [T][CK][WS]
   float* Pl = smem + T * CK * WS;  // [CK][PS]
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   int pixoff[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = (wn * NB + nb) * 16 + lr;
+    const int n = TC ? wn * 16 + lr : (wn * NB + nb) * 16 + lr;
     const int py = n >> p.tw_log2, px = n & (TW - 1);
     pixoff[nb] = py * p.sy * PW + px * p.sx + (kq + 4 * wk) * PS;
   }
@@ -264,22 +270,44 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
     if (PF && ci0 + CK < p.Cin && !(p.dbg & 1)) issue(ci0 + CK);
     if (p.dbg & 2) continue;
     // ---- MFMA over taps x (CK/4) k-steps
-    for (int ky = 0; ky < p.KH; ++ky) {
-      for (int kx = 0; kx < p.KW; ++kx) {
-        const int boff = ky * D * PW + kx * D;
-        const float* wt = Wl + (ky * p.KW + kx) * CK * WS + a_lane;
+    if constexpr (TC) {
 #pragma unroll
-        for (int c4 = 0; c4 < CK / 4; c4 += WK) {  // this wave's k-steps: c4 + wk (folded into a_lane / pixoff)
-          float a[MB], bv[NB];
+      for (int tap = 0; tap < 9; ++tap) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ky = tap / 3, kx = tap % 3;
+        const int ph = (ky & 1) * 2 + (kx & 1);
+        const int boff = (1 - (ky >> 1)) * PW + (1 - (kx >> 1));
+        const float* wt = Wl + tap * CK * WS + a_lane;
+#pragma unroll
+        for (int c4 = 0; c4 < CK / 4; ++c4) {
+          float a[MB];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) a[mb] = wt[c4 * 4 * WS + mb * 16];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bv[nb] = Pl[c4 * 4 * PS + pixoff[nb] + boff];
+          const float bv = Pl[c4 * 4 * PS + pixoff[0] + boff];
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
+            acc[mb][ph] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bv, acc[mb][ph], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int ky = 0; ky < p.KH; ++ky) {
+        for (int kx = 0; kx < p.KW; ++kx) {
+          const int boff = ky * D * PW + kx * D;
+          const float* wt = Wl + (ky * p.KW + kx) * CK * WS + a_lane;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+          for (int c4 = 0; c4 < CK / 4; c4 += WK) {  // this wave's k-steps: c4 + wk (folded into a_lane / pixoff)
+            float a[MB], bv[NB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) a[mb] = wt[c4 * 4 * WS + mb * 16];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = Pl[c4 * 4 * PS + pixoff[nb] + boff];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+          }
         }
       }
     }
@@ -331,53 +359,51 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   float nz[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = (wn * NB + nb) * 16 + lr;
+    const int n = TC ? wn * 16 + lr : (wn * NB + nb) * 16 + lr;
     const int oy = oy0 + (n >> p.tw_log2), ox = ox0 + (n & (TW - 1));
-    const bool ok = (oy < p.OH && ox < p.OW);
+    bool ok = (oy < p.OH && ox < p.OW);
+    int off;
     const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
-    const int off = (oyc * p.osy + p.ooy) * p.y_w + oxc * p.osx + p.oox;
-    nz[nb] = nzp[(oyc * p.OW + oxc) * nzs] * nw;
+    if constexpr (TC) {  // phase nb = (py, px): input position (m, n) -> output (2m+py, 2n+px); even phases run to m = H
+      const int py = nb >> 1, px = nb & 1;
+      ok = ok && (oy < p.H + 1 - py) && (ox < p.W + 1 - px);
+      off = (2 * oyc + py) * p.y_w + 2 * oxc + px;
+      nz[nb] = 0.f;
+    } else {
+      off = (oyc * p.osy + p.ooy) * p.y_w + oxc * p.osx + p.oox;
+      nz[nb] = nzp[(oyc * p.OW + oxc) * nzs] * nw;
+    }
     yoff[nb] = ok ? off : -1;
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float os[4], cs[4], cb[4], b1[4], b2[4], sl2[4];
-    int cbase[4];  // channel plane offset, < 0: channel outside the group
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {  // one channel at a time: 6 parameter registers live instead of 24 (occupancy budget)
       const int cg = co0 + (wm * MB + mb) * 16 + kq * 4 + r;  // channel within the group
-      const bool ok = cg < p.cout_g;
-      const int co = g * p.cout_g + (ok ? cg : 0);
-      os[r] = osp[co * oss];
-      cs[r] = p.csp[co * css];
-      cb[r] = p.cbp[co * cbs];
-      b1[r] = p.b1p[co * b1s];
-      b2[r] = p.b2p[co * b2s];
-      sl2[r] = p.s2p[co * s2s];
-      cbase[r] = ok ? co * y_plane : -1;
-    }
+      const bool cok = cg < p.cout_g;
+      const int co = g * p.cout_g + (cok ? cg : 0);
+      const float os = osp[co * oss];
+      const float cs = p.csp[co * css];
+      const float cb = p.cbp[co * cbs];
+      const float b1 = p.b1p[co * b1s];
+      const float b2 = p.b2p[co * b2s];
+      const float sl2 = p.s2p[co * s2s];
+      const int cbase = co * y_plane;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int yo = yoff[nb] < 0 ? 0 : yoff[nb];
-      float r1v[4], r2v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ro = (cbase[r] < 0 ? 0 : cbase[r]) + yo;
-        r1v[r] = r1b[ro * r1s];
-        r2v[r] = r2b[ro * r2s];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[mb][nb][r] * os[r];
-        v = v * cs[r] + cb[r];
-        v += b1[r];
+      for (int nb = 0; nb < NB; ++nb) {
+        const int ro = cbase + (yoff[nb] < 0 ? 0 : yoff[nb]);
+        const float r1v = r1b[ro * r1s];
+        const float r2v = r2b[ro * r2s];
+        float v = acc[mb][nb][r] * os;
+        v = v * cs + cb;
+        v += b1;
         v = (v > 0.f ? v : v * s1) * g1;
         v += nz[nb];
-        v += b2[r];
-        v = (v > 0.f ? v : v * sl2[r]) * g2;
-        v += r1v[r];
-        v += r2v[r];
-        if (yoff[nb] >= 0 && cbase[r] >= 0) yb[cbase[r] + yo] = v;
+        v += b2;
+        v = (v > 0.f ? v : v * sl2) * g2;
+        v += r1v;
+        v += r2v;
+        if (yoff[nb] >= 0 && cok) yb[ro] = v;
       }
     }
   }
@@ -385,7 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
 
 struct Cfg {
-  int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;
+  int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;  // a name ending in "t" marks a transposed-conv kernel
   const char* name;
   void (*kern)(const ConvK);
 };
@@ -395,6 +421,13 @@ struct Cfg {
   {                                                                                                        \
     MB, NB, WM, WN, CK, WK, PMAX, PF, OCC, #MB "x" #NB "x" #WM "x" #WN "x" #CK "k" #WK "p" #PF "o" #OCC,  \
         conv_igemm_kernel<MB, NB, WM, WN, CK, WK, PMAX, PF, OCC>                                           \
+  }
+
+// transposed (stride-2, 3x3) variants: name suffix "t"
+#define VSP_CFGT(MB, WM, WN, CK, PMAX, PF, OCC)                                                            \
+  {                                                                                                        \
+    MB, 4, WM, WN, CK, 1, PMAX, PF, OCC, #MB "x4x" #WM "x" #WN "x" #CK "k1p" #PF "o" #OCC "t",              \
+        conv_igemm_kernel<MB, 4, WM, WN, CK, 1, PMAX, PF, OCC, true>                                       \
   }
 
 }  // namespace vspconv

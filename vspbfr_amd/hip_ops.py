@@ -188,7 +188,7 @@ def conv2d_out_size(H, W, pc):
 def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out_offset=(0, 0), in_scale=None,
                   in_scale_per_sample=True, in_shift=None, out_scale=None, ch_scale=None, ch_bias=None, act1=False,
                   bias1=None, noise=None, noise_w=None, act2=0, bias2=None, prelu=None, slope2=0.2, gain2=SQRT2, res1=None,
-                  res2=None, res_coff=0, n_out=None, tile_hint=0):
+                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False):
     """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
     compute (defaults to the standard conv output size)."""
     x = _req(x, "x")
@@ -196,7 +196,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     Cin = pc.cin
     if (pc.G - 1) * pc.x_group_stride + Cin != x_ch:
         raise RuntimeError(f"conv2d: input has {x_ch} channels, weight expects {(pc.G - 1) * pc.x_group_stride + Cin}")
-    OH, OW = n_out if n_out is not None else conv2d_out_size(H, W, pc)
+    OH, OW = n_out if n_out is not None else ((H + 1, W + 1) if transposed else conv2d_out_size(H, W, pc))
+    if out is None and transposed:
+        out = torch.empty((B, pc.cout, 2 * H + 1, 2 * W + 1), device=x.device, dtype=x.dtype)
     if out is None:
         yh, yw = out_hw if out_hw is not None else (OH, OW)
         out = torch.empty((B, pc.cout, yh, yw), device=x.device, dtype=x.dtype)
@@ -222,14 +224,16 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     rt = res1 if res1 is not None else res2
     p.res_ch = rt.shape[1] if rt is not None else 0
     p.res_coff = res_coff
+    key = conv_key(B, Cin, H, W, pc, OH, OW) + (",t" if transposed else "")
     if tile_hint == 0 and TUNE:
-        tile_hint = TUNE.get(conv_key(B, Cin, H, W, pc, OH, OW), 0)
+        tile_hint = TUNE.get(key, 0)
         if tile_hint == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
-            tile_hint = TUNE.get(conv_key(8, Cin, H, W, pc, OH, OW), 0)
+            tile_hint = TUNE.get("8" + key[key.index(","):], 0)
     if RECORDER is not None:
-        RECORDER.append((conv_key(B, Cin, H, W, pc, OH, OW), (B, Cin, H, W, OH, OW), pc))
+        RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))
     p.tile_hint = tile_hint
     p.x_ch, p.x_group_stride = x_ch, pc.x_group_stride
+    p.transposed = 1 if transposed else 0
     if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
         raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
     prof = PROFILER
@@ -237,7 +241,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         start = prof.begin()
     check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
-        prof.end(start, 2.0 * B * pc.cout * OH * OW * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G))
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G))
     return out
 
 
@@ -267,8 +271,15 @@ def pack_transposed_s2(weight_oihw):
     return phases
 
 
+def conv_transpose2d_s2_fused(x, pc, **kw):
+    """(B, Cin, H, W) -> (B, Cout, 2H+1, 2W+1): conv_transpose2d(stride=2, padding=0), 3x3, in ONE launch (`pc` is the
+    ordinary packed 3x3 weight).  Supports in_scale / out_scale / per-channel epilogue terms."""
+    return conv2d_packed(x, pc, transposed=True, **kw)
+
+
 def conv_transpose2d_s2(x, phases, **kw):
-    """(B, Cin, H, W) -> (B, Cout, 2H+1, 2W+1): conv_transpose2d(stride=2, padding=0) with a 3x3 kernel."""
+    """(B, Cin, H, W) -> (B, Cout, 2H+1, 2W+1): conv_transpose2d(stride=2, padding=0) with a 3x3 kernel, as four
+    sub-pixel phase launches (kept as the cross-check of the fused kernel)."""
     B, _, H, W = x.shape
     cout = phases[(0, 0)].cout
     out = torch.empty((B, cout, 2 * H + 1, 2 * W + 1), device=x.device, dtype=x.dtype)

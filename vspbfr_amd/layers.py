@@ -10,7 +10,8 @@ works on the published files; the forward passes do NOT follow the reference's o
 * weights are packed ONCE per device into the kernel layout [group][tap][ci][co] with the equalised-lr scale folded in.
 * noise injection, bias, leaky-ReLU, residual adds and channel concatenation run inside the producing kernel's epilogue
   (conv) or the blur's epilogue (up-sampling convs): no standalone elementwise pass over a (B, C, H, W) tensor.
-* a stride-2 transposed conv is four sub-pixel phase convolutions (same MACs as conv_transpose2d) followed by the FIR blur.
+* a stride-2 transposed conv runs all four sub-pixel phases in one launch from one staged input patch (same MACs as
+  conv_transpose2d), followed by the FIR blur whose epilogue carries noise, bias, leaky-ReLU and the residual adds.
 Inference only (no autograd through the HIP ops).
 """
 import math
@@ -149,8 +150,8 @@ class ModulatedConv2d(_Cached):
     def packed(self):
         def build():
             w = self._w_scaled()
-            if self.upsample:
-                return H.pack_transposed_s2(w)
+            if self.upsample:  # one-pass stride-2 transposed conv: ordinary 3x3 packing
+                return H.PackedConv(H.pack_weight(w), 1, self.out_channel, self.in_channel, 3, 3, 1, (1,), (1,))
             return H.PackedConv(H.pack_weight(w), 1, self.out_channel, self.in_channel, self.kernel_size, self.kernel_size,
                                 2 if self.downsample else 1, (self.dilation,), (0 if self.downsample else self.padding,))
         return self._derive("packed", [self.weight], build)
@@ -168,7 +169,7 @@ class ModulatedConv2d(_Cached):
         x = x.contiguous()
         act = act_bias is not None
         if self.upsample:
-            y = H.conv_transpose2d_s2(x, self.packed(), in_scale=mod, out_scale=demod)
+            y = H.conv_transpose2d_s2_fused(x, self.packed(), in_scale=mod, out_scale=demod)
             return H.blur_fused(y, self.blur.kernel, self.blur.pad, noise=noise, noise_w=noise_w, act_bias=act_bias, act=act,
                                 res1=res1, res2=res2)
         if self.downsample:
