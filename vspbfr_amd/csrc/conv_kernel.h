@@ -338,6 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
             acc[mb][nb][r] += red[((((k2 - 1) * (WM * WN) + wmn) * (MB * NB * 4)) + (mb * NB + nb) * 4 + r) * 64 + lane];
   }
 
+  if (p.dbg & 4) return;
   // ---- epilogue: lane holds pixel column lr of block nb, channel rows kq*4 + r of block mb.
   // Branch-free: absent operands read a constant (1 or 0) through a zero stride so that every load of a channel
   // group is issued back to back (a null-pointer branch per element serialises ~10 dependent loads per output).
