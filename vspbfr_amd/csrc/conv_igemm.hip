@@ -42,6 +42,7 @@ constexpr size_t kMaxLds = 100 * 1024;  // > 64 KiB needs hipFuncAttributeMaxDyn
 struct Plan {
   int cfg;
   int tw_log2, th, tiles_x, tiles_y, co_tiles;
+  int strip_col, strip_row;  // transposed mode edge strips (strip_col < 0: ragged tiles instead)
   size_t lds;
 };
 
@@ -64,7 +65,7 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const Cfg& k = kCfgs[c];
   const bool tc = is_tc(k);
   if (tc != (p.transposed != 0)) return false;
-  const int CO_T = 16 * k.MB * k.WM, NPIX = tc ? 16 * k.WN : 16 * k.NB * k.WN;
+  const int CO_T = 16 * k.MB * k.WM, NPIX = tc ? 16 * k.WN * (k.NB / 4) : 16 * k.NB * k.WN;
   const int WS = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
   int twl = ilog2_ceil(p.OW);
   // cap the tile width: 16-pixel MFMA column blocks want >= 16 contiguous pixels; wider tiles cut halo re-reads
@@ -77,7 +78,19 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const int PH = tc ? TH + 1 : (TH - 1) * p.stride_y + (p.KH - 1) * dmax + 1;
   const int PW = tc ? TW + 1 : (TW - 1) * p.stride_x + (p.KW - 1) * dmax + 1;
   if (PW > 256 || PH * PW >= 65536) return false;
-  const int PS = host_round_pitch(PH * PW, !tc && p.stride_x != 1);
+  int plane = PH * PW;
+  out->strip_col = -1;
+  out->strip_row = 0;
+  out->tiles_x = (p.OW + TW - 1) / TW;
+  out->tiles_y = (p.OH + TH - 1) / TH;
+  if (tc && NPIX <= 128 && p.H % TH == 0 && p.W % TW == 0) {
+    out->tiles_x = p.W / TW;
+    out->tiles_y = p.H / TH;
+    out->strip_col = (p.H + NPIX - 1) / NPIX;
+    out->strip_row = (p.W + 1 + NPIX - 1) / NPIX;
+    if ((NPIX + 1) * 2 > plane) plane = (NPIX + 1) * 2;
+  }
+  const int PS = host_round_pitch(plane, !tc && p.stride_x != 1);
   size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)k.CK * PS) * sizeof(float);
   const size_t red = (size_t)(k.WK - 1) * k.WM * k.WN * k.MB * k.NB * 4 * 64 * sizeof(float);
   if (red > lds) lds = red;
@@ -85,8 +98,6 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   out->cfg = c;
   out->tw_log2 = twl;
   out->th = TH;
-  out->tiles_x = (p.OW + TW - 1) / TW;
-  out->tiles_y = (p.OH + TH - 1) / TH;
   out->co_tiles = (p.cout_g + CO_T - 1) / CO_T;
   out->lds = lds;
   return true;
@@ -98,7 +109,7 @@ static double plan_cost(const vsp_conv_params& p, const Plan& pl) {
   const Cfg& k = kCfgs[pl.cfg];
   const int CO_T = 16 * k.MB * k.WM, NPIX = 16 * k.NB * k.WN;
   const int waves = k.WM * k.WN * k.WK;
-  const double blocks = (double)pl.tiles_x * pl.tiles_y * pl.co_tiles * p.G * p.B;
+  const double blocks = ((double)pl.tiles_x * pl.tiles_y + (pl.strip_col > 0 ? pl.strip_col + pl.strip_row : 0)) * pl.co_tiles * p.G * p.B;
   const int cin_pad = (p.Cin + k.CK - 1) / k.CK * k.CK;
   // cycles one block needs on one SIMD-set: each wave issues MB*NB MFMAs (32 cyc) per k-step
   const double ksteps = (double)p.KH * p.KW * cin_pad / 4.0;
@@ -284,6 +295,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   sel(p.res2, kZero, &q.r2p, &q.r2s);
   q.res_ch = p.res_ch; q.res_coff = p.res_coff;
   q.tw_log2 = best.tw_log2; q.th = best.th; q.tiles_x = best.tiles_x; q.tiles_y = best.tiles_y;
+  q.strip_col = best.strip_col;
   q.co_tiles = best.co_tiles;
   q.w_vec4 = (p.cout_g % 4 == 0) && (CO_T % 4 == 0) && vsp::aligned16(p.w) ? 1 : 0;
   q.ps_odd = !p.transposed && p.stride_x != 1;
@@ -307,7 +319,8 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
       raised[best.cfg] = true;
     }
   }
-  dim3 grid((unsigned)(best.tiles_x * best.tiles_y), (unsigned)gy, (unsigned)p.B);
+  dim3 grid((unsigned)(best.tiles_x * best.tiles_y + (best.strip_col > 0 ? best.strip_col + best.strip_row : 0)), (unsigned)gy,
+            (unsigned)p.B);
   dim3 block(64 * k.WM * k.WN * k.WK);
   hipLaunchKernelGGL(k.kern, grid, block, best.lds, vsp::as_stream(stream), q);
   return vsp::check_launch("conv2d");

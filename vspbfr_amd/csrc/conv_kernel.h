@@ -57,6 +57,7 @@ struct ConvK {
   int w_vec4;                                    // weight rows may be read as float4
   int ps_odd;                                    // plane pitch parity target (stride-2 reads)
   int x_ch, x_gs;                                // input channels per image, input-channel stride between groups
+  int strip_col;                                 // transposed mode: edge-strip blocks after the tiles_x*tiles_y main tiles (-1: none)
   int dbg;                                       // ablation switches for kernel tuning (env VSP_CONV_DBG; 0 in production)
 };
 
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   // four N-blocks are the four phases of ONE group of 16 input positions, tap (ky, kx) multiplies the staged input shifted
   // by (-(ky>>1), -(kx>>1)) into phase (ky&1, kx&1).  The staged patch (halo 1 up/left) feeds all 9 taps like a 3x3 conv,
   // instead of four launches that each re-stage the input for 4, 2, 2 and 1 taps.
-  static_assert(!TC || (NB == 4 && WK == 1), "transposed mode: the four N-blocks are the four sub-pixel phases");
+  // NB = 4 * NP there: the wave owns NP groups of 16 input positions and N-block nb = np * 4 + phase.  Each weight tap
+  // serves one phase only, so per MFMA a transposed block stages 4x the weights of a plain conv with the same pixel
+  // count: NP > 1 (more positions per block) is what buys that back.
+  static_assert(!TC || (NB % 4 == 0 && WK == 1), "transposed mode: N-blocks come in groups of four sub-pixel phases");
+  constexpr int NP = TC ? NB / 4 : NB;  // 16-wide groups of patch positions per wave
   // PF = 1: one-chunk register prefetch (ILP hides global latency, ~250 VGPRs, 2 waves/SIMD);
   // PF = 0: loads are consumed in the staging phase itself, the register budget (OCC = min waves/SIMD) buys occupancy and
   //         other blocks' MFMAs hide the latency (TLP).
@@ -102,25 +107,40 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int co0 = (blockIdx.y % p.co_tiles) * CO_T;  // within the group
   const int b = blockIdx.z;
 
-  const int TW = 1 << p.tw_log2, TH = p.th;
+  // Transposed mode, H and W multiples of the tile: the main tiles cover positions [0,H) x [0,W) exactly and the odd
+  // edge (column n = W, row m = H of the (H+1) x (W+1) position grid) is served by strip blocks -- 1 x NPIX column
+  // strips, then NPIX x 1 row strips -- instead of a ragged last tile row and column that are 1/TH and 1/TW full.
+  int twl = p.tw_log2, TH = p.th, oy0 = ty_i * p.th, ox0 = tx_i << p.tw_log2;
+  int mlim = p.H + 1;  // transposed: first invalid position row of this block
+  if (TC && p.strip_col >= 0) {
+    constexpr int NPIXB = 16 * WN * (NB / 4);
+    mlim = p.H;
+    int j = tile - p.tiles_x * p.tiles_y;
+    if (j >= p.strip_col) {  // row strip (includes the corner)
+      j -= p.strip_col;
+      twl = __builtin_ctz(NPIXB); TH = 1; oy0 = p.H; ox0 = j * NPIXB; mlim = p.H + 1;
+    } else if (j >= 0) {     // column strip
+      twl = 0; TH = NPIXB; oy0 = j * NPIXB; ox0 = p.W;
+    }
+  }
+  const int TW = 1 << twl;
   const int gi = p.G > 4 ? 0 : g;  // more than 4 groups = true grouped conv with uniform geometry
   const int D = p.dil[gi];
   const int T = p.KH * p.KW;
   const int PH = TC ? TH + 1 : (TH - 1) * p.sy + (p.KH - 1) * D + 1;
   const int PW = TC ? TW + 1 : (TW - 1) * p.sx + (p.KW - 1) * D + 1;
   const int PS = round_pitch(PH * PW, p.ps_odd);
-  const int oy0 = ty_i * TH, ox0 = tx_i * TW;
   const int iy0 = TC ? oy0 - 1 : oy0 * p.sy - p.pady[gi], ix0 = TC ? ox0 - 1 : ox0 * p.sx - p.padx[gi];
 
   float* Wl = smem;                // [T][CK][WS]
   float* Pl = smem + T * CK * WS;  // [CK][PS]
 
   // per-lane patch offsets of the NB pixel blocks this wave owns
-  int pixoff[NB];
+  int pixoff[NP];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = TC ? wn * 16 + lr : (wn * NB + nb) * 16 + lr;
-    const int py = n >> p.tw_log2, px = n & (TW - 1);
+  for (int nb = 0; nb < NP; ++nb) {
+    const int n = (wn * NP + nb) * 16 + lr;
+    const int py = n >> twl, px = n & (TW - 1);
     pixoff[nb] = py * p.sy * PW + px * p.sx + (kq + 4 * wk) * PS;
   }
   const int a_lane = (kq + 4 * wk) * WS + wm * MB * 16 + lr;
@@ -271,24 +291,39 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
     if (p.dbg & 2) continue;
     // ---- MFMA over taps x (CK/4) k-steps
     if constexpr (TC) {
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        constexpr int dummy = 0;
-        (void)dummy;
+      // Each tap feeds ONE phase, so a tap is only MB*NP MFMAs per k-step against MB+NP fragment reads: without help the
+      // compiler waits for an LDS round trip in front of every pair of MFMAs.  Software pipeline by hand: the fragments
+      // of tap t+1 are requested before the MFMAs of tap t are issued (two register sets, all indices compile-time).
+      constexpr int KS = CK / 4;
+      float af[2][KS][MB], bf[2][KS][NP];
+      auto load_tap = [&](int tap, float (&a)[KS][MB], float (&bq)[KS][NP]) {
         const int ky = tap / 3, kx = tap % 3;
-        const int ph = (ky & 1) * 2 + (kx & 1);
         const int boff = (1 - (ky >> 1)) * PW + (1 - (kx >> 1));
         const float* wt = Wl + tap * CK * WS + a_lane;
 #pragma unroll
-        for (int c4 = 0; c4 < CK / 4; ++c4) {
-          float a[MB];
+        for (int c4 = 0; c4 < KS; ++c4) {
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) a[mb] = wt[c4 * 4 * WS + mb * 16];
-          const float bv = Pl[c4 * 4 * PS + pixoff[0] + boff];
+          for (int mb = 0; mb < MB; ++mb) a[c4][mb] = wt[c4 * 4 * WS + mb * 16];
+#pragma unroll
+          for (int np = 0; np < NP; ++np) bq[c4][np] = Pl[c4 * 4 * PS + pixoff[np] + boff];
+        }
+      };
+      load_tap(0, af[0], bf[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cur = tap & 1;
+        if (tap < 8) load_tap(tap + 1, af[cur ^ 1], bf[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ph = ((tap / 3) & 1) * 2 + ((tap % 3) & 1);
+#pragma unroll
+        for (int c4 = 0; c4 < KS; ++c4)
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
-            acc[mb][ph] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bv, acc[mb][ph], 0, 0, 0);
-        }
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+              acc[mb][np * 4 + ph] =
+                  __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][c4][mb], bf[cur][c4][np], acc[mb][np * 4 + ph], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       for (int ky = 0; ky < p.KH; ++ky) {
@@ -356,25 +391,66 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int r1s = p.r1s, r2s = p.r2s;
   const int y_plane = p.y_h * p.y_w;
 
+  if constexpr (TC) {
+    // position (m, n) of group np feeds outputs (2m+py, 2n+px); the two px phases of a lane are neighbours in memory and
+    // leave as one 8-byte store (rows of 2W+1 floats are only 4-byte aligned: global_store_dwordx2 takes that)
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+    int yoff[NP][2];     // offset of (2m+py, 2n) inside the plane, < 0: row outside
+    bool pair[NP];       // column 2n+1 exists
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+      const int n = (wn * NP + np) * 16 + lr;
+      const int m = oy0 + (n >> twl), c = ox0 + (n & (TW - 1));
+      const bool cok = c <= p.W;
+      pair[np] = c < p.W;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+        yoff[np][py] = (cok && m < mlim && m < p.H + 1 - py) ? (2 * m + py) * p.y_w + 2 * c : -1;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cg = co0 + (wm * MB + mb) * 16 + kq * 4 + r;
+        const bool cok = cg < p.cout_g;
+        const int co = cok ? cg : 0;
+        const float os = osp[co * oss];
+        const float cs = p.csp[co * css];
+        const float cb = p.cbp[co * cbs];
+        const float b1 = p.b1p[co * b1s];
+        const float b2 = p.b2p[co * b2s];
+        const float sl2 = p.s2p[co * s2s];
+        float* yc = yb + (int64_t)co * y_plane;
+        auto fin = [&](float v) {
+          v = v * os * cs + cb + b1;
+          v = (v > 0.f ? v : v * s1) * g1 + b2;
+          return (v > 0.f ? v : v * sl2) * g2;
+        };
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            if (yoff[np][py] < 0 || !cok) continue;
+            const float v0 = fin(acc[mb][np * 4 + py * 2][r]), v1 = fin(acc[mb][np * 4 + py * 2 + 1][r]);
+            if (pair[np])
+              *reinterpret_cast<f32x2u*>(yc + yoff[np][py]) = f32x2u{v0, v1};
+            else
+              yc[yoff[np][py]] = v0;
+          }
+      }
+    }
+    return;
+  }
   int yoff[NB];  // < 0: pixel outside the image
   float nz[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = TC ? wn * 16 + lr : (wn * NB + nb) * 16 + lr;
-    const int oy = oy0 + (n >> p.tw_log2), ox = ox0 + (n & (TW - 1));
-    bool ok = (oy < p.OH && ox < p.OW);
-    int off;
+    const int n = (wn * NB + nb) * 16 + lr;
+    const int oy = oy0 + (n >> twl), ox = ox0 + (n & (TW - 1));
+    const bool ok = (oy < p.OH && ox < p.OW);
     const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
-    if constexpr (TC) {  // phase nb = (py, px): input position (m, n) -> output (2m+py, 2n+px); even phases run to m = H
-      const int py = nb >> 1, px = nb & 1;
-      ok = ok && (oy < p.H + 1 - py) && (ox < p.W + 1 - px);
-      off = (2 * oyc + py) * p.y_w + 2 * oxc + px;
-      nz[nb] = 0.f;
-    } else {
-      off = (oyc * p.osy + p.ooy) * p.y_w + oxc * p.osx + p.oox;
-      nz[nb] = nzp[(oyc * p.OW + oxc) * nzs] * nw;
-    }
-    yoff[nb] = ok ? off : -1;
+    yoff[nb] = ok ? (oyc * p.osy + p.ooy) * p.y_w + oxc * p.osx + p.oox : -1;
+    nz[nb] = nzp[(oyc * p.OW + oxc) * nzs] * nw;
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -425,10 +501,10 @@ struct Cfg {
   }
 
 // transposed (stride-2, 3x3) variants: name suffix "t"
-#define VSP_CFGT(MB, WM, WN, CK, PMAX, PF, OCC)                                                            \
+#define VSP_CFGT(MB, NB, WM, WN, CK, PMAX, PF, OCC)                                                        \
   {                                                                                                        \
-    MB, 4, WM, WN, CK, 1, PMAX, PF, OCC, #MB "x4x" #WM "x" #WN "x" #CK "k1p" #PF "o" #OCC "t",              \
-        conv_igemm_kernel<MB, 4, WM, WN, CK, 1, PMAX, PF, OCC, true>                                       \
+    MB, NB, WM, WN, CK, 1, PMAX, PF, OCC, #MB "x" #NB "x" #WM "x" #WN "x" #CK "k1p" #PF "o" #OCC "t",       \
+        conv_igemm_kernel<MB, NB, WM, WN, CK, 1, PMAX, PF, OCC, true>                                      \
   }
 
 }  // namespace vspconv
