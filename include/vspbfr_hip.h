@@ -39,7 +39,8 @@ int vsp_abi_version(void);
 const char* vsp_last_error(void);
 /* number of HIP devices visible, or a negative VSP_E* code (used by the loader's self-check). */
 int vsp_device_count(void);
-/* sizeof of an ABI struct (0 = vsp_fir_epilogue, 1 = vsp_conv_params, 2 = vsp_gemm_params): lets a binding in
+/* sizeof of an ABI struct (0 = vsp_fir_epilogue, 1 = vsp_conv_params, 2 = vsp_gemm_params,
+ * 3 = vsp_tacc_block, 4 = vsp_tacc_chain_params): lets a binding in
  * another language check its own struct layout when it loads the library. */
 int vsp_struct_size(int which);
 
@@ -267,6 +268,42 @@ int vsp_tacc_tail_f32(float* y, float* pn, const float* P, int ldp, int k_off, i
                       int dim, vsp_stream_t stream);
 int vsp_tacc_head_pre_f32(float* out, const float* e, const float* wcol, int w_stride, const float* ln_w,
                           const float* ln_b, int S, int M, int dim, float t_div, vsp_stream_t stream);
+
+/* The whole sampler chain of Code_diffuser behind one call (replaces the Python loops ldm/ddpm.py:400-429 p_sample_loop /
+ * ldm/ddim.py:130-180 ddim_sampling around models/CodeDiffuser.py:118-140): for s in 0..n_steps-1, with t = step[s]:
+ *   x0 = denoiser(x, cond, t)  (n_blocks TACC blocks);   x <- c1[k] * x0 + c2[k] * x,  k = coef_idx[s] (or t when NULL)
+ * (c1 == c2 == NULL: x <- x0).  `blocks`, `step`, `coef_idx` are HOST arrays; every pointer inside is a device pointer.
+ * Per block: wcat = [Wk; Wv; Wq2; Wv2] rows (2048 x 512), eQ / ek = condition halves of the two Linear(513) layers
+ * ((B*18) x 512), wq / wk = their contiguous t-columns (512), gamma / beta = FiLM heads of steps 0..head_steps-1
+ * (head_steps x (B*18) x 512, from vsp_tacc_head_pre_f32 + vsp_gemm_f32).  x is updated in place; `work` holds
+ * vsp_tacc_chain_work_floats(B) floats of scratch.  3 launches per block and step, nothing synchronises. */
+typedef struct vsp_tacc_block {
+  const float* wcat;
+  const float* eQ;
+  const float* ek;
+  const float* wq;
+  const float* wk;
+  const float* gamma;
+  const float* beta;
+} vsp_tacc_block;
+
+typedef struct vsp_tacc_chain_params {
+  int B, n_tok, dim, n_blocks;
+  const vsp_tacc_block* blocks;
+  float* x;
+  float* work;
+  size_t work_floats;
+  int n_steps;
+  const int* step;
+  const int* coef_idx;
+  const float* c1;
+  const float* c2;
+  float t_div;     /* t enters the condition as t / t_div (Code_diffuser.max_period) */
+  int head_steps;
+} vsp_tacc_chain_params;
+
+size_t vsp_tacc_chain_work_floats(int B);
+int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
 
 #ifdef __cplusplus
 }

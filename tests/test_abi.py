@@ -27,7 +27,8 @@ def test_struct_layouts_match():
     import ctypes as C
 
     from vspbfr_amd import _lib
-    for which, st in ((0, _lib.FirEpilogue), (1, _lib.ConvParams), (2, _lib.GemmParams)):
+    for which, st in ((0, _lib.FirEpilogue), (1, _lib.ConvParams), (2, _lib.GemmParams), (3, _lib.TaccBlock),
+                      (4, _lib.TaccChainParams)):
         assert _lib.lib.vsp_struct_size(which) == C.sizeof(st)
     assert _lib.lib.vsp_abi_version() == 1
     assert _lib.lib.vsp_conv2d_num_configs() >= 8

@@ -75,12 +75,24 @@ def test_diffuser_ddpm_golden(golden, name):
     # teacher-forced steps along the oracle's fp32 trajectory
     _, _, c1, c2 = OM.ddpm_schedule(T, ls, le)
     x = x_T
+    from vspbfr_amd import hip_ops as H
+    state = net.prepare_chain(dev(cond), T)
     for i in reversed(range(T)):
         ti = torch.full((B,), i, dtype=torch.long)
         nxt = c1[i] * OM.code_diffuser(sd, x, cond, ti, T) + c2[i] * x
-        got, _ = ddpm.p_sample(dev(x), ti.to(DEV), dev(cond), clip_denoised=False)
+        got, _ = ddpm.p_sample(dev(x), ti.to(DEV), dev(cond), clip_denoised=False)           # per-op path
+        assert maxerr(got, nxt) < 2e-4, i
+        got, _ = net.chain_step(dev(x), H.pixelnorm_dim1(dev(x)), state, i, ddpm.posterior_mean_coef1,
+                                ddpm.posterior_mean_coef2)                                  # per-launch fused kernels
+        assert maxerr(got, nxt) < 2e-4, i
+        got = H.tacc_chain(dev(x).clone(), state, [i], c1=ddpm.posterior_mean_coef1, c2=ddpm.posterior_mean_coef2,
+                           t_div=T)                                                         # the C chain entry (sampler path)
         assert maxerr(got, nxt) < 2e-4, i
         x = nxt
+    x0 = H.tacc_chain(dev(x_T).clone(), state, [T - 1], t_div=T)                             # no mixing: plain denoiser call
+    assert maxerr(x0, g[name + "/x0_first"]) < 2e-4
+    with pytest.raises(RuntimeError):
+        H.tacc_chain(dev(x_T).clone(), state, [T], t_div=T)                                  # step outside the prepared heads
     # free-running chain
     final = ddpm(x=dev(cond), condi_in=dev(cond), training=False, x_T=dev(x_T))
     sd64 = {k: v.double() for k, v in sd.items()}

@@ -47,6 +47,19 @@ class ConvParams(C.Structure):
     ]
 
 
+class TaccBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wcat", "eQ", "ek", "wq", "wk", "gamma", "beta")]
+
+
+class TaccChainParams(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("n_tok", C.c_int), ("dim", C.c_int), ("n_blocks", C.c_int),
+        ("blocks", C.POINTER(TaccBlock)), ("x", C.c_void_p), ("work", C.c_void_p), ("work_floats", C.c_size_t),
+        ("n_steps", C.c_int), ("step", C.POINTER(C.c_int)), ("coef_idx", C.POINTER(C.c_int)),
+        ("c1", C.c_void_p), ("c2", C.c_void_p), ("t_div", C.c_float), ("head_steps", C.c_int),
+    ]
+
+
 class GemmParams(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("Bm", C.c_void_p), ("C", C.c_void_p),
@@ -89,8 +102,10 @@ SIGNATURES = {
     "vsp_tacc_chan_attn_f32": [_p, _p, _i, _i, _i, _p, _p, _i, _f, _i, _i, _i, _p],
     "vsp_tacc_tail_f32": [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
+    "vsp_tacc_chain_f32": [_p, _p],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
+_SIZET = {"vsp_tacc_chain_work_floats": [_i]}
 
 
 def _load():
@@ -107,9 +122,13 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_char_p
+    for name, args in _SIZET.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_size_t
     if lib.vsp_abi_version() != 1:
         raise ImportError(f"vspbfr_amd: ABI version {lib.vsp_abi_version()} != 1")
-    for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams)):
+    for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams), (3, TaccBlock), (4, TaccChainParams)):
         if lib.vsp_struct_size(which) != C.sizeof(st):
             raise ImportError(f"vspbfr_amd: struct layout mismatch for {st.__name__}: "
                               f"C {lib.vsp_struct_size(which)} vs ctypes {C.sizeof(st)}")
@@ -129,4 +148,4 @@ def check(rc, what):
 
 
 def exported_symbols():
-    return sorted(list(SIGNATURES) + list(_CHARP))
+    return sorted(list(SIGNATURES) + list(_CHARP) + list(_SIZET))

@@ -31,6 +31,8 @@ int vsp_struct_size(int which) {
     case 0: return (int)sizeof(vsp_fir_epilogue);
     case 1: return (int)sizeof(vsp_conv_params);
     case 2: return (int)sizeof(vsp_gemm_params);
+    case 3: return (int)sizeof(vsp_tacc_block);
+    case 4: return (int)sizeof(vsp_tacc_chain_params);
     default: return -1;
   }
 }

@@ -10,13 +10,15 @@
 // per batch by the host), so Q and k2 are rebuilt on the fly as  e + (t/T) * w_lastcol  and never stored per step.
 // All four kernels are VALU/LDS kernels: per sample the block costs ~60 MFLOP, the problem is latency and launch count
 // (4 launches per block and step instead of ~56 in the reference), not arithmetic.
-#include "vsp_common.h"
+#include "tacc_kernels.h"
 #include <cstdlib>
 
 namespace {
 
-constexpr int NTOK = 18;
-constexpr int D = 512;
+using vsptacc::NTOK;
+using vsptacc::D;
+using vsptacc::CA_KP;
+using vsptacc::CA_VP;
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -148,170 +150,11 @@ __global__ __launch_bounds__(256) void tacc_chan_attn_kernel(float* __restrict__
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Channel attention on fp32 MFMA (same contract as tacc_chan_attn_kernel; this is the one the sampler uses).
-//   GEMM 1  logit[r][c] = sum_tok k2[tok][r] * q2[tok][c]      M = 512 rows (wave w owns rows 128w..128w+127 = 8 m-tiles),
-//                                                              N = 32 columns (2 n-tiles), K = 18 tokens padded to 20
-//   softmax over r: per-lane partial max / sum over the 32 values a lane holds per column, xor-shuffles across the 4 row
-//           groups of a wave, 4 x 32 floats of LDS across waves
-//   GEMM 2  t[tok][c] = sum_r v2[tok][r] * e[r][c]             K = rows: the e values never move -- register j of m-tile mt
-//           in the D layout IS the B fragment of the k-step whose 4 slots are rows 16 mt + 4 q + j (q = lane >> 4), so only
-//           the A fragment (v2) is read from LDS with the matching row; each wave reduces over its own 128 rows and the four
-//           partial t tiles meet in LDS.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int CA_KP = D + 16;  // k2 pitch: k-slot groups land on different bank halves
-constexpr int CA_VP = D + 1;   // v2 pitch: 16 token rows hit 16 different banks
-
 __global__ __launch_bounds__(256) void tacc_chan_attn_mfma_kernel(float* __restrict__ tout, const float* __restrict__ P,
                                                                    int ldp, int q2_off, int v2_off,
                                                                    const float* __restrict__ ek, const float* __restrict__ wk,
                                                                    int wk_stride, float tf, float scale) {
-  using f32x4 = __attribute__((ext_vector_type(4))) float;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* k2s = smem;                    // [20][CA_KP], token rows 18, 19 are zero
-  float* v2s = k2s + 20 * CA_KP;        // [18][CA_VP]
-  float* redm = v2s + NTOK * CA_VP;     // [4][32]
-  float* reds = redm + 128;             // [4][32]
-  float* tpart = reds + 128;            // [3][4 tiles][4][64]
-  const int cb = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, kq = lane >> 4;
-
-  if (wk_stride == 1) {  // contiguous condition column (the sampler passes it that way): 16-byte staging loads
-    for (int i = tid; i < 20 * (D / 4); i += 256) {
-      const int tok = i / (D / 4), c4 = i - tok * (D / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tok < NTOK) {
-        v = *reinterpret_cast<const float4*>(ek + ((int64_t)b * NTOK + tok) * D + c4 * 4);
-        const float4 w = *reinterpret_cast<const float4*>(wk + c4 * 4);
-        v.x = fmaf(tf, w.x, v.x); v.y = fmaf(tf, w.y, v.y); v.z = fmaf(tf, w.z, v.z); v.w = fmaf(tf, w.w, v.w);
-      }
-      *reinterpret_cast<float4*>(k2s + tok * CA_KP + c4 * 4) = v;
-    }
-    for (int i = tid; i < NTOK * (D / 4); i += 256) {
-      const int tok = i / (D / 4), c4 = i - tok * (D / 4);
-      const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)b * NTOK + tok) * ldp + v2_off + c4 * 4);
-      float* d = v2s + tok * CA_VP + c4 * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-  } else {
-    for (int i = tid; i < 20 * D; i += 256) {
-      const int tok = i / D, r = i - tok * D;
-      float v = 0.f;
-      if (tok < NTOK) v = ek[((int64_t)b * NTOK + tok) * D + r] + tf * wk[(int64_t)r * wk_stride];
-      k2s[tok * CA_KP + r] = v;
-    }
-    for (int i = tid; i < NTOK * D; i += 256) {
-      const int tok = i / D, r = i - tok * D;
-      v2s[tok * CA_VP + r] = P[((int64_t)b * NTOK + tok) * ldp + v2_off + r];
-    }
-  }
-  float qb[5][2];
-#pragma unroll
-  for (int s = 0; s < 5; ++s)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int tok = 4 * s + kq;
-      qb[s][nt] = tok < NTOK ? P[((int64_t)b * NTOK + tok) * ldp + q2_off + cb * 32 + nt * 16 + lr] * scale : 0.f;
-    }
-  __syncthreads();
-
-  f32x4 L[8][2];
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    L[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    L[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      const float a = k2s[(4 * s + kq) * CA_KP + (wave * 8 + mt) * 16 + lr];
-      L[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qb[s][0], L[mt][0], 0, 0, 0);
-      L[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qb[s][1], L[mt][1], 0, 0, 0);
-    }
-  }
-  // column max over the 512 rows (lane: column lr of n-tile nt, rows 16 mt + 4 kq + j of this wave's 8 m-tiles)
-  float mx[2], sm[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    float m = L[0][nt][0];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m = fmaxf(m, L[mt][nt][j]);
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    mx[nt] = m;
-    if (kq == 0) redm[wave * 32 + nt * 16 + lr] = m;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    float m = redm[nt * 16 + lr];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) m = fmaxf(m, redm[w * 32 + nt * 16 + lr]);
-    float s = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float e = expf(L[mt][nt][j] - m);
-        L[mt][nt][j] = e;
-        s += e;
-      }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    sm[nt] = s;
-    if (kq == 0) reds[wave * 32 + nt * 16 + lr] = s;
-  }
-  (void)mx;
-  // t partial over this wave's rows
-  f32x4 T[2][2];
-#pragma unroll
-  for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) T[mt2][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int tok1 = 16 + lr;
-  const bool ok1 = tok1 < NTOK;
-  const float* va0 = v2s + lr * CA_VP + wave * 128 + kq * 4;
-  const float* va1 = v2s + (ok1 ? tok1 : NTOK - 1) * CA_VP + wave * 128 + kq * 4;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a0 = va0[mt * 16 + j];
-      const float a1 = ok1 ? va1[mt * 16 + j] : 0.f;
-      T[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, L[mt][0][j], T[0][0], 0, 0, 0);
-      T[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, L[mt][1][j], T[0][1], 0, 0, 0);
-      T[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, L[mt][0][j], T[1][0], 0, 0, 0);
-      T[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, L[mt][1][j], T[1][1], 0, 0, 0);
-    }
-  if (wave > 0) {
-#pragma unroll
-    for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tpart[(((wave - 1) * 4 + mt2 * 2 + nt) * 4 + j) * 64 + lane] = T[mt2][nt][j];
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    float den = reds[nt * 16 + lr];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) den += reds[w * 32 + nt * 16 + lr];
-    const float inv = 1.f / den;
-#pragma unroll
-    for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = T[mt2][nt][j];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) v += tpart[(((w - 1) * 4 + mt2 * 2 + nt) * 4 + j) * 64 + lane];
-        const int tok = mt2 * 16 + kq * 4 + j;
-        if (tok < NTOK) tout[((int64_t)b * NTOK + tok) * D + cb * 32 + nt * 16 + lr] = v * inv;
-      }
-  }
-  (void)sm;
+  vsptacc::chan_attn_mfma_body(tout, P, ldp, q2_off, v2_off, ek, wk, wk_stride, tf, scale, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

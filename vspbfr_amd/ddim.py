@@ -83,12 +83,13 @@ class DDIMSampler(object):
         fused = eta == 0. and hasattr(net, "chain_supported") and net.chain_supported(cond)
         if fused:
             state = net.prepare_chain(cond, self.ddpm_num_timesteps)
-            pn = H.pixelnorm_dim1(x)
+            order = list(reversed(range(total)))
+            x = x.clone() if x_T is not None else x  # updated in place
+            x = H.tacc_chain(x, state, [int(self.ddim_timesteps[i]) for i in order], coef_idx=order, c1=self.coef_e,
+                             c2=self.coef_x, t_div=net.max_period)
+            return x, {"x_inter": [x], "pred_x0": []}
         for index in reversed(range(total)):
             step = int(self.ddim_timesteps[index])
-            if fused:
-                x, pn = net.chain_step(x, pn, state, step, self.coef_e, self.coef_x, coef_idx=index)
-                continue
             ts = torch.full((cond.shape[0],), step, device=cond.device, dtype=torch.long)
             e_t = net(x, cond, ts)
             x = H.axpby_idx(e_t.contiguous(), x, self.coef_e, self.coef_x, index)

@@ -125,7 +125,9 @@ class Code_diffuser(nn.Module):
         embd = embd.contiguous()
         return self.run(x.contiguous(), self.condition(self.embed(embd), t, embd.shape[1]))
 
-    # ---- fused sampler path (all samples share t): 4 launches per block and step, see csrc/tacc.hip
+    # ---- fused sampler path (all samples share t): `prepare_chain` + ONE vsp_tacc_chain_f32 call for the whole sampler
+    # (csrc/tacc_chain.hip: 3 launches per block and step, enqueued from C); `chain_step` is the per-step form of the
+    # same computation on the per-launch entry points (csrc/tacc.hip), kept for callers that drive the loop themselves
     def _wcat(self, blk):
         srcs = [blk.k_matrix.weight, blk.v_matrix.weight, blk.attention_layer.q_matrix.weight, blk.attention_layer.v_matrix.weight]
         store = self.__dict__.setdefault("_wcat_cache", {})
@@ -254,10 +256,9 @@ class My_DDPM(nn.Module):
         if (self.parameterization == "x0" and not self.clip_denoised and hasattr(self.model, "chain_supported")
                 and self.model.chain_supported(cond) and self.num_timesteps <= self.model.max_period):
             state = self.model.prepare_chain(cond, self.num_timesteps)
-            pn = H.pixelnorm_dim1(x)
-            for i in reversed(range(self.num_timesteps)):
-                x, pn = self.model.chain_step(x, pn, state, i, self.posterior_mean_coef1, self.posterior_mean_coef2)
-            return x
+            x = x.clone() if x_T is not None else x  # the chain updates x in place
+            return H.tacc_chain(x, state, list(reversed(range(self.num_timesteps))), c1=self.posterior_mean_coef1,
+                                c2=self.posterior_mean_coef2, t_div=self.model.max_period)
         emb = self.model.embed(cond)  # step-independent half of every Linear(513)
         for i in reversed(range(self.num_timesteps)):
             t = torch.full((B,), i, device=cond.device, dtype=torch.long)

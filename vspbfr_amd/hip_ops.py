@@ -494,6 +494,41 @@ def tacc_head_pre(e, wcol, ln_w, ln_b, steps, t_div):
     return out
 
 
+def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None):
+    """Run the whole sampler chain in place on x (B,18,512): for each t in `steps` (host ints, execution order) x <- c1[k] *
+    denoiser(x, t) + c2[k] * x with k = coef_idx[s] (default t); c1 = c2 = None: x <- denoiser(x, t).  `blocks`: one dict per
+    TACC block with device tensors wcat, eQ, ek, wq, wk, gamma, beta (gamma/beta: (head_steps, B, 18, 512))."""
+    from ._lib import TaccBlock, TaccChainParams
+    x = _req(x, "x")
+    B = x.shape[0]
+    n = len(blocks)
+    arr = (TaccBlock * n)()
+    keep = []
+    for i, blk in enumerate(blocks):
+        for name in ("wcat", "eQ", "ek", "wq", "wk", "gamma", "beta"):
+            t = _req(blk[name], name)
+            keep.append(t)
+            setattr(arr[i], name, t.data_ptr())
+    if head_steps is None:
+        head_steps = blocks[0]["gamma"].shape[0] if n else 0
+    nfl = lib.vsp_tacc_chain_work_floats(B)
+    work = torch.empty(nfl, device=x.device, dtype=torch.float32)
+    steps = [int(s) for s in steps]
+    st = (C.c_int * len(steps))(*steps)
+    ci = (C.c_int * len(steps))(*[int(k) for k in coef_idx]) if coef_idx is not None else None
+    p = TaccChainParams()
+    p.B, p.n_tok, p.dim, p.n_blocks = B, 18, 512, n
+    p.blocks = arr
+    p.x, p.work, p.work_floats = x.data_ptr(), work.data_ptr(), nfl
+    p.n_steps, p.step = len(steps), st
+    p.coef_idx = ci
+    p.c1 = _opt(c1, "c1").data_ptr() if c1 is not None else None
+    p.c2 = _opt(c2, "c2").data_ptr() if c2 is not None else None
+    p.t_div, p.head_steps = float(t_div), int(head_steps)
+    check(lib.vsp_tacc_chain_f32(C.byref(p), _stream()), "tacc_chain")
+    return x
+
+
 def quantize_u8_nhwc(x, lo=-1.0, hi=1.0):
     """(B, C, H, W) fp32 -> (B, H, W, C) uint8 with torchvision's save_image(normalize=True, value_range=(lo, hi)) rounding."""
     x = _req(x, "x")
