@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void tacc_chan_attn_kernel(float* __restrict__
 }
 
 
-__global__ __launch_bounds__(256) void tacc_chan_attn_mfma_kernel(float* __restrict__ tout, const float* __restrict__ P,
+__global__ __launch_bounds__(64 * vsptacc::CA_NW) void tacc_chan_attn_mfma_kernel(float* __restrict__ tout, const float* __restrict__ P,
                                                                    int ldp, int q2_off, int v2_off,
                                                                    const float* __restrict__ ek, const float* __restrict__ wk,
                                                                    int wk_stride, float tf, float scale) {
@@ -328,7 +328,7 @@ int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2
   VSP_REQUIRE(t && P && ek && wk, "tacc_chan_attn: null pointer");
   static const bool use_valu = getenv("VSP_TACC_VALU") != nullptr;  // the first (VALU/LDS) version, kept for A/B runs
   const size_t lds = use_valu ? (size_t)(2 * NTOK * D + D * CA_PITCH + 8 * 32) * sizeof(float)
-                              : (size_t)(20 * CA_KP + NTOK * CA_VP + 256 + 3 * 4 * 4 * 64) * sizeof(float);
+                              : vsptacc::CA_LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_chan_attn_kernel),
@@ -344,7 +344,7 @@ int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2
     tacc_chan_attn_kernel<<<grid, 256, lds, vsp::as_stream(stream)>>>(t, P, ldp, q2_off, v2_off, ek, wk, wk_stride, tfrac,
                                                                       1.0f / sqrtf((float)D));
   else
-    tacc_chan_attn_mfma_kernel<<<grid, 256, lds, vsp::as_stream(stream)>>>(t, P, ldp, q2_off, v2_off, ek, wk, wk_stride,
+    tacc_chan_attn_mfma_kernel<<<grid, 64 * vsptacc::CA_NW, lds, vsp::as_stream(stream)>>>(t, P, ldp, q2_off, v2_off, ek, wk, wk_stride,
                                                                            tfrac, 1.0f / sqrtf((float)D));
   return vsp::check_launch("tacc_chan_attn");
 }

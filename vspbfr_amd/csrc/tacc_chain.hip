@@ -10,10 +10,11 @@
 //               18 tokens is computed from the A fragments the wave holds anyway (DPP row reductions), so the previous
 //               block never has to produce a normalised copy and needs no cross-row step.
 //   tacc_attn   heterogeneous grid: workgroups [0, 16B) run the 512x512 channel attention on MFMA (tacc_kernels.h),
-//               workgroups after that run the 18x18 token attention, one wave per token row, Q/V rows straight from L2.
+//               workgroups after that run the 18x18 token attention, one wave per token row (8 rows per workgroup), Q/V rows straight from L2.
 //   tacc_post   one wave per token row: LN(t), LN(h + LN(t)), FiLM, and after the last block the sampler update
 //               x' = c1[k] f(x) + c2[k] x, in place.
 #include "tacc_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -43,96 +44,106 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // P[b*18 + i][n] = sum_c y[b,i,c] * r[b,c] * W[n][c],  r[b,c] = rsqrt(mean_i y[b,i,c]^2 + 1e-8)   (PixelNorm over tokens,
-// models/CodeDiffuser.py:11-12).  grid (N/32, B), 64*KW threads.  k-permutation fragments as in gemm_small.hip: lane
+// models/CodeDiffuser.py:11-12).  grid (N/32) * B, 64*KW threads.  k-permutation fragments as in gemm_small.hip: lane
 // (row lr, slot kq) holds the float4 [row][k0 + 4 kq .. + 3]; MFMA j of a k-step uses component j on both sides.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PJ_KW = 8;                  // waves splitting K
 constexpr int PJ_NS = D / 16 / PJ_KW;     // 16-wide k-steps per wave
+constexpr int PJ_NJ = 4;                  // 16-column blocks per workgroup: the PixelNorm VALU work is redone per workgroup
+                                          // of a sample, so wider tiles (fewer workgroups per sample) cut it
 
 __global__ __launch_bounds__(64 * PJ_KW) void tacc_proj_kernel(float* __restrict__ P, const float* __restrict__ y,
                                                                const float* __restrict__ W, int ldp) {
-  __shared__ float red[(PJ_KW - 1) * 16 * 64];
+  constexpr int NJ = PJ_NJ;
+  extern __shared__ __attribute__((aligned(16))) float pj_smem[];
+  float* red = pj_smem;                            // MFMA partials of every wave: [wave][j][r][lane]
+  float* red2 = pj_smem + PJ_KW * NJ * 4 * 64;     // rows 16, 17: [wave][kq][row][j][lr]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 32, b = blockIdx.y;
+  // XCD-aware mapping: workgroups go round-robin over the 8 XCDs by linear id; XCD x always gets the SAME eighth of the
+  // output columns (for every sample and every step), so each XCD only ever touches its 0.5 MB slice of a block's weights.
+  constexpr int TPX = 4 * D / (16 * NJ) / 8;  // column tiles per XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n0 = (xcd * TPX + slot % TPX) * (16 * NJ), b = slot / TPX;
   const float* y0 = y + ((int64_t)b * NTOK + lr) * D + 4 * kq;
-  const float* y1 = y + ((int64_t)b * NTOK + 16 + (lr < 2 ? lr : 0)) * D + 4 * kq;
+  const float* y16 = y + ((int64_t)b * NTOK + 16) * D + 4 * kq;  // rows 16, 17: same address in the 16 lanes of a k slot
   const float* w0 = W + (int64_t)(n0 + lr) * D + 4 * kq;
-  const float* w1 = w0 + 16 * D;
 
-  float4 a0[PJ_NS], a1[PJ_NS], b0[PJ_NS], b1[PJ_NS];
+  float4 a0[PJ_NS], r16[PJ_NS], r17[PJ_NS], bw[PJ_NS][NJ];
 #pragma unroll
   for (int s = 0; s < PJ_NS; ++s) {
     const int k0 = (wave + PJ_KW * s) * 16;
     a0[s] = *reinterpret_cast<const float4*>(y0 + k0);
-    a1[s] = *reinterpret_cast<const float4*>(y1 + k0);
-    b0[s] = *reinterpret_cast<const float4*>(w0 + k0);
-    b1[s] = *reinterpret_cast<const float4*>(w1 + k0);
+    r16[s] = *reinterpret_cast<const float4*>(y16 + k0);
+    r17[s] = *reinterpret_cast<const float4*>(y16 + D + k0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bw[s][j] = *reinterpret_cast<const float4*>(w0 + (int64_t)j * 16 * D + k0);
   }
-  f32x4 acc[2][2];
+  __builtin_amdgcn_sched_barrier(0);  // keep every load in flight together (the scheduler would sink half of them)
+  // Rows 0..15 of the sample run on MFMA; rows 16 and 17 would cost a second, 7/8 empty MFMA row block (half of all matrix
+  // time), so they are plain FMAs against the B fragments the lane already holds: e[row][j] = partial of
+  // (row, column n0 + 16 j + lr) over this lane's four k -- summed over k slots and waves through LDS at the end.
+  f32x4 acc[NJ];
+  float e[2][NJ];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NJ; ++j) {
+    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    e[0][j] = e[1][j] = 0.f;
+  }
 #pragma unroll
   for (int s = 0; s < PJ_NS; ++s) {
-    if (lr >= 2) a1[s] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows 18..31 of the padded sample
-    float4 a = a0[s], c = a1[s];
-    const float rx = rsqrtf(row16_sum(fmaf(a.x, a.x, c.x * c.x)) * (1.f / NTOK) + 1e-8f);
-    const float ry = rsqrtf(row16_sum(fmaf(a.y, a.y, c.y * c.y)) * (1.f / NTOK) + 1e-8f);
-    const float rz = rsqrtf(row16_sum(fmaf(a.z, a.z, c.z * c.z)) * (1.f / NTOK) + 1e-8f);
-    const float rw = rsqrtf(row16_sum(fmaf(a.w, a.w, c.w * c.w)) * (1.f / NTOK) + 1e-8f);
+    float4 a = a0[s], p = r16[s], q = r17[s];
+    const float rx = rsqrtf((row16_sum(a.x * a.x) + fmaf(p.x, p.x, q.x * q.x)) * (1.f / NTOK) + 1e-8f);
+    const float ry = rsqrtf((row16_sum(a.y * a.y) + fmaf(p.y, p.y, q.y * q.y)) * (1.f / NTOK) + 1e-8f);
+    const float rz = rsqrtf((row16_sum(a.z * a.z) + fmaf(p.z, p.z, q.z * q.z)) * (1.f / NTOK) + 1e-8f);
+    const float rw = rsqrtf((row16_sum(a.w * a.w) + fmaf(p.w, p.w, q.w * q.w)) * (1.f / NTOK) + 1e-8f);
     a.x *= rx; a.y *= ry; a.z *= rz; a.w *= rw;
-    c.x *= rx; c.y *= ry; c.z *= rz; c.w *= rw;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[s].x, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[s].x, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, b0[s].x, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.x, b1[s].x, acc[1][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[s].y, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[s].y, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, b0[s].y, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.y, b1[s].y, acc[1][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[s].z, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[s].z, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, b0[s].z, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.z, b1[s].z, acc[1][1], 0, 0, 0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[s].w, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[s].w, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, b0[s].w, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c.w, b1[s].w, acc[1][1], 0, 0, 0);
+    p.x *= rx; p.y *= ry; p.z *= rz; p.w *= rw;
+    q.x *= rx; q.y *= ry; q.z *= rz; q.w *= rw;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const float4 w = bw[s][j];
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[j], 0, 0, 0);
+      e[0][j] = fmaf(p.x, w.x, fmaf(p.y, w.y, fmaf(p.z, w.z, fmaf(p.w, w.w, e[0][j]))));
+      e[1][j] = fmaf(q.x, w.x, fmaf(q.y, w.y, fmaf(q.z, w.z, fmaf(q.w, w.w, e[1][j]))));
+    }
   }
-  // K-slice reduction through LDS; wave 0 stores.  D layout: lane holds column lr, rows kq*4 + r of each 16-row block.
-  if (wave > 0) {
+  // K-slice reduction through LDS, spread over all waves: wave w finishes the (j, r) accumulator registers w, w + KW, ...
+  // (D layout: lane holds column lr, row kq*4 + r) and the first two waves the rows 16 / 17.
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+  for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[(((wave - 1) * 4 + m * 2 + j) * 4 + r) * 64 + lane] = acc[m][j][r];
+    for (int r = 0; r < 4; ++r) red[((wave * NJ + j) * 4 + r) * 64 + lane] = acc[j][r];
+    red2[(((wave * 4 + kq) * 2 + 0) * NJ + j) * 16 + lr] = e[0][j];
+    red2[(((wave * 4 + kq) * 2 + 1) * NJ + j) * 16 + lr] = e[1][j];
   }
   __syncthreads();
-  if (wave > 0) return;
+  for (int jr = wave; jr < NJ * 4; jr += PJ_KW) {
+    float v = 0.f;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int w = 0; w < PJ_KW; ++w) v += red[(w * NJ * 4 + jr) * 64 + lane];
+    P[((int64_t)b * NTOK + kq * 4 + (jr & 3)) * ldp + n0 + (jr >> 2) * 16 + lr] = v;
+  }
+  if (wave < 2) {  // row 16 + wave: lane -> column (kq, lr) of the first four column blocks, then the next four, ...
+    for (int j = kq; j < NJ; j += 4) {
+      float v = 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[m][j][r];
-#pragma unroll
-        for (int w = 1; w < PJ_KW; ++w) v += red[(((w - 1) * 4 + m * 2 + j) * 4 + r) * 64 + lane];
-        const int row = m * 16 + kq * 4 + r;
-        if (row < NTOK) P[((int64_t)b * NTOK + row) * ldp + n0 + j * 16 + lr] = v;
-      }
+      for (int i = 0; i < PJ_KW * 4; ++i) v += red2[((i * 2 + wave) * NJ + j) * 16 + lr];
+      P[((int64_t)b * NTOK + 16 + wave) * ldp + n0 + j * 16 + lr] = v;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Channel attention (workgroups [0, 16 B)) and token attention (the rest, 4 token rows per workgroup) in one launch.
+// Channel attention (workgroups [0, 16 B)) and token attention (the rest, one token row per wave) in one launch.
 // Token attention, wave = row (b, i), lane owns channels 4 lane + 256 u + {0..3}:
 //   s_j = K_i . (eQ_j + tf wq) / sqrt(18);  p = softmax_j(s);  h_i = sum_j p_j V_j
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tacc_attn_kernel(float* __restrict__ tout, float* __restrict__ hout,
+__global__ __launch_bounds__(64 * vsptacc::CA_NW) void tacc_attn_kernel(float* __restrict__ tout, float* __restrict__ hout,
                                                         const float* __restrict__ P, int ldp, const float* __restrict__ ek,
                                                         const float* __restrict__ wk, const float* __restrict__ eQ,
                                                         const float* __restrict__ wq, float tf, int B) {
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256) void tacc_attn_kernel(float* __restrict__ tout
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int row = ((int)blockIdx.x - nca) * 4 + (threadIdx.x >> 6);
+  const int row = ((int)blockIdx.x - nca) * vsptacc::CA_NW + (threadIdx.x >> 6);
   if (row >= B * NTOK) return;
   const int b = row / NTOK;
   const float sscale = 0.23570226039551584f;  // 1/sqrt(18)
@@ -285,10 +296,14 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
                 "tacc_chain: block %d operands must be 16-byte aligned", i);
   }
   static bool attr_set = false;
-  const size_t lds = (size_t)(20 * vsptacc::CA_KP + NTOK * vsptacc::CA_VP + 256 + 3 * 4 * 4 * 64) * sizeof(float);
+  const size_t lds = vsptacc::CA_LDS_FLOATS * sizeof(float);
+  constexpr size_t pj_lds = (size_t)(PJ_KW * PJ_NJ * 4 * 64 + PJ_KW * 4 * 2 * PJ_NJ * 16) * sizeof(float);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_attn_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)pj_lds);
     if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_chain: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
@@ -308,8 +323,8 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
     for (int bi = 0; bi < p.n_blocks; ++bi) {
       const vsp_tacc_block& k = p.blocks[bi];
       const bool last = bi == p.n_blocks - 1;
-      tacc_proj_kernel<<<dim3(4 * D / 32, p.B), 64 * PJ_KW, 0, st>>>(P, cur, k.wcat, 4 * D);
-      tacc_attn_kernel<<<16 * p.B + row_blocks, 256, lds, st>>>(tb, hb, P, 4 * D, k.ek, k.wk, k.eQ, k.wq, tf, p.B);
+      tacc_proj_kernel<<<(4 * D / (16 * PJ_NJ)) * p.B, 64 * PJ_KW, pj_lds, st>>>(P, cur, k.wcat, 4 * D);
+      tacc_attn_kernel<<<16 * p.B + (M + vsptacc::CA_NW - 1) / vsptacc::CA_NW, 64 * vsptacc::CA_NW, lds, st>>>(tb, hb, P, 4 * D, k.ek, k.wk, k.eQ, k.wq, tf, p.B);
       float* out = last ? p.x : yb[bi & 1];
       const size_t hoff = (size_t)step * M * D;
       tacc_post_kernel<<<row_blocks, 256, 0, st>>>(out, hb, tb, k.gamma + hoff, k.beta + hoff,
