@@ -48,18 +48,26 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int
 }
 
 constexpr int TOH = 32;  // output tile rows
-constexpr int TOW = 64;  // output tile cols (one wave = one row segment of 64 -> 256 B coalesced stores)
-constexpr int ROWS_PER_THREAD = 8;
+constexpr int TOW = 64;  // output tile cols
 
+// 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// One 256-thread block produces a 32x64 output tile of one plane.  Throughput shape: (1) the (32+KH-1) x 68 input window is
+// fetched as three 16-byte loads per thread, ALL issued before the first LDS write (the first version ran ten dependent
+// load -> LDS round trips per block); (2) each thread owns a 2x4 output patch: (KH+1) x 2 ds_read_b128 feed 8 outputs;
+// (3) the epilogue operands (noise, two residuals) are fetched as 16-byte vectors before the FMAs, the result leaves as
+// 16-byte stores.
 template <int KH, int KW>
 __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                         const float* __restrict__ kern, int in_h, int in_w,
                                                         int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
                                                         int tiles_y, Epi epi) {
   constexpr int TIH = TOH + KH - 1;
-  constexpr int TIW = TOW + KW - 1;
-  constexpr int LDW = TIW + 1;  // odd-ish pitch; reads are row-contiguous per wave so conflicts are not an issue
-  __shared__ float tile[TIH * LDW];
+  constexpr int TIW4 = (TOW + KW - 1 + 3) / 4;  // float4 per staged row (17: one spare column for KW = 4)
+  constexpr int LDW = TIW4 * 4;
+  constexpr int NLD = (TIH * TIW4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float tile[TIH * LDW];
 
   const int bid = blockIdx.x;
   const int tx_i = bid % tiles_x;
@@ -69,6 +77,24 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
   const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
   const float* xp = x + (int64_t)plane * in_h * in_w;
 
+  f32x4u v[NLD];
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    const int r = idx / TIW4, c4 = idx - r * TIW4;
+    const int iy = iy0 + r, ix = ix0 + 4 * c4;
+    v[it] = f32x4u{0.f, 0.f, 0.f, 0.f};
+    if (idx < TIH * TIW4 && iy >= 0 && iy < in_h) {
+      const float* src = xp + (int64_t)iy * in_w + ix;
+      if (ix >= 0 && ix + 3 < in_w) {
+        v[it] = *reinterpret_cast<const f32x4u*>(src);
+      } else {  // window crosses the left/right image border
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ix + j >= 0 && ix + j < in_w) v[it][j] = src[j];
+      }
+    }
+  }
   // flipped taps -> registers (wave-uniform loads)
   float taps[KH][KW];
 #pragma unroll
@@ -76,41 +102,94 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) taps[ky][kx] = kern[(KH - 1 - ky) * KW + (KW - 1 - kx)];
 
-  for (int i = threadIdx.x; i < TIH * TIW; i += 256) {
-    const int r = i / TIW, c = i - r * TIW;
-    const int iy = iy0 + r, ix = ix0 + c;
-    float v = 0.f;
-    if (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(int64_t)iy * in_w + ix];
-    tile[r * LDW + c] = v;
+  // this thread's 2 x 4 outputs and their epilogue operands (requested now, consumed after the FMAs)
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int ox = ox0 + 4 * tx, oyb = oy0 + 2 * ty;
+  const bool full = ox + 3 < out_w;
+  const int c = plane % epi.channels, b = plane / epi.channels;
+  f32x4u nz[2], r1[2], r2[2];
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    nz[rr] = r1[rr] = r2[rr] = f32x4u{0.f, 0.f, 0.f, 0.f};
+    const int oy = oyb + rr;
+    if (!epi.enabled || oy >= out_h || ox >= out_w) continue;
+    const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
+    const int64_t on = ((int64_t)b * out_h + oy) * out_w + ox;
+    if (full) {
+      if (epi.noise) nz[rr] = *reinterpret_cast<const f32x4u*>(epi.noise + on);
+      if (epi.res1) r1[rr] = *reinterpret_cast<const f32x4u*>(epi.res1 + o);
+      if (epi.res2) r2[rr] = *reinterpret_cast<const f32x4u*>(epi.res2 + o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ox + j < out_w) {
+          if (epi.noise) nz[rr][j] = epi.noise[on + j];
+          if (epi.res1) r1[rr][j] = epi.res1[o + j];
+          if (epi.res2) r2[rr][j] = epi.res2[o + j];
+        }
+    }
+  }
+  float pscale = 1.f, nw = 0.f, ab = 0.f;
+  if (epi.enabled) {
+    if (epi.plane_scale) pscale = epi.plane_scale[plane];
+    if (epi.noise) nw = epi.noise_w[0];
+    if (epi.act && epi.act_bias) ab = epi.act_bias[c];
+  }
+
+#pragma unroll
+  for (int it = 0; it < NLD; ++it) {
+    const int idx = threadIdx.x + 256 * it;
+    if (idx < TIH * TIW4) *reinterpret_cast<float4*>(tile + idx * 4) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
   }
   __syncthreads();
 
-  const int col = threadIdx.x & 63;
-  const int row0 = (threadIdx.x >> 6) * ROWS_PER_THREAD;
-  const int ox = ox0 + col;
-  float win[KH][KW];
+  float acc[2][4];
 #pragma unroll
-  for (int ky = 0; ky < KH - 1; ++ky)
+  for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-    for (int kx = 0; kx < KW; ++kx) win[ky + 1][kx] = tile[(row0 + ky) * LDW + col + kx];
-
+    for (int j = 0; j < 4; ++j) acc[rr][j] = 0.f;
 #pragma unroll
-  for (int r = 0; r < ROWS_PER_THREAD; ++r) {
+  for (int wr = 0; wr < KH + 1; ++wr) {  // window row wr feeds output row 0 with tap row wr and output row 1 with tap row wr-1
+    const float* rp = tile + (2 * ty + wr) * LDW + 4 * tx;
+    const float4 lo = *reinterpret_cast<const float4*>(rp);
+    const float4 hi = (KW > 1) ? *reinterpret_cast<const float4*>(rp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int ky = 0; ky < KH - 1; ++ky)
+    for (int rr = 0; rr < 2; ++rr) {
+      const int ky = wr - rr;
+      if (ky < 0 || ky >= KH) continue;
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) win[ky][kx] = win[ky + 1][kx];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int kx = 0; kx < KW; ++kx) win[KH - 1][kx] = tile[(row0 + r + KH - 1) * LDW + col + kx];
-    float acc = 0.f;
+        for (int kx = 0; kx < KW; ++kx) acc[rr][j] = fmaf(taps[ky][kx], w[j + kx], acc[rr][j]);
+    }
+  }
 #pragma unroll
-    for (int ky = 0; ky < KH; ++ky)
+  for (int rr = 0; rr < 2; ++rr) {
+    const int oy = oyb + rr;
+    if (oy >= out_h || ox >= out_w) continue;
+    f32x4u o4;
 #pragma unroll
-      for (int kx = 0; kx < KW; ++kx) acc = fmaf(taps[ky][kx], win[ky][kx], acc);
-    const int oy = oy0 + row0 + r;
-    if (oy < out_h && ox < out_w) {
-      acc = epi_apply(epi, acc, plane, oy, ox, out_h, out_w);
-      out[((int64_t)plane * out_h + oy) * out_w + ox] = acc;
+    for (int j = 0; j < 4; ++j) {
+      float a = acc[rr][j];
+      if (epi.enabled) {
+        a = fmaf(nz[rr][j], nw, a * pscale);
+        if (epi.act) {
+          a += ab;
+          a = (a > 0.f ? a : a * epi.slope) * epi.gain;
+        }
+        a += r1[rr][j];
+        a += r2[rr][j];
+      }
+      o4[j] = a;
+    }
+    float* dst = out + ((int64_t)plane * out_h + oy) * out_w + ox;
+    if (full) {
+      *reinterpret_cast<f32x4u*>(dst) = o4;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ox + j < out_w) dst[j] = o4[j];
     }
   }
 }
@@ -172,6 +251,7 @@ extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel
   VSP_REQUIRE((int64_t)major * in_h * in_w * minor < (int64_t)1 << 40, "upfirdn2d: tensor too large");
 
   Epi e{};
+  e.channels = 1;
   if (epi_in) {
     VSP_REQUIRE(minor == 1, "upfirdn2d: fused epilogue needs minor == 1");
     VSP_REQUIRE(epi_in->channels >= 1 && major % epi_in->channels == 0,
