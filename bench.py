@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm", help="ddim = BASELINE configs[2]'s sampler (fp32 here)")
     ap.add_argument("--ddim-steps", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="plain per-batch loop (no A+B / C+D stream overlap across batches)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -118,9 +119,19 @@ def main():
     g = torch.Generator(device=dev).manual_seed(123 + rank)
     lq = torch.rand(B, 3, 512, 512, device=dev, generator=g) * 2 - 1
 
-    def step():
-        out = pipe(lq)["restored"]
-        return gather_restored(out) if world > 1 else out
+    def run(n):
+        """n steps = n batches through A+B+C+D.  --overlap (default): RestorationPipeline.run_batches, i.e. stages A+B of
+        batch i+1 are enqueued on a second HIP stream before stages C+D of batch i (the first batch's A+B is not hidden);
+        every batch is complete when the closing synchronize returns."""
+        res = None
+        if args.no_overlap:
+            for _ in range(n):
+                res = pipe(lq)["restored"]
+                res = gather_restored(res) if world > 1 else res
+        else:
+            for o in pipe.run_batches(lq for _ in range(n)):
+                res = gather_restored(o["restored"]) if world > 1 else o["restored"]
+        return res
 
     def sync():
         if world > 1:
@@ -128,14 +139,21 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+        run(args.warmup)
+        iso = None
+        if not args.no_overlap:
+            # one extra UNTIMED serial step with per-launch events: the conv kernels' durations with nothing else on the GPU
+            # (in the timed, overlapped region a conv's event interval also contains the side stream's kernels)
+            iso = hip_ops.ConvProfiler()
+            hip_ops.PROFILER = iso
+            pipe(lq)
+            hip_ops.PROFILER = None
+            torch.cuda.synchronize()
         prof = hip_ops.ConvProfiler()
         hip_ops.PROFILER = prof
         sync()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            res = step()
+        res = run(args.steps)
         sync()
         dt = time.perf_counter() - t0
         hip_ops.PROFILER = None
@@ -158,6 +176,7 @@ def main():
                                    "forward, fp32, random-init weights",
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
                        "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
+                       "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": conv_traffic(B, args),
@@ -166,6 +185,13 @@ def main():
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
                          "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK_FP32_TFLOPS * world), 4)},
         }
+        if iso is not None:
+            fl, ms, n = iso.summary()
+            line["roofline"]["isolated"] = {
+                "note": "same kernels in one untimed serial step (no second stream): per-launch durations without the "
+                        "overlapped A+B work inside the event intervals",
+                "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                "kernel_ms_per_step": round(ms, 2), "launches": n}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(args.timesteps, threads)

@@ -214,6 +214,32 @@ def test_conv2d_dilation_groups_into_slices(H):
     close(H.conv2d_packed(dev(x), pc), ref, 2e-5, 2e-5)
 
 
+@pytest.mark.parametrize("B,Cin,Cg,Hh,Ww", [(2, 16, 8, 24, 24), (1, 24, 16, 37, 21), (2, 64, 32, 32, 32), (1, 40, 20, 16, 48)])
+def test_conv2d_dilation_groups_fused_kernels(H, B, Cin, Cg, Hh, Ww):
+    """Every 'd' configuration (four dilated branches from one staged patch) incl. style scale, demod and the epilogue."""
+    from vspbfr_amd._lib import lib
+    x = torch.randn(B, Cin, Hh, Ww)
+    ws = [torch.randn(Cg, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(4)]
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, 4 * Cg) + 0.5, torch.randn(4 * Cg)
+    xs = x * s_in.view(B, Cin, 1, 1)
+    ref = torch.cat([F.conv2d(xs, w_, padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1)
+    ref = F.leaky_relu(ref * demod.view(B, -1, 1, 1) + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    ran = 0
+    for c in range(1, lib.vsp_conv2d_num_configs() + 1):
+        if not lib.vsp_conv2d_config_name(c - 1).endswith(b"d"):
+            continue
+        try:
+            y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), tile_hint=c)
+        except RuntimeError as ex:
+            assert "does not fit" in str(ex), str(ex)
+            continue
+        close(y, ref, 3e-5, 3e-5, f"cfg {lib.vsp_conv2d_config_name(c - 1)}")
+        ran += 1
+    assert ran >= 3
+
+
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 12, 8, 8), (1, 16, 16, 5, 9), (1, 64, 32, 32, 32)])
 def test_conv_transpose_s2_phases(H, B, Cin, Cout, Hh, Ww):
     x = torch.randn(B, Cin, Hh, Ww)

@@ -13,6 +13,8 @@ extern const Cfg kCfgsC[];
 extern const int kNumC;
 extern const Cfg kCfgsD[];
 extern const int kNumD;
+extern const Cfg kCfgsE[];
+extern const int kNumE;
 }  // namespace vspconv
 
 namespace {
@@ -34,6 +36,7 @@ static void build_table() {
   for (int i = 0; i < vspconv::kNumB && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsB[i];
   for (int i = 0; i < vspconv::kNumC && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsC[i];
   for (int i = 0; i < vspconv::kNumD && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsD[i];
+  for (int i = 0; i < vspconv::kNumE && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsE[i];
   kNumCfgs = n;
 }
 
@@ -42,6 +45,7 @@ constexpr size_t kMaxLds = 100 * 1024;  // > 64 KiB needs hipFuncAttributeMaxDyn
 struct Plan {
   int cfg;
   int tw_log2, th, tiles_x, tiles_y, co_tiles;
+  bool dg;
   int strip_col, strip_row;  // transposed mode edge strips (strip_col < 0: ragged tiles instead)
   size_t lds;
 };
@@ -60,11 +64,18 @@ static int host_round_pitch(int n, int odd) {
 
 // Fill the geometry of configuration c for problem p; returns false if it does not fit (LDS / index limits).
 static bool is_tc(const Cfg& k) { return k.name[strlen(k.name) - 1] == 't'; }
+static bool is_dg(const Cfg& k) { return k.name[strlen(k.name) - 1] == 'd'; }
 
 static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const Cfg& k = kCfgs[c];
   const bool tc = is_tc(k);
   if (tc != (p.transposed != 0)) return false;
+  const bool dg = is_dg(k);
+  if (dg) {  // four dilated branches over one input, padding = dilation (SMART / LargeConv layers)
+    if (p.G != 4 || p.x_group_stride != 0 || p.stride_y != 1 || p.stride_x != 1 || p.KH != 3 || p.KW != 3) return false;
+    for (int g = 0; g < 4; ++g)
+      if (p.pad_y[g] != p.dil[g] || p.pad_x[g] != p.dil[g]) return false;
+  }
   const int CO_T = 16 * k.MB * k.WM, NPIX = tc ? 16 * k.WN * (k.NB / 4) : 16 * k.NB * k.WN;
   const int WS = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
   int twl = ilog2_ceil(p.OW);
@@ -98,7 +109,8 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   out->cfg = c;
   out->tw_log2 = twl;
   out->th = TH;
-  out->co_tiles = (p.cout_g + CO_T - 1) / CO_T;
+  out->co_tiles = dg ? (p.cout_g + 15) / 16 : (p.cout_g + CO_T - 1) / CO_T;
+  out->dg = dg;
   out->lds = lds;
   return true;
 }
@@ -109,7 +121,7 @@ static double plan_cost(const vsp_conv_params& p, const Plan& pl) {
   const Cfg& k = kCfgs[pl.cfg];
   const int CO_T = 16 * k.MB * k.WM, NPIX = 16 * k.NB * k.WN;
   const int waves = k.WM * k.WN * k.WK;
-  const double blocks = ((double)pl.tiles_x * pl.tiles_y + (pl.strip_col > 0 ? pl.strip_col + pl.strip_row : 0)) * pl.co_tiles * p.G * p.B;
+  const double blocks = ((double)pl.tiles_x * pl.tiles_y + (pl.strip_col > 0 ? pl.strip_col + pl.strip_row : 0)) * pl.co_tiles * (pl.dg ? 1 : p.G) * p.B;
   const int cin_pad = (p.Cin + k.CK - 1) / k.CK * k.CK;
   // cycles one block needs on one SIMD-set: each wave issues MB*NB MFMAs (32 cyc) per k-step
   const double ksteps = (double)p.KH * p.KW * cin_pad / 4.0;
@@ -252,7 +264,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   }
   const Cfg& k = kCfgs[best.cfg];
   const int CO_T = 16 * k.MB * k.WM;
-  const int64_t gy = (int64_t)best.co_tiles * p.G;
+  const int64_t gy = best.dg ? best.co_tiles : (int64_t)best.co_tiles * p.G;
   VSP_REQUIRE(gy <= 65535 && p.B <= 65535, "conv2d: grid too large");
 
   ConvK q{};

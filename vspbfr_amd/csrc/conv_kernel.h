@@ -68,7 +68,7 @@ __device__ __forceinline__ int round_pitch(int n, int odd) {
   return p >= n ? p : p + 32;
 }
 
-template <int MB, int NB, int WM, int WN, int CK, int WK, int PMAX, int PF, int OCC, bool TC = false>
+template <int MB, int NB, int WM, int WN, int CK, int WK, int PMAX, int PF, int OCC, bool TC = false, bool DG = false>
 __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(const ConvK p) {
   // TC = true: stride-2 transposed 3x3 convolution (conv_transpose2d, padding 0) in ONE pass.  Output (2m+py, 2n+px) only
   // sees taps with ky = py, kx = px (mod 2), so every tap belongs to exactly one of the four sub-pixel phases: the wave's
@@ -80,6 +80,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   // count: NP > 1 (more positions per block) is what buys that back.
   static_assert(!TC || (NB % 4 == 0 && WK == 1), "transposed mode: N-blocks come in groups of four sub-pixel phases");
   constexpr int NP = TC ? NB / 4 : NB;  // 16-wide groups of patch positions per wave
+  // DG = true: the four dilated branches of a SMART / LargeConv layer (G = 4 groups over the SAME input, dilation = padding
+  // = 1, 2, 4, 8) fused in one block: the block's four 16-channel M-blocks are the four GROUPS (16 channels of each), all
+  // fed from ONE staged patch with the largest halo.  Per group the separate launch geometry stages an 18^2 ... 32^2
+  // patch for 256 pixels and reuses a weight slab for 16/32 channels only; fused, one 32^2 patch serves 64 channels.
+  static_assert(!DG || (MB == 4 && WM == 1 && WK == 1 && !TC), "dilation-group mode: M-block = group");
   // PF = 1: one-chunk register prefetch (ILP hides global latency, ~250 VGPRs, 2 waves/SIMD);
   // PF = 0: loads are consumed in the staging phase itself, the register budget (OCC = min waves/SIMD) buys occupancy and
   //         other blocks' MFMAs hide the latency (TLP).
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
   const int tile = blockIdx.x;
   const int tx_i = tile % p.tiles_x, ty_i = tile / p.tiles_x;
-  const int g = blockIdx.y / p.co_tiles;
-  const int co0 = (blockIdx.y % p.co_tiles) * CO_T;  // within the group
+  const int g = DG ? 0 : blockIdx.y / p.co_tiles;
+  const int co0 = DG ? blockIdx.y * 16 : (blockIdx.y % p.co_tiles) * CO_T;  // within the group
   const int b = blockIdx.z;
 
   // Transposed mode, H and W multiples of the tile: the main tiles cover positions [0,H) x [0,W) exactly and the odd
@@ -125,12 +130,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   }
   const int TW = 1 << twl;
   const int gi = p.G > 4 ? 0 : g;  // more than 4 groups = true grouped conv with uniform geometry
-  const int D = p.dil[gi];
+  const int D = DG ? max(max(p.dil[0], p.dil[1]), max(p.dil[2], p.dil[3])) : p.dil[gi];
   const int T = p.KH * p.KW;
   const int PH = TC ? TH + 1 : (TH - 1) * p.sy + (p.KH - 1) * D + 1;
   const int PW = TC ? TW + 1 : (TW - 1) * p.sx + (p.KW - 1) * D + 1;
   const int PS = round_pitch(PH * PW, p.ps_odd);
-  const int iy0 = TC ? oy0 - 1 : oy0 * p.sy - p.pady[gi], ix0 = TC ? ox0 - 1 : ox0 * p.sx - p.padx[gi];
+  const int iy0 = TC ? oy0 - 1 : DG ? oy0 - D : oy0 * p.sy - p.pady[gi];
+  const int ix0 = TC ? ox0 - 1 : DG ? ox0 - D : ox0 * p.sx - p.padx[gi];
 
   float* Wl = smem;                // [T][CK][WS]
   float* Pl = smem + T * CK * WS;  // [CK][PS]
@@ -200,7 +206,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
     const int tap = row / CK, cl = row - tap * CK;
     const bool ok = i < wtotal;
     wdst[w] = ok ? row * WS + c4 * 4 : -1;
-    woff[w] = (ok && co0 + c4 * 4 < p.cout_g) ? (tap * p.Cin + cl) * p.cout_g + co0 + c4 * 4 : -1;
+    if constexpr (DG) {  // slab column block c4 >> 2 = group, 16 channels co0.. of each
+      const int cc = co0 + (c4 & 3) * 4;
+      woff[w] = (ok && cc < p.cout_g) ? ((c4 >> 2) * T * p.Cin + tap * p.Cin + cl) * p.cout_g + cc : -1;
+    } else {
+      woff[w] = (ok && co0 + c4 * 4 < p.cout_g) ? (tap * p.Cin + cl) * p.cout_g + co0 + c4 * 4 : -1;
+    }
   }
 
   auto issue = [&](int ci0) {
@@ -324,6 +335,33 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
               acc[mb][np * 4 + ph] =
                   __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][c4][mb], bf[cur][c4][np], acc[mb][np * 4 + ph], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (DG) {
+      int gbase[4];  // centre offset of group g's taps inside the shared patch
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) gbase[gg] = (D - p.dil[gg]) * (PW + 1);
+      for (int ky = 0; ky < 3; ++ky) {
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* wt = Wl + (ky * 3 + kx) * CK * WS + a_lane;
+          int boff[4];
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg) boff[gg] = gbase[gg] + (ky * PW + kx) * p.dil[gg];
+#pragma unroll
+          for (int c4 = 0; c4 < CK / 4; ++c4) {
+            float a[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) a[gg] = wt[c4 * 4 * WS + gg * 16];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+              float bv[NB];
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) bv[nb] = Pl[c4 * 4 * PS + pixoff[nb] + boff[gg]];
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[gg][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gg], bv[nb], acc[gg][nb], 0, 0, 0);
+            }
+          }
+        }
       }
     } else {
       for (int ky = 0; ky < p.KH; ++ky) {
@@ -456,9 +494,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {  // one channel at a time: 6 parameter registers live instead of 24 (occupancy budget)
-      const int cg = co0 + (wm * MB + mb) * 16 + kq * 4 + r;  // channel within the group
+      const int cg = DG ? co0 + kq * 4 + r : co0 + (wm * MB + mb) * 16 + kq * 4 + r;  // channel within the group
       const bool cok = cg < p.cout_g;
-      const int co = g * p.cout_g + (cok ? cg : 0);
+      const int co = (DG ? mb : g) * p.cout_g + (cok ? cg : 0);
       const float os = osp[co * oss];
       const float cs = p.csp[co * css];
       const float cb = p.cbp[co * cbs];
@@ -501,6 +539,19 @@ struct Cfg {
   }
 
 // transposed (stride-2, 3x3) variants: name suffix "t"
+// same as VSP_CFG with the patch-prefetch depth in the name ("m16": 16 hoisted patch words per lane and channel)
+#define VSP_CFGM(MB, NB, WM, WN, CK, WK, PMAX, PF, OCC)                                                          \
+  {                                                                                                              \
+    MB, NB, WM, WN, CK, WK, PMAX, PF, OCC, #MB "x" #NB "x" #WM "x" #WN "x" #CK "k" #WK "p" #PF "o" #OCC "m" #PMAX, \
+        conv_igemm_kernel<MB, NB, WM, WN, CK, WK, PMAX, PF, OCC>                                                 \
+  }
+
+#define VSP_CFGD(NB, WN, CK, PMAX, PF, OCC)                                                                \
+  {                                                                                                        \
+    4, NB, 1, WN, CK, 1, PMAX, PF, OCC, "4x" #NB "x1x" #WN "x" #CK "k1p" #PF "o" #OCC "d",                  \
+        conv_igemm_kernel<4, NB, 1, WN, CK, 1, PMAX, PF, OCC, false, true>                                 \
+  }
+
 #define VSP_CFGT(MB, NB, WM, WN, CK, PMAX, PF, OCC)                                                        \
   {                                                                                                        \
     MB, NB, WM, WN, CK, 1, PMAX, PF, OCC, #MB "x" #NB "x" #WM "x" #WN "x" #CK "k1p" #PF "o" #OCC "t",       \

@@ -42,17 +42,65 @@ class RestorationPipeline:
         self.mixing, self.with_sample = mixing, with_sample
 
     @torch.no_grad()
-    def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
-        """low_imgs (B,3,512,512) in [-1,1] on the device -> dict(restored, style_sample, latent, pre_latent).
-        All keyword tensors are optional explicit replacements of the reference's RNG draws (parity runs)."""
-        B = low_imgs.shape[0]
-        noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
+    def encode(self, low_imgs, x_T=None):
+        """Stages A + B: (low_latent, pre_dic_latent).  Small-map convolutions and the latency-bound sampler chain."""
         low_latent = self.psp.get_w_plus(low_imgs)
         pre = self.diffusion(x=low_latent, condi_in=low_latent, training=False, x_T=x_T)
+        return low_latent, pre
+
+    @torch.no_grad()
+    def decode(self, low_imgs, low_latent, pre, z=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
+        """Stages C + D: the StyleGAN2 prior and the restoration network (the compute-bound 97 % of the FLOPs)."""
+        B = low_imgs.shape[0]
+        noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
         sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
         restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
                                   dec_noise=dec_noise)
         return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
+
+    @torch.no_grad()
+    def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
+        """low_imgs (B,3,512,512) in [-1,1] on the device -> dict(restored, style_sample, latent, pre_latent).
+        All keyword tensors are optional explicit replacements of the reference's RNG draws (parity runs)."""
+        low_latent, pre = self.encode(low_imgs, x_T=x_T)
+        return self.decode(low_imgs, low_latent, pre, z=z, gen_noise=gen_noise, enc_noise=enc_noise, dec_noise=dec_noise,
+                           inject_index=inject_index)
+
+    @torch.no_grad()
+    def run_batches(self, batches):
+        """Software-pipelined loop over an iterable of device batches (the `for batch in loader` of restoration_test.py):
+        stages A + B of batch i+1 run on a second HIP stream while stages C + D of batch i run on the caller's stream.  A + B
+        are small-map / latency-bound work that leaves most CUs idle; overlapped with the big convolutions of the previous
+        batch they cost almost nothing.  Yields the same dicts as __call__, in order."""
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream()
+        side = self._side
+
+        def start(batch):
+            side.wait_stream(main)  # the batch (and everything enqueued before) is visible to the side stream
+            with torch.cuda.stream(side):
+                lat, pre = self.encode(batch)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for t in (lat, pre):
+                t.record_stream(main)  # allocated on the side stream's pool, consumed on the main stream
+            return batch, lat, pre, ev
+
+        it = iter(batches)
+        try:
+            cur = start(next(it))
+        except StopIteration:
+            return
+        while cur is not None:
+            try:
+                nxt = start(next(it))  # enqueue A + B of the next batch BEFORE C + D of this one
+            except StopIteration:
+                nxt = None
+            batch, lat, pre, ev = cur
+            main.wait_event(ev)
+            yield self.decode(batch, lat, pre)
+            cur = nxt
 
 
 def gather_restored(local, counts=None):
