@@ -252,6 +252,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     double best_cost = 0.0;
     for (int c = 0; c < kNumCfgs; ++c) {
       Plan pl{};
+      if (is_dg(kCfgs[c])) continue;  // the fused dilation-group kernels are only used when named (tile_hint / tuned table)
       if (!make_plan(p, c, &pl)) continue;
       const double cost = plan_cost(p, pl);
       if (!found || cost < best_cost) {
