@@ -5,8 +5,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=$1; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal_fetch -o f --output-format csv -- python tools/pmc_calibrate.py > $OUT/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal_write -o w --output-format csv -- python tools/pmc_calibrate.py > $OUT/cal_write.log 2>&1
 python tools/pmc_traffic_summary.py $OUT
