@@ -24,6 +24,9 @@ SHAPES = [
     ("down256", 8, 128, 256, 257, 257, 3, 2, 0, 1, 1),
     ("head64", 8, 512, 512, 64, 64, 3, 2, 1, 1, 1),
     ("irse128", 8, 64, 64, 128, 128, 3, 1, 1, 1, 1),
+    ("irse32", 8, 256, 256, 32, 32, 3, 1, 1, 1, 1),
+    ("c16", 8, 512, 512, 16, 16, 3, 1, 1, 1, 1),
+    ("c8", 8, 512, 512, 8, 8, 3, 1, 1, 1, 1),
 ]
 
 

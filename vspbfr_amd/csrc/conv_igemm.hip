@@ -15,6 +15,8 @@ extern const Cfg kCfgsD[];
 extern const int kNumD;
 extern const Cfg kCfgsE[];
 extern const int kNumE;
+extern const Cfg kCfgsF[];
+extern const int kNumF;
 }  // namespace vspconv
 
 namespace {
@@ -25,7 +27,7 @@ using vspconv::ConvK;
 // neutral operands for absent epilogue inputs (read through a zero stride): [0] = 1, [1] = 0, [4] = 0.2, [5] = 0.01
 __device__ float kConst[8] = {1.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-constexpr int kMaxCfgs = 96;
+constexpr int kMaxCfgs = 192;
 static Cfg kCfgs[kMaxCfgs];
 static int kNumCfgs = 0;
 
@@ -37,6 +39,7 @@ static void build_table() {
   for (int i = 0; i < vspconv::kNumC && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsC[i];
   for (int i = 0; i < vspconv::kNumD && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsD[i];
   for (int i = 0; i < vspconv::kNumE && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsE[i];
+  for (int i = 0; i < vspconv::kNumF && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsF[i];
   kNumCfgs = n;
 }
 
