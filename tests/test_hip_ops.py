@@ -237,7 +237,7 @@ def test_conv2d_dilation_groups_fused_kernels(H, B, Cin, Cg, Hh, Ww):
             continue
         close(y, ref, 3e-5, 3e-5, f"cfg {lib.vsp_conv2d_config_name(c - 1)}")
         ran += 1
-    assert ran >= 3
+    assert ran >= 2
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 12, 8, 8), (1, 16, 16, 5, 9), (1, 64, 32, 32, 32)])
