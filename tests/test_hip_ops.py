@@ -397,3 +397,24 @@ def _grouped_case(H, G):
                     bias=dev(lb), bias_scale=2.0, bias_zs=24)
     ref2 = torch.stack([F.linear(feat[:, g * C_:(g + 1) * C_], lw[g] * 0.5, lb[g] * 2.0) for g in range(G)])
     close(out, ref2, 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 32, 3, 64, 64), (1, 7, 3, 5, 9), (2, 3, 64, 33, 31), (1, 512, 3, 16, 16), (2, 4, 20, 8, 8)])
+def test_pointwise_stream_kernels(H, B, Cin, Cout, Hh, Ww):
+    """ToRGB (few outputs: style scale, bias, skip residual) and the 3 -> 64 input layer (few inputs: two FusedLeakyReLUs)."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin) / math.sqrt(Cin)
+    s_in = torch.rand(B, Cin) + 0.5
+    lin = torch.einsum("bchw,oc->bohw", x * s_in.view(B, Cin, 1, 1), w)
+    if Cout <= 4:
+        cb, res = torch.randn(Cout), torch.randn(B, Cout, Hh, Ww)
+        close(H.pointwise(dev(x), dev(w), in_scale=dev(s_in), ch_bias=dev(cb), res=dev(res)), lin + cb.view(1, -1, 1, 1) + res,
+              2e-5, 2e-5)
+        close(H.pointwise(dev(x), dev(w)), torch.einsum("bchw,oc->bohw", x, w), 2e-5, 2e-5)
+    else:
+        b1, b2 = torch.randn(Cout), torch.randn(Cout)
+        ref = F.leaky_relu(lin + b1.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+        ref = F.leaky_relu(ref + b2.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+        close(H.pointwise(dev(x), dev(w), in_scale=dev(s_in), bias1=dev(b1), bias2=dev(b2)), ref, 2e-5, 2e-5)
+    with pytest.raises(RuntimeError):
+        H.pointwise(dev(torch.randn(1, 8, 4, 4)), dev(torch.randn(8, 8)))

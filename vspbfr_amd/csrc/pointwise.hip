@@ -1,0 +1,162 @@
+// 1x1 convolutions with at most four channels on ONE side, for gfx950: the ToRGB layers (Cin -> 3, reference
+// models/RestoreNet.py:647-666) and the 3 -> 64 input layer.  These are pure HBM streams (2*Cin*Cout <= 512 FLOP per pixel
+// against 4*(Cin+Cout) bytes): an MFMA tile kernel pads the tiny side to 16 and pays LDS staging and barriers for nothing
+// (measured 2.0-2.3 TB/s on the conv kernel).  Here each thread owns 4 consecutive pixels, every plane is touched with
+// 16-byte accesses issued in batches, the (style-scaled) weights sit in LDS and are read as wave-uniform broadcasts.
+#include "vsp_common.h"
+
+namespace {
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ float lrelu2(float v, float bias, int act) {
+  if (!act) return v;
+  v += bias;
+  return (v > 0.f ? v : v * 0.2f) * 1.41421356237309515f;
+}
+
+// Cout <= 4:  y[b,co,p] = sum_ci x[b,ci,p] * (w[co,ci] * s[b,ci]) + bias[co] + res[b,co,p]
+template <int CO>
+__global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ ch_bias, const float* __restrict__ res,
+                                                         int Cin, int64_t HW) {
+  extern __shared__ float wl[];  // [CO][Cin], style folded in
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < CO * Cin; i += 256) {
+    const int ci = i % Cin;
+    wl[i] = w[i] * (in_scale ? in_scale[(int64_t)b * Cin + ci] : 1.f);
+  }
+  __syncthreads();
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= HW) return;
+  const bool full = p0 + 3 < HW;
+  const float* xb = x + (int64_t)b * Cin * HW + p0;
+  f32x4u acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = f32x4u{0.f, 0.f, 0.f, 0.f};
+  constexpr int UN = 8;
+  for (int c0 = 0; c0 < Cin; c0 += UN) {
+    f32x4u v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      v[u] = f32x4u{0.f, 0.f, 0.f, 0.f};
+      if (c0 + u < Cin) {
+        const float* src = xb + (int64_t)(c0 + u) * HW;
+        if (full) {
+          v[u] = *reinterpret_cast<const f32x4u*>(src);
+        } else {
+          for (int j = 0; j < 4 && p0 + j < HW; ++j) v[u][j] = src[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (c0 + u >= Cin) break;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        const float wv = wl[co * Cin + c0 + u];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv, acc[co][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    const int64_t o = ((int64_t)b * CO + co) * HW + p0;
+    const float cb = ch_bias ? ch_bias[co] : 0.f;
+    f32x4u r = f32x4u{0.f, 0.f, 0.f, 0.f};
+    if (res) {
+      if (full) r = *reinterpret_cast<const f32x4u*>(res + o);
+      else for (int j = 0; j < 4 && p0 + j < HW; ++j) r[j] = res[o + j];
+    }
+    f32x4u out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = acc[co][j] + cb + r[j];
+    if (full) *reinterpret_cast<f32x4u*>(y + o) = out;
+    else for (int j = 0; j < 4 && p0 + j < HW; ++j) y[o + j] = out[j];
+  }
+}
+
+// Cin <= 4:  y[b,co,p] = act2(act1(sum_ci x[b,ci,p] * w[co,ci] * s[b,ci] + ch_bias[co]))   (bias + leaky-ReLU(0.2)*sqrt2 each)
+template <int CI>
+__global__ __launch_bounds__(256) void pw_few_in_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ in_scale,
+                                                        const float* __restrict__ ch_bias, const float* __restrict__ bias1,
+                                                        int act1, const float* __restrict__ bias2, int act2, int Cout,
+                                                        int64_t HW) {
+  extern __shared__ float wl[];  // [Cout][CI + 3]: weights, ch_bias, bias1, bias2
+  const int b = blockIdx.y;
+  for (int co = threadIdx.x; co < Cout; co += 256) {
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) wl[co * (CI + 3) + ci] = w[co * CI + ci] * (in_scale ? in_scale[(int64_t)b * CI + ci] : 1.f);
+    wl[co * (CI + 3) + CI] = ch_bias ? ch_bias[co] : 0.f;
+    wl[co * (CI + 3) + CI + 1] = (act1 && bias1) ? bias1[co] : 0.f;
+    wl[co * (CI + 3) + CI + 2] = (act2 && bias2) ? bias2[co] : 0.f;
+  }
+  __syncthreads();
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= HW) return;
+  const bool full = p0 + 3 < HW;
+  f32x4u v[CI];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) {
+    const float* src = x + ((int64_t)b * CI + ci) * HW + p0;
+    v[ci] = f32x4u{0.f, 0.f, 0.f, 0.f};
+    if (full) v[ci] = *reinterpret_cast<const f32x4u*>(src);
+    else for (int j = 0; j < 4 && p0 + j < HW; ++j) v[ci][j] = src[j];
+  }
+  for (int co = 0; co < Cout; ++co) {
+    const float* wr = wl + co * (CI + 3);
+    f32x4u out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = wr[CI];
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) a = fmaf(v[ci][j], wr[ci], a);
+      a = lrelu2(a, wr[CI + 1], act1);
+      out[j] = lrelu2(a, wr[CI + 2], act2);
+    }
+    float* dst = y + ((int64_t)b * Cout + co) * HW + p0;
+    if (full) *reinterpret_cast<f32x4u*>(dst) = out;
+    else for (int j = 0; j < 4 && p0 + j < HW; ++j) dst[j] = out[j];
+  }
+}
+
+}  // namespace
+
+extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const float* in_scale, const float* ch_bias,
+                                 const float* bias1, int act1, const float* bias2, int act2, const float* res, int B,
+                                 int Cin, int Cout, int64_t HW, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && HW >= 0, "pointwise: bad dims");
+  if (B == 0 || HW == 0) return VSP_OK;
+  VSP_REQUIRE(y && x && w, "pointwise: null pointer");
+  VSP_REQUIRE(Cin <= 4 || Cout <= 4, "pointwise: built for <= 4 channels on one side (got %d -> %d); use vsp_conv2d_f32", Cin, Cout);
+  VSP_REQUIRE(B <= 65535, "pointwise: batch too large");
+  const int64_t blocks = (HW + 1023) / 1024;
+  VSP_REQUIRE(blocks < ((int64_t)1 << 31), "pointwise: plane too large");
+  dim3 grid((unsigned)blocks, (unsigned)B);
+  hipStream_t s = vsp::as_stream(stream);
+  if (Cout <= 4) {
+    VSP_REQUIRE(!act1 && !act2, "pointwise: activations are only implemented on the few-input-channels form");
+    VSP_REQUIRE(Cin <= 8192, "pointwise: too many input channels");
+    const size_t lds = (size_t)Cout * Cin * sizeof(float);
+    switch (Cout) {
+      case 1: pw_few_out_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
+      case 2: pw_few_out_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
+      case 3: pw_few_out_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
+      default: pw_few_out_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
+    }
+  } else {
+    VSP_REQUIRE(!res, "pointwise: a residual is only implemented on the few-output-channels form");
+    VSP_REQUIRE(Cout <= 4096, "pointwise: too many output channels");
+    const size_t lds = (size_t)Cout * (Cin + 3) * sizeof(float);
+    switch (Cin) {
+      case 1: pw_few_in_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      case 2: pw_few_in_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      case 3: pw_few_in_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      default: pw_few_in_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+    }
+  }
+  return vsp::check_launch("pointwise");
+}

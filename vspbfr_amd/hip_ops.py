@@ -494,6 +494,19 @@ def tacc_head_pre(e, wcol, ln_w, ln_b, steps, t_div):
     return out
 
 
+def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=None):
+    """1x1 convolution with <= 4 channels on one side as an HBM stream (see vsp_pointwise_f32): x (B,Cin,H,W), w (Cout,Cin);
+    bias1 / bias2 switch on the two FusedLeakyReLU stages (few-input form), res is added last (few-output form)."""
+    x = _req(x, "x")
+    B, Cin, Hh, Ww = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, Cout, Hh, Ww), device=x.device, dtype=x.dtype)
+    check(lib.vsp_pointwise_f32(_ptr(y), _ptr(x), _ptr(_req(w, "w")), _ptr(_opt(in_scale, "in_scale")), _ptr(_opt(ch_bias, "ch_bias")),
+                                _ptr(_opt(bias1, "bias1")), 1 if bias1 is not None else 0, _ptr(_opt(bias2, "bias2")),
+                                1 if bias2 is not None else 0, _ptr(_opt(res, "res")), B, Cin, Cout, Hh * Ww, _stream()), "pointwise")
+    return y
+
+
 def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None):
     """Run the whole sampler chain in place on x (B,18,512): for each t in `steps` (host ints, execution order) x <- c1[k] *
     denoiser(x, t) + c2[k] * x with k = coef_idx[s] (default t); c1 = c2 = None: x <- denoiser(x, t).  `blocks`: one dict per
