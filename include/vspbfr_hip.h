@@ -245,13 +245,15 @@ int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int
 
 /* 1x1 convolution with at most 4 channels on one side, as an HBM stream (no MFMA tile, no padding of the tiny side):
  *   Cout <= 4 (ToRGB: modulated 1x1 conv without demodulation + bias + FIR-upsampled skip, models/RestoreNet.py:647-666):
- *       y[b,co,p] = sum_ci x[b,ci,p] * w[co,ci] * in_scale[b,ci] + ch_bias[co] + res[b,co,p]
+ *       y[b,co,p] = sum_ci x[b,ci,p] * w[co,ci] * in_scale[b,ci] + ch_bias[co] + res[b,co,p] + up(up_src)[b,co,p]
+ *       up(.) = upfirdn2d(up_src (B,Cout,H/2,W/2), up_kernel (4x4), up = 2, pad = (2,1)), the `Upsample` of the RGB skip
+ *       (models/RestoreNet.py:100-118), evaluated inside the kernel: the skip image is never materialised at full size
  *   Cin <= 4 (the 3 -> 64 input layer, two FusedLeakyReLUs in the epilogue, models/RestoreNet.py:725-787 with k = 1):
  *       y[b,co,p] = act2(act1(sum_ci x[b,ci,p] * w[co,ci] * in_scale[b,ci] + ch_bias[co])),  act_i(v) = lrelu(v + bias_i[co], 0.2) * sqrt2
- * x (B,Cin,HW), y / res (B,Cout,HW) dense; in_scale, ch_bias, bias1, bias2, res may be NULL. */
+ * x (B,Cin,HW), y / res (B,Cout,HW) dense, W = row length; in_scale, ch_bias, bias1, bias2, res, up_src may be NULL. */
 int vsp_pointwise_f32(float* y, const float* x, const float* w, const float* in_scale, const float* ch_bias,
-                      const float* bias1, int act1, const float* bias2, int act2, const float* res, int B, int Cin,
-                      int Cout, int64_t HW, vsp_stream_t stream);
+                      const float* bias1, int act1, const float* bias2, int act2, const float* res, const float* up_src,
+                      const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused TACC_block step of Code_diffuser (reference models/CodeDiffuser.py:86-116 and :35-47), 18 tokens x 512

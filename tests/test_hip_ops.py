@@ -411,6 +411,15 @@ def test_pointwise_stream_kernels(H, B, Cin, Cout, Hh, Ww):
         close(H.pointwise(dev(x), dev(w), in_scale=dev(s_in), ch_bias=dev(cb), res=dev(res)), lin + cb.view(1, -1, 1, 1) + res,
               2e-5, 2e-5)
         close(H.pointwise(dev(x), dev(w)), torch.einsum("bchw,oc->bohw", x, w), 2e-5, 2e-5)
+        if Hh % 2 == 0 and Ww % 2 == 0:  # the FIR-upsampled skip evaluated inside the kernel
+            from vspbfr_amd.op import upfirdn2d
+            k1 = torch.tensor([1., 3., 3., 1.])
+            k = k1[:, None] * k1[None, :]
+            k = k / k.sum() * 4
+            skip = torch.randn(B, Cout, Hh // 2, Ww // 2)
+            up = upfirdn2d(dev(skip), dev(k), up=2, down=1, pad=(2, 1)).cpu()
+            close(H.pointwise(dev(x), dev(w), in_scale=dev(s_in), ch_bias=dev(cb), up_src=dev(skip), up_kernel=dev(k)),
+                  lin + cb.view(1, -1, 1, 1) + up, 2e-5, 2e-5)
     else:
         b1, b2 = torch.randn(Cout), torch.randn(Cout)
         ref = F.leaky_relu(lin + b1.view(1, -1, 1, 1), 0.2) * math.sqrt(2)

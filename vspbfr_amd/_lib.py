@@ -97,7 +97,7 @@ SIGNATURES = {
     "vsp_scale_add_f32": [_p, _p, _p, _p, _i64, _i, _p],
     "vsp_subsample_f32": [_p, _p, _i64, _i, _i, _i, _p],
     "vsp_add3_f32": [_p, _p, _p, _p, _i64, _p],
-    "vsp_pointwise_f32": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i64, _p],
+    "vsp_pointwise_f32": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i64, _p],
     "vsp_quantize_u8_nhwc": [_p, _p, _i, _i, _i, _i, _f, _f, _p],
     "vsp_tacc_scores_f32": [_p, _p, _i, _i, _p, _p, _i, _f, _i, _i, _i, _p],
     "vsp_tacc_chan_attn_f32": [_p, _p, _i, _i, _i, _p, _p, _i, _f, _i, _i, _i, _p],

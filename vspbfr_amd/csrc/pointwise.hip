@@ -20,7 +20,8 @@ template <int CO>
 __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                          const float* __restrict__ w, const float* __restrict__ in_scale,
                                                          const float* __restrict__ ch_bias, const float* __restrict__ res,
-                                                         int Cin, int64_t HW) {
+                                                         const float* __restrict__ up_src, const float* __restrict__ up_k,
+                                                         int W, int Cin, int64_t HW) {
   extern __shared__ float wl[];  // [CO][Cin], style folded in
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < CO * Cin; i += 256) {
@@ -69,6 +70,26 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
     if (res) {
       if (full) r = *reinterpret_cast<const f32x4u*>(res + o);
       else for (int j = 0; j < 4 && p0 + j < HW; ++j) r[j] = res[o + j];
+    }
+    if (up_src) {
+      // residual = upfirdn2d(up_src, up_k (4x4), up = 2, pad = (2, 1)) evaluated in place (the Upsample of the RGB skip,
+      // models/RestoreNet.py:100-118): zero insertion leaves one tap per parity and axis, 2 x 2 taps of the half-size map
+      const int Hh = (int)(HW / W), hh = Hh >> 1, hw = W >> 1;
+      const float* sp = up_src + ((int64_t)b * CO + co) * hh * hw;
+      for (int j = 0; j < 4 && p0 + j < HW; ++j) {
+        const int oy = (int)((p0 + j) / W), ox = (int)((p0 + j) - (int64_t)oy * W);
+        float a = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+          const int ky = (oy & 1) + 2 * ty, sy = (oy + ky - 2) >> 1;  // oy + ky even
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx) {
+            const int kx = (ox & 1) + 2 * tx, sx = (ox + kx - 2) >> 1;
+            if (sy >= 0 && sy < hh && sx >= 0 && sx < hw) a = fmaf(up_k[(3 - ky) * 4 + (3 - kx)], sp[sy * hw + sx], a);
+          }
+        }
+        r[j] += a;
+      }
     }
     f32x4u out;
 #pragma unroll
@@ -126,8 +147,9 @@ __global__ __launch_bounds__(256) void pw_few_in_kernel(float* __restrict__ y, c
 }  // namespace
 
 extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const float* in_scale, const float* ch_bias,
-                                 const float* bias1, int act1, const float* bias2, int act2, const float* res, int B,
-                                 int Cin, int Cout, int64_t HW, vsp_stream_t stream) {
+                                 const float* bias1, int act1, const float* bias2, int act2, const float* res,
+                                 const float* up_src, const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW,
+                                 vsp_stream_t stream) {
   VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && HW >= 0, "pointwise: bad dims");
   if (B == 0 || HW == 0) return VSP_OK;
   VSP_REQUIRE(y && x && w, "pointwise: null pointer");
@@ -137,15 +159,17 @@ extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const
   VSP_REQUIRE(blocks < ((int64_t)1 << 31), "pointwise: plane too large");
   dim3 grid((unsigned)blocks, (unsigned)B);
   hipStream_t s = vsp::as_stream(stream);
+  VSP_REQUIRE(!up_src || (up_kernel && Cout <= 4 && W >= 2 && W % 2 == 0 && HW % W == 0 && (HW / W) % 2 == 0),
+              "pointwise: the up-sampled residual needs the few-output form, a 4x4 kernel and even H, W");
   if (Cout <= 4) {
     VSP_REQUIRE(!act1 && !act2, "pointwise: activations are only implemented on the few-input-channels form");
     VSP_REQUIRE(Cin <= 8192, "pointwise: too many input channels");
     const size_t lds = (size_t)Cout * Cin * sizeof(float);
     switch (Cout) {
-      case 1: pw_few_out_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
-      case 2: pw_few_out_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
-      case 3: pw_few_out_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
-      default: pw_few_out_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, Cin, HW); break;
+      case 1: pw_few_out_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      case 2: pw_few_out_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      case 3: pw_few_out_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      default: pw_few_out_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
     }
   } else {
     VSP_REQUIRE(!res, "pointwise: a residual is only implemented on the few-output-channels form");

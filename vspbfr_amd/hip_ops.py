@@ -494,16 +494,18 @@ def tacc_head_pre(e, wcol, ln_w, ln_b, steps, t_div):
     return out
 
 
-def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=None):
+def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=None, up_src=None, up_kernel=None):
     """1x1 convolution with <= 4 channels on one side as an HBM stream (see vsp_pointwise_f32): x (B,Cin,H,W), w (Cout,Cin);
-    bias1 / bias2 switch on the two FusedLeakyReLU stages (few-input form), res is added last (few-output form)."""
+    bias1 / bias2 switch on the two FusedLeakyReLU stages (few-input form), res is added last (few-output form);
+    up_src (B,Cout,H/2,W/2) + up_kernel (4,4): the 2x FIR-upsampled skip is evaluated inside the kernel and added."""
     x = _req(x, "x")
     B, Cin, Hh, Ww = x.shape
     Cout = w.shape[0]
     y = torch.empty((B, Cout, Hh, Ww), device=x.device, dtype=x.dtype)
     check(lib.vsp_pointwise_f32(_ptr(y), _ptr(x), _ptr(_req(w, "w")), _ptr(_opt(in_scale, "in_scale")), _ptr(_opt(ch_bias, "ch_bias")),
                                 _ptr(_opt(bias1, "bias1")), 1 if bias1 is not None else 0, _ptr(_opt(bias2, "bias2")),
-                                1 if bias2 is not None else 0, _ptr(_opt(res, "res")), B, Cin, Cout, Hh * Ww, _stream()), "pointwise")
+                                1 if bias2 is not None else 0, _ptr(_opt(res, "res")), _ptr(_opt(up_src, "up_src")),
+                                _ptr(_opt(up_kernel, "up_kernel")), Ww, B, Cin, Cout, Hh * Ww, _stream()), "pointwise")
     return y
 
 

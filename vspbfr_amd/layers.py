@@ -215,10 +215,16 @@ class ToRGB(nn.Module):
 
     def forward(self, x, style, skip=None):
         """Cin -> 3 is an HBM stream, not a GEMM: the pointwise kernel reads every input plane once with 16-byte accesses."""
-        res = self.upsample(skip) if skip is not None else None
         conv = self.conv
         w = conv._derive("w_rgb", [conv.weight], lambda: (conv.weight[0, :, :, 0, 0] * conv.scale).contiguous())
-        return H.pointwise(x.contiguous(), w, in_scale=conv.modulation(style), ch_bias=self.bias.view(3), res=res)
+        up = {}
+        if skip is not None:  # Upsample(skip) (factor 2, 4x4 kernel, pad (2,1)) is evaluated inside the kernel
+            u = self.upsample
+            if u.factor == 2 and tuple(u.kernel.shape) == (4, 4) and u.pad == (2, 1) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                up = dict(up_src=skip.contiguous(), up_kernel=u.kernel)
+            else:
+                up = dict(res=u(skip))
+        return H.pointwise(x.contiguous(), w, in_scale=conv.modulation(style), ch_bias=self.bias.view(3), **up)
 
 
 class SMARTLayer(_Cached):
