@@ -150,7 +150,8 @@ typedef struct vsp_conv_params {
   const float* res1;      /* NULL or same layout as the y region written (see res_* below) */
   const float* res2;
   int res_ch, res_coff;   /* residual tensors are [B, res_ch, y_h, y_w], read at channel res_coff + co */
-  int tile_hint;          /* 0 = let the library choose; otherwise 1 + configuration index (tests / tuning) */
+  int tile_hint;          /* 0 = let the library choose; n > 0 = configuration n-1, an error if it does not fit (tests / tuning);
+                             n < 0 = prefer configuration -n-1, fall back to the library's choice if it does not fit */
   /* grouped input (true grouped convolution, e.g. the 18 map2style heads of the e4e encoder run as one launch per stage):
    * x has x_ch channels per image (0 = Cin) and group g reads channels [g*x_group_stride, g*x_group_stride + Cin).
    * x_group_stride = 0: all groups read the same Cin channels (the dilation groups of SMART_layer).  With G > 4 every

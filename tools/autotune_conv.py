@@ -49,6 +49,7 @@ def main():
     for key, (dims, pc, count, tr) in uniq.items():
         Bq, Cin, Hh, Ww, OH, OW = dims
         x = torch.randn(Bq, (pc.G - 1) * pc.x_group_stride + Cin, Hh, Ww, device=dev)
+        shift = torch.zeros(Cin, device=dev)
         # generous output tensor: phase convs write strided, give them room
         out = torch.empty(Bq, pc.cout, max(OH, 1) * 2 + 1, max(OW, 1) * 2 + 1, device=dev)
         flops = 2.0 * Bq * pc.cout * (Hh * Ww if tr else OH * OW) * Cin * pc.kh * pc.kw
@@ -56,6 +57,8 @@ def main():
         for c in range(0, n + 1):
             try:
                 kw = dict(transposed=True) if tr else dict(out=out, n_out=(OH, OW))
+                if key.endswith(",s"):  # input shift (folded BatchNorm): not every staging variant serves it
+                    kw["in_shift"] = shift
                 est = timeit(lambda: H.conv2d_packed(x, pc, tile_hint=c, **kw), 1)
                 iters = 3 if est > 0.3 else 10
                 times[c] = timeit(lambda: H.conv2d_packed(x, pc, tile_hint=c, **kw), iters)

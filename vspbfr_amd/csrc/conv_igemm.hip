@@ -17,6 +17,8 @@ extern const Cfg kCfgsE[];
 extern const int kNumE;
 extern const Cfg kCfgsF[];
 extern const int kNumF;
+extern const Cfg kCfgsG[];
+extern const int kNumG;
 }  // namespace vspconv
 
 namespace {
@@ -40,6 +42,7 @@ static void build_table() {
   for (int i = 0; i < vspconv::kNumD && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsD[i];
   for (int i = 0; i < vspconv::kNumE && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsE[i];
   for (int i = 0; i < vspconv::kNumF && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsF[i];
+  for (int i = 0; i < vspconv::kNumG && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsG[i];
   kNumCfgs = n;
 }
 
@@ -105,7 +108,8 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
     if ((NPIX + 1) * 2 > plane) plane = (NPIX + 1) * 2;
   }
   const int PS = host_round_pitch(plane, !tc && p.stride_x != 1);
-  size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)k.CK * PS) * sizeof(float);
+  if (k.PF == 2 && (p.in_shift || p.cout_g % 4 != 0 || !vsp::aligned16(p.w))) return false;  // LDS-DMA staging: no shift
+  size_t lds = ((size_t)p.KH * p.KW * k.CK * WS + (size_t)(k.PF == 2 ? 2 : 1) * k.CK * PS) * sizeof(float);
   const size_t red = (size_t)(k.WK - 1) * k.WM * k.WN * k.MB * k.NB * 4 * 64 * sizeof(float);
   if (red > lds) lds = red;
   if (lds > kMaxLds) return false;
@@ -251,7 +255,12 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     VSP_REQUIRE(p.tile_hint <= kNumCfgs, "conv2d: tile_hint %d out of range", p.tile_hint);
     found = make_plan(p, p.tile_hint - 1, &best);
     VSP_REQUIRE(found, "conv2d: configuration %s does not fit this problem", kCfgs[p.tile_hint - 1].name);
-  } else {
+  } else if (p.tile_hint < 0 && -p.tile_hint <= kNumCfgs) {
+    // a PREFERENCE (tuned table): the table is keyed by geometry only, the same shape may come with an operand this
+    // configuration cannot serve (e.g. an input shift with the LDS-DMA staging) -- then the cost model decides
+    found = make_plan(p, -p.tile_hint - 1, &best);
+  }
+  if (!found) {
     double best_cost = 0.0;
     for (int c = 0; c < kNumCfgs; ++c) {
       Plan pl{};

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int ix0 = TC ? ox0 - 1 : DG ? ox0 - D : ox0 * p.sx - p.padx[gi];
 
   float* Wl = smem;                // [T][CK][WS]
-  float* Pl = smem + T * CK * WS;  // [CK][PS]
+  float* Pl = smem + T * CK * WS;  // [CK][PS]   (PF = 2: two of them, Pl and Pl + CK * PS, used alternately)
 
   // per-lane patch offsets of the NB pixel blocks this wave owns
   int pixoff[NP];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   constexpr int V = CO_T / 4;
   constexpr int WMAX = (9 * CK * V + NT - 1) / NT;  // prefetched weight float4 per thread (covers 3x3 taps)
   float4 wreg[WMAX];
-  float preg[PCH][PMAX];
+  float preg[PF == 2 ? 1 : PCH][PF == 2 ? 1 : PMAX];
   float psc[PCH], psh[PCH];
   const int wtotal = T * CK * V;
   const int chw = p.H * p.W;
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   }
 
   auto issue = [&](int ci0) {
+    if constexpr (PF == 2) return;
     if (p.w_vec4) {
       const float* wc = wg + (int64_t)ci0 * p.cout_g;
 #pragma unroll
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   };
 
   auto commit = [&](int ci0) {
+    if constexpr (PF == 2) return;
     if (p.w_vec4) {
 #pragma unroll
       for (int w = 0; w < WMAX; ++w)
@@ -290,15 +292,69 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
     }
   };
 
-  if (PF) issue(0);
+  // PF = 2: asynchronous staging.  The input patch of chunk i+1 goes global -> LDS directly (global_load_lds: the wave's 64
+  // lanes land on 64 consecutive LDS words, which is exactly the plane layout; lanes outside the image are masked off and
+  // their words keep the zero written once at kernel start), into the second patch buffer, while chunk i is multiplied.
+  // No patch registers, no fma/select/ds_write per staged word; the style scale moves onto the weight rows (w * s[b, ci]),
+  // which still pass through registers (the slab rows are padded, an LDS-DMA wave writes contiguous words only).
+  auto issue_async = [&](int ci0, float* Pdst) {
+    const float* wc = wg + (int64_t)ci0 * p.cout_g;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w) {
+      const int row = (tid + w * NT) / V;
+      const int cl = row & (CK - 1);
+      const bool ok = woff[w] >= 0 && ci0 + cl < p.Cin;
+      const float4 v = *reinterpret_cast<const float4*>(wc + (ok ? woff[w] : 0));
+      const float sc = (ok && p.in_scale) ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci0 + cl] : 1.f;
+      wreg[w] = ok ? make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int pc = 0; pc < PCH; ++pc) {
+      const int cl = wave + pc * NW;
+      const int ci = ci0 + cl;
+      if (cl >= CK || ci >= p.Cin) continue;  // wave-uniform; a stale plane meets zero weight rows
+      const float* xc = xb + (int64_t)ci * chw;
+      float* dstc = Pdst + cl * PS;
+#pragma unroll
+      for (int e = 0; e < PMAX; ++e)
+        if ((pin >> e) & 1u) __builtin_amdgcn_global_load_lds(xc + poff[e], dstc + 64 * e, 4, 0, 0);
+      if (plane > 64 * PMAX) {
+        for (int i0 = 64 * PMAX; i0 < plane; i0 += 64) {  // i0 is wave-uniform: the LDS base of the instruction
+          int off;
+          if (i0 + lane < plane && patch_src(i0 + lane, off)) __builtin_amdgcn_global_load_lds(xc + off, dstc + i0, 4, 0, 0);
+        }
+      }
+    }
+  };
+  auto commit_w = [&]() {
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w)
+      if (wdst[w] >= 0) *reinterpret_cast<float4*>(Wl + wdst[w]) = wreg[w];
+  };
+  if constexpr (PF == 2) {
+    for (int i = tid; i < 2 * CK * PS; i += NT) Pl[i] = 0.f;
+    __syncthreads();
+    issue_async(0, Pl);
+  } else if (PF) {
+    issue(0);
+  }
+  int pbuf = 0;
   for (int ci0 = 0; ci0 < p.Cin; ci0 += CK) {
-    __syncthreads();  // previous chunk's fragment reads are done
-    if (!(p.dbg & 1) || ci0 == 0) {
+    __syncthreads();  // previous chunk's fragment reads are done (PF = 2: and this wave's LDS-DMA of chunk ci0 has landed)
+    if constexpr (PF == 2) {
+      commit_w();
+    } else if (!(p.dbg & 1) || ci0 == 0) {
       if (!PF) issue(ci0);
       commit(ci0);
     }
     __syncthreads();
-    if (PF && ci0 + CK < p.Cin && !(p.dbg & 1)) issue(ci0 + CK);
+    if constexpr (PF == 2) {
+      Pl = smem + T * CK * WS + pbuf * CK * PS;
+      pbuf ^= 1;
+      if (ci0 + CK < p.Cin) issue_async(ci0 + CK, smem + T * CK * WS + pbuf * CK * PS);
+    } else {
+      if (PF && ci0 + CK < p.Cin && !(p.dbg & 1)) issue(ci0 + CK);
+    }
     if (p.dbg & 2) continue;
     // ---- MFMA over taps x (CK/4) k-steps
     if constexpr (TC) {

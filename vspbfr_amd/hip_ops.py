@@ -224,11 +224,12 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     rt = res1 if res1 is not None else res2
     p.res_ch = rt.shape[1] if rt is not None else 0
     p.res_coff = res_coff
-    key = conv_key(B, Cin, H, W, pc, OH, OW) + (",t" if transposed else "")
+    key = conv_key(B, Cin, H, W, pc, OH, OW) + (",t" if transposed else "") + (",s" if in_shift is not None else "")
     if tile_hint == 0 and TUNE:
-        tile_hint = TUNE.get(key, 0)
-        if tile_hint == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
-            tile_hint = TUNE.get("8" + key[key.index(","):], 0)
+        pref = TUNE.get(key, 0)
+        if pref == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
+            pref = TUNE.get("8" + key[key.index(","):], 0)
+        tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
     if RECORDER is not None:
         RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))
     p.tile_hint = tile_hint
