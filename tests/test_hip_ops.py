@@ -427,3 +427,51 @@ def test_pointwise_stream_kernels(H, B, Cin, Cout, Hh, Ww):
         close(H.pointwise(dev(x), dev(w), in_scale=dev(s_in), bias1=dev(b1), bias2=dev(b2)), ref, 2e-5, 2e-5)
     with pytest.raises(RuntimeError):
         H.pointwise(dev(torch.randn(1, 8, 4, 4)), dev(torch.randn(8, 8)))
+
+
+@pytest.mark.parametrize("shape,with_bias", [((2, 8, 9, 7), True), ((3, 16), True), ((2, 4, 6, 6), False)])
+@torch.enable_grad()
+def test_fused_leaky_relu_autograd_any_order(H, shape, with_bias):
+    """first and second derivatives of the op against torch autograd over the oracle's formula."""
+    from oracle import ops as O
+    from vspbfr_amd.op import fused_leaky_relu
+    x = torch.randn(*shape, dtype=torch.float32)
+    b = torch.randn(shape[1]) if with_bias else None
+    g = torch.randn(*shape)
+    xr, br = x.clone().requires_grad_(True), (b.clone().requires_grad_(True) if with_bias else None)
+    xd, bd = dev(x).requires_grad_(True), (dev(b).requires_grad_(True) if with_bias else None)
+    yr, yd = O.fused_leaky_relu(xr, br), fused_leaky_relu(xd, bd)
+    close(yd.detach(), yr.detach(), 1e-6, 1e-6)
+    ins_r, ins_d = ([xr, br] if with_bias else [xr]), ([xd, bd] if with_bias else [xd])
+    gr = torch.autograd.grad(yr, ins_r, g)
+    gd = torch.autograd.grad(yd, ins_d, dev(g))
+    for a, r in zip(gd, gr):
+        close(a.detach(), r.detach(), 1e-5, 1e-5)
+    # second order: d/dg of <grad_x, v> (the mask is piecewise constant: only the g path carries curvature-free terms)
+    v = torch.randn(*shape)
+    g2r = torch.randn(*shape).requires_grad_(True)
+    g2d = dev(g2r.detach()).requires_grad_(True)
+    hr = torch.autograd.grad(O.fused_leaky_relu(xr, br), xr, g2r, create_graph=True)[0]
+    hd = torch.autograd.grad(fused_leaky_relu(xd, bd), xd, g2d, create_graph=True)[0]
+    close(torch.autograd.grad(hd, g2d, dev(v))[0], torch.autograd.grad(hr, g2r, v)[0], 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("up,down,pad,k", [(1, 1, (1, 1), 4), (2, 1, (2, 1), 4), (1, 2, (2, 2), 4), (1, 1, (2, 2), 4), (2, 1, (1, 0), 2),
+                                             (1, 1, (-1, 2), 3)])
+@torch.enable_grad()
+def test_upfirdn2d_autograd_any_order(H, up, down, pad, k):
+    from oracle import ops as O
+    from vspbfr_amd.op import upfirdn2d
+    x = torch.randn(2, 3, 11, 9)
+    kern = torch.rand(k, k) + 0.1
+    xr, xd = x.clone().requires_grad_(True), dev(x).requires_grad_(True)
+    yr, yd = O.upfirdn2d(xr, kern, up=up, down=down, pad=pad), upfirdn2d(xd, dev(kern), up=up, down=down, pad=pad)
+    close(yd.detach(), yr.detach(), 1e-5, 1e-5)
+    g = torch.randn_like(yr).requires_grad_(True)
+    gdv = dev(g.detach()).requires_grad_(True)
+    gr = torch.autograd.grad(yr, xr, g, create_graph=True)[0]
+    gd = torch.autograd.grad(yd, xd, gdv, create_graph=True)[0]
+    assert gd.shape == xd.shape
+    close(gd.detach(), gr.detach(), 1e-5, 1e-5)
+    v = torch.randn_like(x)
+    close(torch.autograd.grad(gd, gdv, dev(v))[0], torch.autograd.grad(gr, g, v)[0], 1e-5, 1e-5)   # double backward
