@@ -44,7 +44,7 @@ def main():
         uniq.setdefault(key, [dims, pc, 0, tr])[2] += 1
     print(f"{len(recs)} conv launches, {len(uniq)} distinct shapes", flush=True)
     n = lib.vsp_conv2d_num_configs()
-    table, report = {}, []
+    table, report, cands = {}, [], {}
     tot_auto = tot_best = 0.0
     for key, (dims, pc, count, tr) in uniq.items():
         Bq, Cin, Hh, Ww, OH, OW = dims
@@ -69,6 +69,8 @@ def main():
             continue
         best = min((c for c in times if c > 0), key=lambda c: times[c])
         table[key] = lib.vsp_conv2d_config_name(best - 1).decode()
+        order = sorted((c for c in times if c > 0), key=lambda c: times[c])[:5]
+        cands[key] = [lib.vsp_conv2d_config_name(c - 1).decode() for c in order]
         tot_auto += times[0] * count
         tot_best += times[best] * count
         report.append((times[best] * count, key, count, lib.vsp_conv2d_config_name(best - 1).decode(), round(times[best] * 1e3, 1),
@@ -79,6 +81,40 @@ def main():
     print(f"sum per pipeline pass: cost model {tot_auto:.1f} ms -> tuned {tot_best:.1f} ms")
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(table, open("gpurun_out/conv_tune.json", "w"), indent=0, sort_keys=True)
+    json.dump(cands, open("gpurun_out/conv_candidates.json", "w"), indent=0, sort_keys=True)
+    insitu(pipe, lq, cands, table)
+
+
+def insitu(pipe, lq, cands, table):
+    """Second stage: the micro-benchmark replays bare launches with warm caches; in the pipeline a layer also loads its
+    epilogue operands and meets whatever the previous kernel left in L2.  Run the pipeline once per candidate rank (every
+    shape uses its rank-j candidate), time each launch with HIP events, keep the per-shape winner."""
+    by_key = {}
+    for j in range(5):
+        H.TUNE = {k: H.CONFIG_IDS[v[min(j, len(v) - 1)]] for k, v in cands.items()}
+        for rep in range(2):
+            prof = H.ConvProfiler()
+            H.PROFILER = prof
+            H.RECORDER = []
+            with torch.no_grad():
+                pipe(lq)
+            torch.cuda.synchronize()
+            H.PROFILER, keys, H.RECORDER = None, H.RECORDER, None
+        for (key, _, _, _), rec in zip(keys, prof.records):
+            by_key.setdefault(key, [0.0] * 5)[j] += rec[1].elapsed_time(rec[2])
+    final, t_micro, t_best = {}, 0.0, 0.0
+    for key, ts in by_key.items():
+        n = len(cands[key])
+        jbest = min(range(n), key=lambda j: ts[j])
+        final[key] = cands[key][jbest]
+        t_micro += ts[0]
+        t_best += ts[jbest]
+        if jbest != 0 and ts[0] - ts[jbest] > 0.02:
+            print(f"in situ: {key}: {cands[key][0]} {ts[0]:.3f} ms -> {cands[key][jbest]} {ts[jbest]:.3f} ms", flush=True)
+    for key in table:
+        final.setdefault(key, table[key])
+    print(f"in-situ conv time per pass: micro-benchmark winners {t_micro:.1f} ms -> in-situ winners {t_best:.1f} ms")
+    json.dump(final, open("gpurun_out/conv_tune.json", "w"), indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":
