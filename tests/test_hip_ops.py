@@ -475,3 +475,29 @@ def test_upfirdn2d_autograd_any_order(H, up, down, pad, k):
     close(gd.detach(), gr.detach(), 1e-5, 1e-5)
     v = torch.randn_like(x)
     close(torch.autograd.grad(gd, gdv, dev(v))[0], torch.autograd.grad(gr, g, v)[0], 1e-5, 1e-5)   # double backward
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 64, 16, 16), (1, 20, 36, 13, 29), (2, 64, 64, 32, 32), (1, 256, 128, 16, 24),
+                                               (1, 3, 4, 7, 5)])
+def test_conv2d_winograd(H, B, Cin, Cout, Hh, Ww):
+    """F(2x2,3x3) kernel against F.conv2d, with the whole prologue / epilogue chain of a StyledConv."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    close(H.conv2d_packed(dev(x), pc, winograd=True), F.conv2d(x, w, padding=1), 3e-5, 3e-5)
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5, torch.randn(Cout)
+    nz, nw = torch.randn(B, 1, Hh, Ww), torch.tensor([0.7])
+    r1, r2 = torch.randn(B, Cout, Hh, Ww), torch.randn(B, Cout, Hh, Ww)
+    ref = F.conv2d(x * s_in.view(B, Cin, 1, 1), w, padding=1) * demod.view(B, Cout, 1, 1) + nz * nw
+    ref = F.leaky_relu(ref + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2) + r1 + r2
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), noise=dev(nz), noise_w=dev(nw), act2=1,
+                        bias2=dev(bias), res1=dev(r1), res2=dev(r2), winograd=True)
+    close(y, ref, 5e-5, 5e-5)
+    # folded BatchNorm input (scale + shift, zero padding AFTER the affine map) and PReLU, as in the IR-SE50 body
+    a, sh, pr = torch.rand(Cin) + 0.5, torch.randn(Cin), torch.rand(Cout) * 0.3
+    ref2 = F.prelu(F.conv2d(x * a.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), w, padding=1), pr)
+    y2 = H.conv2d_packed(dev(x), pc, in_scale=dev(a), in_scale_per_sample=False, in_shift=dev(sh), act2=2, prelu=dev(pr),
+                         winograd=True)
+    close(y2, ref2, 5e-5, 5e-5)
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 2, (1,), (1,)), winograd=True)

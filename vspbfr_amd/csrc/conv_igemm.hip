@@ -197,32 +197,9 @@ static const float* slope_slot(const float* kc, float slope) {
 
 }  // namespace
 
-extern "C" int vsp_conv2d_num_configs(void) {
-  build_table();
-  return kNumCfgs;
-}
-extern "C" const char* vsp_conv2d_config_name(int i) {
-  build_table();
-  return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "";
-}
-
-extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
-  VSP_REQUIRE(pp != nullptr, "conv2d: null params");
-  build_table();
-  vsp_conv_params pcopy = *pp;
-  if (pcopy.transposed) {  // normalise the ignored fields: the launch grid runs over input positions m = 0..H, n = 0..W
-    VSP_REQUIRE(pcopy.KH == 3 && pcopy.KW == 3 && pcopy.G == 1, "conv2d: transposed mode needs a 3x3 kernel and G = 1");
-    VSP_REQUIRE(!pcopy.noise && !pcopy.res1 && !pcopy.res2, "conv2d: transposed mode has no noise / residual epilogue");
-    VSP_REQUIRE(pcopy.y_h == 2 * pcopy.H + 1 && pcopy.y_w == 2 * pcopy.W + 1, "conv2d: transposed output must be (2H+1)x(2W+1)");
-    pcopy.stride_y = pcopy.stride_x = 1;
-    pcopy.dil[0] = 1;
-    pcopy.pad_y[0] = pcopy.pad_x[0] = 1;
-    pcopy.OH = pcopy.H + 1;
-    pcopy.OW = pcopy.W + 1;
-    pcopy.osy = pcopy.osx = 2;
-    pcopy.ooy = pcopy.oox = 0;
-  }
-  const vsp_conv_params& p = pcopy;
+// Argument checks shared by vsp_conv2d_f32 and vsp_conv2d_winograd_f32; *empty = nothing to do.
+static int validate_conv(const vsp_conv_params& p, int* x_ch_out, bool* empty) {
+  *empty = false;
   VSP_REQUIRE(p.x && p.w && p.y, "conv2d: null tensor pointer");
   VSP_REQUIRE(p.B >= 0 && p.Cin >= 1 && p.H >= 1 && p.W >= 1, "conv2d: bad input dims B=%d Cin=%d H=%d W=%d", p.B,
               p.Cin, p.H, p.W);
@@ -238,7 +215,10 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(!p.noise || p.noise_w, "conv2d: noise given without noise_w");
   VSP_REQUIRE(p.act2 != 2 || p.prelu, "conv2d: act2=prelu without slopes");
   for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g) VSP_REQUIRE(p.dil[g] >= 1, "conv2d: dilation must be >= 1");
-  if (p.B == 0 || p.OH == 0 || p.OW == 0) return VSP_OK;
+  if (p.B == 0 || p.OH == 0 || p.OW == 0) {
+    *empty = true;
+    return VSP_OK;
+  }
   const int Cout = p.G * p.cout_g;
   VSP_REQUIRE(p.y_coff >= 0 && p.y_coff + Cout <= p.y_ch, "conv2d: output channel window [%d,%d) outside %d", p.y_coff,
               p.y_coff + Cout, p.y_ch);
@@ -249,38 +229,12 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   if (p.res1 || p.res2)
     VSP_REQUIRE(p.res_coff >= 0 && p.res_coff + Cout <= p.res_ch, "conv2d: residual channel window out of range");
 
-  Plan best{};
-  bool found = false;
-  if (p.tile_hint > 0) {
-    VSP_REQUIRE(p.tile_hint <= kNumCfgs, "conv2d: tile_hint %d out of range", p.tile_hint);
-    found = make_plan(p, p.tile_hint - 1, &best);
-    VSP_REQUIRE(found, "conv2d: configuration %s does not fit this problem", kCfgs[p.tile_hint - 1].name);
-  } else if (p.tile_hint < 0 && -p.tile_hint <= kNumCfgs) {
-    // a PREFERENCE (tuned table): the table is keyed by geometry only, the same shape may come with an operand this
-    // configuration cannot serve (e.g. an input shift with the LDS-DMA staging) -- then the cost model decides
-    found = make_plan(p, -p.tile_hint - 1, &best);
-  }
-  if (!found) {
-    double best_cost = 0.0;
-    for (int c = 0; c < kNumCfgs; ++c) {
-      Plan pl{};
-      if (is_dg(kCfgs[c])) continue;  // the fused dilation-group kernels are only used when named (tile_hint / tuned table)
-      if (!make_plan(p, c, &pl)) continue;
-      const double cost = plan_cost(p, pl);
-      if (!found || cost < best_cost) {
-        best = pl;
-        best_cost = cost;
-        found = true;
-      }
-    }
-    if (!found) return vsp::fail(VSP_ENOTSUP, "conv2d: no tile configuration fits (KH=%d dil=%d)", p.KH, p.dil[0]);
-  }
-  const Cfg& k = kCfgs[best.cfg];
-  const int CO_T = 16 * k.MB * k.WM;
-  const int64_t gy = best.dg ? best.co_tiles : (int64_t)best.co_tiles * p.G;
-  VSP_REQUIRE(gy <= 65535 && p.B <= 65535, "conv2d: grid too large");
+  *x_ch_out = x_ch;
+  return VSP_OK;
+}
 
-  ConvK q{};
+// Everything of the kernel argument block that does not depend on the tile plan (operands resolved to pointer + stride).
+static int fill_convk(const vsp_conv_params& p, int x_ch, ConvK& q) {
   q.x = p.x; q.w = p.w; q.y = p.y;
   q.B = p.B; q.Cin = p.Cin; q.H = p.H; q.W = p.W; q.G = p.G; q.cout_g = p.cout_g;
   q.OH = p.OH; q.OW = p.OW; q.KH = p.KH; q.KW = p.KW; q.sy = p.stride_y; q.sx = p.stride_x;
@@ -319,13 +273,101 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   sel(p.res1, kZero, &q.r1p, &q.r1s);
   sel(p.res2, kZero, &q.r2p, &q.r2s);
   q.res_ch = p.res_ch; q.res_coff = p.res_coff;
+  q.x_ch = x_ch;
+  q.x_gs = p.x_group_stride;
+  return VSP_OK;
+}
+
+extern "C" int vsp_conv2d_num_configs(void) {
+  build_table();
+  return kNumCfgs;
+}
+extern "C" const char* vsp_conv2d_config_name(int i) {
+  build_table();
+  return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "";
+}
+
+extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr, "conv2d_winograd: null params");
+  const vsp_conv_params& p = *pp;
+  VSP_REQUIRE(!p.transposed && p.G == 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 && p.dil[0] == 1 &&
+                  p.pad_y[0] == 1 && p.pad_x[0] == 1 && p.x_group_stride == 0,
+              "conv2d_winograd: only the 3x3, stride 1, dilation 1, padding 1, ungrouped convolution");
+  VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
+  VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
+  VSP_REQUIRE(p.cout_g % 4 == 0 && vsp::aligned16(p.w), "conv2d_winograd: Cout must be a multiple of 4, weights 16-byte aligned");
+  VSP_REQUIRE((int64_t)16 * p.Cin * p.cout_g < ((int64_t)1 << 31), "conv2d_winograd: weight tensor too large");
+  int x_ch = 0;
+  bool empty = false;
+  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  if (empty) return VSP_OK;
+  ConvK q{};
+  if (int rc = fill_convk(p, x_ch, q)) return rc;
+  if (int rc = vspconv::wino_launch(q, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("conv2d_winograd");
+}
+
+extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr, "conv2d: null params");
+  build_table();
+  vsp_conv_params pcopy = *pp;
+  if (pcopy.transposed) {  // normalise the ignored fields: the launch grid runs over input positions m = 0..H, n = 0..W
+    VSP_REQUIRE(pcopy.KH == 3 && pcopy.KW == 3 && pcopy.G == 1, "conv2d: transposed mode needs a 3x3 kernel and G = 1");
+    VSP_REQUIRE(!pcopy.noise && !pcopy.res1 && !pcopy.res2, "conv2d: transposed mode has no noise / residual epilogue");
+    VSP_REQUIRE(pcopy.y_h == 2 * pcopy.H + 1 && pcopy.y_w == 2 * pcopy.W + 1, "conv2d: transposed output must be (2H+1)x(2W+1)");
+    pcopy.stride_y = pcopy.stride_x = 1;
+    pcopy.dil[0] = 1;
+    pcopy.pad_y[0] = pcopy.pad_x[0] = 1;
+    pcopy.OH = pcopy.H + 1;
+    pcopy.OW = pcopy.W + 1;
+    pcopy.osy = pcopy.osx = 2;
+    pcopy.ooy = pcopy.oox = 0;
+  }
+  const vsp_conv_params& p = pcopy;
+  int x_ch = 0;
+  bool empty = false;
+  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  if (empty) return VSP_OK;
+  const int Cout = p.G * p.cout_g;
+  (void)Cout;
+  Plan best{};
+  bool found = false;
+  if (p.tile_hint > 0) {
+    VSP_REQUIRE(p.tile_hint <= kNumCfgs, "conv2d: tile_hint %d out of range", p.tile_hint);
+    found = make_plan(p, p.tile_hint - 1, &best);
+    VSP_REQUIRE(found, "conv2d: configuration %s does not fit this problem", kCfgs[p.tile_hint - 1].name);
+  } else if (p.tile_hint < 0 && -p.tile_hint <= kNumCfgs) {
+    // a PREFERENCE (tuned table): the table is keyed by geometry only, the same shape may come with an operand this
+    // configuration cannot serve (e.g. an input shift with the LDS-DMA staging) -- then the cost model decides
+    found = make_plan(p, -p.tile_hint - 1, &best);
+  }
+  if (!found) {
+    double best_cost = 0.0;
+    for (int c = 0; c < kNumCfgs; ++c) {
+      Plan pl{};
+      if (is_dg(kCfgs[c])) continue;  // the fused dilation-group kernels are only used when named (tile_hint / tuned table)
+      if (!make_plan(p, c, &pl)) continue;
+      const double cost = plan_cost(p, pl);
+      if (!found || cost < best_cost) {
+        best = pl;
+        best_cost = cost;
+        found = true;
+      }
+    }
+    if (!found) return vsp::fail(VSP_ENOTSUP, "conv2d: no tile configuration fits (KH=%d dil=%d)", p.KH, p.dil[0]);
+  }
+  const Cfg& k = kCfgs[best.cfg];
+  const int CO_T = 16 * k.MB * k.WM;
+  const int64_t gy = best.dg ? best.co_tiles : (int64_t)best.co_tiles * p.G;
+  VSP_REQUIRE(gy <= 65535 && p.B <= 65535, "conv2d: grid too large");
+
+  ConvK q{};
+  if (int rc = fill_convk(p, x_ch, q)) return rc;
   q.tw_log2 = best.tw_log2; q.th = best.th; q.tiles_x = best.tiles_x; q.tiles_y = best.tiles_y;
   q.strip_col = best.strip_col;
   q.co_tiles = best.co_tiles;
   q.w_vec4 = (p.cout_g % 4 == 0) && (CO_T % 4 == 0) && vsp::aligned16(p.w) ? 1 : 0;
   q.ps_odd = !p.transposed && p.stride_x != 1;
-  q.x_ch = x_ch;
-  q.x_gs = p.x_group_stride;
   {
     static int dbg = -1;
     if (dbg < 0) {

@@ -61,6 +61,7 @@ def _config_ids():
 # resolved here); shapes that are not in the table use the library's cost model (tile_hint = 0)
 CONFIG_IDS = _config_ids()
 TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_IDS}
+WINO = {k: True for k, v in _load_tune_table().items() if v == "winograd"}  # shapes where the F(2x2,3x3) kernel won
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
@@ -155,7 +156,7 @@ class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
     Built once at model-load time (vspbfr_amd/packing.py)."""
 
-    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride")
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -165,10 +166,18 @@ class PackedConv:
         self.dil = rep(dil, 1)          # one value = the same geometry for every group
         self.pad_y = rep(pad_y, 0)
         self.pad_x = rep(pad_y if pad_x is None else pad_x, 0)
+        self._wino = None
 
     @property
     def cout(self):
         return self.G * self.cout_g
+
+    def winograd_weight(self):
+        """U = G g G^T (16, Cin, Cout), built on first use and kept with the packed weight."""
+        if self._wino is None:
+            with torch.no_grad():
+                self._wino = winograd_weight(self.w)
+        return self._wino
 
 
 def pack_weight(weight, groups=1):
@@ -176,6 +185,22 @@ def pack_weight(weight, groups=1):
     cout, cin, kh, kw = weight.shape
     assert cout % groups == 0
     return weight.reshape(groups, cout // groups, cin, kh * kw).permute(0, 3, 2, 1).contiguous()
+
+
+def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
+    return (not transposed and pc.G == 1 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.dil[0] == 1 and
+            pc.pad_y[0] == 1 and pc.pad_x[0] == 1 and pc.x_group_stride == 0 and pc.cout % 4 == 0 and (OH, OW) == (H, W) and
+            tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0))
+
+
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def winograd_weight(wp):
+    """packed weights (1, 9, Cin, Cout) -> U = G g G^T as (16, Cin, Cout) (see vsp_conv2d_winograd_f32), in float64."""
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=wp.device)
+    g = wp[0].double().view(3, 3, wp.shape[2], wp.shape[3])
+    return torch.einsum("ay,bx,yxio->abio", G, G, g).reshape(16, wp.shape[2], wp.shape[3]).float().contiguous()
 
 
 def conv2d_out_size(H, W, pc):
@@ -188,9 +213,10 @@ def conv2d_out_size(H, W, pc):
 def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out_offset=(0, 0), in_scale=None,
                   in_scale_per_sample=True, in_shift=None, out_scale=None, ch_scale=None, ch_bias=None, act1=False,
                   bias1=None, noise=None, noise_w=None, act2=0, bias2=None, prelu=None, slope2=0.2, gain2=SQRT2, res1=None,
-                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False):
+                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False, winograd=None):
     """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
-    compute (defaults to the standard conv output size)."""
+    compute (defaults to the standard conv output size).  `winograd`: True / False forces / forbids the F(2x2,3x3) kernel
+    (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape."""
     x = _req(x, "x")
     B, x_ch, H, W = x.shape
     Cin = pc.cin
@@ -230,6 +256,11 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         if pref == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
             pref = TUNE.get("8" + key[key.index(","):], 0)
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
+    wino_ok = winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
+    if winograd is None:
+        winograd = wino_ok and tile_hint == 0 and WINO.get(key, WINO.get("8" + key[key.index(","):], False))
+    elif winograd and not wino_ok:
+        raise RuntimeError("conv2d: this layer is not eligible for the Winograd kernel (3x3, stride 1, dilation 1, pad 1, G = 1)")
     if RECORDER is not None:
         RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))
     p.tile_hint = tile_hint
@@ -240,7 +271,13 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     prof = PROFILER
     if prof is not None:
         start = prof.begin()
-    check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
+    if winograd:
+        uw = pc.winograd_weight()
+        keep.append(uw)
+        p.w = uw.data_ptr()
+        check(lib.vsp_conv2d_winograd_f32(C.byref(p), _stream()), "conv2d_winograd")
+    else:
+        check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
         prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G))
     return out
