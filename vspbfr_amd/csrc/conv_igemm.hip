@@ -303,6 +303,10 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
   if (empty) return VSP_OK;
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
+  {
+    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    q.dbg = dbg;
+  }
   if (int rc = vspconv::wino_launch(q, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_winograd");
 }

@@ -81,15 +81,19 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     u_dst[e] = (pos * WCK + ci) * UPITCH + c4 * 4;
     u_src[e] = (co0 + c4 * 4 < Cout) ? (pos * p.Cin + ci) * Cout + co0 + c4 * 4 : -1;
   }
-  float preg[PLD];
+  // prefetch registers: U one chunk ahead (L2-resident, 16 KB per layer and position), the input patch TWO chunks ahead
+  // (it streams from MALL/HBM: its latency is longer than one chunk of work)
+  float preg[PLD], pnext[PLD];
   float4 ureg[ULD];
-  auto issue = [&](int ci0) {
+  auto issue_u = [&](int ci0) {
 #pragma unroll
     for (int e = 0; e < ULD; ++e) {
       const bool ok = u_src[e] >= 0 && ci0 + u_ci[e] < p.Cin;
       const float4 v = *reinterpret_cast<const float4*>(p.w + (int64_t)ci0 * Cout + (ok ? u_src[e] : 0));
       ureg[e] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto issue_p = [&](int ci0) {
 #pragma unroll
     for (int e = 0; e < PLD; ++e) {
       const int ci = ci0 + p_ch[e];
@@ -97,11 +101,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       float v = 0.f;
       if (ok) {
         v = xb[(int64_t)ci * chw + p_src[e]];
-        const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
-        const float sh = p.in_shift ? p.in_shift[ci] : 0.f;
-        v = fmaf(v, sc, sh);
+        if (p.in_shift) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
+          const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
+          v = fmaf(v, sc, p.in_shift[ci]);
+        }
       }
-      preg[e] = v;
+      pnext[e] = v;
     }
   };
 
@@ -120,7 +125,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
+  issue_u(0);
+  issue_p(0);
+#pragma unroll
+  for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
+  if (WCK < p.Cin) issue_p(WCK);
   for (int ci0 = 0; ci0 < p.Cin; ci0 += WCK) {
     __syncthreads();  // previous MFMA phase has finished with Ul / Vl
 #pragma unroll
@@ -129,19 +138,24 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     for (int e = 0; e < PLD; ++e)
       if (p_dst[e] >= 0) Pl[p_dst[e]] = preg[e];
     __syncthreads();
-    if (ci0 + WCK < p.Cin) issue(ci0 + WCK);
+    if (ci0 + WCK < p.Cin) issue_u(ci0 + WCK);
+#pragma unroll
+    for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];  // patch of chunk ci0 + WCK (issued one iteration ago)
+    if (ci0 + 2 * WCK < p.Cin) issue_p(ci0 + 2 * WCK);
     {  // V = B^T d B for this thread's (channel, tile): rows 2h, 2h+1 of W = B^T d, then W B
       float d[3][4];  // rows h, h+1, h+2 of the 4x4 window
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) d[r][c] = t_src[(th + r) * PC + c];
+      float sc = 1.f;  // the style scale rides on V (the transform is linear)
+      if (p.in_scale && !p.in_shift && ci0 + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + ci0 + t_ch];
       float w0[4], w1[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // h = 0: W0 = d0 - d2, W1 = d1 + d2      h = 1: W2 = d2 - d1, W3 = d1 - d3  (rows relative to h: d[0..2] = d_h..d_{h+2})
-        w0[c] = th ? d[1][c] - d[0][c] : d[0][c] - d[2][c];
-        w1[c] = th ? d[0][c] - d[2][c] : d[1][c] + d[2][c];
+        w0[c] = (th ? d[1][c] - d[0][c] : d[0][c] - d[2][c]) * sc;
+        w1[c] = (th ? d[0][c] - d[2][c] : d[1][c] + d[2][c]) * sc;
       }
       const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
       const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
