@@ -105,6 +105,7 @@ SIGNATURES = {
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
     "vsp_tacc_chain_f32": [_p, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
+    "vsp_conv2d_winograd_chunk": [],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
 _SIZET = {"vsp_tacc_chain_work_floats": [_i]}

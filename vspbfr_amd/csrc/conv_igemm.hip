@@ -287,6 +287,8 @@ extern "C" const char* vsp_conv2d_config_name(int i) {
   return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "";
 }
 
+extern "C" int vsp_conv2d_winograd_chunk(void) { return vspconv::wino_chunk(); }
+
 extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d_winograd: null params");
   const vsp_conv_params& p = *pp;
@@ -295,7 +297,7 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
               "conv2d_winograd: only the 3x3, stride 1, dilation 1, padding 1, ungrouped convolution");
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
   VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
-  VSP_REQUIRE(p.cout_g % 4 == 0 && vsp::aligned16(p.w), "conv2d_winograd: Cout must be a multiple of 4, weights 16-byte aligned");
+  VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd: transformed weights must be 16-byte aligned");
   VSP_REQUIRE((int64_t)16 * p.Cin * p.cout_g < ((int64_t)1 << 31), "conv2d_winograd: weight tensor too large");
   int x_ch = 0;
   bool empty = false;

@@ -7,12 +7,16 @@
 // Winograd position and Y = A^T M A, a 2x2 output tile costs 16 MACs per (co, ci) -- sixteen independent (Cout x Cin) x
 // (Cin x tiles) GEMMs on MFMA -- plus transforms that are additions only.
 //
-// One workgroup (8 waves) owns 64 output channels x a 16 x 8 pixel region (8 x 4 tiles) of one image.  Per chunk of 8
-// input channels:
-//   1. the prefetched 18 x 10 input patch and the 16 x 8 x 64 slab of U go from registers to LDS        (barrier)
-//   2. every thread pair turns one (channel, tile) window into its 16 V values (LDS -> LDS, adds only),
-//      while the global loads of the next chunk are already in flight                                    (barrier)
-//   3. wave w multiplies positions 2w, 2w+1: 2 k-steps x (4 co blocks x 2 tile blocks) MFMAs each        (barrier)
+// One workgroup (8 waves) owns 64 output channels x a 16 x 8 pixel region (8 x 4 tiles) of one image; wave w owns the
+// Winograd positions 2w and 2w+1.  What shapes the kernel (ablations on the first version: the global loads were 31 % of
+// the time, LDS writes 5 %, the transform 5 %, and nothing of it overlapped the MFMAs because three barriers per chunk kept
+// the eight waves in lock step):
+//   * U never touches LDS.  No two waves share a position, so the host stores U in FRAGMENT order
+//     [co tile][chunk][wave][lane][16] and a wave fetches its A fragments of a chunk as four 16-byte loads per lane
+//     (4 KB contiguous per wave), one chunk ahead, straight into the registers the MFMAs read.
+//   * the input patch is prefetched two chunks ahead (it streams from MALL/HBM) and double-buffered in LDS, V is
+//     double-buffered too: the transform of chunk i+1, the MFMAs of chunk i and the patch write of chunk i+2 share ONE
+//     barrier interval.
 // Epilogue, per 16-channel block: the sixteen position accumulators meet in LDS, one thread per (channel, tile) applies
 // A^T . A, the same fused operand chain as the direct kernel (demod, bias, two activations, noise, two residuals) and stores
 // the 2x2 pixels.  Numerics: F(2x2,3x3) in fp32 adds ~1e-6 relative error (transform constants are 1 and 1/2).
@@ -22,25 +26,24 @@ namespace vspconv {
 
 namespace {
 
-constexpr int WCK = 8;      // input channels per chunk
+constexpr int WCK = 4;      // input channels per chunk (the host packs U for this value: vsp_conv2d_winograd_chunk())
+constexpr int KS = WCK / 4; // k-steps per chunk
 constexpr int WCO = 64;     // output channels per workgroup
 constexpr int TLX = 8, TLY = 4, NTILE = TLX * TLY;  // Winograd tiles per workgroup (16 x 8 pixels)
 constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2;   // input patch 10 x 18
 constexpr int PPITCH = 192;                         // >= PR * PC
-constexpr int UPITCH = WCO + 16;                    // 80: k-slot rows 16 banks apart
-constexpr int VPITCH = NTILE + 16;                  // 48
+constexpr int VPITCH = NTILE + 16;                  // 48: k-slot rows 16 banks apart
 constexpr int NTHR = 512;
-constexpr int LDS_U = 16 * WCK * UPITCH;            // 10240 floats
-constexpr int LDS_V = 16 * WCK * VPITCH;            // 6144
-constexpr int LDS_P = WCK * PPITCH;                 // 1536
-constexpr int LDS_M = 16 * 16 * NTILE;              // 8192 (epilogue, overlays U)
-constexpr int LDS_FLOATS = LDS_U + LDS_V + LDS_P;
+constexpr int LDS_V = 16 * WCK * VPITCH;            // 6144 floats, two buffers
+constexpr int LDS_P = WCK * PPITCH;                 // 1536 floats, two buffers
+constexpr int LDS_M = 16 * 16 * NTILE;              // 8192 (epilogue, overlays everything)
+constexpr int LDS_STAGE = 2 * LDS_V + 2 * LDS_P;
+constexpr int LDS_FLOATS = LDS_STAGE > LDS_M ? LDS_STAGE : LDS_M;
 
 __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ul = smem;                 // [16][WCK][UPITCH]
-  float* Vl = smem + LDS_U;         // [16][WCK][VPITCH]
-  float* Pl = smem + LDS_U + LDS_V; // [WCK][PPITCH]
+  float* Vl = smem;               // 2 x [16][WCK][VPITCH]
+  float* Pl = smem + 2 * LDS_V;   // 2 x [WCK][PPITCH]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -54,8 +57,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int Cout = p.cout_g;
   const int chw = p.H * p.W;
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
+  const int nchunk = (p.Cin + WCK - 1) / WCK;
 
-  // ---- chunk-invariant staging geometry (one pass per thread)
+  // ---- input patch: chunk-invariant geometry, values prefetched two chunks ahead
   constexpr int PWORDS = WCK * PR * PC;             // 1440 patch words per chunk
   constexpr int PLD = (PWORDS + NTHR - 1) / NTHR;   // 3
   int p_src[PLD], p_dst[PLD], p_ch[PLD];            // image offset (-1: outside / unused), LDS word, channel in chunk
@@ -70,33 +74,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     p_dst[e] = i < PWORDS ? ch * PPITCH + rem : -1;
     p_ch[e] = ch;
   }
-  constexpr int ULD = 16 * WCK * (WCO / 4) / NTHR;  // 4 float4 of U per thread and chunk
-  int u_src[ULD], u_dst[ULD], u_ci[ULD];
-#pragma unroll
-  for (int e = 0; e < ULD; ++e) {
-    const int j = tid + e * NTHR;
-    const int pos = j / (WCK * (WCO / 4)), rem = j - pos * (WCK * (WCO / 4));
-    const int ci = rem / (WCO / 4), c4 = rem - ci * (WCO / 4);
-    u_ci[e] = ci;
-    u_dst[e] = (pos * WCK + ci) * UPITCH + c4 * 4;
-    u_src[e] = (co0 + c4 * 4 < Cout) ? (pos * p.Cin + ci) * Cout + co0 + c4 * 4 : -1;
-  }
-  // prefetch registers: U one chunk ahead (L2-resident, 16 KB per layer and position), the input patch TWO chunks ahead
-  // (it streams from MALL/HBM: its latency is longer than one chunk of work)
   float preg[PLD], pnext[PLD];
-  float4 ureg[ULD];
-  auto issue_u = [&](int ci0) {
-#pragma unroll
-    for (int e = 0; e < ULD; ++e) {
-      const bool ok = u_src[e] >= 0 && ci0 + u_ci[e] < p.Cin;
-      const float4 v = *reinterpret_cast<const float4*>(p.w + (int64_t)ci0 * Cout + (ok ? u_src[e] : 0));
-      ureg[e] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto issue_p = [&](int ci0) {
+  auto issue_p = [&](int c) {  // chunk c -> pnext
 #pragma unroll
     for (int e = 0; e < PLD; ++e) {
-      const int ci = ci0 + p_ch[e];
+      const int ci = c * WCK + p_ch[e];
       const bool ok = p_src[e] >= 0 && ci < p.Cin;
       float v = 0.f;
       if (ok) {
@@ -109,13 +91,51 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       pnext[e] = v;
     }
   };
+  auto commit_p = [&](float* Pdst) {
+#pragma unroll
+    for (int e = 0; e < PLD; ++e)
+      if (p_dst[e] >= 0) Pdst[p_dst[e]] = preg[e];
+  };
+
+  // ---- U fragments: [co tile][chunk][wave][lane][pp 2][ks KS][mb 4] floats, 32 KS bytes per lane and chunk
+  constexpr int UQ = 2 * KS;  // float4 per lane and chunk
+  const float* ufr = p.w + (((int64_t)blockIdx.y * nchunk * 8 + wave) * 64 + lane) * (4 * UQ);
+  auto load_u = [&](int c, float4 (&u)[UQ]) {
+    const float4* src = reinterpret_cast<const float4*>(ufr + (int64_t)c * (8 * 64 * 4 * UQ));
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) u[q] = src[q];
+  };
 
   // ---- transform roles: thread pair q = tid >> 1 owns (channel, tile); half h = tid & 1 produces V rows 2h, 2h+1
   const int tq = tid >> 1, th = tid & 1;
   const int t_ch = tq >> 5, t_tile = tq & 31;
   const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-  const float* t_src = Pl + t_ch * PPITCH + (2 * t_ty) * PC + 2 * t_tx;
-  float* t_dst = Vl + t_ch * VPITCH + t_tile;
+  const int t_src = t_ch * PPITCH + (2 * t_ty) * PC + 2 * t_tx;
+  const int t_dst = t_ch * VPITCH + t_tile;
+  auto transform = [&](const float* Psrc, float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
+    if (tid >= 2 * WCK * NTILE) return;
+    float d[3][4];  // rows h, h+1, h+2 of the 4x4 window
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) d[r][cc] = Psrc[t_src + (th + r) * PC + cc];
+    float sc = 1.f;
+    if (p.in_scale && !p.in_shift && c * WCK + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * WCK + t_ch];
+    float w0[4], w1[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      // h = 0: W0 = d0 - d2, W1 = d1 + d2      h = 1: W2 = d2 - d1, W3 = d1 - d3  (d[0..2] = window rows h..h+2)
+      w0[cc] = (th ? d[1][cc] - d[0][cc] : d[0][cc] - d[2][cc]) * sc;
+      w1[cc] = (th ? d[0][cc] - d[2][cc] : d[1][cc] + d[2][cc]) * sc;
+    }
+    const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
+    const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      Vdst[t_dst + ((2 * th) * 4 + nu) * (WCK * VPITCH)] = v0[nu];
+      Vdst[t_dst + ((2 * th + 1) * 4 + nu) * (WCK * VPITCH)] = v1[nu];
+    }
+  };
 
   f32x4 acc[2][4][2];
 #pragma unroll
@@ -124,67 +144,60 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue_u(0);
-  issue_p(0);
-#pragma unroll
-  for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
-  if (WCK < p.Cin) issue_p(WCK);
-  for (int ci0 = 0; ci0 < p.Cin; ci0 += WCK) {
-    __syncthreads();  // previous MFMA phase has finished with Ul / Vl
-#pragma unroll
-    for (int e = 0; e < ULD; ++e) *reinterpret_cast<float4*>(Ul + u_dst[e]) = ureg[e];
-#pragma unroll
-    for (int e = 0; e < PLD; ++e)
-      if (p_dst[e] >= 0) Pl[p_dst[e]] = preg[e];
-    __syncthreads();
-    if (ci0 + WCK < p.Cin) issue_u(ci0 + WCK);
-#pragma unroll
-    for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];  // patch of chunk ci0 + WCK (issued one iteration ago)
-    if (ci0 + 2 * WCK < p.Cin) issue_p(ci0 + 2 * WCK);
-    {  // V = B^T d B for this thread's (channel, tile): rows 2h, 2h+1 of W = B^T d, then W B
-      float d[3][4];  // rows h, h+1, h+2 of the 4x4 window
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[r][c] = t_src[(th + r) * PC + c];
-      float sc = 1.f;  // the style scale rides on V (the transform is linear)
-      if (p.in_scale && !p.in_shift && ci0 + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + ci0 + t_ch];
-      float w0[4], w1[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // h = 0: W0 = d0 - d2, W1 = d1 + d2      h = 1: W2 = d2 - d1, W3 = d1 - d3  (rows relative to h: d[0..2] = d_h..d_{h+2})
-        w0[c] = (th ? d[1][c] - d[0][c] : d[0][c] - d[2][c]) * sc;
-        w1[c] = (th ? d[0][c] - d[2][c] : d[1][c] + d[2][c]) * sc;
-      }
-      const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
-      const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        t_dst[((2 * th) * 4 + nu) * (WCK * VPITCH)] = v0[nu];
-        t_dst[((2 * th + 1) * 4 + nu) * (WCK * VPITCH)] = v1[nu];
-      }
-    }
-    __syncthreads();
+  auto multiply = [&](const float* Vsrc, const float4 (&u)[UQ]) {
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
-      const int pos = 2 * wave + pp;
-      const float* up = Ul + pos * (WCK * UPITCH) + kq * UPITCH + lr;
-      const float* vp = Vl + pos * (WCK * VPITCH) + kq * VPITCH + lr;
+      const float* vp = Vsrc + (2 * wave + pp) * (WCK * VPITCH) + kq * VPITCH + lr;
 #pragma unroll
-      for (int ks = 0; ks < WCK / 4; ++ks) {
-        float a[4], bv[2];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) a[mb] = up[ks * 4 * UPITCH + mb * 16];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bv[nb] = vp[ks * 4 * VPITCH + nb * 16];
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
-            acc[pp][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], bv[nb], acc[pp][mb][nb], 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 a = u[pp * KS + ks];
+        const float bv0 = vp[ks * 4 * VPITCH], bv1 = vp[ks * 4 * VPITCH + 16];
+        acc[pp][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv0, acc[pp][0][0], 0, 0, 0);
+        acc[pp][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv1, acc[pp][0][1], 0, 0, 0);
+        acc[pp][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv0, acc[pp][1][0], 0, 0, 0);
+        acc[pp][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv1, acc[pp][1][1], 0, 0, 0);
+        acc[pp][2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv0, acc[pp][2][0], 0, 0, 0);
+        acc[pp][2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv1, acc[pp][2][1], 0, 0, 0);
+        acc[pp][3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv0, acc[pp][3][0], 0, 0, 0);
+        acc[pp][3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv1, acc[pp][3][1], 0, 0, 0);
       }
     }
+  };
+
+  // ---- pipeline.  State at the top of step i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ua = U(i) (registers, landed),
+  //      preg = patch(i+2) (landed), in flight: nothing older than one step.
+  float4 ua[UQ], ub[UQ];
+  issue_p(0);
+  load_u(0, ua);
+#pragma unroll
+  for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
+  commit_p(Pl);                                   // patch(0) -> Pl[0]
+  if (nchunk > 1) issue_p(1);
+  __syncthreads();
+  transform(Pl, Vl, 0);                           // V(0) -> Vl[0]
+  if (nchunk > 1) {
+#pragma unroll
+    for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
+    commit_p(Pl + LDS_P);                         // patch(1) -> Pl[1]
+    if (nchunk > 2) issue_p(2);
+  }
+  __syncthreads();
+  auto step = [&](int i, const float4 (&ucur)[UQ], float4 (&unxt)[UQ]) {
+    const int cur = i & 1, nxt = cur ^ 1;
+    if (i + 1 < nchunk) load_u(i + 1, unxt);
+    if (i + 2 < nchunk) {
+#pragma unroll
+      for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one step ago
+    }
+    if (i + 3 < nchunk) issue_p(i + 3);
+    if (i + 1 < nchunk) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
+    multiply(Vl + cur * LDS_V, ucur);
+    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P);        // Pl[cur] held patch(i): consumed one step ago
+    __syncthreads();
+  };
+  for (int i = 0; i < nchunk; i += 2) {
+    step(i, ua, ub);
+    if (i + 1 < nchunk) step(i + 1, ub, ua);
   }
 
   // ---- epilogue: per 16-channel block, all sixteen positions through LDS, one thread per (channel, tile)
@@ -247,10 +260,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 
 }  // namespace
 
+int wino_chunk() { return WCK; }
+
 int wino_launch(ConvK q, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  static_assert(LDS_M <= LDS_FLOATS, "epilogue buffer overlays the staging area");
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

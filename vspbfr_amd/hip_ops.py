@@ -197,10 +197,20 @@ _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
 def winograd_weight(wp):
-    """packed weights (1, 9, Cin, Cout) -> U = G g G^T as (16, Cin, Cout) (see vsp_conv2d_winograd_f32), in float64."""
-    G = torch.tensor(_WINO_G, dtype=torch.float64, device=wp.device)
-    g = wp[0].double().view(3, 3, wp.shape[2], wp.shape[3])
-    return torch.einsum("ay,bx,yxio->abio", G, G, g).reshape(16, wp.shape[2], wp.shape[3]).float().contiguous()
+    """packed weights (1, 9, Cin, Cout) -> U = G g G^T in the FRAGMENT order of vsp_conv2d_winograd_f32:
+    [co tile (64)][chunk (CK ci)][wave 8][lane 64][pp 2][ks CK/4][mb 4] with position = 2 wave + pp, ci = CK chunk + 4 ks + (lane >> 4),
+    co = 64 tile + 16 mb + (lane & 15); Cin / Cout are zero-padded to multiples of 8 / 64.  Computed in float64."""
+    Gm = torch.tensor(_WINO_G, dtype=torch.float64, device=wp.device)
+    cin, cout = wp.shape[2], wp.shape[3]
+    g = wp[0].double().view(3, 3, cin, cout)
+    U = torch.einsum("ay,bx,yxio->abio", Gm, Gm, g).reshape(16, cin, cout)
+    ck = lib.vsp_conv2d_winograd_chunk()
+    nch, nct = (cin + ck - 1) // ck, (cout + 63) // 64
+    Up = U.new_zeros(16, nch * ck, nct * 64)
+    Up[:, :cin, :cout] = U
+    # [wave 8][pp 2][chunk][ks][kq 4][tile][mb 4][lr 16] -> [tile][chunk][wave][kq][lr][pp][ks][mb]
+    Up = Up.view(8, 2, nch, ck // 4, 4, nct, 4, 16).permute(5, 2, 0, 4, 7, 1, 3, 6)
+    return Up.float().contiguous().view(-1)
 
 
 def conv2d_out_size(H, W, pc):
