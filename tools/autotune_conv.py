@@ -15,6 +15,9 @@ from vspbfr_amd import hip_ops as H
 from vspbfr_amd._lib import lib
 
 
+WINO_ID = 1 << 20  # pseudo configuration id of the Winograd kernel in the timing tables
+
+
 def timeit(fn, iters):
     fn()
     torch.cuda.synchronize()
@@ -31,7 +34,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     dev = torch.device("cuda", 0)
-    H.TUNE = {}
+    H.TUNE, H.WINO = {}, {}
     pipe = bench.build_pipeline(dev, T, True)
     lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
     H.RECORDER = []
@@ -67,13 +70,23 @@ def main():
         if not [c for c in times if c > 0]:
             print("no configuration ran for", key, flush=True)
             continue
+        name_of = lambda c: "winograd" if c == WINO_ID else lib.vsp_conv2d_config_name(c - 1).decode()  # noqa: E731
+        if not tr and H.winograd_eligible(pc, Hh, Ww, OH, OW):
+            try:
+                kw = dict(out=out, n_out=(OH, OW), winograd=True)
+                if key.endswith(",s"):
+                    kw["in_shift"] = shift
+                timeit(lambda: H.conv2d_packed(x, pc, **kw), 1)
+                times[WINO_ID] = timeit(lambda: H.conv2d_packed(x, pc, **kw), 5)
+            except RuntimeError:
+                pass
         best = min((c for c in times if c > 0), key=lambda c: times[c])
-        table[key] = lib.vsp_conv2d_config_name(best - 1).decode()
+        table[key] = name_of(best)
         order = sorted((c for c in times if c > 0), key=lambda c: times[c])[:5]
-        cands[key] = [lib.vsp_conv2d_config_name(c - 1).decode() for c in order]
+        cands[key] = [name_of(c) for c in order]
         tot_auto += times[0] * count
         tot_best += times[best] * count
-        report.append((times[best] * count, key, count, lib.vsp_conv2d_config_name(best - 1).decode(), round(times[best] * 1e3, 1),
+        report.append((times[best] * count, key, count, name_of(best), round(times[best] * 1e3, 1),
                        round(times[0] * 1e3, 1), round(flops / times[best] / 1e9, 1)))
     report.sort(reverse=True)
     for r in report[:60]:
@@ -91,7 +104,9 @@ def insitu(pipe, lq, cands, table):
     shape uses its rank-j candidate), time each launch with HIP events, keep the per-shape winner."""
     by_key = {}
     for j in range(5):
-        H.TUNE = {k: H.CONFIG_IDS[v[min(j, len(v) - 1)]] for k, v in cands.items()}
+        pick = {k: v[min(j, len(v) - 1)] for k, v in cands.items()}
+        H.TUNE = {k: H.CONFIG_IDS[v] for k, v in pick.items() if v != "winograd"}
+        H.WINO = {k: True for k, v in pick.items() if v == "winograd"}
         for rep in range(2):
             prof = H.ConvProfiler()
             H.PROFILER = prof
