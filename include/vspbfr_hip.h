@@ -167,17 +167,19 @@ typedef struct vsp_conv_params {
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
 /* Number of tile configurations compiled in, and a description of configuration i ("64x256 ..."). */
-/* The same convolution contract for the 3x3 / stride 1 / dilation 1 / padding 1 / G = 1 case through Winograd F(2x2,3x3):
+/* The same convolution contract for 3x3 / stride 1 / padding = dilation layers (G = 1, or up to four dilation groups over
+ * one shared input: x_group_stride = 0) through Winograd F(2x2,3x3); a dilation d is served as d*d polyphase sub-images.
  * `w` must hold the TRANSFORMED weights U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]) in the kernel's
- * fragment order, with CK = vsp_conv2d_winograd_chunk() input channels per chunk (KS = CK / 4 k-steps) and Cin / Cout
- * zero-padded to multiples of CK / 64:
- *     w[((((tile * nchunk + chunk) * 8 + wave) * 64 + lane) * 2 + pp) * KS + ks) * 4 + mb]
- *         = U[position 2*wave + pp][ci = CK*chunk + 4*ks + (lane >> 4)][co = 64*tile + 16*mb + (lane & 15)]
+ * fragment order.  With CK = vsp_conv2d_winograd_chunk() input channels per chunk, MB = vsp_conv2d_winograd_mbw(cout_g)
+ * 16-channel blocks per workgroup, Cin zero-padded to a multiple of CK and cout_g to a multiple of 16*MB:
+ *     w[((((((g * ntile + tile) * nchunk + chunk) * 8 + wave) * 64 + lane) * 2 + pp) * MB + mb]
+ *         = U_g[position 2*wave + pp][ci = CK*chunk + (lane >> 4)][co = 16*MB*tile + 16*mb + (lane & 15)]
  * (a wave owns two Winograd positions and reads its MFMA A fragments of a chunk as contiguous bytes per lane).
  * Every prologue / epilogue field of vsp_conv_params keeps its meaning, tile_hint is ignored.  16 multiplies per 2x2
  * output tile instead of 36; fp32 error ~1e-6 relative on top of the direct kernel's summation-order noise. */
 int vsp_conv2d_winograd_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_chunk(void);
+int vsp_conv2d_winograd_mbw(int cout_g);
 int vsp_conv2d_num_configs(void);
 const char* vsp_conv2d_config_name(int i);
 

@@ -501,3 +501,21 @@ def test_conv2d_winograd(H, B, Cin, Cout, Hh, Ww):
     close(y2, ref2, 5e-5, 5e-5)
     with pytest.raises(RuntimeError):
         H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 2, (1,), (1,)), winograd=True)
+
+
+@pytest.mark.parametrize("B,Cin,Cg,Hh,Ww", [(2, 16, 8, 24, 24), (1, 24, 16, 37, 21), (2, 64, 32, 32, 32), (1, 40, 64, 16, 48), (1, 32, 128, 19, 19)])
+def test_conv2d_winograd_dilation_groups(H, B, Cin, Cg, Hh, Ww):
+    """The four dilated SMART branches through the polyphase Winograd kernel (one launch, all three channel-block variants)."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    ws = [torch.randn(Cg, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(4)]
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, 4 * Cg) + 0.5, torch.randn(4 * Cg)
+    xs = x * s_in.view(B, Cin, 1, 1)
+    ref = torch.cat([F.conv2d(xs, w_, padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1)
+    ref = F.leaky_relu(ref * demod.view(B, -1, 1, 1) + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), winograd=True)
+    close(y, ref, 5e-5, 5e-5)
+    # a single dilated conv (G = 1, d = 2)
+    pc1 = H.PackedConv(H.pack_weight(dev(ws[1])), 1, Cg, Cin, 3, 3, 1, (2,), (2,))
+    close(H.conv2d_packed(dev(x), pc1, winograd=True), F.conv2d(x, ws[1], padding=2, dilation=2), 5e-5, 5e-5)

@@ -106,6 +106,7 @@ SIGNATURES = {
     "vsp_tacc_chain_f32": [_p, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_winograd_chunk": [],
+    "vsp_conv2d_winograd_mbw": [_i],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
 _SIZET = {"vsp_tacc_chain_work_floats": [_i]}

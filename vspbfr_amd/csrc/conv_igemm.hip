@@ -288,13 +288,18 @@ extern "C" const char* vsp_conv2d_config_name(int i) {
 }
 
 extern "C" int vsp_conv2d_winograd_chunk(void) { return vspconv::wino_chunk(); }
+extern "C" int vsp_conv2d_winograd_mbw(int cout_g) { return vspconv::wino_mbw(cout_g); }
 
 extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d_winograd: null params");
   const vsp_conv_params& p = *pp;
-  VSP_REQUIRE(!p.transposed && p.G == 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 && p.dil[0] == 1 &&
-                  p.pad_y[0] == 1 && p.pad_x[0] == 1 && p.x_group_stride == 0,
-              "conv2d_winograd: only the 3x3, stride 1, dilation 1, padding 1, ungrouped convolution");
+  VSP_REQUIRE(!p.transposed && p.G >= 1 && p.G <= 4 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 &&
+                  p.x_group_stride == 0,
+              "conv2d_winograd: only 3x3, stride 1, at most four groups over one shared input");
+  for (int g = 0; g < p.G; ++g)
+    VSP_REQUIRE(p.dil[g] >= 1 && p.dil[g] <= 64 && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
+                "conv2d_winograd: group %d needs padding = dilation (got dilation %d, padding %d/%d)", g, p.dil[g], p.pad_y[g],
+                p.pad_x[g]);
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
   VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd: transformed weights must be 16-byte aligned");

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
 // conv_wino.hip: Winograd F(2x2,3x3) launch (q.w = transformed weights [16][Cin][Cout]); tiles are set inside
 int wino_launch(ConvK q, hipStream_t stream);
-int wino_chunk();  // input channels per chunk the transformed-weight layout is built for
+int wino_chunk();           // input channels per chunk the transformed-weight layout is built for
+int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout) for a layer with cout_g channels per group
 
 struct Cfg {
   int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;  // a name ending in "t" marks a transposed-conv kernel

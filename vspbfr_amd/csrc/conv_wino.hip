@@ -1,5 +1,5 @@
-// Winograd F(2x2, 3x3) convolution on fp32 MFMA for gfx950: the stride-1, dilation-1, 3x3 layers of the path
-// (StyledConv / SMART fusion / IR-SE convolutions) with 16 multiplies per 2x2 output tile instead of 36.
+// Winograd F(2x2, 3x3) convolution on fp32 MFMA for gfx950: the stride-1 3x3 layers of the path (StyledConv, SMART fusion
+// and SMART dilated branches, IR-SE convolutions) with 16 multiplies per 2x2 output tile instead of 36.
 //
 // The direct kernel (conv_kernel.h) is bound by the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 issues at 1/4 of the bf16
 // rate): its big layers sit at 118 TFLOP/s of a 131 TFLOP/s MFMA-only ceiling.  The only way past that at fp32 is fewer
@@ -7,16 +7,19 @@
 // Winograd position and Y = A^T M A, a 2x2 output tile costs 16 MACs per (co, ci) -- sixteen independent (Cout x Cin) x
 // (Cin x tiles) GEMMs on MFMA -- plus transforms that are additions only.
 //
-// One workgroup (8 waves) owns 64 output channels x a 16 x 8 pixel region (8 x 4 tiles) of one image; wave w owns the
-// Winograd positions 2w and 2w+1.  What shapes the kernel (ablations on the first version: the global loads were 31 % of
-// the time, LDS writes 5 %, the transform 5 %, and nothing of it overlapped the MFMAs because three barriers per chunk kept
-// the eight waves in lock step):
+// One workgroup (8 waves) owns 16 MBW output channels x 16 NBW tiles of one image; wave w owns the Winograd positions 2w
+// and 2w+1.  What shapes the kernel (ablations on the first version: the global loads were 31 % of the time, LDS writes 5 %,
+// the transform 5 %, and nothing of it overlapped the MFMAs because three barriers per chunk kept the eight waves in lock
+// step):
 //   * U never touches LDS.  No two waves share a position, so the host stores U in FRAGMENT order
-//     [co tile][chunk][wave][lane][16] and a wave fetches its A fragments of a chunk as four 16-byte loads per lane
-//     (4 KB contiguous per wave), one chunk ahead, straight into the registers the MFMAs read.
+//     [group][co tile][chunk][wave][lane][pp][mb] and a wave fetches its A fragments of a chunk as one contiguous run per
+//     lane, one chunk ahead, straight into the registers the MFMAs read.
 //   * the input patch is prefetched two chunks ahead (it streams from MALL/HBM) and double-buffered in LDS, V is
 //     double-buffered too: the transform of chunk i+1, the MFMAs of chunk i and the patch write of chunk i+2 share ONE
-//     barrier interval.
+//     barrier interval (4 input channels per chunk keep all of it inside 128 VGPRs: two workgroups per CU).
+//   * dilation d (the SMART branches) is a polyphase problem: output pixels with the same (y mod d, x mod d) form a
+//     (H/d) x (W/d) image on which the layer is an ordinary 3x3 convolution, so a workgroup simply addresses the image with
+//     stride d from its residue; the four dilation groups of a launch differ only in d and in their weight / channel base.
 // Epilogue, per 16-channel block: the sixteen position accumulators meet in LDS, one thread per (channel, tile) applies
 // A^T . A, the same fused operand chain as the direct kernel (demod, bias, two activations, noise, two residuals) and stores
 // the 2x2 pixels.  Numerics: F(2x2,3x3) in fp32 adds ~1e-6 relative error (transform constants are 1 and 1/2).
@@ -26,21 +29,33 @@ namespace vspconv {
 
 namespace {
 
-constexpr int WCK = 4;      // input channels per chunk (the host packs U for this value: vsp_conv2d_winograd_chunk())
-constexpr int KS = WCK / 4; // k-steps per chunk
-constexpr int WCO = 64;     // output channels per workgroup
-constexpr int TLX = 8, TLY = 4, NTILE = TLX * TLY;  // Winograd tiles per workgroup (16 x 8 pixels)
-constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2;   // input patch 10 x 18
-constexpr int PPITCH = 192;                         // >= PR * PC
-constexpr int VPITCH = NTILE + 16;                  // 48: k-slot rows 16 banks apart
+constexpr int WCK = 4;      // input channels per chunk = one MFMA k-step
 constexpr int NTHR = 512;
-constexpr int LDS_V = 16 * WCK * VPITCH;            // 6144 floats, two buffers
-constexpr int LDS_P = WCK * PPITCH;                 // 1536 floats, two buffers
-constexpr int LDS_M = 16 * 16 * NTILE;              // 8192 (epilogue, overlays everything)
-constexpr int LDS_STAGE = 2 * LDS_V + 2 * LDS_P;
-constexpr int LDS_FLOATS = LDS_STAGE > LDS_M ? LDS_STAGE : LDS_M;
 
+template <int MBW>
+struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (MBW * NBW = 8: 64 accumulator registers)
+  static constexpr int NBW = 8 / MBW;
+  static constexpr int WCO = 16 * MBW;
+  static constexpr int NTILE = 16 * NBW;
+  static constexpr int TLX = NBW == 8 ? 16 : 8;
+  static constexpr int TLY = NTILE / TLX;
+  static constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2;
+  static constexpr int PPITCH = (PR * PC + 15) / 16 * 16;
+  static constexpr int VPITCH = NTILE + 16;           // k-slot rows 16 banks apart
+  static constexpr int LDS_V = 16 * WCK * VPITCH;     // floats, two buffers
+  static constexpr int LDS_P = WCK * PPITCH;          // floats, two buffers
+  static constexpr int ETILE = NTILE > 64 ? 64 : NTILE;  // tiles per epilogue pass
+  static constexpr int LDS_M = 16 * 16 * ETILE;
+  static constexpr int LDS_STAGE = 2 * LDS_V + 2 * LDS_P;
+  static constexpr int LDS_FLOATS = LDS_STAGE > LDS_M ? LDS_STAGE : LDS_M;
+  static constexpr int UF = 2 * MBW;                  // U floats per lane and chunk: [pp 2][mb MBW]
+};
+
+template <int MBW>
 __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
+  using Gm = WG<MBW>;
+  constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR, PC = Gm::PC;
+  constexpr int PPITCH = Gm::PPITCH, VPITCH = Gm::VPITCH, LDS_V = Gm::LDS_V, LDS_P = Gm::LDS_P, UF = Gm::UF;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vl = smem;               // 2 x [16][WCK][VPITCH]
   float* Pl = smem + 2 * LDS_V;   // 2 x [WCK][PPITCH]
@@ -49,39 +64,50 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-  const int tile_i = blockIdx.x;
-  const int tx_i = tile_i % p.tiles_x, ty_i = tile_i / p.tiles_x;
-  const int co0 = blockIdx.y * WCO;
   const int b = blockIdx.z;
-  const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);
-  const int Cout = p.cout_g;
+  const int g = blockIdx.y / p.co_tiles, ct = blockIdx.y - g * p.co_tiles;
+  const int d = p.dil[g];                                     // polyphase stride (1 for an ordinary layer)
+  const int SH = (p.H + d - 1) / d, SW = (p.W + d - 1) / d;   // sub-image of one residue class
+  const int tiles_x = (SW + 2 * TLX - 1) / (2 * TLX), tiles_y = (SH + 2 * TLY - 1) / (2 * TLY);
+  const int per_res = tiles_x * tiles_y;
+  if ((int)blockIdx.x >= per_res * d * d) return;             // groups with a smaller dilation have fewer, fuller tiles
+  const int res = blockIdx.x / per_res, tile_i = blockIdx.x - res * per_res;
+  const int ry = res / d, rx = res - ry * d;
+  const int tx_i = tile_i % tiles_x, ty_i = tile_i / tiles_x;
+  const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);   // in sub-image coordinates
+  const int co0 = ct * WCO;                                   // within the group
   const int chw = p.H * p.W;
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
   const int nchunk = (p.Cin + WCK - 1) / WCK;
 
   // ---- input patch: chunk-invariant geometry, values prefetched two chunks ahead
-  constexpr int PWORDS = WCK * PR * PC;             // 1440 patch words per chunk
-  constexpr int PLD = (PWORDS + NTHR - 1) / NTHR;   // 3
-  int p_src[PLD], p_dst[PLD], p_ch[PLD];            // image offset (-1: outside / unused), LDS word, channel in chunk
+  constexpr int PWORDS = WCK * PR * PC;
+  constexpr int PLD = (PWORDS + NTHR - 1) / NTHR;
+  int p_src[PLD];  // image offset of patch word tid + e * NTHR (-1: outside the image / beyond the patch)
+  auto patch_word = [&](int e, int& ch, int& rem) {  // channel in chunk and offset in the plane: cheap to recompute
+    const int i = tid + e * NTHR;
+    ch = i / (PR * PC);
+    rem = i - ch * (PR * PC);
+    return i < PWORDS;
+  };
 #pragma unroll
   for (int e = 0; e < PLD; ++e) {
-    const int i = tid + e * NTHR;
-    const int ch = i / (PR * PC), rem = i - ch * (PR * PC);
+    int ch, rem;
+    const bool in = patch_word(e, ch, rem);
     const int r = rem / PC, c = rem - r * PC;
-    const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
-    const bool ok = i < PWORDS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    p_src[e] = ok ? iy * p.W + ix : -1;
-    p_dst[e] = i < PWORDS ? ch * PPITCH + rem : -1;
-    p_ch[e] = ch;
+    const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
+    const int iy = sy * d + ry, ix = sx * d + rx;
+    p_src[e] = (in && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
   }
   float preg[PLD], pnext[PLD];
   auto issue_p = [&](int c) {  // chunk c -> pnext
 #pragma unroll
     for (int e = 0; e < PLD; ++e) {
-      const int ci = c * WCK + p_ch[e];
-      const bool ok = p_src[e] >= 0 && ci < p.Cin;
+      int ch, rem;
+      patch_word(e, ch, rem);
+      const int ci = c * WCK + ch;
       float v = 0.f;
-      if (ok) {
+      if (p_src[e] >= 0 && ci < p.Cin) {
         v = xb[(int64_t)ci * chw + p_src[e]];
         if (p.in_shift) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
           const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
@@ -93,80 +119,90 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   };
   auto commit_p = [&](float* Pdst) {
 #pragma unroll
-    for (int e = 0; e < PLD; ++e)
-      if (p_dst[e] >= 0) Pdst[p_dst[e]] = preg[e];
+    for (int e = 0; e < PLD; ++e) {
+      int ch, rem;
+      if (patch_word(e, ch, rem)) Pdst[ch * PPITCH + rem] = preg[e];
+    }
   };
 
-  // ---- U fragments: [co tile][chunk][wave][lane][pp 2][ks KS][mb 4] floats, 32 KS bytes per lane and chunk
-  constexpr int UQ = 2 * KS;  // float4 per lane and chunk
-  const float* ufr = p.w + (((int64_t)blockIdx.y * nchunk * 8 + wave) * 64 + lane) * (4 * UQ);
-  auto load_u = [&](int c, float4 (&u)[UQ]) {
-    const float4* src = reinterpret_cast<const float4*>(ufr + (int64_t)c * (8 * 64 * 4 * UQ));
-#pragma unroll
-    for (int q = 0; q < UQ; ++q) u[q] = src[q];
+  // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
+  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk * 8 + wave) * 64 + lane) * UF;
+  auto load_u = [&](int c, float (&u)[UF]) {
+    const float* src = ufr + (int64_t)c * (8 * 64 * UF);
+    if constexpr (UF == 8) {
+      const float4 a = reinterpret_cast<const float4*>(src)[0], bq = reinterpret_cast<const float4*>(src)[1];
+      u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w; u[4] = bq.x; u[5] = bq.y; u[6] = bq.z; u[7] = bq.w;
+    } else if constexpr (UF == 4) {
+      const float4 a = reinterpret_cast<const float4*>(src)[0];
+      u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w;
+    } else {
+      const float2 a = reinterpret_cast<const float2*>(src)[0];
+      u[0] = a.x; u[1] = a.y;
+    }
   };
 
-  // ---- transform roles: thread pair q = tid >> 1 owns (channel, tile); half h = tid & 1 produces V rows 2h, 2h+1
-  const int tq = tid >> 1, th = tid & 1;
-  const int t_ch = tq >> 5, t_tile = tq & 31;
-  const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
-  const int t_src = t_ch * PPITCH + (2 * t_ty) * PC + 2 * t_tx;
-  const int t_dst = t_ch * VPITCH + t_tile;
+  // ---- transform: task = (channel, tile, half); half h produces V rows 2h, 2h+1 of the tile's 4x4 window
+  constexpr int TASKS = 2 * WCK * NTILE;
+  constexpr int TPT = (TASKS + NTHR - 1) / NTHR;
   auto transform = [&](const float* Psrc, float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
-    if (tid >= 2 * WCK * NTILE) return;
-    float d[3][4];  // rows h, h+1, h+2 of the 4x4 window
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int it = 0; it < TPT; ++it) {
+      const int task = tid + it * NTHR;
+      if (task >= TASKS) break;
+      const int th = task & 1, tq = task >> 1;
+      const int t_ch = tq / NTILE, t_tile = tq - t_ch * NTILE;
+      const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
+      const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + 2 * t_tx;
+      float dd[3][4];  // rows h, h+1, h+2 of the 4x4 window
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) d[r][cc] = Psrc[t_src + (th + r) * PC + cc];
-    float sc = 1.f;
-    if (p.in_scale && !p.in_shift && c * WCK + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * WCK + t_ch];
-    float w0[4], w1[4];
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      // h = 0: W0 = d0 - d2, W1 = d1 + d2      h = 1: W2 = d2 - d1, W3 = d1 - d3  (d[0..2] = window rows h..h+2)
-      w0[cc] = (th ? d[1][cc] - d[0][cc] : d[0][cc] - d[2][cc]) * sc;
-      w1[cc] = (th ? d[0][cc] - d[2][cc] : d[1][cc] + d[2][cc]) * sc;
-    }
-    const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
-    const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
+        for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc];
+      float sc = 1.f;
+      if (p.in_scale && !p.in_shift && c * WCK + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * WCK + t_ch];
+      float w0[4], w1[4];
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      Vdst[t_dst + ((2 * th) * 4 + nu) * (WCK * VPITCH)] = v0[nu];
-      Vdst[t_dst + ((2 * th + 1) * 4 + nu) * (WCK * VPITCH)] = v1[nu];
-    }
-  };
-
-  f32x4 acc[2][4][2];
+      for (int cc = 0; cc < 4; ++cc) {
+        // h = 0: W0 = d0 - d2, W1 = d1 + d2      h = 1: W2 = d2 - d1, W3 = d1 - d3  (dd[0..2] = window rows h..h+2)
+        w0[cc] = (th ? dd[1][cc] - dd[0][cc] : dd[0][cc] - dd[2][cc]) * sc;
+        w1[cc] = (th ? dd[0][cc] - dd[2][cc] : dd[1][cc] + dd[2][cc]) * sc;
+      }
+      const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
+      const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
+      float* dst = Vdst + t_ch * VPITCH + t_tile;
 #pragma unroll
-  for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto multiply = [&](const float* Vsrc, const float4 (&u)[UQ]) {
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const float* vp = Vsrc + (2 * wave + pp) * (WCK * VPITCH) + kq * VPITCH + lr;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 a = u[pp * KS + ks];
-        const float bv0 = vp[ks * 4 * VPITCH], bv1 = vp[ks * 4 * VPITCH + 16];
-        acc[pp][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv0, acc[pp][0][0], 0, 0, 0);
-        acc[pp][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv1, acc[pp][0][1], 0, 0, 0);
-        acc[pp][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv0, acc[pp][1][0], 0, 0, 0);
-        acc[pp][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv1, acc[pp][1][1], 0, 0, 0);
-        acc[pp][2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv0, acc[pp][2][0], 0, 0, 0);
-        acc[pp][2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv1, acc[pp][2][1], 0, 0, 0);
-        acc[pp][3][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv0, acc[pp][3][0], 0, 0, 0);
-        acc[pp][3][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv1, acc[pp][3][1], 0, 0, 0);
+      for (int nu = 0; nu < 4; ++nu) {
+        dst[((2 * th) * 4 + nu) * (WCK * VPITCH)] = v0[nu];
+        dst[((2 * th + 1) * 4 + nu) * (WCK * VPITCH)] = v1[nu];
       }
     }
   };
 
-  // ---- pipeline.  State at the top of step i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ua = U(i) (registers, landed),
-  //      preg = patch(i+2) (landed), in flight: nothing older than one step.
-  float4 ua[UQ], ub[UQ];
+  f32x4 acc[2][MBW][NBW];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const float* Vsrc, const float (&u)[UF]) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const float* vp = Vsrc + (2 * wave + pp) * (WCK * VPITCH) + kq * VPITCH + lr;
+      float bv[NBW];
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) bv[nb] = vp[nb * 16];
+#pragma unroll
+      for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+          acc[pp][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pp * MBW + mb], bv[nb], acc[pp][mb][nb], 0, 0, 0);
+    }
+  };
+
+  // ---- pipeline.  State at the top of step i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ucur = U(i) (registers, landed),
+  //      pnext = patch(i+2) (in flight or landed).
+  float ua[UF], ub[UF];
   issue_p(0);
   load_u(0, ua);
 #pragma unroll
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if (nchunk > 2) issue_p(2);
   }
   __syncthreads();
-  auto step = [&](int i, const float4 (&ucur)[UQ], float4 (&unxt)[UQ]) {
+  auto step = [&](int i, const float (&ucur)[UF], float (&unxt)[UF]) {
     const int cur = i & 1, nxt = cur ^ 1;
     if (i + 1 < nchunk) load_u(i + 1, unxt);
     if (i + 2 < nchunk) {
@@ -200,8 +236,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if (i + 1 < nchunk) step(i + 1, ub, ua);
   }
 
-  // ---- epilogue: per 16-channel block, all sixteen positions through LDS, one thread per (channel, tile)
-  float* Ml = smem;  // [16 pos][16 co][NTILE]
+  // ---- epilogue: per 16-channel block and (at most) 64 tiles, all sixteen positions through LDS, one thread per
+  //      (channel, tile): Y = A^T M A, then the fused operand chain of the direct kernel
+  constexpr int ETILE = Gm::ETILE, ENB = ETILE / 16;
+  float* Ml = smem;  // [16 pos][16 co][ETILE]
+  const int Cout = p.G * p.cout_g;
   const float* osp = p.osp + (int64_t)b * Cout * p.oss;
   const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW * p.nzs;
   const float nw = p.nwp[0];
@@ -209,73 +248,102 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r1s;
   const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r2s;
   const int y_plane = p.y_h * p.y_w;
-  const int e_co = tid >> 5, e_tile = tid & 31;
-  const int e_oy = oy0 + 2 * (e_tile >> 3), e_ox = ox0 + 2 * (e_tile & 7);
+  constexpr int EPT = 16 * ETILE / NTHR;  // (channel, tile) pairs per thread and pass
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) {
-    __syncthreads();
+  for (int mb = 0; mb < MBW; ++mb) {
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int th = 0; th < NTILE / ETILE; ++th) {  // tile halves (only the 128-tile geometry has two)
+      if (mb + th > 0) __syncthreads();            // (the chunk loop ended on a barrier)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Ml[((2 * wave + pp) * 16 + kq * 4 + r) * NTILE + nb * 16 + lr] = acc[pp][mb][nb][r];
-    __syncthreads();
-    float m[16];
+        for (int nb = 0; nb < ENB; ++nb)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) m[q] = Ml[(q * 16 + e_co) * NTILE + e_tile];
-    float t0[4], t1[4];
+          for (int r = 0; r < 4; ++r)
+            Ml[((2 * wave + pp) * 16 + kq * 4 + r) * ETILE + nb * 16 + lr] = acc[pp][mb][th * ENB + nb][r];
+      __syncthreads();
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      t0[nu] = m[nu] + m[4 + nu] + m[8 + nu];
-      t1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
-    }
-    const float yv[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
-    const int cg = co0 + mb * 16 + e_co;
-    if (cg >= Cout) continue;
-    const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
-    const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
-    const int cbase = cg * y_plane;
+      for (int it = 0; it < EPT; ++it) {
+        const int pair = tid + it * NTHR;
+        const int e_co = pair / ETILE, e_t = pair - e_co * ETILE;
+        const int e_tile = th * ETILE + e_t;
+        const int sy = oy0 + 2 * (e_tile / TLX), sx = ox0 + 2 * (e_tile % TLX);
+        float m[16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 16; ++q) m[q] = Ml[(q * 16 + e_co) * ETILE + e_t];
+        float t0[4], t1[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int oy = e_oy + i, ox = e_ox + j;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int ro = cbase + oy * p.y_w + ox;
-        float v = yv[i][j] * os;
-        v = v * cs + cb;
-        v += b1;
-        v = (v > 0.f ? v : v * p.s1) * p.g1;
-        v += nzp[(oy * p.OW + ox) * p.nzs] * nw;
-        v += b2;
-        v = (v > 0.f ? v : v * sl2) * p.g2;
-        v += r1b[ro * p.r1s];
-        v += r2b[ro * p.r2s];
-        yb[ro] = v;
+        for (int nu = 0; nu < 4; ++nu) {
+          t0[nu] = m[nu] + m[4 + nu] + m[8 + nu];
+          t1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
+        }
+        const float yv[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
+        const int cgi = co0 + mb * 16 + e_co;  // channel within the group
+        if (cgi >= p.cout_g) continue;
+        const int cg = g * p.cout_g + cgi;
+        const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
+        const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
+        const int cbase = cg * y_plane;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int oy = (sy + i) * d + ry, ox = (sx + j) * d + rx;
+            if (oy >= p.OH || ox >= p.OW) continue;
+            const int ro = cbase + oy * p.y_w + ox;
+            float v = yv[i][j] * os;
+            v = v * cs + cb;
+            v += b1;
+            v = (v > 0.f ? v : v * p.s1) * p.g1;
+            v += nzp[(oy * p.OW + ox) * p.nzs] * nw;
+            v += b2;
+            v = (v > 0.f ? v : v * sl2) * p.g2;
+            v += r1b[ro * p.r1s];
+            v += r2b[ro * p.r2s];
+            yb[ro] = v;
+          }
       }
+    }
   }
+}
+
+template <int MBW>
+int launch_variant(ConvK q, hipStream_t stream) {
+  using Gm = WG<MBW>;
+  static bool attr_set = false;
+  const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<MBW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_winograd: cannot reserve LDS: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  q.co_tiles = (q.cout_g + Gm::WCO - 1) / Gm::WCO;
+  int blocks = 0;  // the largest per-group tile count (groups with a smaller dilation exit early)
+  for (int g = 0; g < q.G; ++g) {
+    const int d = q.dil[g];
+    const int SH = (q.H + d - 1) / d, SW = (q.W + d - 1) / d;
+    const int n = ((SW + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((SH + 2 * Gm::TLY - 1) / (2 * Gm::TLY)) * d * d;
+    blocks = n > blocks ? n : blocks;
+  }
+  dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
+  conv_wino_kernel<MBW><<<grid, NTHR, lds, stream>>>(q);
+  return VSP_OK;
 }
 
 }  // namespace
 
 int wino_chunk() { return WCK; }
 
+// 16-channel blocks per workgroup for a layer with cout_g output channels per group (the weight layout depends on it)
+int wino_mbw(int cout_g) { return cout_g > 32 ? 4 : (cout_g > 16 ? 2 : 1); }
+
 int wino_launch(ConvK q, hipStream_t stream) {
-  static bool attr_set = false;
-  const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_winograd: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
+  switch (wino_mbw(q.cout_g)) {
+    case 4: return launch_variant<4>(q, stream);
+    case 2: return launch_variant<2>(q, stream);
+    default: return launch_variant<1>(q, stream);
   }
-  q.tiles_x = (q.OW + 2 * TLX - 1) / (2 * TLX);
-  q.tiles_y = (q.OH + 2 * TLY - 1) / (2 * TLY);
-  dim3 grid((unsigned)(q.tiles_x * q.tiles_y), (unsigned)((q.cout_g + WCO - 1) / WCO), (unsigned)q.B);
-  conv_wino_kernel<<<grid, NTHR, lds, stream>>>(q);
-  return VSP_OK;
 }
 
 }  // namespace vspconv

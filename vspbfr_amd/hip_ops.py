@@ -188,28 +188,32 @@ def pack_weight(weight, groups=1):
 
 
 def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
-    return (not transposed and pc.G == 1 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.dil[0] == 1 and
-            pc.pad_y[0] == 1 and pc.pad_x[0] == 1 and pc.x_group_stride == 0 and pc.cout % 4 == 0 and (OH, OW) == (H, W) and
-            tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0))
+    """3x3, stride 1, padding = dilation, G = 1 or up to four dilation groups over one shared input, dense output."""
+    if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.x_group_stride != 0 or not 1 <= pc.G <= 4:
+        return False
+    if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] for g in range(pc.G)):
+        return False
+    return (OH, OW) == (H, W) and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0)
 
 
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
 def winograd_weight(wp):
-    """packed weights (1, 9, Cin, Cout) -> U = G g G^T in the FRAGMENT order of vsp_conv2d_winograd_f32:
-    [co tile (64)][chunk (CK ci)][wave 8][lane 64][pp 2][ks CK/4][mb 4] with position = 2 wave + pp, ci = CK chunk + 4 ks + (lane >> 4),
-    co = 64 tile + 16 mb + (lane & 15); Cin / Cout are zero-padded to multiples of 8 / 64.  Computed in float64."""
+    """packed weights (G, 9, Cin, cout_g) -> U = G g G^T in the FRAGMENT order of vsp_conv2d_winograd_f32:
+    [group][co tile][chunk][wave 8][lane 64][pp 2][mb MB] with position = 2 wave + pp, ci = CK chunk + (lane >> 4),
+    co = 16 MB tile + 16 mb + (lane & 15); Cin / cout_g zero-padded to multiples of CK / 16 MB.  Computed in float64."""
     Gm = torch.tensor(_WINO_G, dtype=torch.float64, device=wp.device)
-    cin, cout = wp.shape[2], wp.shape[3]
-    g = wp[0].double().view(3, 3, cin, cout)
-    U = torch.einsum("ay,bx,yxio->abio", Gm, Gm, g).reshape(16, cin, cout)
-    ck = lib.vsp_conv2d_winograd_chunk()
-    nch, nct = (cin + ck - 1) // ck, (cout + 63) // 64
-    Up = U.new_zeros(16, nch * ck, nct * 64)
-    Up[:, :cin, :cout] = U
-    # [wave 8][pp 2][chunk][ks][kq 4][tile][mb 4][lr 16] -> [tile][chunk][wave][kq][lr][pp][ks][mb]
-    Up = Up.view(8, 2, nch, ck // 4, 4, nct, 4, 16).permute(5, 2, 0, 4, 7, 1, 3, 6)
+    ng, cin, cout = wp.shape[0], wp.shape[2], wp.shape[3]
+    g = wp.double().view(ng, 3, 3, cin, cout)
+    U = torch.einsum("ay,bx,gyxio->gabio", Gm, Gm, g).reshape(ng, 16, cin, cout)
+    ck, mb = lib.vsp_conv2d_winograd_chunk(), lib.vsp_conv2d_winograd_mbw(cout)
+    assert ck == 4, "fragment layout below assumes one k-step per chunk"
+    nch, nct = (cin + ck - 1) // ck, (cout + 16 * mb - 1) // (16 * mb)
+    Up = U.new_zeros(ng, 16, nch * ck, nct * 16 * mb)
+    Up[:, :, :cin, :cout] = U
+    # [g][wave 8][pp 2][chunk][kq 4][tile][mb][lr 16] -> [g][tile][chunk][wave][kq][lr][pp][mb]
+    Up = Up.view(ng, 8, 2, nch, 4, nct, mb, 16).permute(0, 5, 3, 1, 4, 7, 2, 6)
     return Up.float().contiguous().view(-1)
 
 
