@@ -45,7 +45,8 @@ struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (
   static constexpr int LDS_V = 16 * WCK * VPITCH;     // floats, two buffers
   static constexpr int LDS_P = WCK * PPITCH;          // floats, two buffers
   static constexpr int ETILE = NTILE > 64 ? 64 : NTILE;  // tiles per epilogue pass
-  static constexpr int LDS_M = 16 * 16 * ETILE;
+  static constexpr int EMB = (MBW >= 2 && ETILE <= 32) ? 2 : 1;  // 16-channel blocks per epilogue pass
+  static constexpr int LDS_M = 16 * 16 * EMB * ETILE;
   static constexpr int LDS_STAGE = 2 * LDS_V + 2 * LDS_P;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_M ? LDS_STAGE : LDS_M;
   static constexpr int UF = 2 * MBW;                  // U floats per lane and chunk: [pp 2][mb MBW]
@@ -248,19 +249,24 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r1s;
   const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r2s;
   const int y_plane = p.y_h * p.y_w;
-  constexpr int EPT = 16 * ETILE / NTHR;  // (channel, tile) pairs per thread and pass
+  constexpr int EMB = Gm::EMB, ECO = 16 * EMB;
+  constexpr int EPT = ECO * ETILE / NTHR;  // (channel, tile) pairs per thread and pass
+  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  const bool vec2 = d == 1 && p.r1s <= 1 && p.r2s <= 1;  // the two pixels of a tile row are neighbours in memory
 #pragma unroll
-  for (int mb = 0; mb < MBW; ++mb) {
+  for (int mb0 = 0; mb0 < MBW; mb0 += EMB) {
 #pragma unroll
     for (int th = 0; th < NTILE / ETILE; ++th) {  // tile halves (only the 128-tile geometry has two)
-      if (mb + th > 0) __syncthreads();            // (the chunk loop ended on a barrier)
+      if (mb0 + th > 0) __syncthreads();           // (the chunk loop ended on a barrier)
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-        for (int nb = 0; nb < ENB; ++nb)
+        for (int m2 = 0; m2 < EMB; ++m2)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            Ml[((2 * wave + pp) * 16 + kq * 4 + r) * ETILE + nb * 16 + lr] = acc[pp][mb][th * ENB + nb][r];
+          for (int nb = 0; nb < ENB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              Ml[((2 * wave + pp) * ECO + m2 * 16 + kq * 4 + r) * ETILE + nb * 16 + lr] = acc[pp][mb0 + m2][th * ENB + nb][r];
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < EPT; ++it) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         const int sy = oy0 + 2 * (e_tile / TLX), sx = ox0 + 2 * (e_tile % TLX);
         float m[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) m[q] = Ml[(q * 16 + e_co) * ETILE + e_t];
+        for (int q = 0; q < 16; ++q) m[q] = Ml[(q * ECO + e_co) * ETILE + e_t];
         float t0[4], t1[4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
@@ -278,30 +284,41 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
           t1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
         }
         const float yv[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
-        const int cgi = co0 + mb * 16 + e_co;  // channel within the group
+        const int cgi = co0 + mb0 * 16 + e_co;  // channel within the group
         if (cgi >= p.cout_g) continue;
         const int cg = g * p.cout_g + cgi;
         const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
         const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
         const int cbase = cg * y_plane;
+        auto fin = [&](float v, float nz, float r1v, float r2v) {
+          v = v * os * cs + cb + b1;
+          v = (v > 0.f ? v : v * p.s1) * p.g1;
+          v += nz * nw + b2;
+          v = (v > 0.f ? v : v * sl2) * p.g2;
+          return v + r1v + r2v;
+        };
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          const int oy = (sy + i) * d + ry, ox = sx * d + rx;
+          if (oy >= p.OH || ox >= p.OW) continue;
+          const int ro = cbase + oy * p.y_w + ox;
+          if (vec2 && ox + 1 < p.OW) {
+            f32x2u nz = {0.f, 0.f}, r1v = {0.f, 0.f}, r2v = {0.f, 0.f};
+            if (p.nzs) nz = *reinterpret_cast<const f32x2u*>(nzp + oy * p.OW + ox);
+            if (p.r1s) r1v = *reinterpret_cast<const f32x2u*>(r1b + ro);
+            if (p.r2s) r2v = *reinterpret_cast<const f32x2u*>(r2b + ro);
+            f32x2u o2 = {fin(yv[i][0], nz[0], r1v[0], r2v[0]), fin(yv[i][1], nz[1], r1v[1], r2v[1])};
+            *reinterpret_cast<f32x2u*>(yb + ro) = o2;
+          } else {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int oy = (sy + i) * d + ry, ox = (sx + j) * d + rx;
-            if (oy >= p.OH || ox >= p.OW) continue;
-            const int ro = cbase + oy * p.y_w + ox;
-            float v = yv[i][j] * os;
-            v = v * cs + cb;
-            v += b1;
-            v = (v > 0.f ? v : v * p.s1) * p.g1;
-            v += nzp[(oy * p.OW + ox) * p.nzs] * nw;
-            v += b2;
-            v = (v > 0.f ? v : v * sl2) * p.g2;
-            v += r1b[ro * p.r1s];
-            v += r2b[ro * p.r2s];
-            yb[ro] = v;
+            for (int j = 0; j < 2; ++j) {
+              const int oxj = ox + j * d;
+              if (oxj >= p.OW) continue;
+              const int rj = ro + j * d;
+              yb[rj] = fin(yv[i][j], nzp[(oy * p.OW + oxj) * p.nzs], r1b[rj * p.r1s], r2b[rj * p.r2s]);
+            }
           }
+        }
       }
     }
   }
