@@ -81,49 +81,38 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
   const int nchunk = (p.Cin + WCK - 1) / WCK;
 
-  // ---- input patch: chunk-invariant geometry, values prefetched two chunks ahead
-  constexpr int PWORDS = WCK * PR * PC;
-  constexpr int PLD = (PWORDS + NTHR - 1) / NTHR;
-  int p_src[PLD];  // image offset of patch word tid + e * NTHR (-1: outside the image / beyond the patch)
-  auto patch_word = [&](int e, int& ch, int& rem) {  // channel in chunk and offset in the plane: cheap to recompute
-    const int i = tid + e * NTHR;
-    ch = i / (PR * PC);
-    rem = i - ch * (PR * PC);
-    return i < PWORDS;
-  };
+  // ---- input patch: chunk-invariant geometry, values prefetched two chunks ahead.  Two waves per channel (128 threads
+  //      walk one 4-channel chunk's plane each): the channel is wave-uniform and no index needs a division per step.
+  constexpr int PLANE = PR * PC;
+  constexpr int PLD = (PLANE + 127) / 128;
+  const int p_ch = tid >> 7, p_t = tid & 127;
+  int p_src[PLD];  // image offset of plane word p_t + 128 e (-1: outside the image / beyond the plane)
 #pragma unroll
   for (int e = 0; e < PLD; ++e) {
-    int ch, rem;
-    const bool in = patch_word(e, ch, rem);
+    const int rem = p_t + 128 * e;
     const int r = rem / PC, c = rem - r * PC;
     const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
     const int iy = sy * d + ry, ix = sx * d + rx;
-    p_src[e] = (in && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
+    p_src[e] = (rem < PLANE && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
   }
   float preg[PLD], pnext[PLD];
-  auto issue_p = [&](int c) {  // chunk c -> pnext
+  auto issue_p = [&](int c) {  // chunk c -> pnext (raw values: nothing may consume them before the commit two steps later)
+    const int ci = c * WCK + p_ch;
+    const float* xc = xb + (int64_t)(ci < p.Cin ? ci : 0) * chw;
 #pragma unroll
-    for (int e = 0; e < PLD; ++e) {
-      int ch, rem;
-      patch_word(e, ch, rem);
-      const int ci = c * WCK + ch;
-      float v = 0.f;
-      if (p_src[e] >= 0 && ci < p.Cin) {
-        v = xb[(int64_t)ci * chw + p_src[e]];
-        if (p.in_shift) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
-          const float sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
-          v = fmaf(v, sc, p.in_shift[ci]);
-        }
-      }
-      pnext[e] = v;
-    }
+    for (int e = 0; e < PLD; ++e) pnext[e] = xc[p_src[e] >= 0 ? p_src[e] : 0];
   };
-  auto commit_p = [&](float* Pdst) {
-#pragma unroll
-    for (int e = 0; e < PLD; ++e) {
-      int ch, rem;
-      if (patch_word(e, ch, rem)) Pdst[ch * PPITCH + rem] = preg[e];
+  auto commit_p = [&](float* Pdst, int c) {  // preg = chunk c
+    const int ci = c * WCK + p_ch;
+    const bool chok = ci < p.Cin;
+    float sc = 1.f, sh = 0.f;
+    if (p.in_shift && chok) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
+      sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
+      sh = p.in_shift[ci];
     }
+#pragma unroll
+    for (int e = 0; e < PLD; ++e)
+      if (p_t + 128 * e < PLANE) Pdst[p_ch * PPITCH + p_t + 128 * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
   };
 
   // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
@@ -208,14 +197,14 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   load_u(0, ua);
 #pragma unroll
   for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
-  commit_p(Pl);                                   // patch(0) -> Pl[0]
+  commit_p(Pl, 0);                                // patch(0) -> Pl[0]
   if (nchunk > 1) issue_p(1);
   __syncthreads();
   transform(Pl, Vl, 0);                           // V(0) -> Vl[0]
   if (nchunk > 1) {
 #pragma unroll
     for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];
-    commit_p(Pl + LDS_P);                         // patch(1) -> Pl[1]
+    commit_p(Pl + LDS_P, 1);                      // patch(1) -> Pl[1]
     if (nchunk > 2) issue_p(2);
   }
   __syncthreads();
@@ -229,7 +218,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if (i + 3 < nchunk) issue_p(i + 3);
     if (i + 1 < nchunk) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
     multiply(Vl + cur * LDS_V, ucur);
-    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P);        // Pl[cur] held patch(i): consumed one step ago
+    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P, i + 2); // Pl[cur] held patch(i): consumed one step ago
     __syncthreads();
   };
   for (int i = 0; i < nchunk; i += 2) {
