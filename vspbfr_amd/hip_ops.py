@@ -387,7 +387,10 @@ def gemm_nt(a, b, out=None, alpha=1.0, bias=None, bias_scale=1.0, act=0, slope=0
 def linear(x, weight, bias=None, alpha=1.0, bias_scale=1.0, act=0):
     """F.linear(x, weight*alpha, bias*bias_scale) (+ fused leaky-relu*sqrt2 when act=1, sigmoid when act=2)."""
     lead = x.shape[:-1]
-    x2 = _req(x, "x").reshape(-1, x.shape[-1])
+    if x.dim() == 2 and x.stride(1) == 1 and x.is_cuda and x.dtype == torch.float32:
+        x2 = x  # rows may be strided (a slice latent[:, i] of a (B, 18, D) tensor): the GEMM takes the row pitch, no copy
+    else:
+        x2 = _req(x, "x").reshape(-1, x.shape[-1])
     out = gemm_nt(x2, _req(weight, "weight"), alpha=alpha, bias=bias, bias_scale=bias_scale, act=act)
     return out.view(*lead, weight.shape[0])
 

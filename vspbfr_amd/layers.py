@@ -65,7 +65,7 @@ class EqualLinear(_Cached):
         self.lr_mul = lr_mul
 
     def forward(self, x):
-        return H.linear(x.contiguous(), self.weight, self.bias, alpha=self.scale, bias_scale=self.lr_mul,
+        return H.linear(x, self.weight, self.bias, alpha=self.scale, bias_scale=self.lr_mul,
                         act=1 if self.activation else 0)
 
 

@@ -99,7 +99,7 @@ class Restoration_net(nn.Module):
         out = self.down_from_big(imgs)
         feats = []
         for ii in range(0, len(self.encoder_convs), 2):
-            sty = latent_cp[:, ii].contiguous()
+            sty = latent_cp[:, ii]
             out = self.encoder_convs[ii](out, sty, enc_noise[ii])
             feats.append(out)
             out = self.encoder_convs[ii + 1](out, sty, enc_noise[ii + 1])  # same latent index as the SMART layer
@@ -135,8 +135,11 @@ class Restoration_net(nn.Module):
 
         x_global, feats = self.encoder_forward(images, latent_cp, enc_noise)
 
+        # decoder styles cat[latent_i, x_global] for all layers in ONE concatenation; sty(i) is then a strided row view
+        sty_all = torch.cat([latent, x_global.unsqueeze(1).expand(-1, latent.shape[1], -1)], dim=2)
+
         def sty(i):
-            return torch.cat([latent[:, i], x_global], dim=1)
+            return sty_all[:, i]
 
         out = self.conv1(feats[0], sty(0), dec_noise[0])
         skip = self.to_rgb1(out, sty(1))
