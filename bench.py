@@ -180,7 +180,7 @@ def main():
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": conv_traffic(B, args),
-                         "kernel": "conv_igemm_kernel (all tile configs)", "launches_per_step": conv_launches // max(args.steps, 1),
+                         "kernel": "conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers", "launches_per_step": conv_launches // max(args.steps, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
                          "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK_FP32_TFLOPS * world), 4)},
