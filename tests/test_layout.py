@@ -56,3 +56,57 @@ def test_shard_range_covers_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_winograd_weight_fragment_layout_cpu():
+    """The host-side Winograd weight transform + fragment ordering (hip_ops.winograd_weight) against a numpy F(2x2,3x3)
+    evaluation that reads U back through the documented index formula of vsp_conv2d_winograd_f32 (no GPU needed)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from vspbfr_amd import hip_ops as H
+    from vspbfr_amd._lib import lib
+    rng = np.random.default_rng(5)
+    for G, cin, cout_g, dils in ((1, 6, 20, (1,)), (4, 5, 16, (1, 2, 4, 8)), (1, 9, 70, (1,))):
+        w = rng.standard_normal((G, cout_g, cin, 3, 3)).astype(np.float32)
+        wp = torch.stack([H.pack_weight(torch.from_numpy(w[g]))[0] for g in range(G)])
+        frag = H.winograd_weight(wp).numpy()
+        ck, mb = lib.vsp_conv2d_winograd_chunk(), lib.vsp_conv2d_winograd_mbw(cout_g)
+        nch, ntile = (cin + ck - 1) // ck, (cout_g + 16 * mb - 1) // (16 * mb)
+        assert frag.size == G * ntile * nch * 8 * 64 * 2 * mb
+
+        def U(g, pos, ci, co):  # the index formula of include/vspbfr_hip.h
+            wave, pp = pos // 2, pos % 2
+            chunk, kq = ci // ck, ci % ck
+            tile, rem = co // (16 * mb), co % (16 * mb)
+            m, lr = rem // 16, rem % 16
+            lane = kq * 16 + lr
+            return frag[(((((g * ntile + tile) * nch + chunk) * 8 + wave) * 64 + lane) * 2 + pp) * mb + m]
+
+        Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+        At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)
+        x = rng.standard_normal((cin, 8, 8))
+        for g in range(G):
+            d = dils[g]
+            ref = F.conv2d(torch.from_numpy(x)[None].float(), torch.from_numpy(w[g]), padding=d, dilation=d)[0].numpy()
+            Ug = np.array([[[U(g, pos, ci, co) for co in range(cout_g)] for ci in range(cin)] for pos in range(16)])
+            xp = np.pad(x, ((0, 0), (d, d), (d, d)))
+            out = np.zeros((cout_g, 8, 8))
+            for ry in range(d):           # polyphase: residue (ry, rx) of the dilation-d grid is a dilation-1 problem
+                for rx in range(d):
+                    sub = xp[:, ry::d, rx::d]                      # padded sub-image (pad 1 in sub coordinates)
+                    sh, sw = (8 - ry + d - 1) // d, (8 - rx + d - 1) // d
+                    for ty in range(0, sh, 2):
+                        for tx in range(0, sw, 2):
+                            win = np.zeros((cin, 4, 4))
+                            blk = sub[:, ty:ty + 4, tx:tx + 4]
+                            win[:, :blk.shape[1], :blk.shape[2]] = blk
+                            V = np.einsum("ar,crs,bs->cab", Bt, win, Bt).reshape(cin, 16)
+                            M = np.einsum("pio,ip->op", Ug, V).reshape(cout_g, 4, 4)
+                            Y = np.einsum("ia,oab,jb->oij", At, M, At)
+                            for i in range(2):
+                                for j in range(2):
+                                    oy, ox = (ty + i) * d + ry, (tx + j) * d + rx
+                                    if ty + i < sh and tx + j < sw and oy < 8 and ox < 8:
+                                        out[:, oy, ox] = Y[:, i, j]
+            assert np.abs(out - ref).max() < 2e-4, (G, cin, cout_g, g, np.abs(out - ref).max())
