@@ -6,6 +6,9 @@ namespace vspconv {
 extern const Cfg kCfgsE[] = {
     VSP_CFGD(4, 4, 4, 16, 0, 2),   // 4 groups x 16 co x 256 pixels
     VSP_CFGD(4, 4, 8, 16, 0, 2),
+    VSP_CFGD(4, 4, 4, 16, 2, 2),   // LDS-DMA patch staging: the shared 32x32 patch arrives asynchronously
+    VSP_CFGD(4, 4, 4, 16, 2, 3),
+    VSP_CFGD(4, 4, 8, 16, 2, 2),
     VSP_CFGM(4, 4, 1, 4, 4, 1, 16, 0, 3),
     VSP_CFGM(4, 4, 1, 4, 4, 1, 16, 0, 4),
     VSP_CFGM(4, 4, 1, 4, 8, 1, 16, 0, 2),
