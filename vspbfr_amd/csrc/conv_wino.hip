@@ -34,6 +34,10 @@ constexpr int NTHR = 512;
 
 template <int MBW>
 struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (MBW * NBW = 8: 64 accumulator registers)
+  // input channels per barrier interval: two MFMA k-steps where the LDS budget allows it (32-tile geometry: 61 KB, two
+  // workgroups per CU) -- half the barriers and a transform task for every thread; one k-step otherwise
+  static constexpr int IVC = MBW == 4 ? 8 : 4;
+  static constexpr int KS = IVC / 4;
   static constexpr int NBW = 8 / MBW;
   static constexpr int WCO = 16 * MBW;
   static constexpr int NTILE = 16 * NBW;
@@ -42,8 +46,8 @@ struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (
   static constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2;
   static constexpr int PPITCH = (PR * PC + 15) / 16 * 16;
   static constexpr int VPITCH = NTILE + 16;           // k-slot rows 16 banks apart
-  static constexpr int LDS_V = 16 * WCK * VPITCH;     // floats, two buffers
-  static constexpr int LDS_P = WCK * PPITCH;          // floats, two buffers
+  static constexpr int LDS_V = 16 * IVC * VPITCH;     // floats, two buffers
+  static constexpr int LDS_P = IVC * PPITCH;          // floats, two buffers
   static constexpr int ETILE = NTILE > 64 ? 64 : NTILE;  // tiles per epilogue pass
   static constexpr int EMB = (MBW >= 2 && ETILE <= 32) ? 2 : 1;  // 16-channel blocks per epilogue pass
   static constexpr int LDS_M = 16 * 16 * EMB * ETILE;
@@ -57,9 +61,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   using Gm = WG<MBW>;
   constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR, PC = Gm::PC;
   constexpr int PPITCH = Gm::PPITCH, VPITCH = Gm::VPITCH, LDS_V = Gm::LDS_V, LDS_P = Gm::LDS_P, UF = Gm::UF;
+  constexpr int IVC = Gm::IVC, KS = Gm::KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Vl = smem;               // 2 x [16][WCK][VPITCH]
-  float* Pl = smem + 2 * LDS_V;   // 2 x [WCK][PPITCH]
+  float* Vl = smem;               // 2 x [16][IVC][VPITCH]
+  float* Pl = smem + 2 * LDS_V;   // 2 x [IVC][PPITCH]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -79,17 +84,19 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int co0 = ct * WCO;                                   // within the group
   const int chw = p.H * p.W;
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
-  const int nchunk = (p.Cin + WCK - 1) / WCK;
+  const int nchunk = (p.Cin + IVC - 1) / IVC;        // barrier intervals
+  const int nchunk4 = (p.Cin + WCK - 1) / WCK;       // 4-channel U chunks (the weight layout's unit)
 
-  // ---- input patch: chunk-invariant geometry, values prefetched two chunks ahead.  Two waves per channel (128 threads
-  //      walk one 4-channel chunk's plane each): the channel is wave-uniform and no index needs a division per step.
+  // ---- input patch: chunk-invariant geometry, values prefetched two intervals ahead.  NTHR / IVC threads walk one
+  //      channel's plane: the channel is wave-uniform and no index needs a division per step.
   constexpr int PLANE = PR * PC;
-  constexpr int PLD = (PLANE + 127) / 128;
-  const int p_ch = tid >> 7, p_t = tid & 127;
-  int p_src[PLD];  // image offset of plane word p_t + 128 e (-1: outside the image / beyond the plane)
+  constexpr int PTH = NTHR / IVC;                  // threads per channel plane
+  constexpr int PLD = (PLANE + PTH - 1) / PTH;
+  const int p_ch = tid / PTH, p_t = tid % PTH;
+  int p_src[PLD];  // image offset of plane word p_t + PTH e (-1: outside the image / beyond the plane)
 #pragma unroll
   for (int e = 0; e < PLD; ++e) {
-    const int rem = p_t + 128 * e;
+    const int rem = p_t + PTH * e;
     const int r = rem / PC, c = rem - r * PC;
     const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
     const int iy = sy * d + ry, ix = sx * d + rx;
@@ -97,13 +104,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   }
   float preg[PLD], pnext[PLD];
   auto issue_p = [&](int c) {  // chunk c -> pnext (raw values: nothing may consume them before the commit two steps later)
-    const int ci = c * WCK + p_ch;
+    const int ci = c * IVC + p_ch;
     const float* xc = xb + (int64_t)(ci < p.Cin ? ci : 0) * chw;
 #pragma unroll
     for (int e = 0; e < PLD; ++e) pnext[e] = xc[p_src[e] >= 0 ? p_src[e] : 0];
   };
   auto commit_p = [&](float* Pdst, int c) {  // preg = chunk c
-    const int ci = c * WCK + p_ch;
+    const int ci = c * IVC + p_ch;
     const bool chok = ci < p.Cin;
     float sc = 1.f, sh = 0.f;
     if (p.in_shift && chok) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
@@ -112,11 +119,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     }
 #pragma unroll
     for (int e = 0; e < PLD; ++e)
-      if (p_t + 128 * e < PLANE) Pdst[p_ch * PPITCH + p_t + 128 * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
+      if (p_t + PTH * e < PLANE) Pdst[p_ch * PPITCH + p_t + PTH * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
   };
 
   // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
-  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk * 8 + wave) * 64 + lane) * UF;
+  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk4 * 8 + wave) * 64 + lane) * UF;
   auto load_u = [&](int c, float (&u)[UF]) {
     const float* src = ufr + (int64_t)c * (8 * 64 * UF);
     if constexpr (UF == 8) {
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   };
 
   // ---- transform: task = (channel, tile, half); half h produces V rows 2h, 2h+1 of the tile's 4x4 window
-  constexpr int TASKS = 2 * WCK * NTILE;
+  constexpr int TASKS = 2 * IVC * NTILE;
   constexpr int TPT = (TASKS + NTHR - 1) / NTHR;
   auto transform = [&](const float* Psrc, float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc];
       float sc = 1.f;
-      if (p.in_scale && !p.in_shift && c * WCK + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * WCK + t_ch];
+      if (p.in_scale && !p.in_shift && c * IVC + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * IVC + t_ch];
       float w0[4], w1[4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       float* dst = Vdst + t_ch * VPITCH + t_tile;
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
-        dst[((2 * th) * 4 + nu) * (WCK * VPITCH)] = v0[nu];
-        dst[((2 * th + 1) * 4 + nu) * (WCK * VPITCH)] = v1[nu];
+        dst[((2 * th) * 4 + nu) * (IVC * VPITCH)] = v0[nu];
+        dst[((2 * th + 1) * 4 + nu) * (IVC * VPITCH)] = v1[nu];
       }
     }
   };
@@ -175,10 +182,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto multiply = [&](const float* Vsrc, const float (&u)[UF]) {
+  auto multiply = [&](const float* Vsrc, int ks, const float (&u)[UF]) {  // k-step ks of the interval: channels 4 ks + kq
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
-      const float* vp = Vsrc + (2 * wave + pp) * (WCK * VPITCH) + kq * VPITCH + lr;
+      const float* vp = Vsrc + (2 * wave + pp) * (IVC * VPITCH) + (4 * ks + kq) * VPITCH + lr;
       float bv[NBW];
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) bv[nb] = vp[nb * 16];
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     }
   };
 
-  // ---- pipeline.  State at the top of step i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ucur = U(i) (registers, landed),
-  //      pnext = patch(i+2) (in flight or landed).
+  // ---- pipeline.  State at the top of interval i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ua = U chunk KS*i (registers,
+  //      landed), pnext = patch(i+2) (in flight or landed).  U rolls one 4-channel k-step ahead of the MFMAs that use it.
   float ua[UF], ub[UF];
   issue_p(0);
   load_u(0, ua);
@@ -208,22 +215,27 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if (nchunk > 2) issue_p(2);
   }
   __syncthreads();
-  auto step = [&](int i, const float (&ucur)[UF], float (&unxt)[UF]) {
+  for (int i = 0; i < nchunk; ++i) {
     const int cur = i & 1, nxt = cur ^ 1;
-    if (i + 1 < nchunk) load_u(i + 1, unxt);
+    if (KS == 2 && KS * i + 1 < nchunk4) load_u(KS * i + 1, ub);
     if (i + 2 < nchunk) {
 #pragma unroll
-      for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one step ago
+      for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one interval ago
     }
     if (i + 3 < nchunk) issue_p(i + 3);
     if (i + 1 < nchunk) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
-    multiply(Vl + cur * LDS_V, ucur);
-    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P, i + 2); // Pl[cur] held patch(i): consumed one step ago
+    if (KS == 2) {
+      multiply(Vl + cur * LDS_V, 0, ua);
+      if (KS * i + 2 < nchunk4) load_u(KS * i + 2, ua);     // next interval's first k-step (the MFMAs above have read ua)
+      if (KS * i + 1 < nchunk4) multiply(Vl + cur * LDS_V, 1, ub);
+    } else {
+      if (i + 1 < nchunk4) load_u(i + 1, ub);
+      multiply(Vl + cur * LDS_V, 0, ua);
+#pragma unroll
+      for (int q = 0; q < UF; ++q) ua[q] = ub[q];
+    }
+    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P, i + 2); // Pl[cur] held patch(i): consumed one interval ago
     __syncthreads();
-  };
-  for (int i = 0; i < nchunk; i += 2) {
-    step(i, ua, ub);
-    if (i + 1 < nchunk) step(i + 1, ub, ua);
   }
 
   // ---- epilogue: per 16-channel block and (at most) 64 tiles, all sixteen positions through LDS, one thread per
