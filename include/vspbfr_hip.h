@@ -183,6 +183,20 @@ int vsp_conv2d_winograd_mbw(int cout_g);
 int vsp_conv2d_num_configs(void);
 const char* vsp_conv2d_config_name(int i);
 
+/* The same convolution contract for 3x3 / stride 1 / padding = dilation layers (G = 1, up to four dilation groups over one
+ * shared input, or true groups with x_group_stride) on the BF16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+ * the "bf16 kernels" configuration of the path (BASELINE configs[2]).  x, y and every prologue / epilogue
+ * operand stay fp32: the kernel scales the input by the style in fp32, rounds to bf16 (RNE) while staging and runs the fp32
+ * epilogue chain of vsp_conv2d_f32 on the fp32 accumulators.  `w` must hold the weights rounded to bf16 in the kernel's LDS
+ * image order; with Cin zero-padded to a multiple of 16, co_pad = cout_g rounded up to 32 and nchunk = ceil(Cin / 16):
+ *     w[(((((g * nchunk + chunk) * 9 + tap) * 2 + octet) * co_pad + co) * 8 + j]      (uint16 bf16 bit patterns)
+ *         = bf16( W_g[tap][ci = 16*chunk + 8*octet + j][co] )
+ * (one 16-byte row per (tap, channel octet, co): what one lane feeds v_mfma as its A fragment; a workgroup copies its rows
+ * global -> LDS with global_load_lds_dwordx4).  tile_hint selects the tile variant (0 = automatic, see conv_bf16.hip).
+ * Error vs the fp32 kernels: ~2^-9 relative per operand, i.e. ~1e-2 relative per layer on random data -- this entry is
+ * a throughput configuration, not the parity path. */
+int vsp_conv2d_bf16(const vsp_conv_params* p, vsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Strided, batched small GEMM on fp32 MFMA -- replaces F.linear / torch.matmul of the path
  * (EqualLinear: models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,

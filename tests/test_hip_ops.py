@@ -519,3 +519,55 @@ def test_conv2d_winograd_dilation_groups(H, B, Cin, Cg, Hh, Ww):
     # a single dilated conv (G = 1, d = 2)
     pc1 = H.PackedConv(H.pack_weight(dev(ws[1])), 1, Cg, Cin, 3, 3, 1, (2,), (2,))
     close(H.conv2d_packed(dev(x), pc1, winograd=True), F.conv2d(x, ws[1], padding=2, dilation=2), 5e-5, 5e-5)
+
+
+def _bf(t):
+    """round to bf16 (RNE) and back: what vsp_conv2d_bf16 feeds the matrix pipe"""
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 16, 64, 32, 32), (1, 40, 36, 13, 29), (2, 64, 64, 64, 64), (1, 256, 128, 16, 24),
+                                               (1, 32, 160, 8, 8), (1, 64, 32, 70, 45)])
+def test_conv2d_bf16(H, B, Cin, Cout, Hh, Ww, variant):
+    """bf16-MFMA kernel: exact (to fp32 summation order) against F.conv2d on the bf16-rounded operands it documents, every
+    tile variant, with the prologue / epilogue chain of a StyledConv; and within bf16 rounding of the fp32 result."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    y = H.conv2d_packed(dev(x), pc, bf16=True, tile_hint=variant)
+    close(y, F.conv2d(_bf(x), _bf(w), padding=1), 2e-5, 2e-5, "plain")
+    close(y, F.conv2d(x, w, padding=1), 2e-2, 2e-2, "vs fp32")
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5, torch.randn(Cout)
+    nz, nw = torch.randn(B, 1, Hh, Ww), torch.tensor([0.7])
+    r1, r2 = torch.randn(B, Cout, Hh, Ww), torch.randn(B, Cout, Hh, Ww)
+    ref = F.conv2d(_bf(x * s_in.view(B, Cin, 1, 1)), _bf(w), padding=1) * demod.view(B, Cout, 1, 1) + nz * nw
+    ref = F.leaky_relu(ref + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2) + r1 + r2
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), noise=dev(nz), noise_w=dev(nw), act2=1,
+                        bias2=dev(bias), res1=dev(r1), res2=dev(r2), bf16=True, tile_hint=variant)
+    close(y, ref, 5e-5, 5e-5, "styled")
+    a, sh, pr = torch.rand(Cin) + 0.5, torch.randn(Cin), torch.rand(Cout) * 0.3
+    xa = (x.double() * a.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()).float()  # = the kernel's fmaf (one rounding)
+    ref2 = F.prelu(F.conv2d(_bf(xa), _bf(w), padding=1), pr)
+    y2 = H.conv2d_packed(dev(x), pc, in_scale=dev(a), in_scale_per_sample=False, in_shift=dev(sh), act2=2, prelu=dev(pr),
+                         bf16=True, tile_hint=variant)
+    close(y2, ref2, 5e-5, 5e-5, "bn+prelu")
+
+
+@pytest.mark.parametrize("B,Cin,Cg,Hh,Ww", [(2, 16, 8, 24, 24), (1, 32, 16, 37, 21), (2, 64, 32, 64, 64), (1, 48, 64, 16, 48), (1, 32, 128, 19, 19)])
+def test_conv2d_bf16_dilation_groups(H, B, Cin, Cg, Hh, Ww):
+    """The four dilated SMART branches in one launch of the bf16 kernel (polyphase sub-images), into a channel slice."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    ws = [torch.randn(Cg, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(4)]
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, 4 * Cg) + 0.5, torch.randn(4 * Cg)
+    xs = _bf(x * s_in.view(B, Cin, 1, 1))
+    ref = torch.cat([F.conv2d(xs, _bf(w_), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1)
+    ref = F.leaky_relu(ref * demod.view(B, -1, 1, 1) + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    out = torch.full((B, 4 * Cg + 3, Hh, Ww), 7.0, device=DEV)
+    H.conv2d_packed(dev(x), pc, out=out, y_coff=2, in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), bf16=True)
+    close(out[:, 2:2 + 4 * Cg], ref, 5e-5, 5e-5)
+    assert (out[:, :2] == 7.0).all() and (out[:, -1] == 7.0).all()
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(ws[0])), 1, Cg, Cin, 3, 3, 2, (1,), (1,)), bf16=True)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
     "vsp_tacc_chain_f32": [_p, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
+    "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
 }

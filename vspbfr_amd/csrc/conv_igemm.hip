@@ -318,6 +318,30 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
   return vsp::check_launch("conv2d_winograd");
 }
 
+extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr, "conv2d_bf16: null params");
+  const vsp_conv_params& p = *pp;
+  VSP_REQUIRE(!p.transposed && p.G >= 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1,
+              "conv2d_bf16: only 3x3, stride 1");
+  VSP_REQUIRE(p.G <= 4 || p.x_group_stride > 0, "conv2d_bf16: more than four groups need their own input slices");
+  for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g)
+    VSP_REQUIRE(p.dil[g] >= 1 && p.dil[g] <= 64 && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
+                "conv2d_bf16: group %d needs padding = dilation (got dilation %d, padding %d/%d)", g, p.dil[g], p.pad_y[g],
+                p.pad_x[g]);
+  VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_bf16: dense output only");
+  VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_bf16: output size must equal the input size");
+  VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_bf16: packed weights must be 16-byte aligned");
+  int x_ch = 0;
+  bool empty = false;
+  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  if (empty) return VSP_OK;
+  VSP_REQUIRE((int64_t)p.G * p.cout_g <= 65535 && p.B <= 65535, "conv2d_bf16: grid too large");
+  ConvK q{};
+  if (int rc = fill_convk(p, x_ch, q)) return rc;
+  if (int rc = vspconv::bf16_launch(q, p.tile_hint, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("conv2d_bf16");
+}
+
 extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d: null params");
   build_table();

@@ -156,7 +156,7 @@ class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
     Built once at model-load time (vspbfr_amd/packing.py)."""
 
-    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino")
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino", "_bf16")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -167,6 +167,7 @@ class PackedConv:
         self.pad_y = rep(pad_y, 0)
         self.pad_x = rep(pad_y if pad_x is None else pad_x, 0)
         self._wino = None
+        self._bf16 = None
 
     @property
     def cout(self):
@@ -178,6 +179,41 @@ class PackedConv:
             with torch.no_grad():
                 self._wino = winograd_weight(self.w)
         return self._wino
+
+
+    def bf16_weight(self):
+        """The weight rounded to bf16 in the LDS-image order of vsp_conv2d_bf16, built on first use."""
+        if self._bf16 is None:
+            with torch.no_grad():
+                self._bf16 = bf16_weight(self.w)
+        return self._bf16
+
+
+# "bf16 kernels" configuration (BASELINE configs[2]): eligible convolutions run on vsp_conv2d_bf16 (bf16 MFMA, fp32
+# accumulate, fp32 activations in HBM).  Off by default: the parity path is fp32 end to end.
+BF16_CONV = False
+
+
+def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
+    """3x3, stride 1, padding = dilation, dense output; G <= 4 dilation groups over one input or true groups."""
+    if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.cin < 16:
+        return False
+    if pc.G > 4 and pc.x_group_stride == 0:
+        return False
+    if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] for g in range(min(pc.G, 4))):
+        return False
+    return (OH, OW) == (H, W) and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0)
+
+
+def bf16_weight(wp):
+    """packed weights (G, 9, Cin, cout_g) fp32 -> bf16 in the LDS-image order of vsp_conv2d_bf16:
+    [group][chunk][tap][octet 2][co_pad][8] with ci = 16 chunk + 8 octet + j; Cin zero-padded to 16, cout_g to 32."""
+    ng, T, cin, cout = wp.shape
+    nch, co_pad = (cin + 15) // 16, (cout + 31) // 32 * 32
+    Wz = wp.new_zeros(ng, T, nch * 16, co_pad)
+    Wz[:, :, :cin, :cout] = wp
+    Wz = Wz.view(ng, T, nch, 2, 8, co_pad).permute(0, 2, 1, 3, 5, 4)
+    return Wz.to(torch.bfloat16).contiguous().view(-1)
 
 
 def pack_weight(weight, groups=1):
@@ -227,10 +263,11 @@ def conv2d_out_size(H, W, pc):
 def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out_offset=(0, 0), in_scale=None,
                   in_scale_per_sample=True, in_shift=None, out_scale=None, ch_scale=None, ch_bias=None, act1=False,
                   bias1=None, noise=None, noise_w=None, act2=0, bias2=None, prelu=None, slope2=0.2, gain2=SQRT2, res1=None,
-                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False, winograd=None):
+                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False, winograd=None, bf16=None):
     """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
     compute (defaults to the standard conv output size).  `winograd`: True / False forces / forbids the F(2x2,3x3) kernel
-    (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape."""
+    (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape.  `bf16`: True runs the
+    layer on vsp_conv2d_bf16 (tile_hint = its variant), None = the module switch BF16_CONV on eligible layers."""
     x = _req(x, "x")
     B, x_ch, H, W = x.shape
     Cin = pc.cin
@@ -270,6 +307,15 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         if pref == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
             pref = TUNE.get("8" + key[key.index(","):], 0)
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
+    bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
+    if bf16 is None:
+        bf16 = BF16_CONV and bf_ok and not winograd
+    elif bf16 and not bf_ok:
+        raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (3x3, stride 1, padding = dilation)")
+    if bf16:
+        winograd = False
+        if tile_hint < 0:
+            tile_hint = 0
     wino_ok = winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     if winograd is None:
         winograd = wino_ok and tile_hint == 0 and WINO.get(key, WINO.get("8" + key[key.index(","):], False))
@@ -285,7 +331,12 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     prof = PROFILER
     if prof is not None:
         start = prof.begin()
-    if winograd:
+    if bf16:
+        bw = pc.bf16_weight()
+        keep.append(bw)
+        p.w = bw.data_ptr()
+        check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+    elif winograd:
         uw = pc.winograd_weight()
         keep.append(uw)
         p.w = uw.data_ptr()
