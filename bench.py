@@ -68,7 +68,7 @@ def conv_traffic(B, args):
     gfx950 calibration, WRITE_SIZE x1, separate passes, tools/pmc_bench.sh).  PMC collection cannot run inside the timed
     process, so the figure is only reported for the configuration it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json")
-    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
+    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or args.conv_dtype != "f32" or not os.path.exists(path):
         return None
     with open(path) as f:
         return round(json.load(f)["conv_hbm_bytes_per_launch"])
@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="plain per-batch loop (no A+B / C+D stream overlap across batches)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--conv-dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
+                         "fp32 activations in HBM); not the parity configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,6 +107,7 @@ def main():
 
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
+    hip_ops.BF16_CONV = args.conv_dtype == "bf16"
     pipe = build_pipeline(dev, args.timesteps, not args.no_sample)
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
@@ -167,30 +171,33 @@ def main():
     if rank == 0:
         imgs = world * B * args.steps
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # bf16 configuration: the dense bf16 MFMA peak (MI355X_MICROARCH.md); the conv family then mixes bf16 (stride-1 3x3)
+        # and fp32 (stride-2, transposed, small-map) launches, all priced against the bf16 peak
+        PEAK = PEAK_FP32_TFLOPS if args.conv_dtype == "f32" else 2500.0
         line = {
             "metric": "restored 512x512 faces/sec", "value": round(imgs / dt, 3), "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.conv_dtype, "data": "synthetic",
             "config": {"workload": f"restoration_test.py hot path A+B+C+D, batch {B}/GPU, 512x512, {args.timesteps}-step DDPM "
                                    f"CodeDiffuser + StyleGAN2 prior{'' if not args.no_sample else ' (no 1024^2 tail)'} + RestoreNet "
-                                   "forward, fp32, random-init weights",
+                                   f"forward, {'fp32' if args.conv_dtype == 'f32' else 'bf16-MFMA convolutions (fp32 accumulate, fp32 activations), rest fp32'}, random-init weights",
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
                        "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": conv_traffic(B, args),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),
                          "kernel": "conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers", "launches_per_step": conv_launches // max(args.steps, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
-                         "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK_FP32_TFLOPS * world), 4)},
+                         "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK * world), 4)},
         }
         if iso is not None:
             fl, ms, n = iso.summary()
             line["roofline"]["isolated"] = {
                 "note": "same kernels in one untimed serial step (no second stream): per-launch durations without the "
                         "overlapped A+B work inside the event intervals",
-                "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK, 4),
                 "kernel_ms_per_step": round(ms, 2), "launches": n}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)

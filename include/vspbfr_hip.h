@@ -183,17 +183,21 @@ int vsp_conv2d_winograd_mbw(int cout_g);
 int vsp_conv2d_num_configs(void);
 const char* vsp_conv2d_config_name(int i);
 
-/* The same convolution contract for 3x3 / stride 1 / padding = dilation layers (G = 1, up to four dilation groups over one
- * shared input, or true groups with x_group_stride) on the BF16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
- * the "bf16 kernels" configuration of the path (BASELINE configs[2]).  x, y and every prologue / epilogue
- * operand stay fp32: the kernel scales the input by the style in fp32, rounds to bf16 (RNE) while staging and runs the fp32
- * epilogue chain of vsp_conv2d_f32 on the fp32 accumulators.  `w` must hold the weights rounded to bf16 in the kernel's LDS
- * image order; with Cin zero-padded to a multiple of 16, co_pad = cout_g rounded up to 32 and nchunk = ceil(Cin / 16):
+/* The same convolution contract on the BF16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the "bf16 kernels"
+ * configuration of the path (BASELINE configs[2]).  Served layers, all 3x3:
+ *   - stride 1, padding = dilation: G = 1, up to four dilation groups over one shared input, or true groups (x_group_stride);
+ *   - stride 2, dilation 1, padding 0 or 1: G = 1 or true groups (StyledConv_down after its blur, IR-SE down-convs, the
+ *     batched e4e style heads);
+ *   - transposed = 1: the stride-2 transposed conv of the up-sampling StyledConvs in one pass (fields as for vsp_conv2d_f32).
+ * x, y and every prologue / epilogue operand stay fp32: the kernel scales the input by the style in fp32, rounds to bf16 (RNE)
+ * while staging and runs the fp32 epilogue chain of vsp_conv2d_f32 on the fp32 accumulators.  `w` must hold the weights
+ * rounded to bf16 in the kernel's LDS image order; with Cin zero-padded to a multiple of 16, co_pad = cout_g rounded up to 32
+ * and nchunk = ceil(Cin / 16):
  *     w[(((((g * nchunk + chunk) * 9 + tap) * 2 + octet) * co_pad + co) * 8 + j]      (uint16 bf16 bit patterns)
  *         = bf16( W_g[tap][ci = 16*chunk + 8*octet + j][co] )
  * (one 16-byte row per (tap, channel octet, co): what one lane feeds v_mfma as its A fragment; a workgroup copies its rows
  * global -> LDS with global_load_lds_dwordx4).  tile_hint selects the tile variant (0 = automatic, see conv_bf16.hip).
- * Error vs the fp32 kernels: ~2^-9 relative per operand, i.e. ~1e-2 relative per layer on random data -- this entry is
+ * Error vs the fp32 kernels: 2^-9 relative per operand, ~2.5e-3 of the output range per layer on random data -- this entry is
  * a throughput configuration, not the parity path. */
 int vsp_conv2d_bf16(const vsp_conv_params* p, vsp_stream_t stream);
 

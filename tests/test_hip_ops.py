@@ -570,4 +570,47 @@ def test_conv2d_bf16_dilation_groups(H, B, Cin, Cg, Hh, Ww):
     close(out[:, 2:2 + 4 * Cg], ref, 5e-5, 5e-5)
     assert (out[:, :2] == 7.0).all() and (out[:, -1] == 7.0).all()
     with pytest.raises(RuntimeError):
-        H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(ws[0])), 1, Cg, Cin, 3, 3, 2, (1,), (1,)), bf16=True)
+        H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(ws[0])), 1, Cg, Cin, 3, 3, 2, (2,), (2,)), bf16=True)  # stride 2 AND dilation
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,pad,variant", [(2, 16, 64, 33, 33, 0, 4), (1, 64, 128, 65, 65, 0, 6), (2, 64, 128, 64, 64, 1, 0),
+                                                       (1, 48, 40, 37, 29, 1, 4), (1, 256, 256, 16, 16, 1, 6), (1, 32, 64, 129, 129, 0, 0)])
+def test_conv2d_bf16_stride2(H, B, Cin, Cout, Hh, Ww, pad, variant):
+    """stride-2 mode (parity planes): StyledConv_down after its blur (padding 0) and the IR-SE / style-head down-convs (1)."""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5, torch.randn(Cout)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 2, (1,), (pad,))
+    ref = F.conv2d(_bf(x * s_in.view(B, Cin, 1, 1)), _bf(w), stride=2, padding=pad)
+    nz, nw = torch.randn(B, 1, ref.shape[2], ref.shape[3]), torch.tensor([0.3])
+    ref = F.leaky_relu(ref * demod.view(B, Cout, 1, 1) + nz * nw + bias.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), noise=dev(nz), noise_w=dev(nw), act2=1,
+                        bias2=dev(bias), bf16=True, tile_hint=variant)
+    close(y, ref, 5e-5, 5e-5)
+
+
+def test_conv2d_bf16_stride2_true_groups(H):
+    """the batched e4e style heads: G groups, each with its own input slice, stride 2, padding 1, LeakyReLU(0.01)"""
+    B, G, Cin, Cg, S = 2, 3, 32, 48, 16
+    x = torch.randn(B, G * Cin, S, S)
+    ws = [torch.randn(Cg, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(G)]
+    bias = torch.randn(G * Cg)
+    ref = torch.cat([F.conv2d(_bf(x[:, g * Cin:(g + 1) * Cin]), _bf(ws[g]), stride=2, padding=1) for g in range(G)], 1)
+    ref = F.leaky_relu(ref + bias.view(1, -1, 1, 1), 0.01)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, G, Cg, Cin, 3, 3, 2, (1,), (1,), x_group_stride=Cin)
+    y = H.conv2d_packed(dev(x), pc, ch_bias=dev(bias), act2=1, slope2=0.01, gain2=1.0, bf16=True)
+    close(y, ref, 5e-5, 5e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,variant", [(2, 16, 64, 32, 32, 4), (1, 64, 32, 64, 64, 5), (1, 40, 72, 13, 21, 0), (2, 128, 64, 16, 16, 0),
+                                                   (1, 32, 32, 70, 33, 0)])
+def test_conv2d_bf16_transposed(H, B, Cin, Cout, Hh, Ww, variant):
+    """stride-2 transposed conv in one pass on the bf16 pipe, against F.conv_transpose2d on the bf16-rounded operands"""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, demod = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    ref = F.conv_transpose2d(_bf(x * s_in.view(B, Cin, 1, 1)), _bf(w).transpose(0, 1), stride=2) * demod.view(B, Cout, 1, 1)
+    y = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bf16=True, tile_hint=variant)
+    close(y, ref, 5e-5, 5e-5)

@@ -1,0 +1,32 @@
+"""Per-shape conv kernel time of one serial step (HIP events per launch), fp32 vs the bf16 configuration."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from vspbfr_amd import hip_ops
+dev = torch.device("cuda", 0)
+B, T = int(os.environ.get("B", 8)), int(os.environ.get("T", 50))
+pipe = bench.build_pipeline(dev, T, True)
+lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
+def step(bf):
+    hip_ops.BF16_CONV = bf
+    with torch.no_grad():
+        pipe(lq); pipe(lq)
+        prof = hip_ops.ConvProfiler(); hip_ops.PROFILER = prof
+        pipe(lq)
+        hip_ops.PROFILER = None
+    torch.cuda.synchronize()
+    agg = collections.OrderedDict()
+    for fl, s, e, tag in prof.records:
+        k = tag[:7]
+        a = agg.setdefault(k, [0, 0.0, 0.0, set()])
+        a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl; a[3].add(tag[7])
+    return agg
+a32, a16 = step(False), step(True)
+tot32 = tot16 = 0.0
+print("Cin,Cout,OH,OW,k,stride,G | n | fp32 ms (TF) kinds | bf16-config ms (TF) kinds")
+for k in sorted(a32, key=lambda k: -a32[k][1]):
+    n, ms, fl, kinds = a32[k]; n2, ms2, fl2, kinds2 = a16[k]
+    tot32 += ms; tot16 += ms2
+    print(f"{k} | {n} | {ms:.2f} ({fl/ms/1e9:.0f}) {','.join(sorted(kinds))} | {ms2:.2f} ({fl2/ms2/1e9:.0f}) {','.join(sorted(kinds2))}")
+print(f"total fp32 {tot32:.2f} ms, bf16 config {tot16:.2f} ms")

@@ -17,9 +17,16 @@
 //   * dilation d is a polyphase problem exactly as in conv_wino.hip: the workgroup addresses the image with stride d from
 //     its residue (ry, rx), in LDS every layer is a dilation-1 convolution; the (up to four) dilation groups of a SMART
 //     branch launch differ only in d and their weight / channel base.
+// Modes (template MODE): 0 = stride-1 convolution as above; 1 = stride-2 convolution: the patch is staged as four PARITY
+// planes (row parity x column parity), tap (ky, kx) reads plane (ky & 1, kx & 1) at unit stride, so the fragment reads stay
+// conflict-free and the global loads stay coalesced (lanes run along the input row and scatter into two planes);
+// 2 = stride-2 TRANSPOSED convolution in one pass, as in conv_kernel.h: a 32-position block keeps four sub-pixel phase
+// accumulators, tap (ky, kx) multiplies the input shifted by (-(ky >> 1), -(kx >> 1)) into phase (ky & 1, kx & 1); the two
+// column phases of a position leave as one 8-byte store.
 // Numerics: operands rounded to bf16 (RNE, 8 significant bits), products exact, accumulation fp32; the epilogue chain is
 // the fp32 one of the direct kernel.  Not a parity path: tests bound its error against the fp32 kernels.
 #include "conv_kernel.h"
+#include <type_traits>
 
 namespace vspconv {
 
@@ -39,9 +46,14 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <int MB, int NB, int WM, int WN, int PT>
+enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
+
+template <int MB, int NB, int WM, int WN, int PT, int MODE>
 __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr bool S2 = MODE == M_S2, TCV = MODE == M_TC;
+  constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
+  constexpr int NPL = S2 ? 4 : 1;          // patch planes per channel octet (stride 2: parity planes)
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN, T = 9;
   constexpr int WSLAB = T * 2 * CO_T;  // 16-byte units per weight buffer: [tap][octet][co]
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -53,8 +65,9 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   const int l32 = lane & 31, kh = lane >> 5;
   const int b = blockIdx.z;
   const int g = blockIdx.y / p.co_tiles, ct = blockIdx.y - g * p.co_tiles;
-  const int d = p.dil[p.G > 4 ? 0 : g];
-  const int SH = (p.H + d - 1) / d, SW = (p.W + d - 1) / d;   // sub-image of one residue class
+  const int d = MODE == M_CONV ? p.dil[p.G > 4 ? 0 : g] : 1;
+  // extent of the tile grid: the sub-image of one residue class / the stride-2 output / the (H+1) x (W+1) position grid
+  const int SH = TCV ? p.H + 1 : S2 ? p.OH : (p.H + d - 1) / d, SW = TCV ? p.W + 1 : S2 ? p.OW : (p.W + d - 1) / d;
   const int twl = p.tw_log2, TW = 1 << twl, TH = NPIX >> twl;
   const int tiles_x = (SW + TW - 1) >> twl, tiles_y = (SH + TH - 1) / TH;
   const int per_res = tiles_x * tiles_y;
@@ -67,24 +80,42 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   const int co_pad = (p.cout_g + 31) & ~31;
   const int chw = p.H * p.W;
   const int nchunk = (p.Cin + BCK - 1) / BCK;
-  const int pitch = p.bf_pitch, PR = TH + 2, PC = TW + 2, PLANE = PR * pitch;
+  const int pitch = p.bf_pitch, PR = MODE == M_CONV ? TH + 2 : TH + 1, PC = MODE == M_CONV ? TW + 2 : TW + 1;
+  const int PLANE = p.bf_plane;     // >= PR * pitch (stride 2: == 8 mod 16 so that the two planes a store hits do not collide)
+  const int PBUF = 2 * NPL * PLANE; // 16-byte units per patch buffer: [octet][plane][position]
 
   u32x4* Wl = smem16;               // 2 x [T][2][CO_T]
-  u32x4* Pl = smem16 + 2 * WSLAB;   // 2 x [2][PLANE]
+  u32x4* Pl = smem16 + 2 * WSLAB;   // 2 x [2][NPL][PLANE]
 
   // ---- patch staging: wave w serves channel octet (w & 1), positions (w >> 1) * 64 + lane + 128 e
   const int oct = wave & 1;
   const int pbase = (wave >> 1) * 64 + lane;
-  int poff[PT];
+  // task index -> (image offset, LDS slot).  Stride 1 / transposed: the task index IS the plane position.  Stride 2: tasks
+  // run over the input patch in raster order (2 TH + 1 rows of 2 PC columns) and scatter into the four parity planes.
+  const int RC = S2 ? 2 * PC : pitch;
+  const int NTASK = S2 ? (2 * PR - 1) * RC : PR * pitch;
+  int poff[PT], pdst[PT];
   unsigned pin = 0, pwr = 0;  // bit e: position inside the image / position exists in the plane
 #pragma unroll
   for (int e = 0; e < PT; ++e) {
     const int idx = pbase + 128 * e;
-    const int r = idx / pitch, c = idx - r * pitch;
-    const bool wr = idx < PLANE && c < PC;
-    const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
-    const int iy = sy * d + ry, ix = sx * d + rx;
-    const bool in = wr && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W;
+    const int r = idx / RC, c = idx - r * RC;
+    bool wr, in;
+    int iy, ix;
+    if constexpr (S2) {
+      wr = idx < NTASK && c < 2 * PC - 1;
+      iy = 2 * oy0 - p.pady[0] + r;
+      ix = 2 * ox0 - p.padx[0] + c;
+      in = wr && iy >= 0 && ix >= 0 && iy < p.H && ix < p.W;
+      pdst[e] = ((r & 1) * 2 + (c & 1)) * PLANE + (r >> 1) * pitch + (c >> 1);
+    } else {
+      wr = idx < NTASK && c < PC;
+      const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
+      iy = sy * d + ry;
+      ix = sx * d + rx;
+      in = wr && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W;
+      pdst[e] = idx;
+    }
     poff[e] = in ? iy * p.W + ix : 0;
     pin |= in ? (1u << e) : 0u;
     pwr |= wr ? (1u << e) : 0u;
@@ -99,7 +130,7 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
       const float* xc = xb + (int64_t)(ci < p.Cin ? ci : 0) * chw;  // wave-uniform base
 #pragma unroll
       for (int e = 0; e < PT; ++e)
-        if (128 * e < PLANE) preg[e][j] = xc[poff[e]];
+        if (128 * e < NTASK) preg[e][j] = xc[poff[e]];
     }
   };
   auto commit_p = [&](u32x4* Pdst, int c) {
@@ -119,7 +150,7 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = in ? fmaf(preg[e][j], sc[j], sh[j]) : 0.f;
-      Pdst[oct * PLANE + pbase + 128 * e] =
+      Pdst[oct * NPL * PLANE + pdst[e]] =
           u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
     }
   };
@@ -142,15 +173,15 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = (wn * NB + nb) * 32 + l32;
-    pixpos[nb] = (n >> twl) * pitch + (n & (TW - 1)) + kh * PLANE;
+    pixpos[nb] = (n >> twl) * pitch + (n & (TW - 1)) + kh * NPL * PLANE;
   }
   const int a_lane = kh * CO_T + wm * MB * 32 + l32;
 
-  f32x16 acc[MB][NB];
+  f32x16 acc[MB][NACC];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NACC; ++nb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
@@ -162,76 +193,217 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   for (int c = 0; c < nchunk; ++c) {
     const int cur = c & 1, nxt = cur ^ 1;
     const bool more = c + 1 < nchunk;
-    if (more) {
+    if (more && !(p.dbg & 1)) {
       issue_w(Wl + nxt * WSLAB, c + 1);
       issue_p(c + 1);
     }
     const u32x4* Wc = Wl + cur * WSLAB + a_lane;
-    const u32x4* Pc = Pl + cur * 2 * PLANE;
+    const u32x4* Pc = Pl + cur * PBUF;
+    if constexpr (TCV) {
+      bf16x8 bq[NB][4];  // the position block shifted by (-(ky >> 1), -(kx >> 1)): four distinct fragments serve the nine taps
 #pragma unroll
-    for (int tap = 0; tap < T; ++tap) {
-      const int toff = (tap / 3) * pitch + (tap % 3);
-      bf16x8 a[MB], bq[NB];
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) a[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
+        for (int s4 = 0; s4 < 4; ++s4)
+          bq[nb][s4] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + (1 - (s4 >> 1)) * pitch + (1 - (s4 & 1))]);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bq[nb] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + toff]);
+      for (int tap = 0; tap < T; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int ph = (ky & 1) * 2 + (kx & 1), s4 = (ky >> 1) * 2 + (kx >> 1);
+        bf16x8 a[MB];
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb) a[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb], acc[mb][nb], 0, 0, 0);
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb * 4 + ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb][s4], acc[mb][nb * 4 + ph], 0, 0, 0);
+      }
+    } else {
+      if (!(p.dbg & 2))
+#pragma unroll
+      for (int tap = 0; tap < T; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = S2 ? ((ky & 1) * 2 + (kx & 1)) * PLANE + (ky >> 1) * pitch + (kx >> 1) : ky * pitch + kx;
+        bf16x8 a[MB], bq[NB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bq[nb] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + toff]);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb], acc[mb][nb], 0, 0, 0);
+      }
     }
-    if (more) commit_p(Pl + nxt * 2 * PLANE, c + 1);
+    if (more && !(p.dbg & 1)) commit_p(Pl + nxt * PBUF, c + 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds pixel l32 of block nb; accumulator i is channel 8 (i >> 2) + 4 kh + (i & 3) of block mb
+  if (p.dbg & 4) return;
+  // ---- epilogue.  The accumulators hold one pixel x 16 channels per lane; stored like that every store instruction moves
+  // 4 bytes per lane and every channel operand is a per-lane load (measured: half of a 64-channel 512^2 layer).  Instead the
+  // tile is transposed through LDS, one 32-channel block row (mb) at a time: E[channel][pixel] fp32, then one lane owns 4
+  // consecutive pixels of one channel -> 16-byte noise / residual loads and stores, and (256-pixel tiles) the channel is
+  // wave-uniform, so its six operands come through the scalar cache.
   const int Cout = p.G * p.cout_g;
   const float* osp = p.osp + (int64_t)b * Cout * p.oss;
-  const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW * p.nzs;
+  const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW;
   const float nw = p.nwp[0];
   const float s1 = p.s1, g1 = p.g1, g2 = p.g2;
   float* yb = p.y + ((int64_t)b * p.y_ch + p.y_coff) * p.y_h * p.y_w;
-  const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r1s;
-  const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r2s;
-  const int r1s = p.r1s, r2s = p.r2s;
+  const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
+  const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
+  const bool has_nz = p.nzs != 0, has_r1 = p.r1s != 0, has_r2 = p.r2s != 0;
   const int y_plane = p.y_h * p.y_w;
-  int yoff[NB];
-  float nz[NB];
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int Q = NPIX / 4;                 // pixel quads per channel row
+  constexpr int EROWS = 32 * WM;              // channel rows per pass
+  constexpr int EIT = EROWS * Q / BNT;
+  float* El = reinterpret_cast<float*>(smem16);  // [EROWS][NPIX]
+  if constexpr (TCV) {
+    // position (m, n) feeds outputs (2m + py, 2n + px); no noise / residual here (they follow the blur in the reference).
+    // The two px phases of a lane are neighbours in memory: one 8-byte store (rows of 2W+1 floats are only 4-byte aligned)
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = (wn * NB + nb) * 32 + l32;
-    const int oy = (oy0 + (n >> twl)) * d + ry, ox = (ox0 + (n & (TW - 1))) * d + rx;
-    const bool ok = oy < p.OH && ox < p.OW;
-    yoff[nb] = ok ? oy * p.y_w + ox : -1;
-    nz[nb] = nzp[(ok ? oy * p.OW + ox : 0) * p.nzs] * nw;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l32;
+      const int m = oy0 + (n >> twl), c = ox0 + (n & (TW - 1));
+      if (m > p.H || c > p.W) continue;
+      const bool pair = c < p.W;  // column 2c + 1 exists
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int cg = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+          if (cg >= p.cout_g) continue;
+          const int co = g * p.cout_g + cg;
+          const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
+          const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
+          float* yc = yb + (int64_t)co * y_plane;
+          auto fin = [&](float v) {
+            v = v * os + cb;
+            v = (v > 0.f ? v : v * s1) * g1 + b2;
+            return (v > 0.f ? v : v * sl2) * g2;
+          };
+#pragma unroll
+          for (int py = 0; py < 2; ++py) {
+            if (m + py > p.H) continue;  // row 2m + 1 exists only for m < H
+            const int yo = (2 * m + py) * p.y_w + 2 * c;
+            const float v0 = fin(acc[mb][nb * 4 + py * 2][i]), v1 = fin(acc[mb][nb * 4 + py * 2 + 1][i]);
+            if (pair)
+              *reinterpret_cast<f32x2u*>(yc + yo) = f32x2u{v0, v1};
+            else
+              yc[yo] = v0;
+          }
+        }
+      }
+    }
+    return;
+  } else if (d > 1) {
+    // polyphase sub-image: neighbouring pixels of the tile are d apart in memory, nothing to vectorise -- straight from the
+    // accumulators, lanes along the row (a store touches as few 32-byte sectors as the stride allows)
+    int yoff[NB];
+    float nz[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = (wn * NB + nb) * 32 + l32;
+      const int oy = (oy0 + (n >> twl)) * d + ry, ox = (ox0 + (n & (TW - 1))) * d + rx;
+      const bool ok = oy < p.OH && ox < p.OW;
+      yoff[nb] = ok ? oy * p.y_w + ox : -1;
+      nz[nb] = (ok && has_nz) ? nzp[oy * p.OW + ox] * nw : 0.f;
+    }
+    auto direct = [&](auto res_tag) {  // two straight-line bodies: a per-element branch on an absent residual costs more
+      constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int cg = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+          const bool cok = cg < p.cout_g;
+          const int co = g * p.cout_g + (cok ? cg : 0);
+          const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
+          const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
+          const int cbase = co * y_plane;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int ro = cbase + (yoff[nb] < 0 ? 0 : yoff[nb]);
+            float r = 0.f;
+            if constexpr (RES) r = (has_r1 ? r1b[ro] : 0.f) + (has_r2 ? r2b[ro] : 0.f);
+            float v = acc[mb][nb][i] * os + cb;
+            v = (v > 0.f ? v : v * s1) * g1;
+            v += nz[nb] + b2;
+            v = (v > 0.f ? v : v * sl2) * g2;
+            if (yoff[nb] >= 0 && cok) yb[ro] = v + r;
+          }
+        }
+      }
+    };
+    if (has_r1 || has_r2) direct(std::true_type{}); else direct(std::false_type{});
+    return;
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
+    if (mb > 0) __syncthreads();  // (the chunk loop ended on a barrier)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int cg = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-      const bool cok = cg < p.cout_g;
-      const int co = g * p.cout_g + (cok ? cg : 0);
-      const float os = osp[co * p.oss], cs = p.csp[co * p.css], cb = p.cbp[co * p.cbs];
-      const float b1 = p.b1p[co * p.b1s], b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
-      const int cbase = co * y_plane;
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int ro = cbase + (yoff[nb] < 0 ? 0 : yoff[nb]);
-        const float r1v = r1b[ro * r1s];
-        const float r2v = r2b[ro * r2s];
-        float v = acc[mb][nb][i] * os;
-        v = v * cs + cb;
-        v += b1;
-        v = (v > 0.f ? v : v * s1) * g1;
-        v += nz[nb];
-        v += b2;
-        v = (v > 0.f ? v : v * sl2) * g2;
-        v += r1v;
-        v += r2v;
-        if (yoff[nb] >= 0 && cok) yb[ro] = v;
+      for (int i = 0; i < 16; ++i)
+        El[(wm * 32 + 8 * (i >> 2) + 4 * kh + (i & 3)) * NPIX + (wn * NB + nb) * 32 + l32] = acc[mb][TCV ? 0 : nb][i];
+    __syncthreads();
+    auto operands = [&](int row, int& co, float& os, float& cb, float& b2, float& sl2) -> bool {
+      const int cg = co0 + ((row >> 5) * MB + mb) * 32 + (row & 31);
+      if (cg >= p.cout_g) return false;
+      co = g * p.cout_g + cg;
+      os = osp[co * p.oss] * p.csp[co * p.css];
+      cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
+      b2 = p.b2p[co * p.b2s];
+      sl2 = p.s2p[co * p.s2s];
+      return true;
+    };
+    {
+#pragma unroll 2
+      for (int it = 0; it < EIT; ++it) {
+        int row, q;
+        if constexpr (Q == 64) {
+          row = it * 4 + wave;  // wave-uniform
+          q = lane;
+        } else {
+          const int L = it * BNT + tid;
+          row = L / Q;
+          q = L - row * Q;
+        }
+        int co;
+        float os, cb, b2, sl2;
+        if (!operands(row, co, os, cb, b2, sl2)) continue;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(El + row * NPIX + 4 * q);
+        const int n = 4 * q;
+        const int oy = oy0 + (n >> twl), ox = ox0 + (n & (TW - 1));
+        if (oy >= p.OH || ox >= p.OW) continue;
+        auto fin = [&](float v, float nzv, float r1v, float r2v) {
+          v = v * os + cb;
+          v = (v > 0.f ? v : v * s1) * g1;
+          v += nzv * nw + b2;
+          v = (v > 0.f ? v : v * sl2) * g2;
+          return v + r1v + r2v;
+        };
+        const int ro = co * y_plane + oy * p.y_w + ox;
+        if (ox + 3 < p.OW) {
+          f32x4u nzv = {0.f, 0.f, 0.f, 0.f}, r1v = nzv, r2v = nzv;
+          if (has_nz) nzv = *reinterpret_cast<const f32x4u*>(nzp + oy * p.OW + ox);
+          if (has_r1) r1v = *reinterpret_cast<const f32x4u*>(r1b + ro);
+          if (has_r2) r2v = *reinterpret_cast<const f32x4u*>(r2b + ro);
+          const f32x4u o4 = {fin(av[0], nzv[0], r1v[0], r2v[0]), fin(av[1], nzv[1], r1v[1], r2v[1]),
+                             fin(av[2], nzv[2], r1v[2], r2v[2]), fin(av[3], nzv[3], r1v[3], r2v[3])};
+          *reinterpret_cast<f32x4u*>(yb + ro) = o4;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (ox + j >= p.OW) continue;
+            yb[ro + j] = fin(av[j], has_nz ? nzp[oy * p.OW + ox + j] : 0.f, has_r1 ? r1b[ro + j] : 0.f, has_r2 ? r2b[ro + j] : 0.f);
+          }
+        }
       }
     }
   }
@@ -251,73 +423,109 @@ static int bf_pitch(int twl, int pc) {
   return pch >= pc ? pch : pch + 16;
 }
 
-static BfGeom bf_geom(const ConvK& q, int co_t, int npix) {
-  int dmin = q.dil[0];
-  for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmin = q.dil[g] < dmin ? q.dil[g] : dmin;
-  int dmax = q.dil[0];
-  for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
-  const int sw = (q.W + dmax - 1) / dmax;  // the narrowest sub-image decides the tile width
+static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows) {
+  int sw;  // width of the tile grid (the narrowest sub-image of a dilation-group launch decides the tile width)
+  if (mode == M_TC) sw = q.W + 1;
+  else if (mode == M_S2) sw = q.OW;
+  else {
+    int dmax = q.dil[0];
+    for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
+    sw = (q.W + dmax - 1) / dmax;
+  }
   BfGeom r;
   r.twl = sw >= 32 ? 5 : (sw > 8 ? 4 : 3);
   const int TW = 1 << r.twl, TH = npix >> r.twl;
-  r.pitch = bf_pitch(r.twl, TW + 2);
-  r.plane = (TH + 2) * r.pitch;
-  r.pt = (r.plane + 127) / 128;
-  r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * r.plane) * 16;
-  (void)dmin;
+  const int PR = mode == M_CONV ? TH + 2 : TH + 1, PC = mode == M_CONV ? TW + 2 : TW + 1;
+  r.pitch = bf_pitch(r.twl, PC);
+  r.plane = PR * r.pitch;
+  int ntask = r.plane, npl = 1;
+  if (mode == M_S2) {
+    r.plane = (r.plane & ~15) + 8 >= r.plane ? (r.plane & ~15) + 8 : (r.plane & ~15) + 24;  // == 8 (mod 16)
+    ntask = (2 * PR - 1) * 2 * PC;
+    npl = 4;
+  }
+  r.pt = (ntask + 127) / 128;
+  r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * npl * r.plane) * 16;
+  const size_t epi = (size_t)erows * npix * sizeof(float);  // epilogue transpose buffer
+  if (epi > r.lds) r.lds = epi;
   return r;
 }
 
-template <int MB, int NB, int WM, int WN, int PT>
+template <int MB, int NB, int WM, int WN, int PT, int MODE>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_bf16: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
   }
   q.tw_log2 = gm.twl;
   q.bf_pitch = gm.pitch;
+  q.bf_plane = gm.plane;
   q.co_tiles = (q.cout_g + CO_T - 1) / CO_T;
   const int TW = 1 << gm.twl, TH = NPIX >> gm.twl;
   int blocks = 0;
-  for (int g = 0; g < (q.G > 4 ? 1 : q.G); ++g) {
-    const int d = q.dil[g];
-    const int SH = (q.H + d - 1) / d, SW = (q.W + d - 1) / d;
-    const int n = ((SW + TW - 1) / TW) * ((SH + TH - 1) / TH) * d * d;
-    blocks = n > blocks ? n : blocks;
+  if (MODE == M_CONV) {
+    for (int g = 0; g < (q.G > 4 ? 1 : q.G); ++g) {
+      const int d = q.dil[g];
+      const int SH = (q.H + d - 1) / d, SW = (q.W + d - 1) / d;
+      const int n = ((SW + TW - 1) / TW) * ((SH + TH - 1) / TH) * d * d;
+      blocks = n > blocks ? n : blocks;
+    }
+  } else {
+    const int EH = MODE == M_TC ? q.H + 1 : q.OH, EW = MODE == M_TC ? q.W + 1 : q.OW;
+    blocks = ((EW + TW - 1) / TW) * ((EH + TH - 1) / TH);
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_bf16_kernel<MB, NB, WM, WN, PT><<<grid, BNT, gm.lds, stream>>>(q);
+  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE><<<grid, BNT, gm.lds, stream>>>(q);
   return VSP_OK;
 }
 
-template <int MB, int NB, int WM, int WN>
+template <int MB, int NB, int WM, int WN, int MODE>
 int launch_shape(const ConvK& q, hipStream_t stream) {
-  const BfGeom gm = bf_geom(q, 32 * MB * WM, 32 * NB * WN);
+  const BfGeom gm = bf_geom(q, MODE, 32 * MB * WM, 32 * NB * WN, 32 * WM);
   if (gm.lds > 150 * 1024) return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: tile does not fit LDS");
-  if (gm.pt <= 3) return launch_bf<MB, NB, WM, WN, 3>(q, gm, stream);
-  if (gm.pt <= 7) return launch_bf<MB, NB, WM, WN, 7>(q, gm, stream);
+  if (gm.pt <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE>(q, gm, stream);
+  if (MODE == M_S2 && gm.pt <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE>(q, gm, stream);
+  if (MODE != M_S2 && gm.pt <= 7) return launch_bf<MB, NB, WM, WN, 7, MODE>(q, gm, stream);
   return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: patch plane of %d positions is too large", gm.plane);
 }
 
 }  // namespace
 
-// variant: 0 = automatic, 1 = 32 ch x 256 px, 2 = 64 ch x 256 px, 3 = 128 ch x 128 px, 4 = 64 ch x 128 px
-int bf16_launch(const ConvK& q, int variant, hipStream_t stream) {
+// mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv.
+// variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
+//          stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
+int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
+  if (mode == M_TC) {
+    if (variant == 0) variant = q.cout_g <= 32 ? 5 : 4;
+    switch (variant) {
+      case 4: return launch_shape<2, 1, 1, 4, M_TC>(q, stream);
+      case 5: return launch_shape<1, 1, 1, 4, M_TC>(q, stream);
+      default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown transposed variant %d", variant);
+    }
+  }
+  if (mode == M_S2) {
+    if (variant == 0) variant = (q.cout_g >= 128 && (int64_t)q.OH * q.OW <= 64 * 64) ? 6 : 4;
+    switch (variant) {
+      case 4: return launch_shape<2, 1, 1, 4, M_S2>(q, stream);
+      case 6: return launch_shape<2, 1, 2, 2, M_S2>(q, stream);
+      default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown stride-2 variant %d", variant);
+    }
+  }
   if (variant == 0) {
     const int64_t px = (int64_t)q.H * q.W;
     if (q.cout_g <= 32) variant = 1;
     else if (q.cout_g <= 64) variant = px >= 128 * 128 ? 2 : 4;
-    else variant = px >= 128 * 128 ? 3 : 4;
+    else variant = px >= 64 * 64 ? 2 : 4;
   }
   switch (variant) {
-    case 1: return launch_shape<1, 2, 1, 4>(q, stream);
-    case 2: return launch_shape<2, 2, 1, 4>(q, stream);
-    case 3: return launch_shape<2, 2, 2, 2>(q, stream);
-    case 4: return launch_shape<2, 1, 1, 4>(q, stream);
+    case 1: return launch_shape<1, 2, 1, 4, M_CONV>(q, stream);
+    case 2: return launch_shape<2, 2, 1, 4, M_CONV>(q, stream);
+    case 3: return launch_shape<2, 2, 2, 2, M_CONV>(q, stream);
+    case 4: return launch_shape<2, 1, 1, 4, M_CONV>(q, stream);
     default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown variant %d", variant);
   }
 }

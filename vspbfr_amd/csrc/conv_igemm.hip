@@ -320,16 +320,39 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
 
 extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d_bf16: null params");
-  const vsp_conv_params& p = *pp;
-  VSP_REQUIRE(!p.transposed && p.G >= 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1,
-              "conv2d_bf16: only 3x3, stride 1");
-  VSP_REQUIRE(p.G <= 4 || p.x_group_stride > 0, "conv2d_bf16: more than four groups need their own input slices");
-  for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g)
-    VSP_REQUIRE(p.dil[g] >= 1 && p.dil[g] <= 64 && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
-                "conv2d_bf16: group %d needs padding = dilation (got dilation %d, padding %d/%d)", g, p.dil[g], p.pad_y[g],
-                p.pad_x[g]);
-  VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_bf16: dense output only");
-  VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_bf16: output size must equal the input size");
+  vsp_conv_params pcopy = *pp;
+  int mode = 0;
+  VSP_REQUIRE(pcopy.KH == 3 && pcopy.KW == 3 && pcopy.G >= 1, "conv2d_bf16: 3x3 kernels only");
+  if (pcopy.transposed) {  // same normalisation as vsp_conv2d_f32: the grid runs over input positions m = 0..H, n = 0..W
+    mode = 2;
+    VSP_REQUIRE(pcopy.G == 1, "conv2d_bf16: transposed mode needs G = 1");
+    VSP_REQUIRE(!pcopy.noise && !pcopy.res1 && !pcopy.res2, "conv2d_bf16: transposed mode has no noise / residual epilogue");
+    VSP_REQUIRE(pcopy.y_h == 2 * pcopy.H + 1 && pcopy.y_w == 2 * pcopy.W + 1, "conv2d_bf16: transposed output must be (2H+1)x(2W+1)");
+    pcopy.stride_y = pcopy.stride_x = 1;
+    pcopy.dil[0] = 1;
+    pcopy.pad_y[0] = pcopy.pad_x[0] = 1;
+    pcopy.OH = pcopy.H + 1;
+    pcopy.OW = pcopy.W + 1;
+    pcopy.osy = pcopy.osx = 2;
+    pcopy.ooy = pcopy.oox = 0;
+  } else if (pcopy.stride_y == 2 && pcopy.stride_x == 2) {
+    mode = 1;
+    VSP_REQUIRE(pcopy.dil[0] == 1 && pcopy.pad_y[0] == pcopy.pad_x[0] && (pcopy.pad_y[0] == 0 || pcopy.pad_y[0] == 1),
+                "conv2d_bf16: stride 2 needs dilation 1 and padding 0 or 1");
+    VSP_REQUIRE(pcopy.G == 1 || pcopy.x_group_stride > 0, "conv2d_bf16: stride-2 groups need their own input slices");
+    VSP_REQUIRE(pcopy.OH <= (pcopy.H + 2 * pcopy.pad_y[0] - 3) / 2 + 1 && pcopy.OW <= (pcopy.W + 2 * pcopy.pad_x[0] - 3) / 2 + 1,
+                "conv2d_bf16: output larger than the stride-2 convolution of the input");
+  } else {
+    VSP_REQUIRE(pcopy.stride_y == 1 && pcopy.stride_x == 1, "conv2d_bf16: stride must be 1 or 2");
+    VSP_REQUIRE(pcopy.G <= 4 || pcopy.x_group_stride > 0, "conv2d_bf16: more than four groups need their own input slices");
+    for (int g = 0; g < (pcopy.G > 4 ? 1 : pcopy.G); ++g)
+      VSP_REQUIRE(pcopy.dil[g] >= 1 && pcopy.dil[g] <= 64 && pcopy.pad_y[g] == pcopy.dil[g] && pcopy.pad_x[g] == pcopy.dil[g],
+                  "conv2d_bf16: group %d needs padding = dilation (got dilation %d, padding %d/%d)", g, pcopy.dil[g],
+                  pcopy.pad_y[g], pcopy.pad_x[g]);
+    VSP_REQUIRE(pcopy.OH == pcopy.H && pcopy.OW == pcopy.W, "conv2d_bf16: output size must equal the input size");
+  }
+  const vsp_conv_params& p = pcopy;
+  if (mode != 2) VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_bf16: dense output only");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_bf16: packed weights must be 16-byte aligned");
   int x_ch = 0;
   bool empty = false;
@@ -338,7 +361,11 @@ extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE((int64_t)p.G * p.cout_g <= 65535 && p.B <= 65535, "conv2d_bf16: grid too large");
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
-  if (int rc = vspconv::bf16_launch(q, p.tile_hint, vsp::as_stream(stream))) return rc;
+  {
+    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    q.dbg = dbg;
+  }
+  if (int rc = vspconv::bf16_launch(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_bf16");
 }
 

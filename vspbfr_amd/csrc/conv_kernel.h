@@ -59,7 +59,7 @@ struct ConvK {
   int x_ch, x_gs;                                // input channels per image, input-channel stride between groups
   int strip_col;                                 // transposed mode: edge-strip blocks after the tiles_x*tiles_y main tiles (-1: none)
   int dbg;                                       // ablation switches for kernel tuning (env VSP_CONV_DBG; 0 in production)
-  int bf_pitch;                                  // conv_bf16.hip: patch row pitch in positions
+  int bf_pitch, bf_plane;                        // conv_bf16.hip: patch row pitch and plane size in positions
 };
 
 __device__ __forceinline__ int round_pitch(int n, int odd) {
@@ -588,7 +588,7 @@ int wino_chunk();           // input channels per chunk the transformed-weight l
 int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout) for a layer with cout_g channels per group
 
 // conv_bf16.hip: 3x3 stride-1 convolution on the bf16 matrix pipe (q.w = bf16 weights in LDS-image order)
-int bf16_launch(const ConvK& q, int variant, hipStream_t stream);
+int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream);
 
 struct Cfg {
   int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;  // a name ending in "t" marks a transposed-conv kernel

@@ -195,14 +195,34 @@ BF16_CONV = False
 
 
 def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
-    """3x3, stride 1, padding = dilation, dense output; G <= 4 dilation groups over one input or true groups."""
-    if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.cin < 16:
+    """What vsp_conv2d_bf16 serves: 3x3 kernels with >= 16 input channels as (a) stride 1, padding = dilation, G <= 4 dilation
+    groups over one input or true groups; (b) stride 2, dilation 1, padding 0 or 1, G = 1 or true groups; (c) the stride-2
+    transposed conv (G = 1); dense output for (a) and (b)."""
+    if pc.kh != 3 or pc.kw != 3 or pc.cin < 16:
         return False
-    if pc.G > 4 and pc.x_group_stride == 0:
+    if transposed:
+        return pc.G == 1
+    if tuple(out_stride) != (1, 1) or tuple(out_offset) != (0, 0):
+        return False
+    if pc.stride == 2:
+        return (pc.dil[0] == 1 and pc.pad_y[0] == pc.pad_x[0] and pc.pad_y[0] in (0, 1) and (pc.G == 1 or pc.x_group_stride > 0)
+                and (OH, OW) == conv2d_out_size(H, W, pc))
+    if pc.stride != 1 or (pc.G > 4 and pc.x_group_stride == 0):
         return False
     if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] for g in range(min(pc.G, 4))):
         return False
-    return (OH, OW) == (H, W) and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0)
+    return (OH, OW) == (H, W)
+
+
+def bf16_profitable(pc, H, W, OH, OW, transposed=False):
+    """Shapes on which the bf16 kernel beats the fp32 kernels (tools/bench_bf16.py, tools/conv_breakdown.py): 32-pixel row
+    segments need maps (polyphase sub-images for dilation groups) at least 8-16 pixels wide."""
+    if transposed:
+        return W >= 16
+    if pc.stride == 2:
+        return OW >= 8
+    dmax = max(pc.dil[:min(pc.G, 4)])
+    return W >= 16 and W // dmax >= 8
 
 
 def bf16_weight(wp):
@@ -309,9 +329,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     if bf16 is None:
-        bf16 = BF16_CONV and bf_ok and not winograd
+        bf16 = BF16_CONV and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
     elif bf16 and not bf_ok:
-        raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (3x3, stride 1, padding = dilation)")
+        raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
     if bf16:
         winograd = False
         if tile_hint < 0:
@@ -344,7 +364,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     else:
         check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G))
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, "bf16" if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct"))))
     return out
 
 
