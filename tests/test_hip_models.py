@@ -302,3 +302,47 @@ def test_pipeline_run_batches_matches_call():
         assert torch.equal(o["latent"], pipe.psp.get_w_plus(lq))
         assert torch.isfinite(o["restored"]).all() and o["restored"].shape == (1, 3, 512, 512)
     assert list(pipe.run_batches([])) == []
+
+
+def test_pipeline512_bf16_config(golden):
+    """The bf16-kernel configuration (BASELINE configs[2]; hip_ops.BF16_CONV) on the pinned 512^2 case: stage A's codes and
+    stages C + D teacher-forced on the reference's latent, against the reference's fp32 golden.  bf16 operands cannot meet
+    the 1e-3 parity bound (SURVEY 7 "hard parts"); this records the delta (gpurun_out/parity_pipeline512_bf16.json) and bounds
+    it at bf16 rounding accumulated over the ~40 convolutions of the decoders."""
+    import json
+    import os
+    from vspbfr_amd import hip_ops
+    case, B = "pipeline512", 1
+    pipe = build_pipeline()
+    lq = cases.image_batch(case, B, 512)
+    gno = [dev(n) for n in cases.noise_list(case, "g", OM.generator_noise_shapes(1024, B))]
+    enc_s, dec_s = OM.restoration_noise_shapes(512, B)
+    z = [dev(cases.tensor(case, "z", (B, 512)))]
+    en = [dev(n) for n in cases.noise_list(case, "enc", enc_s)]
+    dn = [dev(n) for n in cases.noise_list(case, "dec", dec_s)]
+    g = golden(case)
+    hip_ops.BF16_CONV = True
+    try:
+        codes = pipe.psp.get_w_plus(dev(lq))
+        pre = dev(torch.from_numpy(g["pre_latent"]))
+        sample_tf, feats_tf = pipe.psp.get_stylegan_feats(pre, noise=gno)
+        r_tf = pipe.generator(dev(lq), feats_tf, pre, z, enc_noise=en, dec_noise=dn)
+    finally:
+        hip_ops.BF16_CONV = False
+    dr = (r_tf[:, :, ::8, ::8].cpu() - torch.from_numpy(g["restored_sub"]))
+    ds = (sample_tf[:, :, ::8, ::8].cpu() - torch.from_numpy(g["sample_sub"]))
+    q = OM.save_image_quantize(r_tf[:, :, ::8, ::8].cpu()).numpy().astype(np.int32)
+    qg = OM.save_image_quantize(torch.from_numpy(g["restored_sub"])).numpy().astype(np.int32)
+    rep = {"codes_max": maxerr(codes, g["codes"]), "codes_absmax": float(np.abs(g["codes"]).max()),
+           "restored_max": float(dr.abs().max()), "restored_rms": float(dr.pow(2).mean().sqrt()),
+           "restored_std_ref": float(torch.from_numpy(g["restored_sub"]).std()),
+           "style_sample_max": float(ds.abs().max()), "style_sample_rms": float(ds.pow(2).mean().sqrt()),
+           "restored_8bit_lsb_max": int(np.abs(q - qg).max()), "restored_8bit_lsb_mean": float(np.abs(q - qg).mean())}
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/parity_pipeline512_bf16.json", "w"), indent=1)
+    print(rep)
+    assert np.isfinite(r_tf.cpu().numpy()).all()
+    assert rep["codes_max"] < 0.05 * max(rep["codes_absmax"], 1.0)
+    # measured on MI355X: restored max 1.6e-2, rms 2.9e-3 on an image of std 0.93; <= 2 LSB (mean 0.17) after save_image
+    assert rep["restored_rms"] < 0.01 * rep["restored_std_ref"] and rep["restored_max"] < 0.06 * rep["restored_std_ref"]
+    assert rep["style_sample_rms"] < 0.03 and rep["restored_8bit_lsb_mean"] < 0.5 and rep["restored_8bit_lsb_max"] <= 4

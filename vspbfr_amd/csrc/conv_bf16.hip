@@ -497,7 +497,7 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 
 // mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv.
 // variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
-//          stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
+//          6 = 128 ch x 64 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_TC) {
     if (variant == 0) variant = q.cout_g <= 32 ? 5 : 4;
@@ -516,8 +516,12 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
     }
   }
   if (variant == 0) {
-    const int64_t px = (int64_t)q.H * q.W;
+    int dmax = q.dil[0];
+    for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
+    const int64_t px = (int64_t)((q.H + dmax - 1) / dmax) * ((q.W + dmax - 1) / dmax);  // the smallest polyphase sub-image
     if (q.cout_g <= 32) variant = 1;
+    else if (px <= 64 && q.cout_g >= 128) variant = 6;
+    else if (q.G > 1) variant = 4;
     else if (q.cout_g <= 64) variant = px >= 128 * 128 ? 2 : 4;
     else variant = px >= 64 * 64 ? 2 : 4;
   }
@@ -526,6 +530,7 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
     case 2: return launch_shape<2, 2, 1, 4, M_CONV>(q, stream);
     case 3: return launch_shape<2, 2, 2, 2, M_CONV>(q, stream);
     case 4: return launch_shape<2, 1, 1, 4, M_CONV>(q, stream);
+    case 6: return launch_shape<2, 1, 2, 2, M_CONV>(q, stream);
     default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown variant %d", variant);
   }
 }
