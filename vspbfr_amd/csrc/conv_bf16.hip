@@ -48,12 +48,16 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 
 enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 
+// DEEP (PT <= 3, 64-channel tiles and up): two patch register sets, loads two chunks ahead, conversion spread over the tap loop.  Larger planes
+// (narrow tiles, 5-7 positions per lane) keep ONE set: loads one chunk ahead, conversion after the taps.
 template <int MB, int NB, int WM, int WN, int PT, int MODE>
-__global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
+__global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr bool S2 = MODE == M_S2, TCV = MODE == M_TC;
   constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
   constexpr int NPL = S2 ? 4 : 1;          // patch planes per channel octet (stride 2: parity planes)
+  // 32-channel tiles (40 KB LDS) live on occupancy instead (<= 128 VGPRs); the transposed mode has 128 accumulator registers
+  constexpr bool DEEP = PT <= 3 && !(MB == 1 && MODE == M_CONV) && MODE != M_TC;
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN, T = 9;
   constexpr int WSLAB = T * 2 * CO_T;  // 16-byte units per weight buffer: [tap][octet][co]
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   // run over the input patch in raster order (2 TH + 1 rows of 2 PC columns) and scatter into the four parity planes.
   const int RC = S2 ? 2 * PC : pitch;
   const int NTASK = S2 ? (2 * PR - 1) * RC : PR * pitch;
-  int poff[PT], pdst[PT];
+  unsigned poff[PT];  // BYTE offset inside a channel plane, unsigned 32-bit: the loads take the scalar-base + lane-offset form
+  int pdst[PT];
   unsigned pin = 0, pwr = 0;  // bit e: position inside the image / position exists in the plane
 #pragma unroll
   for (int e = 0; e < PT; ++e) {
@@ -116,43 +121,51 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
       in = wr && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W;
       pdst[e] = idx;
     }
-    poff[e] = in ? iy * p.W + ix : 0;
+    poff[e] = in ? (unsigned)(iy * p.W + ix) * 4u : 0u;
     pin |= in ? (1u << e) : 0u;
     pwr |= wr ? (1u << e) : 0u;
   }
   const float* xb = p.x + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * chw;
-  float preg[PT][8];
-  auto issue_p = [&](int c) {
+  // Two register sets: chunk k lives in set k & 1.  Its loads are issued TWO intervals before its MFMAs (top of interval
+  // k - 2), its conversion + LDS write is spread over the tap loop of interval k - 1 (VALU work in the shadow of the MFMAs).
+  float pregA[PT][8], pregB[PT][8];
+  const float* iscp = p.in_scale + (int64_t)b * p.in_scale_bstride;
+  const float* ishp = p.in_shift;
+  // Cin is a multiple of 8 (host): a wave's channel octet is either wholly inside or wholly past Cin
+  auto issue_p = [&](float (&pr)[PT][8], int c) {
     const int cib = c * BCK + 8 * oct;
+    if (cib >= p.Cin) return;                                  // wave-uniform; the octet is committed as zeros
+    const char* xc = reinterpret_cast<const char*>(xb + (int64_t)cib * chw);  // wave-uniform base, stepped by one channel plane
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ci = cib + j;
-      const float* xc = xb + (int64_t)(ci < p.Cin ? ci : 0) * chw;  // wave-uniform base
 #pragma unroll
-      for (int e = 0; e < PT; ++e)
-        if (128 * e < NTASK) preg[e][j] = xc[poff[e]];
+      for (int e = 0; e < PT; ++e)  // (tasks past the plane read element 0 and are never written)
+        pr[e][j] = *reinterpret_cast<const float*>(xc + poff[e]);
+      xc += (int64_t)chw * 4;
     }
   };
-  auto commit_p = [&](u32x4* Pdst, int c) {
-    const int cib = c * BCK + 8 * oct;
-    float sc[8], sh[8];
+  auto load_scales = [&](int c, float (&sc)[8], float (&sh)[8]) -> bool {  // wave-uniform: scalar loads
+    const int cib = min(c * BCK + 8 * oct, p.Cin - 8);
+    // constant address space: a uniform load from it goes through the scalar cache (a plain global pointer does not, the
+    // compiler cannot know that nothing stores to it).  Absent operands: a device constant through stride 0 (host).
+    typedef const float __attribute__((address_space(4))) * cfp4;
+    cfp4 s0 = (cfp4)(uintptr_t)(iscp + cib * p.bf_isc_s);
+    cfp4 h0 = (cfp4)(uintptr_t)(ishp + cib * p.bf_ish_s);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int ci = cib + j;
-      const bool chok = ci < p.Cin;
-      sc[j] = chok ? (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f) : 0.f;
-      sh[j] = (chok && p.in_shift) ? p.in_shift[ci] : 0.f;
+      sc[j] = s0[j * p.bf_isc_s];
+      sh[j] = h0[j * p.bf_ish_s];
     }
+    return c * BCK + 8 * oct < p.Cin;
+  };
+  auto commit_one = [&](u32x4* Pdst, const float (&pr)[PT][8], const float (&sc)[8], const float (&sh)[8], bool oct_ok, int e) {
+    if (!((pwr >> e) & 1u)) return;
+    const bool in = ((pin >> e) & 1u) && oct_ok;
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < PT; ++e) {
-      if (!((pwr >> e) & 1u)) continue;
-      const bool in = (pin >> e) & 1u;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = in ? fmaf(preg[e][j], sc[j], sh[j]) : 0.f;
-      Pdst[oct * NPL * PLANE + pdst[e]] =
-          u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-    }
+    for (int j = 0; j < 8; ++j) v[j] = in ? fmaf(pr[e][j], sc[j], sh[j]) : 0.f;
+    Pdst[oct * NPL * PLANE + pdst[e]] =
+        u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
   };
 
   // ---- weight slab by LDS-DMA: the chunk's [tap][octet] rows of this co tile, 64 rows (1 KiB) per wave instruction
@@ -160,10 +173,12 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)g * nchunk * (T * 2) * co_pad;
   auto issue_w = [&](u32x4* Wdst, int c) {
     const u32x4* src = wsrc + (int64_t)c * (T * 2) * co_pad;
-    for (int i = wave; i < NDMA; i += 4) {
+#pragma unroll
+    for (int k = 0; k < (NDMA + 3) / 4; ++k) {
+      const int i = wave + 4 * k;
       const int L = i * 64 + lane;
       const int row = L / CO_T, co = L - row * CO_T;
-      if (co0 + co < co_pad)
+      if (i < NDMA && co0 + co < co_pad)
         __builtin_amdgcn_global_load_lds(src + row * co_pad + co0 + co, Wdst + i * 64, 16, 0, 0);
     }
   };
@@ -185,18 +200,25 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
-  // ---- pipeline: at the top of interval c, W[c&1] and P[c&1] hold chunk c (made visible by the closing barrier of c-1)
-  issue_w(Wl, 0);
-  issue_p(0);
-  commit_p(Pl, 0);
-  __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
+  // ---- pipeline: at the top of interval c, W[c&1] and P[c&1] hold chunk c (made visible by the closing barrier of c-1),
+  //      the register set (c+1)&1 holds the raw patch of chunk c+1
+  auto interval = [&](int c, float (&prLoad)[PT][8], float (&prCommit)[PT][8]) {
     const int cur = c & 1, nxt = cur ^ 1;
-    const bool more = c + 1 < nchunk;
-    if (more && !(p.dbg & 1)) {
-      issue_w(Wl + nxt * WSLAB, c + 1);
-      issue_p(c + 1);
+    // order matters: with an LDS-DMA in flight hipcc waits for vmcnt(0) at the first use of ANY loaded register, so the
+    // weight DMA of chunk c+1 is issued only after the last commit of this interval (PT taps in); the patch loads of
+    // chunk c+2 go first and have the whole interval to land
+    if constexpr (DEEP) {
+      if (c + 2 < nchunk) issue_p(prLoad, c + 2);
+    } else {
+      if (c + 1 < nchunk) {
+        issue_w(Wl + nxt * WSLAB, c + 1);
+        issue_p(prCommit, c + 1);
+      }
     }
+    float sc[8], sh[8];
+    const bool oct_ok = load_scales(c + 1, sc, sh);
+    constexpr int DMA_TAP = PT - 1;
+    u32x4* Pn = Pl + nxt * PBUF;
     const u32x4* Wc = Wl + cur * WSLAB + a_lane;
     const u32x4* Pc = Pl + cur * PBUF;
     if constexpr (TCV) {
@@ -218,9 +240,12 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb * 4 + ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb][s4], acc[mb][nb * 4 + ph], 0, 0, 0);
+        if constexpr (DEEP) {
+          if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
+          if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
+        }
       }
     } else {
-      if (!(p.dbg & 2))
 #pragma unroll
       for (int tap = 0; tap < T; ++tap) {
         const int ky = tap / 3, kx = tap % 3;
@@ -235,13 +260,39 @@ __global__ __launch_bounds__(BNT, 2) void conv_bf16_kernel(const ConvK p) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb], acc[mb][nb], 0, 0, 0);
+        if constexpr (DEEP) {
+          if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
+          if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
+        }
       }
     }
-    if (more && !(p.dbg & 1)) commit_p(Pl + nxt * PBUF, c + 1);
+    if constexpr (!DEEP) {
+      if (c + 1 < nchunk) {
+#pragma unroll
+        for (int e = 0; e < PT; ++e) commit_one(Pn, prCommit, sc, sh, oct_ok, e);
+      }
+    }
+    __syncthreads();
+  };
+  {
+    issue_w(Wl, 0);
+    issue_p(pregA, 0);
+    if (DEEP && nchunk > 1) issue_p(pregB, 1);
+    float sc[8], sh[8];
+    const bool oct_ok = load_scales(0, sc, sh);
+#pragma unroll
+    for (int e = 0; e < PT; ++e) commit_one(Pl, pregA, sc, sh, oct_ok, e);
     __syncthreads();
   }
+  if constexpr (DEEP) {
+    for (int c = 0; c < nchunk; c += 2) {
+      interval(c, pregA, pregB);
+      if (c + 1 < nchunk) interval(c + 1, pregB, pregA);
+    }
+  } else {
+    for (int c = 0; c < nchunk; ++c) interval(c, pregA, pregA);
+  }
 
-  if (p.dbg & 4) return;
   // ---- epilogue.  The accumulators hold one pixel x 16 channels per lane; stored like that every store instruction moves
   // 4 bytes per lane and every channel operand is a per-lane load (measured: half of a 64-channel 512^2 layer).  Instead the
   // tile is transposed through LDS, one 32-channel block row (mb) at a time: E[channel][pixel] fp32, then one lane owns 4

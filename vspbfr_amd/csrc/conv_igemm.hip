@@ -354,6 +354,7 @@ extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
   const vsp_conv_params& p = pcopy;
   if (mode != 2) VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_bf16: dense output only");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_bf16: packed weights must be 16-byte aligned");
+  VSP_REQUIRE(p.Cin % 8 == 0, "conv2d_bf16: Cin must be a multiple of 8 (got %d)", p.Cin);
   int x_ch = 0;
   bool empty = false;
   if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
@@ -361,9 +362,12 @@ extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE((int64_t)p.G * p.cout_g <= 65535 && p.B <= 65535, "conv2d_bf16: grid too large");
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
-  {
-    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
-    q.dbg = dbg;
+  {  // the bf16 kernel reads its prologue operands unconditionally: absent ones are device constants through stride 0
+    const float* kc = device_consts();
+    q.bf_isc_s = q.in_scale ? 1 : 0;
+    q.bf_ish_s = q.in_shift ? 1 : 0;
+    if (!q.in_scale) { q.in_scale = kc; q.in_scale_bstride = 0; }
+    if (!q.in_shift) q.in_shift = kc + 1;
   }
   if (int rc = vspconv::bf16_launch(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_bf16");

@@ -60,6 +60,7 @@ struct ConvK {
   int strip_col;                                 // transposed mode: edge-strip blocks after the tiles_x*tiles_y main tiles (-1: none)
   int dbg;                                       // ablation switches for kernel tuning (env VSP_CONV_DBG; 0 in production)
   int bf_pitch, bf_plane;                        // conv_bf16.hip: patch row pitch and plane size in positions
+  int bf_isc_s, bf_ish_s;                        // conv_bf16.hip: channel stride of in_scale / in_shift (0: absent -> constant)
 };
 
 __device__ __forceinline__ int round_pitch(int n, int odd) {

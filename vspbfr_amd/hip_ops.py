@@ -198,7 +198,7 @@ def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_off
     """What vsp_conv2d_bf16 serves: 3x3 kernels with >= 16 input channels as (a) stride 1, padding = dilation, G <= 4 dilation
     groups over one input or true groups; (b) stride 2, dilation 1, padding 0 or 1, G = 1 or true groups; (c) the stride-2
     transposed conv (G = 1); dense output for (a) and (b)."""
-    if pc.kh != 3 or pc.kw != 3 or pc.cin < 16:
+    if pc.kh != 3 or pc.kw != 3 or pc.cin < 16 or pc.cin % 8:
         return False
     if transposed:
         return pc.G == 1
