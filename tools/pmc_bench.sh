@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM traffic of the conv kernel family over one bench step (GPU box): separate PMC passes for FETCH_SIZE and WRITE_SIZE
 # (TCC slots do not fit both), plus a calibration pass on kernels with known byte counts.
-# usage: tools/pmc_bench.sh <outdir>
+# usage: tools/pmc_bench.sh <outdir> [extra bench.py arguments, e.g. --conv-dtype bf16]
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=$1; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal_fetch -o f --output-format csv -- python tools/pmc_calibrate.py > $OUT/cal_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal_write -o w --output-format csv -- python tools/pmc_calibrate.py > $OUT/cal_write.log 2>&1
-python tools/pmc_traffic_summary.py $OUT
+OUT=$1; shift; mkdir -p $OUT
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap "$@" > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-overlap "$@" > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal_fetch -o f --output-format csv -- python3 tools/pmc_calibrate.py > $OUT/cal_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal_write -o w --output-format csv -- python3 tools/pmc_calibrate.py > $OUT/cal_write.log 2>&1
+python3 tools/pmc_traffic_summary.py $OUT
+rm -f $OUT/*/*.db $OUT/*/*/*.db

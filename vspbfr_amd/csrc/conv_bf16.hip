@@ -67,16 +67,32 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l32 = lane & 31, kh = lane >> 5;
-  const int b = blockIdx.z;
-  const int g = blockIdx.y / p.co_tiles, ct = blockIdx.y - g * p.co_tiles;
+  // XCD-aware work order.  The dispatcher deals workgroups round-robin over the 8 XCDs (each with its own L2), so neighbours
+  // in launch order never share an L2.  Remap (bijective for any grid size) so that every XCD walks a CONTIGUOUS range of a
+  // logical order in which the workgroups that read the same input are adjacent: fastest the output-channel tiles of one
+  // pixel tile (same patch), then neighbouring tiles (shared halo), then images.  Dilation-group launches keep the launch
+  // order (residue-major): there the column residues of a tile, which read the same 32-byte sectors, already follow each other
+  // on one XCD two slots apart, and packing them into the same instant instead measured 25 % slower.
+  const int GX = gridDim.x, GY = gridDim.y, GN = GX * GY, GT = GN * gridDim.z;
+  int b = blockIdx.z, xl = blockIdx.x, yy = blockIdx.y;
+  if (p.G == 1) {
+    const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
+    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+    b = lid / GN;
+    const int lrem = lid - b * GN;
+    xl = lrem / GY;
+    yy = lrem - xl * GY;
+  }
+  const int g = yy / p.co_tiles, ct = yy - g * p.co_tiles;
   const int d = MODE == M_CONV ? p.dil[p.G > 4 ? 0 : g] : 1;
   // extent of the tile grid: the sub-image of one residue class / the stride-2 output / the (H+1) x (W+1) position grid
   const int SH = TCV ? p.H + 1 : S2 ? p.OH : (p.H + d - 1) / d, SW = TCV ? p.W + 1 : S2 ? p.OW : (p.W + d - 1) / d;
   const int twl = p.tw_log2, TW = 1 << twl, TH = NPIX >> twl;
   const int tiles_x = (SW + TW - 1) >> twl, tiles_y = (SH + TH - 1) / TH;
   const int per_res = tiles_x * tiles_y;
-  if ((int)blockIdx.x >= per_res * d * d) return;              // groups with a smaller dilation have fewer, fuller tiles
-  const int res = blockIdx.x / per_res, tile_i = blockIdx.x - res * per_res;
+  if (xl >= per_res * d * d) return;                           // groups with a smaller dilation have fewer, fuller tiles
+  const int res = xl / per_res, tile_i = xl - res * per_res;
   const int ry = res / d, rx = res - ry * d;
   const int ty_i = tile_i / tiles_x, tx_i = tile_i - ty_i * tiles_x;
   const int oy0 = ty_i * TH, ox0 = tx_i << twl;                // sub-image coordinates
