@@ -174,6 +174,11 @@ def main():
         # bf16 configuration: the dense bf16 MFMA peak (MI355X_MICROARCH.md); the conv family then mixes bf16 (stride-1 3x3)
         # and fp32 (stride-2, transposed, small-map) launches, all priced against the bf16 peak
         PEAK = PEAK_FP32_TFLOPS if args.conv_dtype == "f32" else 2500.0
+        KERNEL_NOTE = ("conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = "
+                       "algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
+            "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + the fp32 "
+            "conv_igemm_kernel on small maps and 1x1 layers; achieved = algorithmic FLOPs / time against the dense bf16 MFMA peak; with "
+            "fp32 activations in HBM the 512^2 / 256^2 layers are fabric-bound (DESIGN 9)")
         line = {
             "metric": "restored 512x512 faces/sec", "value": round(imgs / dt, 3), "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -187,7 +192,7 @@ def main():
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),
-                         "kernel": "conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers", "launches_per_step": conv_launches // max(args.steps, 1),
+                         "kernel": KERNEL_NOTE, "launches_per_step": conv_launches // max(args.steps, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
                          "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK * world), 4)},
