@@ -148,6 +148,8 @@ def main():
         if not args.no_overlap:
             # one extra UNTIMED serial step with per-launch events: the conv kernels' durations with nothing else on the GPU
             # (in the timed, overlapped region a conv's event interval also contains the side stream's kernels)
+            pipe(lq)  # the serial call path allocates from the main stream's pool: warm it before measuring
+            torch.cuda.synchronize()
             iso = hip_ops.ConvProfiler()
             hip_ops.PROFILER = iso
             pipe(lq)
