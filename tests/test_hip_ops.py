@@ -526,7 +526,7 @@ def _bf(t):
     return t.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 7])
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 16, 64, 32, 32), (1, 40, 36, 13, 29), (2, 64, 64, 64, 64), (1, 256, 128, 16, 24),
                                                (1, 32, 160, 8, 8), (1, 64, 32, 70, 45)])
 def test_conv2d_bf16(H, B, Cin, Cout, Hh, Ww, variant):

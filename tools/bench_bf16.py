@@ -14,7 +14,7 @@ def run(x, pc, sc, fl, tag):
     uf = t(lambda: H.conv2d_packed(x, pc, in_scale=sc))
     ref = H.conv2d_packed(x, pc, in_scale=sc)
     out = [f"{tag}: fp32 {uf:.0f} us {fl/uf/1e6:.0f} TF |"]
-    for v in (0, 1, 2, 3, 4, 6):
+    for v in (0, 1, 2, 3, 4, 6, 7):
         try:
             ub = t(lambda: H.conv2d_packed(x, pc, in_scale=sc, bf16=True, tile_hint=v))
         except RuntimeError as ex:

@@ -1,19 +1,23 @@
-"""Single-batch latency and host/GPU balance: wall time per batch vs the sum of kernel time (HIP events over the step)."""
+"""Host/GPU balance: wall time per batch vs the host time to ENQUEUE a batch (plain serial loop), fp32 and bf16 configurations."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
+from vspbfr_amd import hip_ops
 dev = torch.device("cuda", 0)
-for B, T in ((1, 4), (1, 50), (2, 4), (4, 4)):
+cfgs = [(8, 50), (1, 4), (16, 50)] if len(sys.argv) < 2 else [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+for B, T in cfgs:
     pipe = bench.build_pipeline(dev, T, True)
     lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
-    with torch.no_grad():
-        for _ in range(3): pipe(lq)
-        torch.cuda.synchronize()
-        N = 10
-        t0 = time.perf_counter()
-        for _ in range(N): pipe(lq)
-        t_host = time.perf_counter() - t0      # time to ENQUEUE N steps
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-    print(f"B={B} T={T}: {t_all/N*1e3:.2f} ms per batch wall, host enqueue {t_host/N*1e3:.2f} ms per batch -> {B*N/t_all:.1f} img/s")
+    for bf in (False, True):
+        hip_ops.BF16_CONV = bf
+        with torch.no_grad():
+            for _ in range(3): pipe(lq)
+            torch.cuda.synchronize()
+            N = 6
+            t0 = time.perf_counter()
+            for _ in range(N): pipe(lq)
+            t_host = time.perf_counter() - t0      # time to ENQUEUE N steps
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+        print(f"B={B} T={T} {'bf16' if bf else 'fp32'}: {t_all/N*1e3:.2f} ms per batch wall, host enqueue {t_host/N*1e3:.2f} ms per batch -> {B*N/t_all:.1f} img/s", flush=True)

@@ -14,9 +14,12 @@
 //     wave-uniform, lanes run along the row -> coalesced), scaled by the per-sample style in fp32, converted with
 //     v_cvt_pk_bf16_f32 and written as one ds_write_b128 per position after the MFMAs of the current chunk.
 //   * weights and patch are double-buffered: ONE barrier per 16-channel chunk.
-//   * dilation d is a polyphase problem exactly as in conv_wino.hip: the workgroup addresses the image with stride d from
-//     its residue (ry, rx), in LDS every layer is a dilation-1 convolution; the (up to four) dilation groups of a SMART
-//     branch launch differ only in d and their weight / channel base.
+//   * dilation d is polyphase in ROWS only: a workgroup owns rows ry, ry + d, ry + 2d, ... (consecutive rows of the patch in
+//     LDS, so the vertical taps are one patch row apart) and a DENSE run of 32 columns with a halo of d columns, the
+//     horizontal taps being d positions apart in LDS (fragment reads are conflict-free for any offset).  Global loads and
+//     stores therefore stay whole 128-byte row segments for every dilation (a column-polyphase form reads and writes 4 bytes
+//     per 32-byte sector at d = 8: measured 6.1 GB fetched for a 0.7 GB input on the 64 -> 4x16 branch at 512^2).  The (up to
+//     four) dilation groups of a SMART branch launch differ only in d and their weight / channel base.
 // Modes (template MODE): 0 = stride-1 convolution as above; 1 = stride-2 convolution: the patch is staged as four PARITY
 // planes (row parity x column parity), tap (ky, kx) reads plane (ky & 1, kx & 1) at unit stride, so the fragment reads stay
 // conflict-free and the global loads stay coalesced (lanes run along the input row and scatter into two planes);
@@ -51,7 +54,7 @@ enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 // DEEP (PT <= 3, 64-channel tiles and up): two patch register sets, loads two chunks ahead, conversion spread over the tap loop.  Larger planes
 // (narrow tiles, 5-7 positions per lane) keep ONE set: loads one chunk ahead, conversion after the taps.
 template <int MB, int NB, int WM, int WN, int PT, int MODE>
-__global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
+__global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr bool S2 = MODE == M_S2, TCV = MODE == M_TC;
   constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
@@ -87,20 +90,19 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
   const int g = yy / p.co_tiles, ct = yy - g * p.co_tiles;
   const int d = MODE == M_CONV ? p.dil[p.G > 4 ? 0 : g] : 1;
   // extent of the tile grid: the sub-image of one residue class / the stride-2 output / the (H+1) x (W+1) position grid
-  const int SH = TCV ? p.H + 1 : S2 ? p.OH : (p.H + d - 1) / d, SW = TCV ? p.W + 1 : S2 ? p.OW : (p.W + d - 1) / d;
+  const int SH = TCV ? p.H + 1 : S2 ? p.OH : (p.H + d - 1) / d, SW = TCV ? p.W + 1 : S2 ? p.OW : p.W;
   const int twl = p.tw_log2, TW = 1 << twl, TH = NPIX >> twl;
   const int tiles_x = (SW + TW - 1) >> twl, tiles_y = (SH + TH - 1) / TH;
   const int per_res = tiles_x * tiles_y;
-  if (xl >= per_res * d * d) return;                           // groups with a smaller dilation have fewer, fuller tiles
-  const int res = xl / per_res, tile_i = xl - res * per_res;
-  const int ry = res / d, rx = res - ry * d;
+  if (xl >= per_res * d) return;                               // (row counts that d does not divide leave a few spare blocks)
+  const int ry = xl / per_res, tile_i = xl - ry * per_res;
   const int ty_i = tile_i / tiles_x, tx_i = tile_i - ty_i * tiles_x;
   const int oy0 = ty_i * TH, ox0 = tx_i << twl;                // sub-image coordinates
   const int co0 = ct * CO_T;
   const int co_pad = (p.cout_g + 31) & ~31;
   const int chw = p.H * p.W;
   const int nchunk = (p.Cin + BCK - 1) / BCK;
-  const int pitch = p.bf_pitch, PR = MODE == M_CONV ? TH + 2 : TH + 1, PC = MODE == M_CONV ? TW + 2 : TW + 1;
+  const int pitch = p.bf_pitch, PR = MODE == M_CONV ? TH + 2 : TH + 1, PC = MODE == M_CONV ? TW + 2 * d : TW + 1;
   const int PLANE = p.bf_plane;     // >= PR * pitch (stride 2: == 8 mod 16 so that the two planes a store hits do not collide)
   const int PBUF = 2 * NPL * PLANE; // 16-byte units per patch buffer: [octet][plane][position]
 
@@ -131,9 +133,9 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
       pdst[e] = ((r & 1) * 2 + (c & 1)) * PLANE + (r >> 1) * pitch + (c >> 1);
     } else {
       wr = idx < NTASK && c < PC;
-      const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
+      const int sy = oy0 - 1 + r, sx = ox0 - d + c;   // (transposed mode: d = 1)
       iy = sy * d + ry;
-      ix = sx * d + rx;
+      ix = sx;
       in = wr && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W;
       pdst[e] = idx;
     }
@@ -145,19 +147,22 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
   // Two register sets: chunk k lives in set k & 1.  Its loads are issued TWO intervals before its MFMAs (top of interval
   // k - 2), its conversion + LDS write is spread over the tap loop of interval k - 1 (VALU work in the shadow of the MFMAs).
   float pregA[PT][8], pregB[PT][8];
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
   const float* iscp = p.in_scale + (int64_t)b * p.in_scale_bstride;
   const float* ishp = p.in_shift;
   // Cin is a multiple of 8 (host): a wave's channel octet is either wholly inside or wholly past Cin
   auto issue_p = [&](float (&pr)[PT][8], int c) {
     const int cib = c * BCK + 8 * oct;
     if (cib >= p.Cin) return;                                  // wave-uniform; the octet is committed as zeros
-    const char* xc = reinterpret_cast<const char*>(xb + (int64_t)cib * chw);  // wave-uniform base, stepped by one channel plane
+    // buffer loads: resource = this image, scalar offset = the channel plane (wave-uniform), vector offset = the lane's 32-bit
+    // byte offset inside a plane.  (With flat pointers hipcc hoists 24 loop-invariant 64-bit per-lane addresses = 48 VGPRs.)
+    int soff = cib * chw * 4;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
       for (int e = 0; e < PT; ++e)  // (tasks past the plane read element 0 and are never written)
-        pr[e][j] = *reinterpret_cast<const float*>(xc + poff[e]);
-      xc += (int64_t)chw * 4;
+        pr[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)poff[e], soff, 0));
+      soff += chw * 4;
     }
   };
   auto load_scales = [&](int c, float (&sc)[8], float (&sh)[8]) -> bool {  // wave-uniform: scalar loads
@@ -262,24 +267,32 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
         }
       }
     } else {
+      // hand-pipelined: the fragments of tap t+1 are requested before the MFMAs of tap t, and a scheduling barrier per tap
+      // keeps the compiler from hoisting all 36 fragment reads to the top (256 VGPRs and spills otherwise)
+      bf16x8 a[2][MB], bq[2][NB];
+      auto load_tap = [&](int tap, bf16x8 (&af)[MB], bf16x8 (&bf)[NB]) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = S2 ? ((ky & 1) * 2 + (kx & 1)) * PLANE + (ky >> 1) * pitch + (kx >> 1) : ky * pitch + kx * d;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) af[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bf[nb] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + toff]);
+      };
+      load_tap(0, a[0], bq[0]);
 #pragma unroll
       for (int tap = 0; tap < T; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
-        const int toff = S2 ? ((ky & 1) * 2 + (kx & 1)) * PLANE + (ky >> 1) * pitch + (kx >> 1) : ky * pitch + kx;
-        bf16x8 a[MB], bq[NB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bq[nb] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + toff]);
+        const int cs = tap & 1;
+        if (tap + 1 < T) load_tap(tap + 1, a[cs ^ 1], bq[cs ^ 1]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb], acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][mb], bq[cs][nb], acc[mb][nb], 0, 0, 0);
         if constexpr (DEEP) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
           if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if constexpr (!DEEP) {
@@ -368,47 +381,6 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
       }
     }
     return;
-  } else if (d > 1) {
-    // polyphase sub-image: neighbouring pixels of the tile are d apart in memory, nothing to vectorise -- straight from the
-    // accumulators, lanes along the row (a store touches as few 32-byte sectors as the stride allows)
-    int yoff[NB];
-    float nz[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = (wn * NB + nb) * 32 + l32;
-      const int oy = (oy0 + (n >> twl)) * d + ry, ox = (ox0 + (n & (TW - 1))) * d + rx;
-      const bool ok = oy < p.OH && ox < p.OW;
-      yoff[nb] = ok ? oy * p.y_w + ox : -1;
-      nz[nb] = (ok && has_nz) ? nzp[oy * p.OW + ox] * nw : 0.f;
-    }
-    auto direct = [&](auto res_tag) {  // two straight-line bodies: a per-element branch on an absent residual costs more
-      constexpr bool RES = decltype(res_tag)::value;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int cg = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-          const bool cok = cg < p.cout_g;
-          const int co = g * p.cout_g + (cok ? cg : 0);
-          const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
-          const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
-          const int cbase = co * y_plane;
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const int ro = cbase + (yoff[nb] < 0 ? 0 : yoff[nb]);
-            float r = 0.f;
-            if constexpr (RES) r = (has_r1 ? r1b[ro] : 0.f) + (has_r2 ? r2b[ro] : 0.f);
-            float v = acc[mb][nb][i] * os + cb;
-            v = (v > 0.f ? v : v * s1) * g1;
-            v += nz[nb] + b2;
-            v = (v > 0.f ? v : v * sl2) * g2;
-            if (yoff[nb] >= 0 && cok) yb[ro] = v + r;
-          }
-        }
-      }
-    };
-    if (has_r1 || has_r2) direct(std::true_type{}); else direct(std::false_type{});
-    return;
   }
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
@@ -446,7 +418,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0) ? 4 : 2) void conv_bf16
         if (!operands(row, co, os, cb, b2, sl2)) continue;
         const f32x4 av = *reinterpret_cast<const f32x4*>(El + row * NPIX + 4 * q);
         const int n = 4 * q;
-        const int oy = oy0 + (n >> twl), ox = ox0 + (n & (TW - 1));
+        const int oy = (oy0 + (n >> twl)) * d + ry, ox = ox0 + (n & (TW - 1));   // polyphase rows, dense columns
         if (oy >= p.OH || ox >= p.OW) continue;
         auto fin = [&](float v, float nzv, float r1v, float r2v) {
           v = v * os + cb;
@@ -495,14 +467,15 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows) {
   if (mode == M_TC) sw = q.W + 1;
   else if (mode == M_S2) sw = q.OW;
   else {
-    int dmax = q.dil[0];
-    for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
-    sw = (q.W + dmax - 1) / dmax;
+    sw = q.W;
   }
+  int dmax = 1;
+  if (mode == M_CONV)
+    for (int g = 0; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
   BfGeom r;
   r.twl = sw >= 32 ? 5 : (sw > 8 ? 4 : 3);
   const int TW = 1 << r.twl, TH = npix >> r.twl;
-  const int PR = mode == M_CONV ? TH + 2 : TH + 1, PC = mode == M_CONV ? TW + 2 : TW + 1;
+  const int PR = mode == M_CONV ? TH + 2 : TH + 1, PC = mode == M_CONV ? TW + 2 * dmax : TW + 1;
   r.pitch = bf_pitch(r.twl, PC);
   r.plane = PR * r.pitch;
   int ntask = r.plane, npl = 1;
@@ -537,8 +510,8 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   if (MODE == M_CONV) {
     for (int g = 0; g < (q.G > 4 ? 1 : q.G); ++g) {
       const int d = q.dil[g];
-      const int SH = (q.H + d - 1) / d, SW = (q.W + d - 1) / d;
-      const int n = ((SW + TW - 1) / TW) * ((SH + TH - 1) / TH) * d * d;
+      const int SH = (q.H + d - 1) / d, SW = q.W;
+      const int n = ((SW + TW - 1) / TW) * ((SH + TH - 1) / TH) * d;
       blocks = n > blocks ? n : blocks;
     }
   } else {
@@ -555,7 +528,7 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
   const BfGeom gm = bf_geom(q, MODE, 32 * MB * WM, 32 * NB * WN, 32 * WM);
   if (gm.lds > 150 * 1024) return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: tile does not fit LDS");
   if (gm.pt <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE>(q, gm, stream);
-  if (MODE == M_S2 && gm.pt <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE>(q, gm, stream);
+  if (MODE != M_TC && gm.pt <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE>(q, gm, stream);
   if (MODE != M_S2 && gm.pt <= 7) return launch_bf<MB, NB, WM, WN, 7, MODE>(q, gm, stream);
   return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: patch plane of %d positions is too large", gm.plane);
 }
@@ -564,7 +537,7 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 
 // mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv.
 // variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
-//          6 = 128 ch x 64 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
+//          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_TC) {
     if (variant == 0) variant = q.cout_g <= 32 ? 5 : 4;
@@ -585,10 +558,10 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (variant == 0) {
     int dmax = q.dil[0];
     for (int g = 1; g < (q.G > 4 ? 1 : q.G); ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
-    const int64_t px = (int64_t)((q.H + dmax - 1) / dmax) * ((q.W + dmax - 1) / dmax);  // the smallest polyphase sub-image
+    const int64_t px = (int64_t)((q.H + dmax - 1) / dmax) * q.W;  // the smallest row-polyphase sub-image
     if (q.cout_g <= 32) variant = 1;
     else if (px <= 64 && q.cout_g >= 128) variant = 6;
-    else if (q.G > 1) variant = 4;
+    else if (q.G > 1) variant = px >= 512 ? 2 : 4;
     else if (q.cout_g <= 64) variant = px >= 128 * 128 ? 2 : 4;
     else variant = px >= 64 * 64 ? 2 : 4;
   }
@@ -598,6 +571,7 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
     case 3: return launch_shape<2, 2, 2, 2, M_CONV>(q, stream);
     case 4: return launch_shape<2, 1, 1, 4, M_CONV>(q, stream);
     case 6: return launch_shape<2, 1, 2, 2, M_CONV>(q, stream);
+    case 7: return launch_shape<1, 1, 1, 4, M_CONV>(q, stream);
     default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown variant %d", variant);
   }
 }

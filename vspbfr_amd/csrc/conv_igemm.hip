@@ -355,6 +355,8 @@ extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
   if (mode != 2) VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_bf16: dense output only");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_bf16: packed weights must be 16-byte aligned");
   VSP_REQUIRE(p.Cin % 8 == 0, "conv2d_bf16: Cin must be a multiple of 8 (got %d)", p.Cin);
+  VSP_REQUIRE((int64_t)(p.x_ch > 0 ? p.x_ch : p.Cin) * p.H * p.W * 4 < ((int64_t)1 << 31),
+              "conv2d_bf16: one input image must be smaller than 2 GiB (32-bit buffer offsets)");
   int x_ch = 0;
   bool empty = false;
   if (int rc = validate_conv(p, &x_ch, &empty)) return rc;

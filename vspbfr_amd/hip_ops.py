@@ -222,7 +222,7 @@ def bf16_profitable(pc, H, W, OH, OW, transposed=False):
     if pc.stride == 2:
         return OW >= 8
     dmax = max(pc.dil[:min(pc.G, 4)])
-    return W >= 16 and W // dmax >= 8
+    return W >= 16 and H // dmax >= 2
 
 
 def bf16_weight(wp):
