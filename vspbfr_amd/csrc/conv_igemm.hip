@@ -297,13 +297,15 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
                   p.x_group_stride == 0,
               "conv2d_winograd: only 3x3, stride 1, at most four groups over one shared input");
   for (int g = 0; g < p.G; ++g)
-    VSP_REQUIRE(p.dil[g] >= 1 && p.dil[g] <= 64 && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
-                "conv2d_winograd: group %d needs padding = dilation (got dilation %d, padding %d/%d)", g, p.dil[g], p.pad_y[g],
-                p.pad_x[g]);
+    VSP_REQUIRE((p.dil[g] == 1 || p.dil[g] == 2 || p.dil[g] == 4 || p.dil[g] == 8) && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
+                "conv2d_winograd: group %d needs dilation 1, 2, 4 or 8 and padding = dilation (got dilation %d, padding %d/%d)", g,
+                p.dil[g], p.pad_y[g], p.pad_x[g]);
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
   VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd: transformed weights must be 16-byte aligned");
   VSP_REQUIRE((int64_t)16 * p.Cin * p.cout_g < ((int64_t)1 << 31), "conv2d_winograd: weight tensor too large");
+  VSP_REQUIRE((int64_t)(p.x_ch > 0 ? p.x_ch : p.Cin) * p.H * p.W * 4 < ((int64_t)1 << 31),
+              "conv2d_winograd: one input image must be smaller than 2 GiB (32-bit buffer offsets)");
   int x_ch = 0;
   bool empty = false;
   if (int rc = validate_conv(p, &x_ch, &empty)) return rc;

@@ -17,9 +17,12 @@
 //   * the input patch is prefetched two chunks ahead (it streams from MALL/HBM) and double-buffered in LDS, V is
 //     double-buffered too: the transform of chunk i+1, the MFMAs of chunk i and the patch write of chunk i+2 share ONE
 //     barrier interval (4 input channels per chunk keep all of it inside 128 VGPRs: two workgroups per CU).
-//   * dilation d (the SMART branches) is a polyphase problem: output pixels with the same (y mod d, x mod d) form a
-//     (H/d) x (W/d) image on which the layer is an ordinary 3x3 convolution, so a workgroup simply addresses the image with
-//     stride d from its residue; the four dilation groups of a launch differ only in d and in their weight / channel base.
+//   * dilation d (the SMART branches) is polyphase in ROWS only: a workgroup owns rows ry, ry + d, ... (consecutive patch rows)
+//     and a DENSE run of 2 TLX columns with a halo of d columns; its TLX tile columns are the d column residues x TLX / d tile
+//     positions (tile tx: residue tx % d, first column residue + 2 d (tx / d)), and the transform reads its four window columns d
+//     apart.  Global loads and stores stay whole row segments for every dilation (a column-polyphase form touches a 32-byte
+//     sector per 4-byte element at d = 8).  The four dilation groups of a launch differ only in d and in their weight / channel
+//     base.  Template DMAX = the largest dilation the patch buffer is sized for (1: ordinary layers, 8: SMART branches).
 // Epilogue, per 16-channel block: the sixteen position accumulators meet in LDS, one thread per (channel, tile) applies
 // A^T . A, the same fused operand chain as the direct kernel (demod, bias, two activations, noise, two residuals) and stores
 // the 2x2 pixels.  Numerics: F(2x2,3x3) in fp32 adds ~1e-6 relative error (transform constants are 1 and 1/2).
@@ -32,7 +35,7 @@ namespace {
 constexpr int WCK = 4;      // input channels per chunk = one MFMA k-step
 constexpr int NTHR = 512;
 
-template <int MBW>
+template <int MBW, int DMAX>
 struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (MBW * NBW = 8: 64 accumulator registers)
   // input channels per barrier interval: two MFMA k-steps where the LDS budget allows it (32-tile geometry: 61 KB, two
   // workgroups per CU) -- half the barriers and a transform task for every thread; one k-step otherwise
@@ -43,7 +46,7 @@ struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (
   static constexpr int NTILE = 16 * NBW;
   static constexpr int TLX = NBW == 8 ? 16 : 8;
   static constexpr int TLY = NTILE / TLX;
-  static constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2;
+  static constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2 * DMAX;  // PC: the widest patch row (dilation DMAX)
   static constexpr int PPITCH = (PR * PC + 15) / 16 * 16;
   static constexpr int VPITCH = NTILE + 16;           // k-slot rows 16 banks apart
   static constexpr int LDS_V = 16 * IVC * VPITCH;     // floats, two buffers
@@ -56,10 +59,10 @@ struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (
   static constexpr int UF = 2 * MBW;                  // U floats per lane and chunk: [pp 2][mb MBW]
 };
 
-template <int MBW>
+template <int MBW, int DMAX>
 __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
-  using Gm = WG<MBW>;
-  constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR, PC = Gm::PC;
+  using Gm = WG<MBW, DMAX>;
+  constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR;
   constexpr int PPITCH = Gm::PPITCH, VPITCH = Gm::VPITCH, LDS_V = Gm::LDS_V, LDS_P = Gm::LDS_P, UF = Gm::UF;
   constexpr int IVC = Gm::IVC, KS = Gm::KS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,15 +75,15 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int lr = lane & 15, kq = lane >> 4;
   const int b = blockIdx.z;
   const int g = blockIdx.y / p.co_tiles, ct = blockIdx.y - g * p.co_tiles;
-  const int d = p.dil[g];                                     // polyphase stride (1 for an ordinary layer)
-  const int SH = (p.H + d - 1) / d, SW = (p.W + d - 1) / d;   // sub-image of one residue class
-  const int tiles_x = (SW + 2 * TLX - 1) / (2 * TLX), tiles_y = (SH + 2 * TLY - 1) / (2 * TLY);
+  const int d = DMAX == 1 ? 1 : p.dil[g];                     // row-polyphase stride and column tap spacing (1, 2, 4 or 8)
+  const int SH = (p.H + d - 1) / d;                           // rows of one residue class
+  const int tiles_x = (p.W + 2 * TLX - 1) / (2 * TLX), tiles_y = (SH + 2 * TLY - 1) / (2 * TLY);
   const int per_res = tiles_x * tiles_y;
-  if ((int)blockIdx.x >= per_res * d * d) return;             // groups with a smaller dilation have fewer, fuller tiles
-  const int res = blockIdx.x / per_res, tile_i = blockIdx.x - res * per_res;
-  const int ry = res / d, rx = res - ry * d;
+  if ((int)blockIdx.x >= per_res * d) return;                 // (row counts that d does not divide leave a few spare blocks)
+  const int ry = blockIdx.x / per_res, tile_i = blockIdx.x - ry * per_res;
   const int tx_i = tile_i % tiles_x, ty_i = tile_i / tiles_x;
-  const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);   // in sub-image coordinates
+  const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);   // sub-image rows, image columns
+  const int PC = 2 * TLX + 2 * d;                             // patch row of this group
   const int co0 = ct * WCO;                                   // within the group
   const int chw = p.H * p.W;
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
@@ -89,25 +92,31 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 
   // ---- input patch: chunk-invariant geometry, values prefetched two intervals ahead.  NTHR / IVC threads walk one
   //      channel's plane: the channel is wave-uniform and no index needs a division per step.
-  constexpr int PLANE = PR * PC;
+  const int PLANE = PR * PC;
   constexpr int PTH = NTHR / IVC;                  // threads per channel plane
-  constexpr int PLD = (PLANE + PTH - 1) / PTH;
-  const int p_ch = tid / PTH, p_t = tid % PTH;
+  constexpr int PLD = (PR * Gm::PC + PTH - 1) / PTH;
+  const int p_ch = __builtin_amdgcn_readfirstlane(tid / PTH), p_t = tid % PTH;  // (PTH is a multiple of 64: wave-uniform)
   int p_src[PLD];  // image offset of plane word p_t + PTH e (-1: outside the image / beyond the plane)
 #pragma unroll
   for (int e = 0; e < PLD; ++e) {
     const int rem = p_t + PTH * e;
     const int r = rem / PC, c = rem - r * PC;
-    const int sy = oy0 - 1 + r, sx = ox0 - 1 + c;
-    const int iy = sy * d + ry, ix = sx * d + rx;
-    p_src[e] = (rem < PLANE && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
+    const int sy = oy0 - 1 + r, ix = ox0 - d + c;
+    const int iy = sy * d + ry;
+    p_src[e] = (rem < PLANE && sy >= 0 && ix >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
   }
+  // buffer loads: resource = this image, scalar offset = the channel plane, vector offset = the lane's byte offset in a plane
+  // (flat pointers cost a 64-bit VALU add per load and the registers of the 64-bit lane addresses)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+  int p_voff[PLD];
+#pragma unroll
+  for (int e = 0; e < PLD; ++e) p_voff[e] = (p_src[e] >= 0 ? p_src[e] : 0) * 4;
   float preg[PLD], pnext[PLD];
   auto issue_p = [&](int c) {  // chunk c -> pnext (raw values: nothing may consume them before the commit two steps later)
     const int ci = c * IVC + p_ch;
-    const float* xc = xb + (int64_t)(ci < p.Cin ? ci : 0) * chw;
+    const int soff = (ci < p.Cin ? ci : 0) * chw * 4;
 #pragma unroll
-    for (int e = 0; e < PLD; ++e) pnext[e] = xc[p_src[e] >= 0 ? p_src[e] : 0];
+    for (int e = 0; e < PLD; ++e) pnext[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, p_voff[e], soff, 0));
   };
   auto commit_p = [&](float* Pdst, int c) {  // preg = chunk c
     const int ci = c * IVC + p_ch;
@@ -149,12 +158,14 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       const int th = task & 1, tq = task >> 1;
       const int t_ch = tq / NTILE, t_tile = tq - t_ch * NTILE;
       const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
-      const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + 2 * t_tx;
-      float dd[3][4];  // rows h, h+1, h+2 of the 4x4 window
+      // tile column t_tx: column residue t_tx % d, position t_tx / d -> first window column (patch coordinates) rx + 2 d pos
+      const int c0 = DMAX == 1 ? 2 * t_tx : (t_tx % d) + 2 * d * (t_tx / d);
+      const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + c0;
+      float dd[3][4];  // rows h, h+1, h+2 of the 4x4 window (columns d apart)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc];
+        for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc * d];
       float sc = 1.f;
       if (p.in_scale && !p.in_shift && c * IVC + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * IVC + t_ch];
       float w0[4], w1[4];
@@ -274,7 +285,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         const int pair = tid + it * NTHR;
         const int e_co = pair / ETILE, e_t = pair - e_co * ETILE;
         const int e_tile = th * ETILE + e_t;
-        const int sy = oy0 + 2 * (e_tile / TLX), sx = ox0 + 2 * (e_tile % TLX);
+        const int e_tx = e_tile % TLX;
+        const int sy = oy0 + 2 * (e_tile / TLX);
+        const int sx = ox0 + (DMAX == 1 ? 2 * e_tx : (e_tx % d) + 2 * d * (e_tx / d));   // first output column of the tile
         float m[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) m[q] = Ml[(q * ECO + e_co) * ETILE + e_t];
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         };
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int oy = (sy + i) * d + ry, ox = sx * d + rx;
+          const int oy = (sy + i) * d + ry, ox = sx;
           if (oy >= p.OH || ox >= p.OW) continue;
           const int ro = cbase + oy * p.y_w + ox;
           if (vec2 && ox + 1 < p.OW) {
@@ -325,13 +338,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   }
 }
 
-template <int MBW>
+template <int MBW, int DMAX>
 int launch_variant(ConvK q, hipStream_t stream) {
-  using Gm = WG<MBW>;
+  using Gm = WG<MBW, DMAX>;
   static bool attr_set = false;
   const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<MBW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<MBW, DMAX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_winograd: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
@@ -340,12 +353,12 @@ int launch_variant(ConvK q, hipStream_t stream) {
   int blocks = 0;  // the largest per-group tile count (groups with a smaller dilation exit early)
   for (int g = 0; g < q.G; ++g) {
     const int d = q.dil[g];
-    const int SH = (q.H + d - 1) / d, SW = (q.W + d - 1) / d;
-    const int n = ((SW + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((SH + 2 * Gm::TLY - 1) / (2 * Gm::TLY)) * d * d;
+    const int SH = (q.H + d - 1) / d;
+    const int n = ((q.W + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((SH + 2 * Gm::TLY - 1) / (2 * Gm::TLY)) * d;
     blocks = n > blocks ? n : blocks;
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_wino_kernel<MBW><<<grid, NTHR, lds, stream>>>(q);
+  conv_wino_kernel<MBW, DMAX><<<grid, NTHR, lds, stream>>>(q);
   return VSP_OK;
 }
 
@@ -357,10 +370,19 @@ int wino_chunk() { return WCK; }
 int wino_mbw(int cout_g) { return cout_g > 32 ? 4 : (cout_g > 16 ? 2 : 1); }
 
 int wino_launch(ConvK q, hipStream_t stream) {
+  int dmax = 1;
+  for (int g = 0; g < q.G; ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
+  if (dmax == 1) {
+    switch (wino_mbw(q.cout_g)) {
+      case 4: return launch_variant<4, 1>(q, stream);
+      case 2: return launch_variant<2, 1>(q, stream);
+      default: return launch_variant<1, 1>(q, stream);
+    }
+  }
   switch (wino_mbw(q.cout_g)) {
-    case 4: return launch_variant<4>(q, stream);
-    case 2: return launch_variant<2>(q, stream);
-    default: return launch_variant<1>(q, stream);
+    case 4: return launch_variant<4, 8>(q, stream);
+    case 2: return launch_variant<2, 8>(q, stream);
+    default: return launch_variant<1, 8>(q, stream);
   }
 }
 

@@ -247,7 +247,7 @@ def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out
     """3x3, stride 1, padding = dilation, G = 1 or up to four dilation groups over one shared input, dense output."""
     if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.x_group_stride != 0 or not 1 <= pc.G <= 4:
         return False
-    if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] for g in range(pc.G)):
+    if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] or pc.dil[g] not in (1, 2, 4, 8) for g in range(pc.G)):
         return False
     return (OH, OW) == (H, W) and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0)
 
