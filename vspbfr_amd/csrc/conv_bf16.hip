@@ -540,7 +540,7 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 //          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_TC) {
-    if (variant == 0) variant = q.cout_g <= 32 ? 5 : 4;
+    if (variant == 0) variant = 5;  // 32-channel tiles: 122 VGPRs, more workgroups in flight (tools/bench_bf16_s2t.py)
     switch (variant) {
       case 4: return launch_shape<2, 1, 1, 4, M_TC>(q, stream);
       case 5: return launch_shape<1, 1, 1, 4, M_TC>(q, stream);
@@ -548,7 +548,7 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
     }
   }
   if (mode == M_S2) {
-    if (variant == 0) variant = (q.cout_g >= 128 && (int64_t)q.OH * q.OW <= 64 * 64) ? 6 : 4;
+    if (variant == 0) variant = (q.cout_g >= 128 && (int64_t)q.OH * q.OW <= 16 * 16) ? 6 : 4;
     switch (variant) {
       case 4: return launch_shape<2, 1, 1, 4, M_S2>(q, stream);
       case 6: return launch_shape<2, 1, 2, 2, M_S2>(q, stream);
