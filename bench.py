@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="plain per-batch loop (no A+B / C+D stream overlap across batches)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay stages A+B and C+D as two captured HIP graphs (same kernels, same two-stream overlap, no per-launch host work)")
     ap.add_argument("--conv-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
                          "fp32 activations in HBM); not the parity configuration")
@@ -132,6 +134,9 @@ def main():
             for _ in range(n):
                 res = pipe(lq)["restored"]
                 res = gather_restored(res) if world > 1 else res
+        elif args.graphs:
+            for o in pipe.run_batches_graphed(lq for _ in range(n)):
+                res = gather_restored(o["restored"]) if world > 1 else o["restored"]
         else:
             for o in pipe.run_batches(lq for _ in range(n)):
                 res = gather_restored(o["restored"]) if world > 1 else o["restored"]
@@ -143,6 +148,8 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        if args.graphs:
+            pipe.capture_graphs(lq)
         run(args.warmup)
         iso = None
         if not args.no_overlap:
@@ -191,6 +198,7 @@ def main():
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
                        "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
+                       "launch": "two captured HIP graphs (A+B, C+D) replayed per batch" if args.graphs else "eager (one host launch per kernel)",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),
@@ -201,6 +209,10 @@ def main():
         }
         if iso is not None:
             fl, ms, n = iso.summary()
+            if args.graphs:  # graph replays carry no per-launch events: the roofline figures are the isolated step's
+                rl = line["roofline"]
+                rl["achieved"], rl["frac"] = round(fl / (ms * 1e-3) / 1e12, 2), round(fl / (ms * 1e-3) / 1e12 / PEAK, 4)
+                rl["launches_per_step"], rl["algorithmic_gflop_per_step"], rl["kernel_ms_per_step"] = n, round(fl / 1e9, 1), round(ms, 2)
             line["roofline"]["isolated"] = {
                 "note": "same kernels in one untimed serial step (no second stream): per-launch durations without the "
                         "overlapped A+B work inside the event intervals",

@@ -346,3 +346,25 @@ def test_pipeline512_bf16_config(golden):
     # measured on MI355X: restored max 1.6e-2, rms 2.9e-3 on an image of std 0.93; <= 2 LSB (mean 0.17) after save_image
     assert rep["restored_rms"] < 0.01 * rep["restored_std_ref"] and rep["restored_max"] < 0.06 * rep["restored_std_ref"]
     assert rep["style_sample_rms"] < 0.03 and rep["restored_8bit_lsb_mean"] < 0.5 and rep["restored_8bit_lsb_max"] <= 4
+
+
+def test_pipeline_graph_replay_matches_eager():
+    """Stages A+B and C+D captured as two HIP graphs (RestorationPipeline.capture_graphs) replay the same kernels on the same
+    inputs: with every noise tensor pinned, two batches through run_batches_graphed (A+B of the second replayed on the side
+    stream under C+D of the first) equal the eager per-batch results bit for bit."""
+    B = 1
+    pipe = build_pipeline(with_sample=False)
+    lq = [dev(cases.image_batch("graph%d" % i, B, 512)) for i in range(2)]
+    enc_s, dec_s = OM.restoration_noise_shapes(512, B)
+    fixed = dict(x_T=dev(cases.tensor("graph", "x_T", (B, 18, 512))), z=[dev(cases.tensor("graph", "z", (B, 512)))],
+                 gen_noise=[dev(n) for n in cases.noise_list("graph", "g", OM.generator_noise_shapes(1024, B))],
+                 enc_noise=[dev(n) for n in cases.noise_list("graph", "enc", enc_s)],
+                 dec_noise=[dev(n) for n in cases.noise_list("graph", "dec", dec_s)])
+    eager = [pipe(x, **fixed)["restored"].clone() for x in lq]
+    pipe.capture_graphs(lq[0], **fixed)
+    outs = [o["restored"].clone() for o in pipe.run_batches_graphed(iter(lq))]
+    torch.cuda.synchronize()
+    assert len(outs) == 2
+    for a, b in zip(outs, eager):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert not torch.equal(outs[0], outs[1])

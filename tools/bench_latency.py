@@ -21,3 +21,19 @@ for B, T in cfgs:
             torch.cuda.synchronize()
             t_all = time.perf_counter() - t0
         print(f"B={B} T={T} {'bf16' if bf else 'fp32'}: {t_all/N*1e3:.2f} ms per batch wall, host enqueue {t_host/N*1e3:.2f} ms per batch -> {B*N/t_all:.1f} img/s", flush=True)
+    if os.environ.get("GRAPHS"):
+        for bf in (False, True):
+            hip_ops.BF16_CONV = bf
+            p2 = bench.build_pipeline(dev, T, True)
+            with torch.no_grad():
+                p2.capture_graphs(lq)
+                for _ in range(2):
+                    for o in p2.run_batches_graphed([lq]): pass
+                torch.cuda.synchronize()
+                N = 6
+                t0 = time.perf_counter()
+                for _ in range(N):
+                    for o in p2.run_batches_graphed([lq]): pass
+                    torch.cuda.synchronize()     # latency: one batch at a time
+                t_all = time.perf_counter() - t0
+            print(f"B={B} T={T} {'bf16' if bf else 'fp32'} graphs, one batch at a time: {t_all/N*1e3:.2f} ms per batch -> {B*N/t_all:.1f} img/s", flush=True)

@@ -103,6 +103,85 @@ class RestorationPipeline:
             cur = nxt
 
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # hipGraph replay.  One batch is ~1000 kernel launches (about 10 ms of Python + launch work): at batch 1 the host, not the
+    # GPU, sets the latency, and at batch 8 the small-map levels of C + D leave bubbles.  Stages A + B and stages C + D are
+    # captured ONCE as two HIP graphs (torch.cuda.CUDAGraph: the C ABI enqueues on whatever stream is current, so its launches
+    # record like any other; device RNG draws are graph-safe) and replayed per batch; run_batches keeps the two-stream overlap
+    # by replaying the A + B graph of batch i+1 on the side stream under the C + D graph of batch i.
+    @torch.no_grad()
+    def capture_graphs(self, example, x_T=None, z=None, gen_noise=None, enc_noise=None, dec_noise=None):
+        """Capture for batches shaped like `example` (B,3,512,512, device).  Needs mixing == 0 (the reference's style mixing
+        draws from Python's `random`, which changes the launch sequence from batch to batch).  The optional tensors replace
+        the device RNG draws as in __call__; they are captured by reference (static: overwrite their contents between replays
+        to change the noise)."""
+        if self.mixing != 0:
+            raise RuntimeError("capture_graphs: style mixing draws host random numbers per batch; use mixing=0")
+        cur = torch.cuda.current_stream()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):  # first calls pack weights, raise LDS limits, resolve device constants: not capturable
+            for _ in range(2):
+                self(example)
+        cur.wait_stream(warm)
+        torch.cuda.synchronize()
+        g = {"e_in": example.clone()}
+        g["E"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["E"]):
+            g["e_lat"], g["e_pre"] = self.encode(g["e_in"], x_T=x_T)
+        g["d_in"], g["d_lat"], g["d_pre"] = example.clone(), g["e_lat"].clone(), g["e_pre"].clone()
+        g["D"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["D"]):
+            g["out"] = self.decode(g["d_in"], g["d_lat"], g["d_pre"], z=z, gen_noise=gen_noise, enc_noise=enc_noise,
+                                   dec_noise=dec_noise)
+        self._graphs = g
+        return self
+
+    @torch.no_grad()
+    def run_batches_graphed(self, batches):
+        """run_batches over the captured graphs.  The yielded dict holds the graphs' STATIC output tensors: consume (or copy)
+        them before asking for the next batch."""
+        g = self._graphs
+        main = torch.cuda.current_stream()
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream()
+        side = self._side
+
+        def start(batch, after):
+            """A + B of `batch` on the side stream, once `after` (the main stream's copy of the previous latents) is done."""
+            if after is not None:
+                side.wait_event(after)
+            else:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g["e_in"].copy_(batch)
+                g["E"].replay()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return batch, ev
+
+        it = iter(batches)
+        try:
+            cur = start(next(it), None)
+        except StopIteration:
+            return
+        while cur is not None:
+            batch, ev = cur
+            main.wait_event(ev)
+            g["d_in"].copy_(batch)
+            g["d_lat"].copy_(g["e_lat"])
+            g["d_pre"].copy_(g["e_pre"])
+            copied = torch.cuda.Event()
+            copied.record(main)
+            try:
+                nxt = start(next(it), copied)  # enqueue A + B of the next batch BEFORE C + D of this one
+            except StopIteration:
+                nxt = None
+            g["D"].replay()
+            yield g["out"]
+            cur = nxt
+
+
 def gather_restored(local, counts=None):
     """All-gather the per-rank restored images (B_r,3,H,W) into the full batch on every rank (RCCL all-gather over
     xGMI; gloo on CPU in tests).  `counts` = per-rank batch sizes when the split is ragged."""
