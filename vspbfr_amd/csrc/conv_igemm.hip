@@ -398,6 +398,8 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   bool empty = false;
   if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
   if (empty) return VSP_OK;
+  VSP_REQUIRE((int64_t)x_ch * p.H * p.W * 4 < ((int64_t)1 << 31) && (int64_t)p.KH * p.KW * p.Cin * p.cout_g * 4 < ((int64_t)1 << 31),
+              "conv2d: one input image and one group's weights must each be smaller than 2 GiB (32-bit buffer offsets)");
   const int Cout = p.G * p.cout_g;
   (void)Cout;
   Plan best{};

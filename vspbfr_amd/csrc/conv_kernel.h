@@ -161,6 +161,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
   const float* xb = p.x + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * p.H * p.W;
   const float* wg = p.w + (int64_t)g * T * p.Cin * p.cout_g;
+  // buffer resources: a load is (resource, wave-uniform scalar byte offset, 32-bit lane byte offset) -- with flat pointers every
+  // staged word carries a 64-bit lane address (a VALU add per load and two VGPRs per hoisted offset)
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, 0x7fffffff, 0x00020000);
   const int plane = PH * PW;
   // exact floor(idx / PW) for idx < 2^16, PW <= 2^8 (host guarantees both)
   const unsigned pw_magic = (unsigned)(((1ull << 32) + PW - 1) / PW);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
     const int i = lane + 64 * e;
     int off;
     const bool in = (i < plane) && patch_src(i, off);
-    poff[e] = in ? off : 0;
+    poff[e] = in ? off * 4 : 0;   // byte offset inside the channel plane
     pin |= in ? (1u << e) : 0u;
   }
   int woff[WMAX];        // weight word offset relative to the chunk's first input channel; -1: zero fill
@@ -219,14 +223,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   auto issue = [&](int ci0) {
     if constexpr (PF == 2) return;
     if (p.w_vec4) {
-      const float* wc = wg + (int64_t)ci0 * p.cout_g;
+      const int wsoff = ci0 * p.cout_g * 4;
 #pragma unroll
       for (int w = 0; w < WMAX; ++w) {
         const int row = (tid + w * NT) / V;
         const int cl = row & (CK - 1);
         const bool ok = woff[w] >= 0 && ci0 + cl < p.Cin;
-        const float4 v = *reinterpret_cast<const float4*>(wc + (ok ? woff[w] : 0));
-        wreg[w] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ok ? woff[w] * 4 : 0, wsoff, 0));
+        wreg[w] = ok ? make_float4(v[0], v[1], v[2], v[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
@@ -237,9 +241,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
       const int cic = chok ? ci : 0;
       psc[pc] = chok ? (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + cic] : 1.f) : 0.f;
       psh[pc] = chok ? (p.in_shift ? p.in_shift[cic] : 0.f) : 0.f;
-      const float* xc = xb + (int64_t)cic * chw;
+      const int xsoff = cic * chw * 4;
 #pragma unroll
-      for (int e = 0; e < PMAX; ++e) preg[pc][e] = xc[poff[e]];
+      for (int e = 0; e < PMAX; ++e) preg[pc][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, poff[e], xsoff, 0));
     }
   };
 
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
       float* dstc = Pdst + cl * PS;
 #pragma unroll
       for (int e = 0; e < PMAX; ++e)
-        if ((pin >> e) & 1u) __builtin_amdgcn_global_load_lds(xc + poff[e], dstc + 64 * e, 4, 0, 0);
+        if ((pin >> e) & 1u) __builtin_amdgcn_global_load_lds(xc + (poff[e] >> 2), dstc + 64 * e, 4, 0, 0);
       if (plane > 64 * PMAX) {
         for (int i0 = 64 * PMAX; i0 < plane; i0 += 64) {  // i0 is wave-uniform: the LDS base of the instruction
           int off;
