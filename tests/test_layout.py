@@ -110,3 +110,52 @@ def test_winograd_weight_fragment_layout_cpu():
                                     if ty + i < sh and tx + j < sw and oy < 8 and ox < 8:
                                         out[:, oy, ox] = Y[:, i, j]
             assert np.abs(out - ref).max() < 2e-4, (G, cin, cout_g, g, np.abs(out - ref).max())
+
+
+def test_bf16_weight_lds_image_layout_cpu():
+    """hip_ops.bf16_weight against the documented index formula of vsp_conv2d_bf16 (include/vspbfr_hip.h): reading the packed
+    bf16 words back through the formula and convolving on the host reproduces F.conv2d on the bf16-rounded weights; and the
+    eligibility rules of the bf16 configuration (no GPU needed)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from vspbfr_amd import hip_ops as H
+    rng = np.random.default_rng(7)
+    for G, cin, cout_g in ((1, 24, 20), (4, 16, 16), (2, 40, 70)):
+        w = rng.standard_normal((G, cout_g, cin, 3, 3)).astype(np.float32)
+        wp = torch.stack([H.pack_weight(torch.from_numpy(w[g]))[0] for g in range(G)])
+        packed = H.bf16_weight(wp)
+        assert packed.dtype == torch.bfloat16
+        nch, co_pad = (cin + 15) // 16, (cout_g + 31) // 32 * 32
+        assert packed.numel() == G * nch * 9 * 2 * co_pad * 8
+        flat = packed.float().numpy()
+
+        def W(g, tap, ci, co):  # the index formula of include/vspbfr_hip.h
+            chunk, octet, j = ci // 16, (ci % 16) // 8, ci % 8
+            return flat[(((((g * nch + chunk) * 9 + tap) * 2 + octet) * co_pad + co) * 8) + j]
+
+        for g in range(G):
+            back = np.array([[[[W(g, ky * 3 + kx, ci, co) for kx in range(3)] for ky in range(3)] for ci in range(cin)]
+                             for co in range(cout_g)], np.float32)
+            assert np.array_equal(back, torch.from_numpy(w[g]).to(torch.bfloat16).float().numpy())
+        # zero padding of the channel octets past Cin and of the output-channel rows past cout_g
+        full = flat.reshape(G, nch, 9, 2, co_pad, 8)
+        assert not full[:, :, :, :, cout_g:, :].any()
+        if cin % 16:
+            assert not full[:, -1, :, 1 if cin % 16 <= 8 else 2:, :, :].any()
+    x = torch.from_numpy(rng.standard_normal((1, 24, 9, 9)).astype(np.float32))
+    w0 = torch.from_numpy(rng.standard_normal((20, 24, 3, 3)).astype(np.float32))
+    ref = F.conv2d(x.to(torch.bfloat16).float(), w0.to(torch.bfloat16).float(), padding=1)
+    assert torch.isfinite(ref).all()
+    pc = lambda **kw: H.PackedConv(torch.zeros(1), kw.get("G", 1), 32, kw.get("cin", 64), kw.get("k", 3), kw.get("k", 3),
+                                   kw.get("stride", 1), kw.get("dil", (1,)), kw.get("pad", (1,)), x_group_stride=kw.get("xgs", 0))
+    assert H.bf16_eligible(pc(), 64, 64, 64, 64)
+    assert H.bf16_eligible(pc(G=4, dil=(1, 2, 4, 8), pad=(1, 2, 4, 8)), 64, 64, 64, 64)
+    assert H.bf16_eligible(pc(stride=2, pad=(0,)), 65, 65, 32, 32) and H.bf16_eligible(pc(stride=2), 64, 64, 32, 32)
+    assert H.bf16_eligible(pc(), 32, 32, 33, 33, transposed=True)
+    assert not H.bf16_eligible(pc(k=1, pad=(0,)), 64, 64, 64, 64)          # 1x1
+    assert not H.bf16_eligible(pc(cin=12), 64, 64, 64, 64)                 # Cin not a multiple of 8
+    assert not H.bf16_eligible(pc(stride=2, dil=(2,), pad=(2,)), 64, 64, 32, 32)
+    assert not H.bf16_eligible(pc(G=8), 64, 64, 64, 64)                    # > 4 groups over one shared input
+    assert H.bf16_eligible(pc(G=8, xgs=64), 64, 64, 64, 64)                # true groups
+    assert not H.bf16_profitable(pc(), 8, 8, 8, 8) and H.bf16_profitable(pc(), 16, 16, 16, 16)
