@@ -604,7 +604,7 @@ def test_conv2d_bf16_stride2_true_groups(H):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,variant", [(2, 16, 64, 32, 32, 4), (1, 64, 32, 64, 64, 5), (1, 40, 72, 13, 21, 0), (2, 128, 64, 16, 16, 0),
-                                                   (1, 32, 32, 70, 33, 0)])
+                                                   (1, 32, 32, 70, 33, 0), (1, 48, 40, 37, 66, 8)])
 def test_conv2d_bf16_transposed(H, B, Cin, Cout, Hh, Ww, variant):
     """stride-2 transposed conv in one pass on the bf16 pipe, against F.conv_transpose2d on the bf16-rounded operands"""
     x = torch.randn(B, Cin, Hh, Ww)

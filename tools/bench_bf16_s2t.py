@@ -38,7 +38,7 @@ for (Cin, Cout, S) in [(64, 32, 512), (128, 64, 256), (256, 128, 128), (512, 256
     fl = 2.0 * B * Cout * Cin * 9 * S * S
     uf = t(lambda: H.conv_transpose2d_s2_fused(x, pc, in_scale=sc))
     out = [f"{Cin}->{Cout} @{S}->{2*S+1}: fp32 {uf:.0f} us {fl/uf/1e6:.0f} TF |"]
-    for v in (0, 4, 5):
+    for v in (0, 4, 5, 8):
         ub = t(lambda: H.conv_transpose2d_s2_fused(x, pc, in_scale=sc, bf16=True, tile_hint=v))
         out.append(f" v{v} {ub:.0f} us {fl/ub/1e6:.0f} TF x{uf/ub:.2f} |")
     print("".join(out), flush=True)

@@ -537,13 +537,15 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 
 // mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv.
 // variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
-//          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions
+//          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions,
+//          8 = 32 ch x 256 positions
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_TC) {
     if (variant == 0) variant = 5;  // 32-channel tiles: 122 VGPRs, more workgroups in flight (tools/bench_bf16_s2t.py)
     switch (variant) {
       case 4: return launch_shape<2, 1, 1, 4, M_TC>(q, stream);
       case 5: return launch_shape<1, 1, 1, 4, M_TC>(q, stream);
+      case 8: return launch_shape<1, 2, 1, 4, M_TC>(q, stream);
       default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown transposed variant %d", variant);
     }
   }
