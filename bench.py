@@ -67,8 +67,8 @@ def conv_traffic(B, args):
     """HBM bytes per conv launch from the committed PMC passes (profiles/r01_conv_traffic_pmc.json: FETCH_SIZE x2 per the
     gfx950 calibration, WRITE_SIZE x1, separate passes, tools/pmc_bench.sh).  PMC collection cannot run inside the timed
     process, so the figure is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json")
-    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or args.conv_dtype != "f32" or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json" if args.conv_dtype == "f32" else "r01_conv_traffic_pmc_bf16.json")
+    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
         return None
     with open(path) as f:
         return round(json.load(f)["conv_hbm_bytes_per_launch"])
