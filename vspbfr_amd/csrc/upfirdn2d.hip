@@ -47,8 +47,14 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int
   return v;
 }
 
-constexpr int TOH = 32;  // output tile rows
-constexpr int TOW = 64;  // output tile cols
+// Output tile of one 256-thread block (each thread 2 rows x 4 columns): 32 x 64.  (16 x 128 -- longer, better aligned row
+// segments -- measured identical on the large maps and worse at 64^2: the plain blur is bound by bytes in flight per workgroup,
+// not by cache-line efficiency, and forcing 8 waves/SIMD (<= 64 VGPRs) spills: 15 % slower; tools/bench_fir.py.)
+#ifndef VSP_FIR_TOW
+#define VSP_FIR_TOW 64
+#endif
+constexpr int TOW = VSP_FIR_TOW;          // output tile cols
+constexpr int TOH = 2 * (256 / (TOW / 4)); // output tile rows
 
 // 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     for (int kx = 0; kx < KW; ++kx) taps[ky][kx] = kern[(KH - 1 - ky) * KW + (KW - 1 - kx)];
 
   // this thread's 2 x 4 outputs and their epilogue operands (requested now, consumed after the FMAs)
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int tx = threadIdx.x % (TOW / 4), ty = threadIdx.x / (TOW / 4);
   const int ox = ox0 + 4 * tx, oyb = oy0 + 2 * ty;
   const bool full = ox + 3 < out_w;
   const int c = plane % epi.channels, b = plane / epi.channels;
