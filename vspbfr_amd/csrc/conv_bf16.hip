@@ -61,6 +61,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
   constexpr int NPL = S2 ? 4 : 1;          // patch planes per channel octet (stride 2: parity planes)
   // 32-channel tiles (40 KB LDS) live on occupancy instead (<= 128 VGPRs); the transposed mode has 128 accumulator registers
   constexpr bool DEEP = PT <= 3 && !(MB == 1 && MODE == M_CONV) && MODE != M_TC;
+#ifndef VSP_BF16_COMMIT_FIRST
+#define VSP_BF16_COMMIT_FIRST 0   // 1: convert at the top of the interval and issue the weight DMA there (measured equal: the
+#endif                             // interval is bound by the load latency that the closing vmcnt(0) + barrier exposes)
+  constexpr bool COMMIT_FIRST = VSP_BF16_COMMIT_FIRST;
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN, T = 9;
   constexpr int WSLAB = T * 2 * CO_T;  // 16-byte units per weight buffer: [tap][octet][co]
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
@@ -228,7 +232,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
     // order matters: with an LDS-DMA in flight hipcc waits for vmcnt(0) at the first use of ANY loaded register, so the
     // weight DMA of chunk c+1 is issued only after the last commit of this interval (PT taps in); the patch loads of
     // chunk c+2 go first and have the whole interval to land
-    if constexpr (DEEP) {
+    float sc[8], sh[8];
+    const bool oct_ok = load_scales(c + 1, sc, sh);
+    u32x4* Pn = Pl + nxt * PBUF;
+    if constexpr (DEEP && COMMIT_FIRST) {
+      // everything the previous interval loaded is complete (its closing barrier waited for vmcnt(0)): convert it first, then
+      // give the weight DMA and the next patch loads the WHOLE interval to land
+#pragma unroll
+      for (int e = 0; e < PT; ++e) commit_one(Pn, prCommit, sc, sh, oct_ok, e);
+      if (c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
+      if (c + 2 < nchunk) issue_p(prLoad, c + 2);
+    } else if constexpr (DEEP) {
       if (c + 2 < nchunk) issue_p(prLoad, c + 2);
     } else {
       if (c + 1 < nchunk) {
@@ -236,10 +250,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
         issue_p(prCommit, c + 1);
       }
     }
-    float sc[8], sh[8];
-    const bool oct_ok = load_scales(c + 1, sc, sh);
     constexpr int DMA_TAP = PT - 1;
-    u32x4* Pn = Pl + nxt * PBUF;
     const u32x4* Wc = Wl + cur * WSLAB + a_lane;
     const u32x4* Pc = Pl + cur * PBUF;
     if constexpr (TCV) {
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb * 4 + ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb][s4], acc[mb][nb * 4 + ph], 0, 0, 0);
-        if constexpr (DEEP) {
+        if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
           if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
         }
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][mb], bq[cs][nb], acc[mb][nb], 0, 0, 0);
-        if constexpr (DEEP) {
+        if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
           if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
         }
