@@ -54,7 +54,15 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int
 #define VSP_FIR_TOW 64
 #endif
 constexpr int TOW = VSP_FIR_TOW;          // output tile cols
-constexpr int TOH = 2 * (256 / (TOW / 4)); // output tile rows
+#ifndef VSP_FIR_RPT
+#define VSP_FIR_RPT 2
+#endif
+constexpr int RPT = VSP_FIR_RPT;          // output rows per thread (x 4 columns)
+#ifndef VSP_FIR_NTB
+#define VSP_FIR_NTB 2
+#endif
+constexpr int NTB = VSP_FIR_NTB;          // tiles per block
+constexpr int TOH = RPT * (256 / (TOW / 4)); // output tile rows
 
 // 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -68,39 +76,43 @@ template <int KH, int KW>
 __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                         const float* __restrict__ kern, int in_h, int in_w,
                                                         int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
-                                                        int tiles_y, Epi epi) {
+                                                        int tiles_y, int total_tiles, Epi epi) {
   constexpr int TIH = TOH + KH - 1;
   constexpr int TIW4 = (TOW + KW - 1 + 3) / 4;  // float4 per staged row (17: one spare column for KW = 4)
   constexpr int LDW = TIW4 * 4;
   constexpr int NLD = (TIH * TIW4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float tile[TIH * LDW];
 
-  const int bid = blockIdx.x;
-  const int tx_i = bid % tiles_x;
-  const int ty_i = (bid / tiles_x) % tiles_y;
-  const int plane = bid / (tiles_x * tiles_y);
-  const int oy0 = ty_i * TOH, ox0 = tx_i * TOW;
-  const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-  const float* xp = x + (int64_t)plane * in_h * in_w;
-
-  f32x4u v[NLD];
+  auto decode = [&](int t, int& plane, int& oy0, int& ox0) {
+    const int tx_i = t % tiles_x;
+    const int ty_i = (t / tiles_x) % tiles_y;
+    plane = t / (tiles_x * tiles_y);
+    oy0 = ty_i * TOH;
+    ox0 = tx_i * TOW;
+  };
+  auto load_window = [&](int t, f32x4u (&v)[NLD]) {
+    int plane, oy0, ox0;
+    decode(t, plane, oy0, ox0);
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    const float* xp = x + (int64_t)plane * in_h * in_w;
 #pragma unroll
-  for (int it = 0; it < NLD; ++it) {
-    const int idx = threadIdx.x + 256 * it;
-    const int r = idx / TIW4, c4 = idx - r * TIW4;
-    const int iy = iy0 + r, ix = ix0 + 4 * c4;
-    v[it] = f32x4u{0.f, 0.f, 0.f, 0.f};
-    if (idx < TIH * TIW4 && iy >= 0 && iy < in_h) {
-      const float* src = xp + (int64_t)iy * in_w + ix;
-      if (ix >= 0 && ix + 3 < in_w) {
-        v[it] = *reinterpret_cast<const f32x4u*>(src);
-      } else {  // window crosses the left/right image border
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      const int r = idx / TIW4, c4 = idx - r * TIW4;
+      const int iy = iy0 + r, ix = ix0 + 4 * c4;
+      v[it] = f32x4u{0.f, 0.f, 0.f, 0.f};
+      if (idx < TIH * TIW4 && iy >= 0 && iy < in_h) {
+        const float* src = xp + (int64_t)iy * in_w + ix;
+        if (ix >= 0 && ix + 3 < in_w) {
+          v[it] = *reinterpret_cast<const f32x4u*>(src);
+        } else {  // window crosses the left/right image border
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ix + j >= 0 && ix + j < in_w) v[it][j] = src[j];
+          for (int j = 0; j < 4; ++j)
+            if (ix + j >= 0 && ix + j < in_w) v[it][j] = src[j];
+        }
       }
     }
-  }
+  };
   // flipped taps -> registers (wave-uniform loads)
   float taps[KH][KW];
 #pragma unroll
@@ -108,95 +120,112 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx) taps[ky][kx] = kern[(KH - 1 - ky) * KW + (KW - 1 - kx)];
 
-  // this thread's 2 x 4 outputs and their epilogue operands (requested now, consumed after the FMAs)
-  const int tx = threadIdx.x % (TOW / 4), ty = threadIdx.x / (TOW / 4);
-  const int ox = ox0 + 4 * tx, oyb = oy0 + 2 * ty;
-  const bool full = ox + 3 < out_w;
-  const int c = plane % epi.channels, b = plane / epi.channels;
-  f32x4u nz[2], r1[2], r2[2];
+  auto process = [&](int t, const f32x4u (&v)[NLD]) {
+    int plane, oy0, ox0;
+    decode(t, plane, oy0, ox0);
+    // this thread's 2 x 4 outputs and their epilogue operands (requested now, consumed after the FMAs)
+    const int tx = threadIdx.x % (TOW / 4), ty = threadIdx.x / (TOW / 4);
+    const int ox = ox0 + 4 * tx, oyb = oy0 + RPT * ty;
+    const bool full = ox + 3 < out_w;
+    const int c = plane % epi.channels, b = plane / epi.channels;
+    f32x4u nz[RPT], r1[RPT], r2[RPT];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    nz[rr] = r1[rr] = r2[rr] = f32x4u{0.f, 0.f, 0.f, 0.f};
-    const int oy = oyb + rr;
-    if (!epi.enabled || oy >= out_h || ox >= out_w) continue;
-    const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
-    const int64_t on = ((int64_t)b * out_h + oy) * out_w + ox;
-    if (full) {
-      if (epi.noise) nz[rr] = *reinterpret_cast<const f32x4u*>(epi.noise + on);
-      if (epi.res1) r1[rr] = *reinterpret_cast<const f32x4u*>(epi.res1 + o);
-      if (epi.res2) r2[rr] = *reinterpret_cast<const f32x4u*>(epi.res2 + o);
-    } else {
+    for (int rr = 0; rr < RPT; ++rr) {
+      nz[rr] = r1[rr] = r2[rr] = f32x4u{0.f, 0.f, 0.f, 0.f};
+      const int oy = oyb + rr;
+      if (!epi.enabled || oy >= out_h || ox >= out_w) continue;
+      const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
+      const int64_t on = ((int64_t)b * out_h + oy) * out_w + ox;
+      if (full) {
+        if (epi.noise) nz[rr] = *reinterpret_cast<const f32x4u*>(epi.noise + on);
+        if (epi.res1) r1[rr] = *reinterpret_cast<const f32x4u*>(epi.res1 + o);
+        if (epi.res2) r2[rr] = *reinterpret_cast<const f32x4u*>(epi.res2 + o);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (ox + j < out_w) {
-          if (epi.noise) nz[rr][j] = epi.noise[on + j];
-          if (epi.res1) r1[rr][j] = epi.res1[o + j];
-          if (epi.res2) r2[rr][j] = epi.res2[o + j];
-        }
-    }
-  }
-  float pscale = 1.f, nw = 0.f, ab = 0.f;
-  if (epi.enabled) {
-    if (epi.plane_scale) pscale = epi.plane_scale[plane];
-    if (epi.noise) nw = epi.noise_w[0];
-    if (epi.act && epi.act_bias) ab = epi.act_bias[c];
-  }
-
-#pragma unroll
-  for (int it = 0; it < NLD; ++it) {
-    const int idx = threadIdx.x + 256 * it;
-    if (idx < TIH * TIW4) *reinterpret_cast<float4*>(tile + idx * 4) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-  }
-  __syncthreads();
-
-  float acc[2][4];
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[rr][j] = 0.f;
-#pragma unroll
-  for (int wr = 0; wr < KH + 1; ++wr) {  // window row wr feeds output row 0 with tap row wr and output row 1 with tap row wr-1
-    const float* rp = tile + (2 * ty + wr) * LDW + 4 * tx;
-    const float4 lo = *reinterpret_cast<const float4*>(rp);
-    const float4 hi = (KW > 1) ? *reinterpret_cast<const float4*>(rp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int ky = wr - rr;
-      if (ky < 0 || ky >= KH) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kx = 0; kx < KW; ++kx) acc[rr][j] = fmaf(taps[ky][kx], w[j + kx], acc[rr][j]);
-    }
-  }
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int oy = oyb + rr;
-    if (oy >= out_h || ox >= out_w) continue;
-    f32x4u o4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a = acc[rr][j];
-      if (epi.enabled) {
-        a = fmaf(nz[rr][j], nw, a * pscale);
-        if (epi.act) {
-          a += ab;
-          a = (a > 0.f ? a : a * epi.slope) * epi.gain;
-        }
-        a += r1[rr][j];
-        a += r2[rr][j];
+        for (int j = 0; j < 4; ++j)
+          if (ox + j < out_w) {
+            if (epi.noise) nz[rr][j] = epi.noise[on + j];
+            if (epi.res1) r1[rr][j] = epi.res1[o + j];
+            if (epi.res2) r2[rr][j] = epi.res2[o + j];
+          }
       }
-      o4[j] = a;
     }
-    float* dst = out + ((int64_t)plane * out_h + oy) * out_w + ox;
-    if (full) {
-      *reinterpret_cast<f32x4u*>(dst) = o4;
-    } else {
+    float pscale = 1.f, nw = 0.f, ab = 0.f;
+    if (epi.enabled) {
+      if (epi.plane_scale) pscale = epi.plane_scale[plane];
+      if (epi.noise) nw = epi.noise_w[0];
+      if (epi.act && epi.act_bias) ab = epi.act_bias[c];
+    }
+
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (ox + j < out_w) dst[j] = o4[j];
+    for (int it = 0; it < NLD; ++it) {
+      const int idx = threadIdx.x + 256 * it;
+      if (idx < TIH * TIW4) *reinterpret_cast<float4*>(tile + idx * 4) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
     }
+    __syncthreads();
+
+    float acc[RPT][4];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[rr][j] = 0.f;
+#pragma unroll
+    for (int wr = 0; wr < KH + RPT - 1; ++wr) {  // window row wr feeds output row rr with tap row wr - rr
+      const float* rp = tile + (RPT * ty + wr) * LDW + 4 * tx;
+      const float4 lo = *reinterpret_cast<const float4*>(rp);
+      const float4 hi = (KW > 1) ? *reinterpret_cast<const float4*>(rp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) {
+        const int ky = wr - rr;
+        if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int kx = 0; kx < KW; ++kx) acc[rr][j] = fmaf(taps[ky][kx], w[j + kx], acc[rr][j]);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int oy = oyb + rr;
+      if (oy >= out_h || ox >= out_w) continue;
+      f32x4u o4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = acc[rr][j];
+        if (epi.enabled) {
+          a = fmaf(nz[rr][j], nw, a * pscale);
+          if (epi.act) {
+            a += ab;
+            a = (a > 0.f ? a : a * epi.slope) * epi.gain;
+          }
+          a += r1[rr][j];
+          a += r2[rr][j];
+        }
+        o4[j] = a;
+      }
+      float* dst = out + ((int64_t)plane * out_h + oy) * out_w + ox;
+      if (full) {
+        *reinterpret_cast<f32x4u*>(dst) = o4;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ox + j < out_w) dst[j] = o4[j];
+      }
+    }
+  };
+  // NTB adjacent tiles per block, ALL windows requested up front: the plain blur is bound by bytes in flight (3.0 TB/s with one
+  // window per block against 5.2 TB/s of a plain copy); every further window adds them for 12 more VGPRs
+  f32x4u v[NTB][NLD];
+  const int t0 = NTB * blockIdx.x;
+#pragma unroll
+  for (int k = 0; k < NTB; ++k)
+    if (t0 + k < total_tiles) load_window(t0 + k, v[k]);
+#pragma unroll
+  for (int k = 0; k < NTB; ++k) {
+    if (t0 + k >= total_tiles) break;
+    if (k > 0) __syncthreads();
+    process(t0 + k, v[k]);
   }
 }
 
@@ -282,14 +311,14 @@ extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
     VSP_REQUIRE(blocks < ((int64_t)1 << 31), "upfirdn2d: grid too large");
     if (kh == 4)
-      fir_tile_kernel<4, 4><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                             pad_y0, tiles_x, tiles_y, e);
+      fir_tile_kernel<4, 4><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
     else if (kh == 3)
-      fir_tile_kernel<3, 3><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                             pad_y0, tiles_x, tiles_y, e);
+      fir_tile_kernel<3, 3><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
     else
-      fir_tile_kernel<2, 2><<<(unsigned)blocks, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                             pad_y0, tiles_x, tiles_y, e);
+      fir_tile_kernel<2, 2><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
     return vsp::check_launch("upfirdn2d(tile)");
   }
   int64_t blocks = (total + 255) / 256;
