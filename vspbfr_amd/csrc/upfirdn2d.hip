@@ -59,7 +59,7 @@ constexpr int TOW = VSP_FIR_TOW;          // output tile cols
 #endif
 constexpr int RPT = VSP_FIR_RPT;          // output rows per thread (x 4 columns)
 #ifndef VSP_FIR_NTB
-#define VSP_FIR_NTB 2
+#define VSP_FIR_NTB 1
 #endif
 constexpr int NTB = VSP_FIR_NTB;          // tiles per block
 constexpr int TOH = RPT * (256 / (TOW / 4)); // output tile rows
@@ -214,8 +214,10 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
       }
     }
   };
-  // NTB adjacent tiles per block, ALL windows requested up front: the plain blur is bound by bytes in flight (3.0 TB/s with one
-  // window per block against 5.2 TB/s of a plain copy); every further window adds them for 12 more VGPRs
+  // NTB adjacent tiles per block, all windows requested up front.  In the micro-benchmark (tools/bench_fir.py) a second window
+  // lifts the plain blur from 3.05 to 3.4-3.9 TB/s (bytes in flight); inside the pipeline -- the input was just written by the
+  // transposed conv, small maps need the blocks -- one tile per block measures best (rocprofv3: 10.0 ms against 13.3 ms for the
+  // 76 blur launches of four steps), so NTB = 1 ships.
   f32x4u v[NTB][NLD];
   const int t0 = NTB * blockIdx.x;
 #pragma unroll
