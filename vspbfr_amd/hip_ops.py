@@ -64,6 +64,22 @@ TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_I
 WINO = {k: True for k, v in _load_tune_table().items() if v == "winograd"}  # shapes where the F(2x2,3x3) kernel won
 
 
+def _load_bf16_tune():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune_bf16.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {k: int(v) for k, v in json.load(f).items()}
+
+
+# shape key -> tile variant of vsp_conv2d_bf16 measured fastest INSIDE the pipeline (tools/autotune_bf16.py); other shapes use the
+# library's rule.  BF16_FORCE (tuner only): variant tried on every launch it fits.
+BF16_TUNE = _load_bf16_tune()
+BF16_FORCE = 0
+
+
 def conv_key(B, Cin, H, W, pc, OH, OW):
     return f"{B},{Cin},{H},{W},{pc.G},{pc.cout_g},{pc.kh},{pc.kw},{pc.stride},{pc.dil[0]},{OH},{OW}" + (
         f",g{pc.x_group_stride}" if pc.x_group_stride else "")
@@ -355,7 +371,17 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         bw = pc.bf16_weight()
         keep.append(bw)
         p.w = bw.data_ptr()
-        check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+        if tile_hint == 0:
+            p.tile_hint = BF16_TUNE.get(key, BF16_TUNE.get("8" + key[key.index(","):], 0))
+            if BF16_FORCE:
+                p.tile_hint = BF16_FORCE
+                if lib.vsp_conv2d_bf16(C.byref(p), _stream()) != 0:  # the forced variant does not serve this launch
+                    p.tile_hint = 0
+                    check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+            else:
+                check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+        else:
+            check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
     elif winograd:
         uw = pc.winograd_weight()
         keep.append(uw)
@@ -364,7 +390,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     else:
         check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, "bf16" if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct"))))
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, "bf16" if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct")), key))
     return out
 
 
