@@ -40,6 +40,25 @@ def test_invalid_arguments_report_errors_without_a_gpu():
     assert _lib.lib.vsp_conv2d_f32(None, None) == -1
     assert "null params" in _lib.last_error()
     assert _lib.lib.vsp_gemm_f32(None, None) == -1
+    # the bf16 entry validates before it touches the device: null params, non-3x3 kernels, stride-2 dilation, Cin % 8
+    import ctypes as C
+    assert _lib.lib.vsp_conv2d_bf16(None, None) == -1 and "null params" in _lib.last_error()
+    p = _lib.ConvParams()
+    p.x = p.w = p.y = 256  # non-null, 16-byte aligned dummies: never dereferenced on these paths
+    p.B, p.Cin, p.H, p.W, p.G, p.cout_g, p.OH, p.OW = 1, 16, 8, 8, 1, 32, 8, 8
+    p.KH = p.KW = 1
+    p.stride_y = p.stride_x = p.osy = p.osx = 1
+    for g in range(4):
+        p.dil[g], p.pad_y[g], p.pad_x[g] = 1, 1, 1
+    assert _lib.lib.vsp_conv2d_bf16(C.byref(p), None) == -1 and "3x3" in _lib.last_error()
+    p.KH = p.KW = 3
+    p.stride_y = p.stride_x = 2
+    p.dil[0] = 2
+    p.OH = p.OW = 4
+    assert _lib.lib.vsp_conv2d_bf16(C.byref(p), None) == -1 and "stride 2" in _lib.last_error()
+    p.stride_y = p.stride_x = 1
+    p.dil[0], p.OH, p.OW, p.Cin = 1, 8, 8, 12
+    assert _lib.lib.vsp_conv2d_bf16(C.byref(p), None) == -1 and "multiple of 8" in _lib.last_error()
 
 
 def test_product_does_not_import_oracle():

@@ -614,3 +614,18 @@ def test_conv2d_bf16_transposed(H, B, Cin, Cout, Hh, Ww, variant):
     ref = F.conv_transpose2d(_bf(x * s_in.view(B, Cin, 1, 1)), _bf(w).transpose(0, 1), stride=2) * demod.view(B, Cout, 1, 1)
     y = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bf16=True, tile_hint=variant)
     close(y, ref, 5e-5, 5e-5)
+
+
+def test_conv2d_bf16_empty_batch_and_errors(H):
+    """edge cases of the bf16 entry: an empty batch is a no-op, ineligible layers raise RuntimeError (no silent fp32 fallback
+    when bf16=True is asked for explicitly)"""
+    w = torch.randn(32, 16, 3, 3)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, 32, 16, 3, 3, 1, (1,), (1,))
+    y = H.conv2d_packed(torch.empty(0, 16, 8, 8, device=DEV), pc, bf16=True)
+    assert y.shape == (0, 32, 8, 8)
+    pc1 = H.PackedConv(H.pack_weight(dev(torch.randn(32, 16, 1, 1))), 1, 32, 16, 1, 1, 1, (1,), (0,))
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(torch.randn(1, 16, 8, 8, device=DEV), pc1, bf16=True)
+    pc12 = H.PackedConv(H.pack_weight(dev(torch.randn(32, 12, 3, 3))), 1, 32, 12, 3, 3, 1, (1,), (1,))
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(torch.randn(1, 12, 8, 8, device=DEV), pc12, bf16=True)
