@@ -316,6 +316,8 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         yh, yw = out_hw if out_hw is not None else (OH, OW)
         out = torch.empty((B, pc.cout, yh, yw), device=x.device, dtype=x.dtype)
     _req(out, "out")
+    if B == 0:  # empty batch: nothing to enqueue (an empty tensor has no device pointer to hand to the C ABI)
+        return out
     p = ConvParams()
     keep = [x, pc.w, out, _opt(in_scale, "in_scale"), _opt(in_shift, "in_shift"), _opt(out_scale, "out_scale"),
             _opt(ch_scale, "ch_scale"), _opt(ch_bias, "ch_bias"), _opt(bias1, "bias1"), _opt(noise, "noise"),
