@@ -114,7 +114,7 @@ int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major
  * The output stride/offset (osy, osx, ooy, oox) lets a stride-2 transposed conv run as four sub-pixel phase
  * convolutions writing one (2H+1)x(2W+1) tensor (same MACs as conv_transpose2d).
  * Wp is the launch's weight, packed by the host once at model-load time:
- *   Wp[g][tap][ci][co_g], co_g contiguous (see vspbfr_amd/packing.py).
+ *   Wp[g][tap][ci][co_g], co_g contiguous (see hip_ops.pack_weight in vspbfr_amd/hip_ops.py).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct vsp_conv_params {
   const float* x;  /* [B, Cin, H, W] */

@@ -170,7 +170,7 @@ def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_b
 # ----------------------------------------------------------------------------------------------- conv2d
 class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
-    Built once at model-load time (vspbfr_amd/packing.py)."""
+    Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino", "_bf16")
 
