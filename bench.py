@@ -68,7 +68,7 @@ def conv_traffic(B, args):
     gfx950 calibration, WRITE_SIZE x1, separate passes, tools/pmc_bench.sh).  PMC collection cannot run inside the timed
     process, so the figure is only reported for the configuration it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json" if args.conv_dtype == "f32" else "r01_conv_traffic_pmc_bf16.json")
-    if B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
+    if args.conv_dtype == "bf16x3" or B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
         return None
     with open(path) as f:
         return round(json.load(f)["conv_hbm_bytes_per_launch"])
@@ -89,9 +89,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--graphs", action="store_true",
                     help="replay stages A+B and C+D as two captured HIP graphs (same kernels, same two-stream overlap, no per-launch host work)")
-    ap.add_argument("--conv-dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--conv-dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
                     help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
-                         "fp32 activations in HBM); not the parity configuration")
+                         "fp32 activations in HBM); not the parity configuration.  bf16x3 = the same kernels with hi + lo bf16 "
+                         "operand pairs and three MFMAs per product (vsp_conv2d_bf16x3): fp32-grade results on the bf16 pipe")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,7 +110,7 @@ def main():
 
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
-    hip_ops.BF16_CONV = args.conv_dtype == "bf16"
+    hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
     pipe = build_pipeline(dev, args.timesteps, not args.no_sample)
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
@@ -182,7 +183,7 @@ def main():
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         # bf16 configuration: the dense bf16 MFMA peak (MI355X_MICROARCH.md); the conv family then mixes bf16 (stride-1 3x3)
         # and fp32 (stride-2, transposed, small-map) launches, all priced against the bf16 peak
-        PEAK = PEAK_FP32_TFLOPS if args.conv_dtype == "f32" else 2500.0
+        PEAK = {"f32": PEAK_FP32_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.conv_dtype]  # bf16x3: three MFMAs per product
         KERNEL_NOTE = ("conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = "
                        "algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
             "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + the fp32 "
@@ -194,7 +195,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.conv_dtype, "data": "synthetic",
             "config": {"workload": f"restoration_test.py hot path A+B+C+D, batch {B}/GPU, 512x512, {args.timesteps}-step DDPM "
                                    f"CodeDiffuser + StyleGAN2 prior{'' if not args.no_sample else ' (no 1024^2 tail)'} + RestoreNet "
-                                   f"forward, {'fp32' if args.conv_dtype == 'f32' else 'bf16-MFMA convolutions (fp32 accumulate, fp32 activations), rest fp32'}, random-init weights",
+                                   "forward, " + {"f32": "fp32", "bf16": "bf16-MFMA convolutions (fp32 accumulate, fp32 activations), rest fp32",
+                                                 "bf16x3": "split-precision bf16-MFMA convolutions (hi + lo operand pairs, 3 MFMAs per product, fp32 "
+                                                           "accumulate; transposed and small-map layers fp32), rest fp32"}[args.conv_dtype] + ", random-init weights",
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
                        "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",

@@ -201,6 +201,15 @@ const char* vsp_conv2d_config_name(int i);
  * a throughput configuration, not the parity path. */
 int vsp_conv2d_bf16(const vsp_conv_params* p, vsp_stream_t stream);
 
+/* The split-precision form of vsp_conv2d_bf16 ("bf16x3") for the stride-1 and stride-2 layers: both operands are carried as
+ * hi + lo bf16 pairs (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and every product is evaluated as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi into the same fp32 accumulator -- three MFMAs per tile pair on the bf16 pipe, relative
+ * error ~2^-16 per product instead of 2^-8: fp32-grade results for layers that the fp32 matrix pipe (1/16 of the bf16 rate)
+ * bounds.  Same contract and operands as vsp_conv2d_bf16; `w` holds BOTH weight parts, chunk by chunk:
+ *     w[((((((g * nchunk + chunk) * 2 + part) * 9 + tap) * 2 + octet) * co_pad + co) * 8 + j]
+ *         part 0 = bf16(W), part 1 = bf16(W - float(bf16(W)))   (hip_ops.bf16x3_weight). */
+int vsp_conv2d_bf16x3(const vsp_conv_params* p, vsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Strided, batched small GEMM on fp32 MFMA -- replaces F.linear / torch.matmul of the path
  * (EqualLinear: models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,

@@ -304,7 +304,8 @@ def test_pipeline_run_batches_matches_call():
     assert list(pipe.run_batches([])) == []
 
 
-def test_pipeline512_bf16_config(golden):
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_pipeline512_bf16_config(golden, mode):
     """The bf16-kernel configuration (BASELINE configs[2]; hip_ops.BF16_CONV) on the pinned 512^2 case: stage A's codes and
     stages C + D teacher-forced on the reference's latent, against the reference's fp32 golden.  bf16 operands cannot meet
     the 1e-3 parity bound (SURVEY 7 "hard parts"); this records the delta (gpurun_out/parity_pipeline512_bf16.json) and bounds
@@ -321,7 +322,7 @@ def test_pipeline512_bf16_config(golden):
     en = [dev(n) for n in cases.noise_list(case, "enc", enc_s)]
     dn = [dev(n) for n in cases.noise_list(case, "dec", dec_s)]
     g = golden(case)
-    hip_ops.BF16_CONV = True
+    hip_ops.BF16_CONV = True if mode == "bf16" else "x3"
     try:
         codes = pipe.psp.get_w_plus(dev(lq))
         pre = dev(torch.from_numpy(g["pre_latent"]))
@@ -339,9 +340,13 @@ def test_pipeline512_bf16_config(golden):
            "style_sample_max": float(ds.abs().max()), "style_sample_rms": float(ds.pow(2).mean().sqrt()),
            "restored_8bit_lsb_max": int(np.abs(q - qg).max()), "restored_8bit_lsb_mean": float(np.abs(q - qg).mean())}
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(rep, open("gpurun_out/parity_pipeline512_bf16.json", "w"), indent=1)
+    json.dump(rep, open("gpurun_out/parity_pipeline512_%s.json" % mode, "w"), indent=1)
     print(rep)
     assert np.isfinite(r_tf.cpu().numpy()).all()
+    if mode == "bf16x3":  # split precision: inside BASELINE's 1e-3 parity bound on stages C + D, like the fp32 kernels
+        assert rep["restored_max"] < 1e-3 and rep["style_sample_max"] < 1e-3 and rep["restored_8bit_lsb_max"] <= 1
+        assert rep["codes_max"] < 1e-3
+        return
     assert rep["codes_max"] < 0.05 * max(rep["codes_absmax"], 1.0)
     # measured on MI355X: restored max 1.6e-2, rms 2.9e-3 on an image of std 0.93; <= 2 LSB (mean 0.17) after save_image
     assert rep["restored_rms"] < 0.01 * rep["restored_std_ref"] and rep["restored_max"] < 0.06 * rep["restored_std_ref"]

@@ -629,3 +629,39 @@ def test_conv2d_bf16_empty_batch_and_errors(H):
     pc12 = H.PackedConv(H.pack_weight(dev(torch.randn(32, 12, 3, 3))), 1, 32, 12, 3, 3, 1, (1,), (1,))
     with pytest.raises(RuntimeError):
         H.conv2d_packed(torch.randn(1, 12, 8, 8, device=DEV), pc12, bf16=True)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 4, 7])
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 16, 64, 32, 32), (1, 40, 36, 13, 29), (1, 256, 128, 16, 24), (1, 64, 32, 70, 45)])
+def test_conv2d_bf16x3(H, B, Cin, Cout, Hh, Ww, variant):
+    """split-precision form: hi + lo bf16 operands, three MFMAs per product -- fp32-grade against F.conv2d in float64"""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, demod, bias = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5, torch.randn(Cout)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    ref = F.conv2d((x * s_in.view(B, Cin, 1, 1)).double(), w.double(), padding=1) * demod.view(B, Cout, 1, 1).double()
+    ref = (F.leaky_relu(ref + bias.view(1, -1, 1, 1).double(), 0.2) * math.sqrt(2)).float()
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), bf16="x3", tile_hint=variant)
+    close(y, ref, 6e-5, 6e-5)      # 2^-16 per product; plain bf16 operands sit at 2e-2 on the same data
+    # stride 2 (parity planes) and the four dilation groups
+    pc2 = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 2, (1,), (1,))
+    close(H.conv2d_packed(dev(x), pc2, bf16="x3"), F.conv2d(x.double(), w.double(), stride=2, padding=1).float(), 6e-5, 6e-5)
+    if Cout % 4 == 0:
+        ws = [torch.randn(Cout // 4, Cin, 3, 3) / math.sqrt(Cin * 9) for _ in range(4)]
+        wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+        pc4 = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+        ref4 = torch.cat([F.conv2d(x.double(), w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], 1).float()
+        close(H.conv2d_packed(dev(x), pc4, bf16="x3"), ref4, 6e-5, 6e-5)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 16, 64, 32, 32), (1, 40, 72, 13, 21), (1, 128, 64, 33, 64)])
+def test_conv2d_bf16x3_transposed(H, B, Cin, Cout, Hh, Ww):
+    """split-precision transposed mode against F.conv_transpose2d in float64"""
+    x = torch.randn(B, Cin, Hh, Ww)
+    w = torch.randn(Cout, Cin, 3, 3) / math.sqrt(Cin * 9)
+    s_in, demod = torch.rand(B, Cin) + 0.5, torch.rand(B, Cout) + 0.5
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    ref = (F.conv_transpose2d((x * s_in.view(B, Cin, 1, 1)).double(), w.double().transpose(0, 1), stride=2)
+           * demod.view(B, Cout, 1, 1).double()).float()
+    y = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bf16="x3")
+    close(y, ref, 6e-5, 6e-5)

@@ -9,7 +9,7 @@ B, T = int(os.environ.get("B", 8)), int(os.environ.get("T", 50))
 pipe = bench.build_pipeline(dev, T, True)
 lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
 def step(bf):
-    hip_ops.BF16_CONV = bf
+    hip_ops.BF16_CONV = (os.environ.get("X3") and "x3" or True) if bf else False
     with torch.no_grad():
         pipe(lq); pipe(lq)
         prof = hip_ops.ConvProfiler(); hip_ops.PROFILER = prof

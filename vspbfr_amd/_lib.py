@@ -106,6 +106,7 @@ SIGNATURES = {
     "vsp_tacc_chain_f32": [_p, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
+    "vsp_conv2d_bf16x3": [_p, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
 }

@@ -53,20 +53,25 @@ enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 
 // DEEP (PT <= 3, 64-channel tiles and up): two patch register sets, loads two chunks ahead, conversion spread over the tap loop.  Larger planes
 // (narrow tiles, 5-7 positions per lane) keep ONE set: loads one chunk ahead, conversion after the taps.
-template <int MB, int NB, int WM, int WN, int PT, int MODE>
-__global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
+// SPLIT ("bf16x3"): both operands are carried as hi + lo bf16 pairs (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a
+// product is a_hi b_hi + a_hi b_lo + a_lo b_hi on the same fp32 accumulator -- fp32-grade results (relative error ~2^-16 per
+// product instead of 2^-8) at three MFMAs per tile pair; the LDS images and the weight DMA double ([part][...]).
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false>
+__global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int NPART = SPLIT ? 2 : 1;
   constexpr bool S2 = MODE == M_S2, TCV = MODE == M_TC;
   constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
   constexpr int NPL = S2 ? 4 : 1;          // patch planes per channel octet (stride 2: parity planes)
   // 32-channel tiles (40 KB LDS) live on occupancy instead (<= 128 VGPRs); the transposed mode has 128 accumulator registers
-  constexpr bool DEEP = PT <= 3 && !(MB == 1 && MODE == M_CONV) && MODE != M_TC;
+  constexpr bool DEEP = PT <= 3 && !(MB == 1 && MODE == M_CONV) && MODE != M_TC && !SPLIT;
 #ifndef VSP_BF16_COMMIT_FIRST
 #define VSP_BF16_COMMIT_FIRST 0   // 1: convert at the top of the interval and issue the weight DMA there (measured equal: the
 #endif                             // interval is bound by the load latency that the closing vmcnt(0) + barrier exposes)
   constexpr bool COMMIT_FIRST = VSP_BF16_COMMIT_FIRST;
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN, T = 9;
-  constexpr int WSLAB = T * 2 * CO_T;  // 16-byte units per weight buffer: [tap][octet][co]
+  constexpr int WPART = T * 2 * CO_T;      // 16-byte units of one precision part: [tap][octet][co]
+  constexpr int WSLAB = NPART * WPART;     // per weight buffer: [part][tap][octet][co]
   extern __shared__ __attribute__((aligned(16))) u32x4 smem16[];
 
   const int tid = threadIdx.x;
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
   const int nchunk = (p.Cin + BCK - 1) / BCK;
   const int pitch = p.bf_pitch, PR = MODE == M_CONV ? TH + 2 : TH + 1, PC = MODE == M_CONV ? TW + 2 * d : TW + 1;
   const int PLANE = p.bf_plane;     // >= PR * pitch (stride 2: == 8 mod 16 so that the two planes a store hits do not collide)
-  const int PBUF = 2 * NPL * PLANE; // 16-byte units per patch buffer: [octet][plane][position]
+  const int PPART = 2 * NPL * PLANE;   // 16-byte units of one precision part: [octet][plane][position]
+  const int PBUF = NPART * PPART;      // per patch buffer
 
   u32x4* Wl = smem16;               // 2 x [T][2][CO_T]
   u32x4* Pl = smem16 + 2 * WSLAB;   // 2 x [2][NPL][PLANE]
@@ -189,15 +195,25 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = in ? fmaf(pr[e][j], sc[j], sh[j]) : 0.f;
-    Pdst[oct * NPL * PLANE + pdst[e]] =
-        u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    const u32x4 hi = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+    Pdst[oct * NPL * PLANE + pdst[e]] = hi;
+    if constexpr (SPLIT) {  // lo = bf16(v - hi): the next eight significant bits
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned hb = (j & 1) ? (hi[j >> 1] & 0xffff0000u) : (hi[j >> 1] << 16);
+        r[j] = v[j] - __builtin_bit_cast(float, hb);
+      }
+      Pdst[PPART + oct * NPL * PLANE + pdst[e]] =
+          u32x4{pack_bf16(r[0], r[1]), pack_bf16(r[2], r[3]), pack_bf16(r[4], r[5]), pack_bf16(r[6], r[7])};
+    }
   };
 
   // ---- weight slab by LDS-DMA: the chunk's [tap][octet] rows of this co tile, 64 rows (1 KiB) per wave instruction
   constexpr int NDMA = WSLAB / 64;
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)g * nchunk * (T * 2) * co_pad;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)g * nchunk * (NPART * T * 2) * co_pad;
   auto issue_w = [&](u32x4* Wdst, int c) {
-    const u32x4* src = wsrc + (int64_t)c * (T * 2) * co_pad;
+    const u32x4* src = wsrc + (int64_t)c * (NPART * T * 2) * co_pad;
 #pragma unroll
     for (int k = 0; k < (NDMA + 3) / 4; ++k) {
       const int i = wave + 4 * k;
@@ -254,24 +270,34 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
     const u32x4* Wc = Wl + cur * WSLAB + a_lane;
     const u32x4* Pc = Pl + cur * PBUF;
     if constexpr (TCV) {
-      bf16x8 bq[NB][4];  // the position block shifted by (-(ky >> 1), -(kx >> 1)): four distinct fragments serve the nine taps
+      bf16x8 bq[NPART][NB][4];  // the position block shifted by (-(ky >> 1), -(kx >> 1)): four distinct fragments serve the nine taps
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+      for (int pt = 0; pt < NPART; ++pt)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          bq[nb][s4] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + (1 - (s4 >> 1)) * pitch + (1 - (s4 & 1))]);
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            bq[pt][nb][s4] = __builtin_bit_cast(bf16x8, Pc[pt * PPART + pixpos[nb] + (1 - (s4 >> 1)) * pitch + (1 - (s4 & 1))]);
 #pragma unroll
       for (int tap = 0; tap < T; ++tap) {
         const int ky = tap / 3, kx = tap % 3;
         const int ph = (ky & 1) * 2 + (kx & 1), s4 = (ky >> 1) * 2 + (kx >> 1);
-        bf16x8 a[MB];
+        bf16x8 a[NPART][MB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
+        for (int pt = 0; pt < NPART; ++pt)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) a[pt][mb] = __builtin_bit_cast(bf16x8, Wc[pt * WPART + tap * 2 * CO_T + mb * 32]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb * 4 + ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb], bq[nb][s4], acc[mb][nb * 4 + ph], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb) {
+            f32x16& ac = acc[mb][nb * 4 + ph];
+            if constexpr (SPLIT) {
+              ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][mb], bq[0][nb][s4], ac, 0, 0, 0);
+              ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mb], bq[1][nb][s4], ac, 0, 0, 0);
+            }
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mb], bq[0][nb][s4], ac, 0, 0, 0);
+          }
         if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
           if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
@@ -280,14 +306,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
     } else {
       // hand-pipelined: the fragments of tap t+1 are requested before the MFMAs of tap t, and a scheduling barrier per tap
       // keeps the compiler from hoisting all 36 fragment reads to the top (256 VGPRs and spills otherwise)
-      bf16x8 a[2][MB], bq[2][NB];
-      auto load_tap = [&](int tap, bf16x8 (&af)[MB], bf16x8 (&bf)[NB]) {
+      bf16x8 a[2][NPART][MB], bq[2][NPART][NB];
+      auto load_tap = [&](int tap, bf16x8 (&af)[NPART][MB], bf16x8 (&bf)[NPART][NB]) {
         const int ky = tap / 3, kx = tap % 3;
         const int toff = S2 ? ((ky & 1) * 2 + (kx & 1)) * PLANE + (ky >> 1) * pitch + (kx >> 1) : ky * pitch + kx * d;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) af[mb] = __builtin_bit_cast(bf16x8, Wc[tap * 2 * CO_T + mb * 32]);
+        for (int pt = 0; pt < NPART; ++pt) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bf[nb] = __builtin_bit_cast(bf16x8, Pc[pixpos[nb] + toff]);
+          for (int mb = 0; mb < MB; ++mb) af[pt][mb] = __builtin_bit_cast(bf16x8, Wc[pt * WPART + tap * 2 * CO_T + mb * 32]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bf[pt][nb] = __builtin_bit_cast(bf16x8, Pc[pt * PPART + pixpos[nb] + toff]);
+        }
       };
       load_tap(0, a[0], bq[0]);
 #pragma unroll
@@ -297,8 +326,13 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3) ? 4 : 2) voi
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][mb], bq[cs][nb], acc[mb][nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb) {
+            if constexpr (SPLIT) {  // small terms first
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][1][mb], bq[cs][0][nb], acc[mb][nb], 0, 0, 0);
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0][mb], bq[cs][1][nb], acc[mb][nb], 0, 0, 0);
+            }
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cs][0][mb], bq[cs][0][nb], acc[mb][nb], 0, 0, 0);
+          }
         if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
           if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
@@ -473,7 +507,7 @@ static int bf_pitch(int twl, int pc) {
   return pch >= pc ? pch : pch + 16;
 }
 
-static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows) {
+static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, int npart) {
   int sw;  // width of the tile grid (the narrowest sub-image of a dilation-group launch decides the tile width)
   if (mode == M_TC) sw = q.W + 1;
   else if (mode == M_S2) sw = q.OW;
@@ -496,18 +530,18 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows) {
     npl = 4;
   }
   r.pt = (ntask + 127) / 128;
-  r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * npl * r.plane) * 16;
+  r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * npl * r.plane) * 16 * npart;
   const size_t epi = (size_t)erows * npix * sizeof(float);  // epilogue transpose buffer
   if (epi > r.lds) r.lds = epi;
   return r;
 }
 
-template <int MB, int NB, int WM, int WN, int PT, int MODE>
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_bf16: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
@@ -530,13 +564,22 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
     blocks = ((EW + TW - 1) / TW) * ((EH + TH - 1) / TH);
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE><<<grid, BNT, gm.lds, stream>>>(q);
+  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT><<<grid, BNT, gm.lds, stream>>>(q);
   return VSP_OK;
 }
 
 template <int MB, int NB, int WM, int WN, int MODE>
+int launch_split(const ConvK& q, hipStream_t stream) {
+  const BfGeom gm = bf_geom(q, MODE, 32 * MB * WM, 32 * NB * WN, 32 * WM, 2);
+  if (gm.lds > 150 * 1024) return vsp::fail(VSP_ENOTSUP, "conv2d_bf16x3: tile does not fit LDS");
+  if (gm.pt <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE, true>(q, gm, stream);
+  if (gm.pt <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE, true>(q, gm, stream);
+  return vsp::fail(VSP_ENOTSUP, "conv2d_bf16x3: patch plane of %d positions is too large", gm.plane);
+}
+
+template <int MB, int NB, int WM, int WN, int MODE>
 int launch_shape(const ConvK& q, hipStream_t stream) {
-  const BfGeom gm = bf_geom(q, MODE, 32 * MB * WM, 32 * NB * WN, 32 * WM);
+  const BfGeom gm = bf_geom(q, MODE, 32 * MB * WM, 32 * NB * WN, 32 * WM, 1);
   if (gm.lds > 150 * 1024) return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: tile does not fit LDS");
   if (gm.pt <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE>(q, gm, stream);
   if (MODE != M_TC && gm.pt <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE>(q, gm, stream);
@@ -550,6 +593,31 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 // variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
 //          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions,
 //          8 = 32 ch x 256 positions
+// split = 1: the bf16x3 form (stride-1 / stride-2 modes): variants 1 = 32 ch x 256 px, 4 = 64 ch x 128 px, 7 = 32 ch x 128 px
+int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream) {
+  if (mode == M_S2) {
+    switch (variant) {
+      case 0:
+      case 7: return launch_split<1, 1, 1, 4, M_S2>(q, stream);  // 32 ch x 128 px: the doubled parity planes leave room for no more
+      default: return vsp::fail(VSP_EINVAL, "conv2d_bf16x3: unknown stride-2 variant %d", variant);
+    }
+  }
+  if (mode == M_TC) {
+    switch (variant) {
+      case 0:
+      case 5: return launch_split<1, 1, 1, 4, M_TC>(q, stream);
+      default: return vsp::fail(VSP_EINVAL, "conv2d_bf16x3: unknown transposed variant %d", variant);
+    }
+  }
+  if (variant == 0) variant = q.cout_g <= 32 ? 1 : 4;
+  switch (variant) {
+    case 1: return launch_split<1, 2, 1, 4, M_CONV>(q, stream);
+    case 4: return launch_split<2, 1, 1, 4, M_CONV>(q, stream);
+    case 7: return launch_split<1, 1, 1, 4, M_CONV>(q, stream);
+    default: return vsp::fail(VSP_EINVAL, "conv2d_bf16x3: unknown variant %d", variant);
+  }
+}
+
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_TC) {
     if (variant == 0) variant = 5;  // 32-channel tiles: 122 VGPRs, more workgroups in flight (tools/bench_bf16_s2t.py)

@@ -320,7 +320,11 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
   return vsp::check_launch("conv2d_winograd");
 }
 
-extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split);
+extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false); }
+extern "C" int vsp_conv2d_bf16x3(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, true); }
+
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split) {
   VSP_REQUIRE(pp != nullptr, "conv2d_bf16: null params");
   vsp_conv_params pcopy = *pp;
   int mode = 0;
@@ -372,6 +376,10 @@ extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) {
     q.bf_ish_s = q.in_shift ? 1 : 0;
     if (!q.in_scale) { q.in_scale = kc; q.in_scale_bstride = 0; }
     if (!q.in_shift) q.in_shift = kc + 1;
+  }
+  if (split) {
+    if (int rc = vspconv::bf16_launch_split(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
+    return vsp::check_launch("conv2d_bf16x3");
   }
   if (int rc = vspconv::bf16_launch(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_bf16");

@@ -172,7 +172,7 @@ class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
-    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino", "_bf16")
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino", "_bf16", "_bf16x3")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -184,6 +184,7 @@ class PackedConv:
         self.pad_x = rep(pad_y if pad_x is None else pad_x, 0)
         self._wino = None
         self._bf16 = None
+        self._bf16x3 = None
 
     @property
     def cout(self):
@@ -205,9 +206,17 @@ class PackedConv:
         return self._bf16
 
 
+    def bf16x3_weight(self):
+        """hi + lo bf16 parts of the weight in the LDS-image order of vsp_conv2d_bf16x3, built on first use."""
+        if self._bf16x3 is None:
+            with torch.no_grad():
+                self._bf16x3 = bf16x3_weight(self.w)
+        return self._bf16x3
+
+
 # "bf16 kernels" configuration (BASELINE configs[2]): eligible convolutions run on vsp_conv2d_bf16 (bf16 MFMA, fp32
 # accumulate, fp32 activations in HBM).  Off by default: the parity path is fp32 end to end.
-BF16_CONV = False
+BF16_CONV = False   # True: bf16 operands; "x3": split precision (hi + lo bf16 pairs, three MFMAs per product: fp32-grade results)
 
 
 def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
@@ -250,6 +259,19 @@ def bf16_weight(wp):
     Wz[:, :, :cin, :cout] = wp
     Wz = Wz.view(ng, T, nch, 2, 8, co_pad).permute(0, 2, 1, 3, 5, 4)
     return Wz.to(torch.bfloat16).contiguous().view(-1)
+
+
+def bf16x3_weight(wp):
+    """packed weights (G, 9, Cin, cout_g) fp32 -> [group][chunk][part 2][tap][octet 2][co_pad][8] bf16 with part 0 = bf16(W),
+    part 1 = bf16(W - float(bf16(W))) (vsp_conv2d_bf16x3)."""
+    ng, T, cin, cout = wp.shape
+    nch, co_pad = (cin + 15) // 16, (cout + 31) // 32 * 32
+    Wz = wp.new_zeros(ng, T, nch * 16, co_pad)
+    Wz[:, :, :cin, :cout] = wp
+    hi = Wz.to(torch.bfloat16)
+    lo = (Wz - hi.float()).to(torch.bfloat16)
+    parts = torch.stack([hi, lo], 0).view(2, ng, T, nch, 2, 8, co_pad).permute(1, 3, 0, 2, 4, 6, 5)
+    return parts.contiguous().view(-1)
 
 
 def pack_weight(weight, groups=1):
@@ -346,8 +368,12 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             pref = TUNE.get("8" + key[key.index(","):], 0)
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
+    x3 = bf16 == "x3" or (bf16 is None and BF16_CONV == "x3")
     if bf16 is None:
-        bf16 = BF16_CONV and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
+        bf16 = bool(BF16_CONV) and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
+        if x3 and bf16:  # split precision: doubled LDS images -- the layers where it beats the tuned fp32 kernels (tools/conv_breakdown.py)
+            bf16 = (transposed and W >= 32) or (not transposed and (
+                (pc.stride == 1 and pc.cout_g >= 32) or (pc.stride == 2 and pc.G == 1 and OW >= 32)))
     elif bf16 and not bf_ok:
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
     if bf16:
@@ -369,7 +395,17 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     prof = PROFILER
     if prof is not None:
         start = prof.begin()
-    if bf16:
+    if bf16 and x3:
+        bw = pc.bf16x3_weight()
+        keep.append(bw)
+        p.w = bw.data_ptr()
+        rc = lib.vsp_conv2d_bf16x3(C.byref(p), _stream())
+        if rc == -3:  # VSP_ENOTSUP: the doubled LDS images of this shape do not fit (small stride-2 maps) -> the fp32 kernel
+            p.w, bf16 = pc.w.data_ptr(), False
+            check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
+        else:
+            check(rc, "conv2d_bf16x3")
+    elif bf16:
         bw = pc.bf16_weight()
         keep.append(bw)
         p.w = bw.data_ptr()
@@ -392,7 +428,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     else:
         check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, "bf16" if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct")), key))
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else "bf16") if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct")), key))
     return out
 
 
