@@ -143,6 +143,16 @@ def test_bf16_weight_lds_image_layout_cpu():
         assert not full[:, :, :, :, cout_g:, :].any()
         if cin % 16:
             assert not full[:, -1, :, 1 if cin % 16 <= 8 else 2:, :, :].any()
+    # split-precision packing (vsp_conv2d_bf16x3): part 0 + part 1 reproduce the weight to 2^-16, parts are chunk-interleaved
+    w = rng.standard_normal((2, 20, 24, 3, 3)).astype(np.float32)
+    wp = torch.stack([H.pack_weight(torch.from_numpy(w[g]))[0] for g in range(2)])
+    both = H.bf16x3_weight(wp).float().numpy().reshape(2, 2, 2, 9, 2, 32, 8)   # [g][chunk][part][tap][octet][co_pad][8]
+    rec = both[:, :, 0] + both[:, :, 1]                                        # [g][chunk][tap][octet][co][8]
+    for g in range(2):
+        for ci in range(24):
+            got = rec[g, ci // 16, :, (ci % 16) // 8, :20, ci % 8]                    # [tap][co]
+            want = w[g, :, ci].reshape(20, 9).T
+            assert np.abs(got - want).max() <= np.abs(want).max() * 2.0 ** -15
     x = torch.from_numpy(rng.standard_normal((1, 24, 9, 9)).astype(np.float32))
     w0 = torch.from_numpy(rng.standard_normal((20, 24, 3, 3)).astype(np.float32))
     ref = F.conv2d(x.to(torch.bfloat16).float(), w0.to(torch.bfloat16).float(), padding=1)

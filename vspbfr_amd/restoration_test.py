@@ -65,12 +65,13 @@ def main(argv=None):
     ap.add_argument("--data_name_list", type=str, default="")
     ap.add_argument("--timesteps", type=int, default=4, help="extension: DDPM steps (the reference hard-codes 4, :35-38)")
     ap.add_argument("--no_sample", action="store_true", help="extension: skip the 1024^2 tail and the *_sample.png output")
-    ap.add_argument("--conv_dtype", choices=["f32", "bf16"], default="f32",
-                    help="extension: bf16 = the bf16-kernel configuration (vsp_conv2d_bf16; not the parity path)")
+    ap.add_argument("--conv_dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="extension: bf16 = the bf16-kernel configuration (vsp_conv2d_bf16; not the parity path); "
+                         "bf16x3 = split-precision operands on the bf16 pipe (fp32-grade)")
     args = ap.parse_args(argv)
     args.latent, args.n_mlp = 512, 8
     from . import hip_ops
-    hip_ops.BF16_CONV = args.conv_dtype == "bf16"
+    hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
