@@ -10,17 +10,18 @@ def t(f, n=5):
     for _ in range(n): f()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1000
+X3 = bool(os.environ.get("X3"))   # X3=1: the split-precision form (vsp_conv2d_bf16x3, variants 1 / 4 / 7)
 def run(x, pc, sc, fl, tag):
     uf = t(lambda: H.conv2d_packed(x, pc, in_scale=sc))
     ref = H.conv2d_packed(x, pc, in_scale=sc)
     out = [f"{tag}: fp32 {uf:.0f} us {fl/uf/1e6:.0f} TF |"]
-    for v in (0, 1, 2, 3, 4, 6, 7):
+    for v in ((0, 1, 4, 7) if X3 else (0, 1, 2, 3, 4, 6, 7)):
         try:
-            ub = t(lambda: H.conv2d_packed(x, pc, in_scale=sc, bf16=True, tile_hint=v))
+            ub = t(lambda: H.conv2d_packed(x, pc, in_scale=sc, bf16="x3" if X3 else True, tile_hint=v))
         except RuntimeError as ex:
             out.append(f" v{v} n/a"); continue
         out.append(f" v{v} {ub:.0f} us {fl/ub/1e6:.0f} TF x{uf/ub:.2f} |")
-    err = (H.conv2d_packed(x, pc, in_scale=sc, bf16=True) - ref).abs().max().item() / ref.abs().max().item()
+    err = (H.conv2d_packed(x, pc, in_scale=sc, bf16="x3" if X3 else True) - ref).abs().max().item() / ref.abs().max().item()
     print("".join(out) + f" rel err {err:.1e}", flush=True)
 B = int(os.environ.get("B", 8))
 for (Cin, Cout, S) in [(64, 64, 512), (128, 128, 256), (256, 256, 128), (512, 512, 64), (512, 512, 32), (256, 256, 32),

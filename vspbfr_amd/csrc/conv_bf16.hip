@@ -609,7 +609,8 @@ int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream)
       default: return vsp::fail(VSP_EINVAL, "conv2d_bf16x3: unknown transposed variant %d", variant);
     }
   }
-  if (variant == 0) variant = q.cout_g <= 32 ? 1 : 4;
+  if (variant == 0)  // tools/bench_bf16.py with X3=1: the 32-channel tiles keep two workgroups per CU with the doubled LDS images
+    variant = (q.G == 1 && (int64_t)q.H * q.W >= 64 * 64) ? 1 : 7;
   switch (variant) {
     case 1: return launch_split<1, 2, 1, 4, M_CONV>(q, stream);
     case 4: return launch_split<2, 1, 1, 4, M_CONV>(q, stream);

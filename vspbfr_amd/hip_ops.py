@@ -373,7 +373,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         bf16 = bool(BF16_CONV) and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
         if x3 and bf16:  # split precision: doubled LDS images -- the layers where it beats the tuned fp32 kernels (tools/conv_breakdown.py)
             bf16 = (transposed and W >= 32) or (not transposed and (
-                (pc.stride == 1 and pc.cout_g >= 32) or (pc.stride == 2 and pc.G == 1 and OW >= 32)))
+                pc.stride == 1 or (pc.stride == 2 and pc.G == 1 and OW >= 32)))
     elif bf16 and not bf_ok:
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
     if bf16:
