@@ -64,10 +64,10 @@ TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_I
 WINO = {k: True for k, v in _load_tune_table().items() if v == "winograd"}  # shapes where the F(2x2,3x3) kernel won
 
 
-def _load_bf16_tune():
+def _load_bf16_tune(name="conv_tune_bf16.json"):
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune_bf16.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     if not os.path.exists(path):
         return {}
     with open(path) as f:
@@ -77,6 +77,7 @@ def _load_bf16_tune():
 # shape key -> tile variant of vsp_conv2d_bf16 measured fastest INSIDE the pipeline (tools/autotune_bf16.py); other shapes use the
 # library's rule.  BF16_FORCE (tuner only): variant tried on every launch it fits.
 BF16_TUNE = _load_bf16_tune()
+BF16X3_TUNE = _load_bf16_tune("conv_tune_bf16x3.json")
 BF16_FORCE = 0
 
 
@@ -399,7 +400,14 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         bw = pc.bf16x3_weight()
         keep.append(bw)
         p.w = bw.data_ptr()
+        if tile_hint == 0:
+            p.tile_hint = BF16X3_TUNE.get(key, BF16X3_TUNE.get("8" + key[key.index(","):], 0))
+            if BF16_FORCE:
+                p.tile_hint = BF16_FORCE
         rc = lib.vsp_conv2d_bf16x3(C.byref(p), _stream())
+        if rc != 0 and BF16_FORCE and tile_hint == 0:  # tuner: the forced variant does not serve this launch
+            p.tile_hint = 0
+            rc = lib.vsp_conv2d_bf16x3(C.byref(p), _stream())
         if rc == -3:  # VSP_ENOTSUP: the doubled LDS images of this shape do not fit (small stride-2 maps) -> the fp32 kernel
             p.w, bf16 = pc.w.data_ptr(), False
             check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
