@@ -36,13 +36,13 @@ def measure(force, reps=3):
     return agg
 
 
-res = {v: measure(v) for v in ((0, 1, 4, 5, 7) if X3 else (0, 1, 2, 3, 4, 5, 6, 7, 8))}
+res = {v: measure(v) for v in ((0, 1, 4, 5, 6, 7) if X3 else (0, 1, 2, 3, 4, 5, 6, 7, 8))}
 best, tot_auto, tot_best = {}, 0.0, 0.0
 for key in sorted(res[0], key=lambda k: -res[0][k]):
     f = key.split(",")
     valid = {4, 5, 8} if key.endswith(",t") else ({4, 6} if f[8] == "2" else {1, 2, 3, 4, 6, 7})  # variants of the launch's mode
     if X3:
-        valid = {5} if key.endswith(",t") else ({7} if f[8] == "2" else {1, 4, 7})
+        valid = {5} if key.endswith(",t") else ({6, 7} if f[8] == "2" else {1, 4, 7})
     cand = {v: r[key] for v, r in res.items() if key in r and (v == 0 or v in valid)}  # (others fell back to the library rule)
     v = min(cand, key=cand.get)
     tot_auto += cand[0]; tot_best += cand[v]

@@ -597,8 +597,9 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream) {
   if (mode == M_S2) {
     switch (variant) {
-      case 0:
-      case 7: return launch_split<1, 1, 1, 4, M_S2>(q, stream);  // 32 ch x 128 px: the doubled parity planes leave room for no more
+      case 7: return launch_split<1, 1, 1, 4, M_S2>(q, stream);  // 32 ch x 128 px
+      case 0:   // 64 ch x 64 px: half the patch staging per MFMA (the doubled parity planes leave room for one workgroup per CU
+      case 6: return launch_split<1, 1, 2, 2, M_S2>(q, stream);  // either way); stem 512 -> 5632: 3.2 -> 2.7 ms
       default: return vsp::fail(VSP_EINVAL, "conv2d_bf16x3: unknown stride-2 variant %d", variant);
     }
   }
