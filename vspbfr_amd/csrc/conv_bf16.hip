@@ -64,7 +64,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
   constexpr int NPL = S2 ? 4 : 1;          // patch planes per channel octet (stride 2: parity planes)
   // 32-channel tiles (40 KB LDS) live on occupancy instead (<= 128 VGPRs); the transposed mode has 128 accumulator registers
-  constexpr bool DEEP = PT <= 3 && !(MB == 1 && MODE == M_CONV) && MODE != M_TC && !SPLIT;
+#ifndef VSP_X3_DEEP
+#define VSP_X3_DEEP 0   // two-set prefetch under SPLIT measured equal (three MFMAs per product already cover the load latency)
+#endif
+  constexpr bool DEEP = PT <= 3 && MODE != M_TC && (SPLIT ? bool(VSP_X3_DEEP) : !(MB == 1 && MODE == M_CONV));
 #ifndef VSP_BF16_COMMIT_FIRST
 #define VSP_BF16_COMMIT_FIRST 0   // 1: convert at the top of the interval and issue the weight DMA there (measured equal: the
 #endif                             // interval is bound by the load latency that the closing vmcnt(0) + barrier exposes)
