@@ -1,11 +1,17 @@
 """bench.py -- throughput of the restoration hot path on MI355X (contract in the round prompt).
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched through torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torchrun environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+CHILD process before anything in this process touches the GPU and exits with its code (rank 0's JSON line passes through);
+launched by torchrun itself (RANK / WORLD_SIZE set) it is one rank of the job.
 
 One step = one batch through A (e4e encoder) -> B (Code_diffuser DDPM chain) -> C (StyleGAN2 prior decoder, up to
 1024^2 as the reference does) -> D (Restoration_net), LQ batch resident in HBM, restored batch left in HBM
 (BASELINE.json configs[1]: batch 8 per GPU, 512x512, T = 50, fp32, random-init weights, synthetic inputs).
-N > 1: every rank runs the same per-GPU batch (weak scaling) and the restored images are all-gathered with RCCL.
+N > 1: every rank runs its own shard of the global batch (weak scaling: the per-GPU batch is fixed) and the restored images
+are all-gathered with RCCL.  Inputs and every noise draw are functions of (seed, GLOBAL image index): the job restores the
+same images whatever N is (vsp_keyed_fill_f32).
 """
 import argparse
 import json
@@ -23,7 +29,54 @@ PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 M
 ALGO_GFLOP_PER_IMAGE = lambda T: 706.9 + 0.455 * T  # noqa: E731  SURVEY.md section 8(d)
 
 
-def build_pipeline(dev, T, with_sample):
+def self_launch(n):
+    """--gpus N > 1 outside torchrun: run the N-rank job as a child process.  Nothing here may initialise the GPU: replacing or
+    forking a process that holds a HIP context is what the GPU boxes forbid (torch.cuda.device_count() does not initialise)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "--launch-check" not in sys.argv:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+PRESETS = {  # BASELINE.json configs[1..3]
+    "c2": dict(batch=8, timesteps=50, sampler="ddpm", conv_dtype="f32"),
+    "c3": dict(batch=16, timesteps=50, sampler="ddim", ddim_steps=25, conv_dtype="bf16"),
+    "c4": dict(batch=16, timesteps=50, sampler="ddpm", conv_dtype="f32"),
+}
+
+
+def launch_check(args, world, rank):
+    """--launch-check: the job's control path without a GPU (tests/test_distributed_cpu.py): ranks rendezvous over gloo, every
+    rank takes its shard of a stand-in global batch whose values encode the GLOBAL image index, the shards are all-gathered
+    by the path's own gather_restored and rank 0 prints the JSON line (value null: nothing was measured)."""
+    import torch.distributed as dist
+    from vspbfr_amd.pipeline import gather_restored, shard_range
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = args.batch
+    lo, hi = shard_range(world * B, rank, world)
+    assert (lo, hi) == (rank * B, (rank + 1) * B)
+    local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 3, 8, 8).contiguous()
+    full = gather_restored(local) if world > 1 else local
+    ok = torch.equal(full[:, 0, 0, 0], torch.arange(world * B, dtype=torch.float32))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "restored 512x512 faces/sec", "value": None, "unit": "img/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "launch_check": "ok" if ok else "gathered batch out of order"}), flush=True)
+    return 0 if ok else 1
+
+
+def build_pipeline(dev, T, with_sample, noise_seed=None):
     from vspbfr_amd.diffusion import Code_diffuser, My_DDPM
     from vspbfr_amd.e4e import E4e_embedding, Encoder4Editing, Generator
     from vspbfr_amd.pipeline import RestorationPipeline
@@ -40,7 +93,7 @@ def build_pipeline(dev, T, with_sample):
             "opts": {"encoder_type": "Encoder4Editing", "stylegan_size": 1024, "start_from_latent_avg": True}}
     psp = E4e_embedding(ckpt, out_size=512, size=1024, device=dev, use_generator=True)
     ddpm = My_DDPM(denoise=net.to(dev).eval(), timesteps=T).to(dev)  # default betas (1e-4, 2e-2), SURVEY 8a row 8
-    return RestorationPipeline(gen.to(dev).eval(), psp, ddpm, mixing=0.0, with_sample=with_sample)
+    return RestorationPipeline(gen.to(dev).eval(), psp, ddpm, mixing=0.0, with_sample=with_sample, noise_seed=noise_seed)
 
 
 def cpu_baseline(T, threads, sample_steps=2):
@@ -93,15 +146,28 @@ def main():
                     help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
                          "fp32 activations in HBM); not the parity configuration.  bf16x3 = the same kernels with hi + lo bf16 "
                          "operand pairs and three MFMAs per product (vsp_conv2d_bf16x3): fp32-grade results on the bf16 pipe")
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configuration: c2 = batch 8, 50-step DDPM, fp32 (the default); c3 = batch 16, DDIM 25, bf16 "
+                         "kernels; c4 = batch 16 per GPU (128 on 8 GPUs), 50-step DDPM, fp32")
+    ap.add_argument("--seed", type=int, default=123, help="seed of the keyed input / noise draws")
+    ap.add_argument("--torch-rng", action="store_true", help="draw noise from torch's device RNG stream (one randn per consumer, "
+                                                              "as the reference does) instead of the keyed single-launch draws")
+    ap.add_argument("--launch-check", action="store_true", help="no GPU work: self-launch, rendezvous (gloo), shard + all-gather "
+                                                                 "of a stand-in batch, JSON line with value null")
     args = ap.parse_args()
+    if args.preset:
+        for k, v in PRESETS[args.preset].items():
+            setattr(args, k, v)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...")
+    if args.launch_check:
+        raise SystemExit(launch_check(args, world, rank))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -111,7 +177,7 @@ def main():
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
     hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
-    pipe = build_pipeline(dev, args.timesteps, not args.no_sample)
+    pipe = build_pipeline(dev, args.timesteps, not args.no_sample, None if args.torch_rng else args.seed)
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
         ddpm, S = pipe.diffusion, args.ddim_steps
@@ -123,8 +189,16 @@ def main():
                                       verbose=False, x_T=x_T)[0]
         pipe.diffusion = _DDIM()
     B = args.batch
-    g = torch.Generator(device=dev).manual_seed(123 + rank)
-    lq = torch.rand(B, 3, 512, 512, device=dev, generator=g) * 2 - 1
+    # this rank's shard of the global LQ batch: images [rank*B, (rank+1)*B), uniform(-1, 1) keyed by the global image index
+    lq = hip_ops.keyed_fill([(B, 3, 512, 512)], [hip_ops.SEG_LQ], args.seed, rank * B, dist="uniform", device=dev)[0]
+    step_no = [0]
+
+    def batches(n):
+        """n steps: the same LQ shard with fresh noise -- step k restores global images [k*W*B, (k+1)*W*B)."""
+        for _ in range(n):
+            k = step_no[0]
+            step_no[0] += 1
+            yield lq, (k * world + rank) * B
 
     def run(n):
         """n steps = n batches through A+B+C+D.  --overlap (default): RestorationPipeline.run_batches, i.e. stages A+B of
@@ -132,14 +206,14 @@ def main():
         every batch is complete when the closing synchronize returns."""
         res = None
         if args.no_overlap:
-            for _ in range(n):
-                res = pipe(lq)["restored"]
+            for x, i0 in batches(n):
+                res = pipe(x, image_index0=i0)["restored"]
                 res = gather_restored(res) if world > 1 else res
         elif args.graphs:
-            for o in pipe.run_batches_graphed(lq for _ in range(n)):
+            for o in pipe.run_batches_graphed(batches(n)):
                 res = gather_restored(o["restored"]) if world > 1 else o["restored"]
         else:
-            for o in pipe.run_batches(lq for _ in range(n)):
+            for o in pipe.run_batches(batches(n)):
                 res = gather_restored(o["restored"]) if world > 1 else o["restored"]
         return res
 
@@ -202,6 +276,8 @@ def main():
                        "sampler": args.sampler if args.sampler == "ddpm" else f"ddim S={args.ddim_steps}",
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
                        "launch": "two captured HIP graphs (A+B, C+D) replayed per batch" if args.graphs else "eager (one host launch per kernel)",
+                       "rng": "torch device RNG, one randn per consumer" if args.torch_rng else
+                              "keyed Philox draws by (seed, global image index): 2 launches per batch, world-size invariant",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),

@@ -358,6 +358,19 @@ typedef struct vsp_tacc_chain_params {
 size_t vsp_tacc_chain_work_floats(int B);
 int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Keyed random tensors -- replaces the path's global-RNG draws: one `image.new_empty(B,1,H,W).normal_()` per NoiseInjection
+ * (reference models/RestoreNet.py:564-569, e4e/models/stylegan2/model.py:287-292), `torch.randn(shape)` for x_T
+ * (ldm/ddpm.py:423), `torch.randn(batch, latent_dim)` for z (restoration_test.py:77-82) and the synthetic LQ batch of the
+ * benchmark.  ONE launch fills n_seg tensors laid out back to back in `out`, segment s = [B][seg_elems[s]] floats;
+ *   value(s, b, e) = f( Philox4x32-10( key = seed, counter = (e / 4, seg_ids[s], image_index0 + b) ) word e % 4 ),
+ * dist 0: standard normal (Box-Muller), dist 1: uniform(-1, 1).  The value depends on the GLOBAL image index only, so a
+ * batch sharded over ranks draws what a single GPU would (SURVEY 8e "per-rank RNG streams derived from (seed, global image
+ * index)").  seg_elems / seg_ids are HOST arrays; n_seg <= VSP_NOISE_MAX_SEGMENTS. */
+#define VSP_NOISE_MAX_SEGMENTS 64
+int vsp_keyed_fill_f32(float* out, int B, const int64_t* seg_elems, const int32_t* seg_ids, int n_seg, uint64_t seed,
+                       int64_t image_index0, const int64_t* image_index0_dev, int dist, vsp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ DIFFUSER_CASES = {
     # name -> (batch, timesteps, linear_start, linear_end)
     "ddpm_T4": (2, 4, 0.1, 0.99),          # what restoration_test.py:35-38 runs
     "ddpm_T10": (2, 10, 1e-4, 2e-2),
+    "ddpm_T50": (2, 50, 1e-4, 2e-2),       # BASELINE configs[1]: the full-length chain, default betas (ldm/ddpm.py:256-257)
 }
 DDIM_CASE = ("ddim_T50_S25", 2, 50, 25)  # name, batch, DDPM steps, DDIM steps (BASELINE config 3; default betas)
 

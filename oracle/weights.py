@@ -71,6 +71,21 @@ def synth_tensor(model, name, shape, dtype, seed):
     if model == "diffuser":
         if re.search(r"(gamma_|beta_)\.1\.(weight|bias)$", name):  # LayerNorm affine
             return U(0.5, 1.5) if leaf == "weight" else N(0.1)
+        if re.search(r"beta_\.3\.(weight|bias)$", name):
+            # Conditioning of the sampler chain x <- c1*f(x, c) + c2*x (ldm/ddpm.py:400-429).  Every TACC block sees x
+            # only through PixelNorm over the 18 tokens (models/CodeDiffuser.py:86), so its Jacobian w.r.t. x is
+            # L_block / rms(x) with L_block ~ 2-4 for random projections, and rms(x) is set by the previous block's
+            # output LN(.)*(1+gamma) + beta.  With the plain fan-in init the x-independent shift beta is O(1), the gain per
+            # block is ~1.6 and T steps amplify a 1e-5 perturbation ~40x (T=4) to ~600x (T=50): the reference's own fp32
+            # run is then 5e-4 ... 5e-3 away from its fp64 evaluation and no fp32 implementation can be pinned to 1e-3.
+            # A trained denoiser contracts.  Scaling the output layer of the beta head by 4 (shapes and keys untouched) makes
+            # the synthetic one contractive for BOTH kinds of condition the tests use: independent N(0,1) tokens (gain w.r.t.
+            # x_T 4e-3 at T=4) and the e4e encoder's codes, whose 18 tokens share the w0 component (psp_encoders.py:181-198:
+            # gain 0.11 at T=4, 0.01 at T=50; with x2 that case still expands 18x).  The reference's fp32 run is then
+            # 3-5e-5 from its fp64 evaluation on latents of |max| ~25 -- which is what ONE TACC block evaluated in fp32 is
+            # from fp64 on the same input, i.e. the chain no longer amplifies.  tools/condition_probe.py prints these
+            # figures from the reference itself.
+            return (N(0.1) if leaf == "bias" else N(1.0 / math.sqrt(_fan_in(shape)))) * 4.0
         if leaf == "bias":
             return N(0.1)
         w = N(1.0 / math.sqrt(_fan_in(shape)))
@@ -97,7 +112,7 @@ def synth_tensor(model, name, shape, dtype, seed):
     if name.endswith("fusion.0.weight") and model == "restorenet":
         w = w * 0.5
     if re.search(r"to_rgbs?\d*\.(\d+\.)?conv\.weight$", name):
-        w = w * 0.25
+        w = w * 0.15  # ToRGB is not demodulated: its output scales with the latent's rms (~4.4 after the sampler chain)
     return w
 
 

@@ -1,6 +1,10 @@
-"""Multi-process check of the data-parallel plumbing (gloo, world_size 2, CPU): the batch split covers every image once,
-ragged splits work, and the all-gather reassembles the restored batch in rank order on every rank -- the same code path
-bench.py / the CLI use with RCCL on the GPUs."""
+"""Multi-process checks of the data-parallel path (gloo, world_size 2, CPU):
+  * the batch split covers every image once, ragged splits work, and the all-gather reassembles the restored batch in rank
+    order on every rank -- the same code path bench.py / the CLI use with RCCL on the GPUs;
+  * a restoration-shaped computation (the oracle's size-64 Restoration_net standing in for the HIP kernels, which need a GPU)
+    whose inputs and noise maps are keyed by the GLOBAL image index (oracle/device_rng.py = the numpy restatement of
+    vsp_keyed_fill_f32) gives the same images rank-split as on one rank;
+  * `python bench.py --gpus 2` launches itself (child torchrun, no GPU touched by the parent) and relays rank 0's JSON line."""
 import os
 import socket
 import subprocess
@@ -48,3 +52,71 @@ def test_shard_and_gather_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\\n{o}"
         assert f"rank {r} ok" in o
+
+
+PIPE_WORKER = textwrap.dedent("""
+    import os, sys, numpy as np, torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from oracle import cases, device_rng as R, models as OM, weights
+    from vspbfr_amd.pipeline import shard_range, gather_restored, noise_map_shapes
+    from vspbfr_amd import hip_ops as H
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(3)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    size, n, seed, step0 = 64, 3, 77, 40           # ragged global batch (2 + 1), images 40..42 of the job
+    sd = weights.synth_state_dict("restorenet", weights.load_specs()["restorenet64"], cases.SEED)
+
+    def restore(lo, hi):
+        # everything an image consumes is a function of its GLOBAL index lo + b
+        B, i0 = hi - lo, step0 + lo
+        k = lambda shape, sid, dist_="normal": torch.from_numpy(R.keyed_fill((B,) + tuple(shape[1:]), sid, seed, i0, dist_))
+        _, enc_s, dec_s = noise_map_shapes(size, B)
+        assert (enc_s, dec_s) == OM.restoration_noise_shapes(size, B)
+        lq = k((B, 3, size, size), H.SEG_LQ, "uniform")
+        feats = [k((B, 512, 2 ** (j + 2), 2 ** (j + 2)), 200 + j) * 0.5 for j in range(5)]
+        pre, z = k((B, 18, 512), H.SEG_XT), k((B, 512), H.SEG_Z)
+        en = [k(s, H.SEG_ENC + j) for j, s in enumerate(enc_s)]
+        dn = [k(s, H.SEG_DEC + j) for j, s in enumerate(dec_s)]
+        return OM.restoration_net(sd, size, lq, feats, pre, [z], en, dn)
+
+    lo, hi = shard_range(n, rank, world)
+    counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    out = gather_restored(restore(lo, hi).contiguous(), counts)
+    full = restore(0, n)                           # what one rank computes for the whole batch
+    err = float((out - full).abs().max())
+    assert out.shape == (n, 3, size, size) and err < 1e-5, err   # CPU conv kernels are not batch-size invariant bit for bit
+    assert float((full[0] - full[1]).abs().max()) > 1e-2          # the images really differ
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok", err)
+""" % ROOT)
+
+
+def test_sharded_restoration_equals_single_rank(tmp_path):
+    script = tmp_path / "pipe_worker.py"
+    script.write_text(PIPE_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_bench_self_launch_world2():
+    """`python bench.py --gpus 2` with no torchrun environment must start the 2-rank job by itself (as a child process) and
+    hand rank 0's JSON line through; --launch-check runs that control path without GPU work."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["launch_check"] == "ok"

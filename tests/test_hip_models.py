@@ -58,11 +58,10 @@ def test_large_conv_layer_golden(golden, name):
 
 @pytest.mark.parametrize("name", list(cases.DIFFUSER_CASES))
 def test_diffuser_ddpm_golden(golden, name):
-    """Denoiser call: tight.  T-step chain: the map is not contractive with random weights, so fp32 rounding differences
-    accumulate -- the reference's own CPU fp32 chain sits ~4e-4 (T=4) / ~2e-3 (T=10) away from an fp64 evaluation of the
-    same chain.  The chain is therefore checked three ways: teacher-forced per step against the oracle (tight), against the
-    reference's golden end state (bound ~ the fp32 conditioning), and against fp64 truth relative to the reference's own
-    distance from it."""
+    """Denoiser call, teacher-forced steps along the oracle's trajectory (three code paths) and the FREE-RUNNING T-step chain
+    against the reference's golden end state, all to <= 2e-4 ... 3e-4 on latents of |max| ~14 (BASELINE's bound is 1e-3).
+    The synthetic denoiser is mildly contractive (oracle/weights.py, tools/condition_probe.py): the reference's own fp32
+    run is 3-6e-5 from its fp64 evaluation, which is also what ONE TACC block evaluated in fp32 is from fp64."""
     from vspbfr_amd.diffusion import Code_diffuser, My_DDPM
     B, T, ls, le = cases.DIFFUSER_CASES[name]
     sd = weights.synth_state_dict("diffuser", weights.load_specs()["diffuser"], cases.SEED)
@@ -101,8 +100,10 @@ def test_diffuser_ddpm_golden(golden, name):
         x64 = c1[i].double() * OM.code_diffuser(sd64, x64, cond.double(), torch.full((B,), i, dtype=torch.long), T) + c2[i].double() * x64
     e_ref = float(np.abs(g[name + "/final"] - x64.numpy()).max())
     e_hip = float(np.abs(final.cpu().numpy() - x64.numpy()).max())
-    assert e_hip <= max(3 * e_ref, 5e-4), (e_hip, e_ref)
-    assert maxerr(final, g[name + "/final"]) <= max(4 * e_ref, 1e-3)
+    e_gold = maxerr(final, g[name + "/final"])
+    print(f"{name}: free-running chain  HIP vs golden {e_gold:.2e}  HIP vs fp64 {e_hip:.2e}  reference vs fp64 {e_ref:.2e}")
+    assert e_ref < 1e-4            # the fixture itself is well conditioned
+    assert e_gold < 3e-4 and e_hip < 3e-4
 
 
 def test_ddim_sampler_golden(golden):
@@ -216,7 +217,7 @@ def test_pipeline512_golden(golden):
     r = out["restored"]
     q = OM.save_image_quantize(r[:, :, ::8, ::8].cpu()).numpy().astype(np.int32)
     qg = OM.save_image_quantize(torch.from_numpy(g["restored_sub"])).numpy().astype(np.int32)
-    # stages C+D teacher-forced on the reference's denoised latent (isolates the chain's fp32 conditioning)
+    # stages C+D teacher-forced on the reference's denoised latent (stage-wise attribution of the delta)
     sample_tf, feats_tf = pipe.psp.get_stylegan_feats(dev(torch.from_numpy(g["pre_latent"])), noise=gno)
     r_tf = pipe.generator(dev(lq), feats_tf, dev(torch.from_numpy(g["pre_latent"])), z, enc_noise=en, dec_noise=dn)
     rep = {
@@ -242,17 +243,13 @@ def test_pipeline512_golden(golden):
     rep["chain_hip_vs_fp64"] = float(np.abs(out["pre_latent"].cpu().numpy() - x64.numpy()).max())
     json.dump(rep, open("gpurun_out/parity_pipeline512.json", "w"), indent=1)
     print(rep)
-    # stage A, and stages C, D teacher-forced on the reference's latent: BASELINE.json's |d| <= 1e-3 with a wide margin
+    # BASELINE.json's |d| <= 1e-3 per pixel, FREE-RUNNING through A -> B -> C -> D, and every intermediate stage
     assert rep["codes"] < 3e-4
-    assert rep["teacher_forced_restored_sub"] < 1e-3
-    assert rep["teacher_forced_style_sample_sub"] < 1e-3
-    # stage B: with random weights the 4-step chain amplifies a 1e-5 perturbation of its condition ~2000x; the reference's
-    # own fp32 run is rep["chain_ref_fp32_vs_fp64"] (~7e-3) away from fp64 truth.  The HIP chain must be as close to the
-    # truth as the reference is (x3), and the free-running image delta must be explained by the latent delta.
-    assert rep["chain_hip_vs_fp64"] <= 3 * rep["chain_ref_fp32_vs_fp64"] + 1e-4
-    assert rep["pre_latent"] <= 4 * rep["chain_ref_fp32_vs_fp64"] + 1e-4
-    assert rep["restored_sub"] <= 1.0 * rep["pre_latent"] + 1e-4 and rep["restored_crop"] <= 1.0 * rep["pre_latent"] + 1e-4
-    assert rep["style_sample_sub"] <= 3.0 * rep["pre_latent"] + 1e-4
+    assert rep["pre_latent"] < 1e-3
+    assert rep["style_sample_sub"] < 1e-3
+    assert rep["restored_sub"] < 1e-3 and rep["restored_crop"] < 1e-3
+    assert rep["teacher_forced_restored_sub"] < 1e-3 and rep["teacher_forced_style_sample_sub"] < 1e-3
+    assert rep["chain_ref_fp32_vs_fp64"] < 1e-4 and rep["chain_hip_vs_fp64"] < 1e-3
     assert rep["restored_8bit_lsb"] <= 1
     st = np.array([r.mean().item(), r.std().item(), r.abs().max().item()], dtype=np.float32)
     np.testing.assert_allclose(st, g["restored_stats"], rtol=5e-3, atol=5e-3)
@@ -373,3 +370,110 @@ def test_pipeline_graph_replay_matches_eager():
     for a, b in zip(outs, eager):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     assert not torch.equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------- keyed draws / full-size configurations
+def test_pipeline_keyed_noise_is_shard_invariant():
+    """with keyed draws (noise_seed) an image's result depends on its GLOBAL index only -- a batch of 4 at images
+    8..11 equals two batches of 2 at 8..9 and 10..11 (what two ranks would compute), through __call__ and through the
+    two-stream loop; a different index or seed gives a different image."""
+    pipe = build_pipeline(with_sample=False)
+    pipe.noise_seed = 5
+    lq = dev(cases.image_batch("keyed", 4, 512))
+    full = pipe(lq, image_index0=8)
+    halves = [pipe(lq[0:2].contiguous(), image_index0=8), pipe(lq[2:4].contiguous(), image_index0=10)]
+    for k in ("pre_latent", "restored"):
+        assert maxerr(torch.cat([h[k] for h in halves]), full[k]) < 1e-5, k      # conv tile choice depends on B: not bit-exact
+    looped = list(pipe.run_batches([(lq[0:2].contiguous(), 8), (lq[2:4].contiguous(), 10)]))
+    assert maxerr(torch.cat([o["restored"] for o in looped]), full["restored"]) < 1e-5
+    assert maxerr(pipe(lq[0:2].contiguous(), image_index0=9)["restored"], halves[0]["restored"]) > 1e-3
+    pipe.noise_seed = 6
+    assert maxerr(pipe(lq[0:2].contiguous(), image_index0=8)["restored"], halves[0]["restored"]) > 1e-3
+    # the draws are exactly what the numpy restatement of the generator gives for these global indices
+    from oracle import device_rng as R
+    from vspbfr_amd import hip_ops as H
+    zs, gen, enc, dec = pipe.draw_decode_noise(2, 10, DEV)
+    assert len(zs) == 1 and len(gen) == 15 and len(enc) == 14 and len(dec) == 15
+    assert maxerr(enc[0], R.keyed_fill((2, 1, 512, 512), H.SEG_ENC, 6, 10)) < 2e-6
+    assert maxerr(dec[-1], R.keyed_fill((2, 1, 512, 512), H.SEG_DEC + 14, 6, 10)) < 2e-6
+
+
+def _oracle_chain(sd, codes, x_T, T, ls=1e-4, le=2e-2):
+    return OM.ddpm_sample(sd, codes, x_T, T, ls, le)
+
+
+def test_config_c2_full_size():
+    """BASELINE.json configs[1] exactly: batch 8, 512^2, 50-step DDPM (default betas), fp32 kernels, prior decoded to 1024^2.
+    (a) the T = 50 chain of all 8 images, FREE-RUNNING on the HIP encoder's codes, against the CPU oracle on the same codes
+    and x_T; (b) every image of the batch against its own batch-1 run (the sharding premise at the benchmark's size);
+    (c) the step through the two-stream loop equals the plain call."""
+    from oracle import device_rng as R
+    from vspbfr_amd import hip_ops as H
+    B, T, seed, i0 = 8, 50, 2025, 16
+    pipe = build_pipeline(T=T, linear_start=1e-4, linear_end=2e-2, with_sample=True)
+    pipe.noise_seed = seed
+    lq = H.keyed_fill([(B, 3, 512, 512)], [H.SEG_LQ], seed, i0, dist="uniform")[0]
+    out = pipe(lq, image_index0=i0)
+    assert out["restored"].shape == (B, 3, 512, 512) and out["style_sample"].shape == (B, 3, 512, 512)
+    assert torch.isfinite(out["restored"]).all() and torch.isfinite(out["style_sample"]).all()
+    # (a)
+    sd = weights.synth_state_dict("diffuser", weights.load_specs()["diffuser"], cases.SEED)
+    x_T = torch.from_numpy(R.keyed_fill((B, 18, 512), H.SEG_XT, seed, i0))
+    e_chain = maxerr(out["pre_latent"], _oracle_chain(sd, out["latent"].cpu(), x_T, T))
+    # (b)
+    e_one = 0.0
+    for b in range(B):
+        one = pipe(lq[b:b + 1].contiguous(), image_index0=i0 + b)
+        e_one = max(e_one, maxerr(one["restored"], out["restored"][b:b + 1]), maxerr(one["style_sample"], out["style_sample"][b:b + 1]))
+    # (c)
+    looped = list(pipe.run_batches([(lq, i0)]))[0]
+    print(f"C2: chain vs oracle {e_chain:.2e}   image vs its batch-1 run {e_one:.2e}   |restored|max {float(out['restored'].abs().max()):.2f}")
+    assert e_chain < 5e-4     # measured 2.3e-4 over 8 images x 50 steps on latents of |max| ~25 (BASELINE: 1e-3)
+    assert e_one < 1e-5
+    assert torch.equal(looped["restored"], out["restored"])
+
+
+def test_config_c3_full_size():
+    """BASELINE.json configs[2] exactly: batch 16, 512^2, DDIM S = 25 on T = 50, bf16 kernels.  The fp32 HIP run of the same
+    step is the yardstick: (a) its DDIM chain against the oracle's sampler on the same codes; (b) the bf16 configuration's
+    restored batch against it -- bf16 operands (2^-8 relative per product) cannot meet the 1e-3 parity bound, the bound here is
+    rms <= 3 % / max <= 25 % of the image's std, and <= 2 LSB on average after the save_image quantiser."""
+    from oracle import device_rng as R
+    from vspbfr_amd import hip_ops as H
+    from vspbfr_amd.ddim import DDIMSampler
+    B, T, S, seed, i0 = 16, 50, 25, 77, 0
+    pipe = build_pipeline(T=T, linear_start=1e-4, linear_end=2e-2, with_sample=True)
+    pipe.noise_seed = seed
+    ddpm = pipe.diffusion
+    sampler = DDIMSampler(ddpm, device=DEV)
+
+    class _DDIM(torch.nn.Module):
+        def forward(self, x=None, condi_in=None, training=False, x_T=None):
+            return sampler.sample(S=S, batch_size=condi_in.shape[0], shape=18 * 512, conditioning=condi_in, eta=0.0, verbose=False,
+                                  x_T=x_T)[0].view(condi_in.shape)
+    pipe.diffusion = _DDIM()
+    lq = H.keyed_fill([(B, 3, 512, 512)], [H.SEG_LQ], seed, i0, dist="uniform")[0]
+    ref = pipe(lq, image_index0=i0)                                   # fp32 kernels
+    sd = weights.synth_state_dict("diffuser", weights.load_specs()["diffuser"], cases.SEED)
+    x_T = torch.from_numpy(R.keyed_fill((B, 18, 512), H.SEG_XT, seed, i0))
+    e_chain = maxerr(ref["pre_latent"], OM.ddim_sample(sd, ref["latent"].cpu(), x_T, T, S))
+    H.BF16_CONV = True
+    try:
+        out = pipe(lq, image_index0=i0)
+    finally:
+        H.BF16_CONV = False
+    assert out["restored"].shape == (B, 3, 512, 512) and torch.isfinite(out["restored"]).all()
+    d = (out["restored"] - ref["restored"]).float()
+    std = float(ref["restored"].std())
+    q = OM.save_image_quantize(out["restored"][:, :, ::4, ::4].cpu()).int() - OM.save_image_quantize(ref["restored"][:, :, ::4, ::4].cpu()).int()
+    rep = {"ddim_chain_vs_oracle": e_chain, "restored_std": std, "bf16_restored_rms": float(d.pow(2).mean().sqrt()),
+           "bf16_restored_max": float(d.abs().max()), "bf16_codes_max": maxerr(out["latent"], ref["latent"]),
+           "bf16_pre_latent_max": maxerr(out["pre_latent"], ref["pre_latent"]), "lsb_mean": float(q.abs().float().mean()),
+           "lsb_max": int(q.abs().max())}
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/parity_c3_b16_ddim25_bf16.json", "w"), indent=1)
+    print("C3:", rep)
+    assert e_chain < 3e-4
+    assert rep["bf16_restored_rms"] < 0.03 * std and rep["bf16_restored_max"] < 0.25 * std and rep["lsb_mean"] < 2.0

@@ -665,3 +665,36 @@ def test_conv2d_bf16x3_transposed(H, B, Cin, Cout, Hh, Ww):
            * demod.view(B, Cout, 1, 1).double()).float()
     y = H.conv_transpose2d_s2_fused(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bf16="x3")
     close(y, ref, 6e-5, 6e-5)
+
+
+# ------------------------------------------------------------------------------------------------ keyed random tensors
+def test_keyed_fill_matches_restatement_and_is_shard_invariant(H):
+    """vsp_keyed_fill_f32 against oracle/device_rng.py (Philox4x32-10 words are integer arithmetic: any mismatch there shows
+    as an O(1) difference; Box-Muller differs by libm rounding only), several tensors in one launch incl. a ragged one, and
+    the sharding property: images [lo, hi) drawn alone equal rows lo..hi-1 of the full batch, bit for bit."""
+    from oracle import device_rng as R
+    shapes = [(5, 1, 32, 32), (5, 18, 512), (5, 512), (5, 1, 4, 4), (5, 7)]   # (5, 7): per-image size not a multiple of 4, last
+    ids = [H.SEG_GEN + 3, H.SEG_XT, H.SEG_Z, H.SEG_ENC, 999]
+    seed, i0 = 0x1234_5678_9ABC_DEF0, (1 << 33) + 11                          # 64-bit seed and image index both reach the counter
+    full = H.keyed_fill(shapes, ids, seed, i0)
+    for t, s, i in zip(full, shapes, ids):
+        assert t.shape == s and t.is_contiguous()
+        close(t, R.keyed_fill(s, i, seed, i0), 2e-6, 2e-6, f"segment {i}")
+    part = H.keyed_fill([(2,) + s[1:] for s in shapes], ids, seed, i0 + 2)
+    for t, p in zip(full, part):
+        assert torch.equal(t[2:4], p)
+    alone = H.keyed_fill([shapes[0]], [ids[0]], seed, i0)[0]                  # independent of what else is drawn with it
+    assert torch.equal(alone, full[0])
+    u = H.keyed_fill([(3, 3, 64, 64)], [H.SEG_LQ], 7, 0, dist="uniform")[0]
+    close(u, R.keyed_fill((3, 3, 64, 64), H.SEG_LQ, 7, 0, dist="uniform"), 0, 1e-7)
+    assert float(u.min()) > -1.0 and float(u.max()) < 1.0
+    big = H.keyed_fill([(8, 1, 512, 512)], [H.SEG_DEC], 1, 0)[0]             # moments of 2M draws
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1.0) < 3e-3
+    assert abs(float((big ** 4).mean()) - 3.0) < 0.05
+    assert H.keyed_fill([], [], 1, 0) == []
+    with pytest.raises(RuntimeError):
+        H.keyed_fill([(2, 4), (3, 4)], [1, 2], 1, 0)                          # mixed batch sizes
+    with pytest.raises(RuntimeError):
+        H.keyed_fill([(2, 4)] * 65, list(range(65)), 1, 0)                    # more segments than one launch takes
+    with pytest.raises(RuntimeError):
+        H.keyed_fill([(2, 7), (2, 8)], [1, 2], 1, 0)                          # a vector segment behind an odd-sized one

@@ -107,6 +107,7 @@ SIGNATURES = {
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
+    "vsp_keyed_fill_f32": [_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _i, C.c_uint64, _i64, _p, _i, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
 }

@@ -750,3 +750,38 @@ def quantize_u8_nhwc(x, lo=-1.0, hi=1.0):
     check(lib.vsp_quantize_u8_nhwc(C.c_void_p(out.data_ptr()), _ptr(x), B, Cc, Hh, Ww, float(lo), float(hi), _stream()),
           "quantize_u8_nhwc")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- keyed random tensors
+# segment ids of the path's draws (they enter the Philox counter: a tensor keeps its values whatever else is drawn with it)
+SEG_LQ, SEG_XT, SEG_Z = 1, 2, 3           # synthetic LQ batch (bench), x_T (ldm/ddpm.py:423), z (restoration_test.py:77-82; +1: second mixing code)
+SEG_GEN, SEG_ENC, SEG_DEC = 16, 48, 80    # + layer index: prior decoder / Restoration_net encoder / decoder NoiseInjection maps
+
+
+def keyed_fill(shapes, ids, seed, image_index0, dist="normal", device=None, index_tensor=None):
+    """[tensor of shape s for s in shapes], every shape = (B, ...) with the same B, all drawn by ONE launch of
+    vsp_keyed_fill_f32 into one allocation: value = f(seed, image_index0 + b, id, element).  dist: "normal" | "uniform"
+    (-1, 1).  index_tensor: optional device int64 scalar added to image_index0 at run time (graph replays)."""
+    shapes = [tuple(int(d) for d in s) for s in shapes]
+    if not shapes:
+        return []
+    B = shapes[0][0]
+    if any(s[0] != B for s in shapes) or len(ids) != len(shapes):
+        raise RuntimeError("keyed_fill: every tensor needs the same leading batch dimension and one id")
+    elems = [math.prod(s[1:]) for s in shapes]
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise RuntimeError("keyed_fill: CUDA(HIP) device required")
+    if index_tensor is not None and (index_tensor.dtype != torch.int64 or not index_tensor.is_cuda or index_tensor.numel() != 1):
+        raise RuntimeError("keyed_fill: index_tensor must be a device int64 scalar")
+    flat = torch.empty(B * sum(elems), device=dev, dtype=torch.float32)
+    n = len(shapes)
+    check(lib.vsp_keyed_fill_f32(_ptr(flat), B, (C.c_int64 * n)(*elems), (C.c_int32 * n)(*[int(i) for i in ids]), n,
+                                 C.c_uint64(int(seed) & (2 ** 64 - 1)), int(image_index0),
+                                 None if index_tensor is None else C.c_void_p(index_tensor.data_ptr()), {"normal": 0, "uniform": 1}[dist],
+                                 _stream()), "keyed_fill")
+    out, off = [], 0
+    for s, e in zip(shapes, elems):
+        out.append(flat[off:off + B * e].view(s))
+        off += B * e
+    return out

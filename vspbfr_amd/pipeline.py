@@ -35,20 +35,56 @@ def load_ddpm(ddpm_ckpt, device="cuda", timesteps=4, linear_start=0.1, linear_en
     return My_DDPM(denoise=net, linear_start=linear_start, linear_end=linear_end, timesteps=timesteps).to(device)
 
 
+def noise_map_shapes(size, batch, gen_size=None):
+    """Shapes of the NoiseInjection draws in call order: (prior decoder [4, then (r, r) for r = 8..gen_size] -- reference
+    e4e/models/stylegan2/model.py:526-540; Restoration_net encoder [SMART at r, down-conv at r/2 for r = size..8] and decoder
+    [4, then (r, r) for r = 8..size] -- models/RestoreNet.py:922-927, 1022-1037)."""
+    import math
+    ls = int(math.log2(size))
+    enc = []
+    for i in range(ls, 2, -1):
+        enc += [(batch, 1, 2 ** i, 2 ** i), (batch, 1, 2 ** (i - 1), 2 ** (i - 1))]
+    pyramid = lambda top: [(batch, 1, 4, 4)] + [(batch, 1, 2 ** i, 2 ** i) for i in range(3, top + 1) for _ in (0, 1)]  # noqa: E731
+    return pyramid(int(math.log2(gen_size or size))), enc, pyramid(ls)
+
+
 class RestorationPipeline:
     def __init__(self, generator: Restoration_net, psp_embedding: E4e_embedding, diffusion: My_DDPM, mixing=0.5,
-                 with_sample=True):
+                 with_sample=True, noise_seed=None):
+        """noise_seed=None: every random draw comes from torch's device RNG stream, one `randn` per consumer, as in the
+        reference.  noise_seed=int: KEYED draws (hip_ops.keyed_fill): x_T, z and all 46 noise maps of a batch are functions of
+        (noise_seed, global image index, tensor id) drawn by two launches (one per stage pair) -- the result for an image does
+        not depend on the batch it travels in or on the rank that computes it."""
         self.generator, self.psp, self.diffusion = generator.eval(), psp_embedding.eval(), diffusion.eval()
-        self.mixing, self.with_sample = mixing, with_sample
+        self.mixing, self.with_sample, self.noise_seed = mixing, with_sample, noise_seed
+        self._index_tensor = None  # device int64 base index (graph replays)
         # option for the split-precision configuration: keep the encoder on the fp32 kernels.  Off: measured on the pinned case the
         # free-running result is the same either way (codes 2.5e-5 vs 4e-6, restored 3.0e-3 vs 3.6e-3 from the reference -- the
         # sampler chain's own fp32 conditioning dominates, DESIGN 2), and it costs 5 % throughput (tools/x3_free_running.py)
         self.encoder_fp32_under_x3 = False
 
+    def draw_decode_noise(self, B, image_index0, device):
+        """z, prior-decoder, encoder and decoder noise maps of one batch in ONE launch (keyed mode)."""
+        import random
+        from . import hip_ops as H
+        size = self.generator.size
+        gen, enc, dec = noise_map_shapes(size, B, gen_size=self.psp.E4Enet.decoder.size if self.with_sample else size)
+        # the reference flips ONE coin per batch for style mixing (restoration_test.py:77-82): keyed by the batch's first image
+        two = self.mixing > 0 and random.Random(hash((self.noise_seed, int(image_index0)))).random() < self.mixing
+        zs = [(B, self.generator.style_dim)] * (2 if two else 1)
+        ids = ([H.SEG_Z + i for i in range(len(zs))] + [H.SEG_GEN + i for i in range(len(gen))]
+               + [H.SEG_ENC + i for i in range(len(enc))] + [H.SEG_DEC + i for i in range(len(dec))])
+        t = H.keyed_fill(zs + gen + enc + dec, ids, self.noise_seed, image_index0, device=device, index_tensor=self._index_tensor)
+        a, b, c = len(zs), len(zs) + len(gen), len(zs) + len(gen) + len(enc)
+        return t[:a], t[a:b], t[b:c], t[c:]
+
     @torch.no_grad()
-    def encode(self, low_imgs, x_T=None):
+    def encode(self, low_imgs, x_T=None, image_index0=0):
         """Stages A + B: (low_latent, pre_dic_latent).  Small-map convolutions and the latency-bound sampler chain."""
         from . import hip_ops
+        if x_T is None and self.noise_seed is not None:
+            x_T = hip_ops.keyed_fill([(low_imgs.shape[0], 18, 512)], [hip_ops.SEG_XT], self.noise_seed, image_index0,
+                                     device=low_imgs.device, index_tensor=self._index_tensor)[0]
         mode = hip_ops.BF16_CONV
         if mode == "x3" and self.encoder_fp32_under_x3:
             # the sampler chain amplifies a perturbation of its condition ~2000x with random weights (DESIGN 2): the encoder that
@@ -62,9 +98,18 @@ class RestorationPipeline:
         return low_latent, pre
 
     @torch.no_grad()
-    def decode(self, low_imgs, low_latent, pre, z=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
+    def decode(self, low_imgs, low_latent, pre, z=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None,
+               image_index0=0):
         """Stages C + D: the StyleGAN2 prior and the restoration network (the compute-bound 97 % of the FLOPs)."""
         B = low_imgs.shape[0]
+        if self.noise_seed is not None and (z is None or gen_noise is None or enc_noise is None or dec_noise is None):
+            kz, kg, ke, kd = self.draw_decode_noise(B, image_index0, low_imgs.device)
+            z = kz if z is None else z
+            if len(z) > 1 and inject_index is None:
+                import random
+                inject_index = random.Random(hash((self.noise_seed, int(image_index0), 1))).randint(1, self.generator.n_latent - 1)
+            gen_noise = kg if gen_noise is None else gen_noise
+            enc_noise, dec_noise = (ke if enc_noise is None else enc_noise), (kd if dec_noise is None else dec_noise)
         noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
         sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
         restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
@@ -72,33 +117,40 @@ class RestorationPipeline:
         return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
 
     @torch.no_grad()
-    def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None):
+    def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None,
+                 image_index0=0):
         """low_imgs (B,3,512,512) in [-1,1] on the device -> dict(restored, style_sample, latent, pre_latent).
-        All keyword tensors are optional explicit replacements of the reference's RNG draws (parity runs)."""
-        low_latent, pre = self.encode(low_imgs, x_T=x_T)
+        All keyword tensors are optional explicit replacements of the reference's RNG draws (parity runs); image_index0 =
+        GLOBAL index of the batch's first image (keyed mode)."""
+        low_latent, pre = self.encode(low_imgs, x_T=x_T, image_index0=image_index0)
         return self.decode(low_imgs, low_latent, pre, z=z, gen_noise=gen_noise, enc_noise=enc_noise, dec_noise=dec_noise,
-                           inject_index=inject_index)
+                           inject_index=inject_index, image_index0=image_index0)
 
     @torch.no_grad()
     def run_batches(self, batches):
         """Software-pipelined loop over an iterable of device batches (the `for batch in loader` of restoration_test.py):
         stages A + B of batch i+1 run on a second HIP stream while stages C + D of batch i run on the caller's stream.  A + B
         are small-map / latency-bound work that leaves most CUs idle; overlapped with the big convolutions of the previous
-        batch they cost almost nothing.  Yields the same dicts as __call__, in order."""
+        batch they cost almost nothing.  Yields the same dicts as __call__, in order.  An item is a device batch or a pair
+        (batch, image_index0) (keyed mode: GLOBAL index of its first image; plain batches count up from 0)."""
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream()
         side = self._side
 
-        def start(batch):
+        counter = [0]
+
+        def start(item):
+            batch, idx0 = item if isinstance(item, (tuple, list)) else (item, counter[0])
+            counter[0] = idx0 + batch.shape[0]
             side.wait_stream(main)  # the batch (and everything enqueued before) is visible to the side stream
             with torch.cuda.stream(side):
-                lat, pre = self.encode(batch)
+                lat, pre = self.encode(batch, image_index0=idx0)
                 ev = torch.cuda.Event()
                 ev.record(side)
             for t in (lat, pre):
                 t.record_stream(main)  # allocated on the side stream's pool, consumed on the main stream
-            return batch, lat, pre, ev
+            return batch, lat, pre, ev, idx0
 
         it = iter(batches)
         try:
@@ -110,9 +162,9 @@ class RestorationPipeline:
                 nxt = start(next(it))  # enqueue A + B of the next batch BEFORE C + D of this one
             except StopIteration:
                 nxt = None
-            batch, lat, pre, ev = cur
+            batch, lat, pre, ev, idx0 = cur
             main.wait_event(ev)
-            yield self.decode(batch, lat, pre)
+            yield self.decode(batch, lat, pre, image_index0=idx0)
             cur = nxt
 
 
@@ -139,14 +191,24 @@ class RestorationPipeline:
         cur.wait_stream(warm)
         torch.cuda.synchronize()
         g = {"e_in": example.clone()}
-        g["E"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["E"]):
-            g["e_lat"], g["e_pre"] = self.encode(g["e_in"], x_T=x_T)
-        g["d_in"], g["d_lat"], g["d_pre"] = example.clone(), g["e_lat"].clone(), g["e_pre"].clone()
-        g["D"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["D"]):
-            g["out"] = self.decode(g["d_in"], g["d_lat"], g["d_pre"], z=z, gen_noise=gen_noise, enc_noise=enc_noise,
-                                   dec_noise=dec_noise)
+        if self.noise_seed is not None:
+            # keyed draws inside a graph: the kernels read the batch's global image index from device memory (one scalar per
+            # graph: A + B of batch i+1 replays while C + D of batch i is still running)
+            g["idx_e"] = torch.zeros(1, dtype=torch.int64, device=example.device)
+            g["idx_d"] = torch.zeros(1, dtype=torch.int64, device=example.device)
+        try:
+            self._index_tensor = g.get("idx_e")
+            g["E"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["E"]):
+                g["e_lat"], g["e_pre"] = self.encode(g["e_in"], x_T=x_T)
+            g["d_in"], g["d_lat"], g["d_pre"] = example.clone(), g["e_lat"].clone(), g["e_pre"].clone()
+            self._index_tensor = g.get("idx_d")
+            g["D"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["D"]):
+                g["out"] = self.decode(g["d_in"], g["d_lat"], g["d_pre"], z=z, gen_noise=gen_noise, enc_noise=enc_noise,
+                                       dec_noise=dec_noise)
+        finally:
+            self._index_tensor = None
         self._graphs = g
         return self
 
@@ -160,18 +222,24 @@ class RestorationPipeline:
             self._side = torch.cuda.Stream()
         side = self._side
 
-        def start(batch, after):
+        counter = [0]
+
+        def start(item, after):
             """A + B of `batch` on the side stream, once `after` (the main stream's copy of the previous latents) is done."""
+            batch, idx0 = item if isinstance(item, (tuple, list)) else (item, counter[0])
+            counter[0] = idx0 + batch.shape[0]
             if after is not None:
                 side.wait_event(after)
             else:
                 side.wait_stream(main)
             with torch.cuda.stream(side):
                 g["e_in"].copy_(batch)
+                if "idx_e" in g:
+                    g["idx_e"].fill_(idx0)
                 g["E"].replay()
                 ev = torch.cuda.Event()
                 ev.record(side)
-            return batch, ev
+            return batch, ev, idx0
 
         it = iter(batches)
         try:
@@ -179,8 +247,10 @@ class RestorationPipeline:
         except StopIteration:
             return
         while cur is not None:
-            batch, ev = cur
+            batch, ev, idx0 = cur
             main.wait_event(ev)
+            if "idx_d" in g:
+                g["idx_d"].fill_(idx0)
             g["d_in"].copy_(batch)
             g["d_lat"].copy_(g["e_lat"])
             g["d_pre"].copy_(g["e_pre"])

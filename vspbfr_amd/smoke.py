@@ -57,5 +57,5 @@ def run_smoke():
     torch.cuda.synchronize()
     print(f"smoke: max|d| vs oracle  chain={e_b:.2e}  prior={e_c:.2e}  restorenet={e_d:.2e}  ({time.time() - t0:.1f}s, "
           f"lib={_lib.LIB_PATH})")
-    assert e_b < 3e-3 and e_c < 2e-4 and e_d < 2e-4, (e_b, e_c, e_d)
+    assert e_b < 2e-4 and e_c < 2e-4 and e_d < 2e-4, (e_b, e_c, e_d)
     assert torch.isfinite(out).all()
