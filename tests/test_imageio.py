@@ -41,6 +41,29 @@ def test_loader_matches_reference_recipe(tmp_path):
     assert torch.equal(load_image(files[1]), ds[1])
 
 
+def test_loader_matches_reference_classes(golden):
+    """tests/golden/loader.npz = what the reference's ImageFolder_restore_test_no_gt / ImageFolder_restore_test return
+    (tools/make_golden.py::gen_loader, transform=None -> PIL image) for the committed folder tests/golden/loader_images;
+    ToTensor + Normalize(0.5, 0.5) is the caller's transform (restoration_test.py:89-94): x / 255, then (x - 0.5) / 0.5."""
+    import os
+    from vspbfr_amd.imageio import RestoreTestSet
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loader_images")
+    g = golden("loader")
+
+    def tens(u8):
+        return (torch.from_numpy(u8.copy()).permute(2, 0, 1).float() / 255 - 0.5) / 0.5
+    ds = RestoreTestSet(os.path.join(root, "lq"), im_size=(64, 64))
+    assert [os.path.relpath(f, root) for f in ds.lq] == [str(f) for f in g["no_gt/files"]]   # sorted, recursive, .txt filtered
+    for i in range(len(ds)):
+        assert torch.equal(ds[i], tens(g[f"no_gt/{i}"])), i
+    ds2 = RestoreTestSet(os.path.join(root, "lq"), os.path.join(root, "hq"), im_size=(64, 64))
+    assert [os.path.relpath(f, root) for f in ds2.hq] == [str(f) for f in g["gt/hq_files"]]
+    assert len(ds2) == 4                                      # the LQ list decides the length (dataset.py:406-407); hq has 4 too
+    for i in range(len(ds2)):
+        lq, hq = ds2[i]
+        assert torch.equal(lq, tens(g[f"gt/{i}/lq"])) and torch.equal(hq, tens(g[f"gt/{i}/hq"])), i
+
+
 def test_output_names():
     from vspbfr_amd.imageio import output_name
     assert output_name("out/x", 7, 0, "celeba", "restore") == "out/x/000007_0_celeba_restore.png"

@@ -267,8 +267,55 @@ def gen_pipeline512():
     print("pipeline512.npz: restored stats", out["restored_stats"], "sample stats", out["sample_stats"], "%.1fs" % (time.time() - t0))
 
 
+def gen_loader():
+    """The test-time loaders of the reference (dataset.py:376-495: ImageFolder_restore_test / _no_gt) on a small committed
+    image folder (tests/golden/loader_images: written here, deterministic): sorted recursive listing, extension filter,
+    LANCZOS resize-to-cover + centre crop.  `transform=None`: the classes return the PIL image; the caller's transform is
+    ToTensor + Normalize(0.5, 0.5) (restoration_test.py:89-94, torchvision, not installed here) which the test applies.
+    dataset.py imports my_basicsr.my_degradations -> torchvision.transforms.functional.rgb_to_grayscale at module level
+    (training-time degradations, never reached by these classes): an empty stand-in module lets the import through."""
+    import types
+    from PIL import Image
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.transforms.functional"].rgb_to_grayscale = None
+    import dataset as ref_dataset
+    root = os.path.join(GOLD, "loader_images")
+    os.makedirs(os.path.join(root, "lq", "sub"), exist_ok=True)
+    os.makedirs(os.path.join(root, "hq"), exist_ok=True)
+    yy, xx = np.mgrid[0:1:200j, 0:1:200j]
+
+    def picture(w, h, k):  # smooth, compressible, different per k
+        y, x = yy[:h, :w] * (1 + 0.3 * k), xx[:h, :w] * (1 + 0.2 * k)
+        rgb = np.stack([np.sin(6 * x + k) * np.cos(4 * y), np.cos(5 * x * y + 0.5 * k), np.sin(3 * (x - y) + k)], -1)
+        return Image.fromarray(np.clip((rgb * 0.5 + 0.5) * 255, 0, 255).astype(np.uint8))
+    files = [("lq/b_wide.png", 100, 70), ("lq/a_exact.png", 64, 64), ("lq/sub/tall_small.png", 30, 50), ("lq/c_photo.jpg", 90, 81),
+             ("lq/notes.txt", 0, 0), ("hq/a_exact.png", 64, 64), ("hq/b_wide.png", 120, 80), ("hq/c_photo.png", 90, 81), ("hq/d_tall.png", 60, 100)]
+    for k, (rel, w, h) in enumerate(files):
+        path = os.path.join(root, rel)
+        if rel.endswith(".txt"):
+            open(path, "w").write("not an image\n")
+        else:
+            picture(w, h, k).save(path, quality=90) if rel.endswith(".jpg") else picture(w, h, k).save(path)
+    out = {}
+    ds = ref_dataset.ImageFolder_restore_test_no_gt(lq_root=os.path.join(root, "lq"), transform=None, im_size=(64, 64))
+    out["no_gt/files"] = np.array([os.path.relpath(f, root) for f in ds.lq_frame])
+    for i in range(len(ds)):
+        out[f"no_gt/{i}"] = np.asarray(ds[i], dtype=np.uint8)
+    ds2 = ref_dataset.ImageFolder_restore_test(lq_root=os.path.join(root, "lq"), hq_root=os.path.join(root, "hq"), transform=None,
+                                               im_size=(64, 64))
+    out["gt/lq_files"] = np.array([os.path.relpath(f, root) for f in ds2.lq_frame])
+    out["gt/hq_files"] = np.array([os.path.relpath(f, root) for f in ds2.hq_frame])
+    for i in range(len(ds2)):
+        lq, hq = ds2[i]
+        out[f"gt/{i}/lq"], out[f"gt/{i}/hq"] = np.asarray(lq, dtype=np.uint8), np.asarray(hq, dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "loader.npz"), **out)
+    print("loader.npz:", list(out["no_gt/files"]), {k: v.shape for k, v in out.items() if not k.endswith("files")})
+
+
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -61,6 +61,7 @@ struct ConvK {
   int dbg;                                       // ablation switches for kernel tuning (env VSP_CONV_DBG; 0 in production)
   int bf_pitch, bf_plane;                        // conv_bf16.hip: patch row pitch and plane size in positions
   int bf_isc_s, bf_ish_s;                        // conv_bf16.hip: channel stride of in_scale / in_shift (0: absent -> constant)
+  int wg_order;                                  // conv_wino.hip: 0 = dispatch order, 1 = pixel-tile-major per XCD, 2 = channel-tile-major per XCD
 };
 
 __device__ __forceinline__ int round_pitch(int n, int odd) {

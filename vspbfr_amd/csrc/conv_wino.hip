@@ -27,6 +27,7 @@
 // A^T . A, the same fused operand chain as the direct kernel (demod, bias, two activations, noise, two residuals) and stores
 // the 2x2 pixels.  Numerics: F(2x2,3x3) in fp32 adds ~1e-6 relative error (transform constants are 1 and 1/2).
 #include "conv_kernel.h"
+#include <type_traits>
 
 namespace vspconv {
 
@@ -73,19 +74,35 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, kq = lane >> 4;
-  // XCD-aware work order (single-group launches): the dispatcher deals workgroups round-robin over the 8 XCDs, so neighbouring
-  // tiles -- which share their halo rows / columns, 40 % of a 10 x 18 patch -- never meet in one L2.  Bijective remap: every XCD
-  // walks a contiguous range of (image, tile, channel tile) with the channel tiles of one pixel tile adjacent.
+  // XCD-aware work order.  The dispatcher deals workgroups round-robin over the 8 XCDs (each with its own 4 MB L2), so in
+  // dispatch order every L2 sees every pixel tile and every channel tile.  Bijective remap: XCD x walks a CONTIGUOUS range of
+  // the work list, ordered either
+  //   1 = pixel-tile-major (image, pixel tile, channel tile): neighbouring tiles share their halo (40 % of a 10 x 18 patch)
+  //       and the channel tiles of one pixel tile read the same patch -- right when U is small (<= 64 channels), or
+  //   2 = channel-tile-major (channel tile, image, pixel tile): a workgroup streams its whole U slice (64 co x Cin x 16
+  //       positions x 4 B = 2 MB at 512 channels) and NO two waves share any of it, so U is the kernel's dominant fetch
+  //       (32 KB per 8-channel interval against 5.8 KB of patch: 4.3 GB per 512 -> 512 launch at 64^2, ~5 TB/s).  In
+  //       pixel-major order all 8 channel tiles (16.8 MB) compete for one 4 MB L2 and U streams from MALL / HBM; in
+  //       channel-major order an XCD works on one or two channel tiles at a time and U stays L2-resident.
   int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (DMAX == 1 && p.G == 1) {
-    const int GX = gridDim.x, GY = gridDim.y, GN = GX * GY, GT = GN * gridDim.z;
+  if (p.wg_order) {
+    const int GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z, GT = GX * GY * GZ;
     const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
     const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
-    b = lid / GN;
-    const int lrem = lid - b * GN;
-    bx = lrem / GY;
-    by = lrem - bx * GY;
+    if (p.wg_order == 1) {
+      const int GN = GX * GY;
+      b = lid / GN;
+      const int lrem = lid - b * GN;
+      bx = lrem / GY;
+      by = lrem - bx * GY;
+    } else {
+      const int GN = GX * GZ;
+      by = lid / GN;
+      const int lrem = lid - by * GN;
+      b = lrem / GX;
+      bx = lrem - b * GX;
+    }
   }
   const int g = by / p.co_tiles, ct = by - g * p.co_tiles;
   const int d = DMAX == 1 ? 1 : p.dil[g];                     // row-polyphase stride and column tap spacing (1, 2, 4 or 8)
@@ -169,7 +186,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       const int task = tid + it * NTHR;
       if (task >= TASKS) break;
       const int th = task & 1, tq = task >> 1;
-      const int t_ch = tq / NTILE, t_tile = tq - t_ch * NTILE;
+      // (2 NTILE tasks per channel, a multiple of 64: the channel is wave-uniform -> the style scale comes through the scalar
+      //  cache on lgkmcnt; as a per-lane global load it put a vmcnt(0) -- i.e. the latency of the patch and U prefetches just
+      //  issued -- into every interval)
+      const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
       const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
       // tile column t_tx: column residue t_tx % d, position t_tx / d -> first window column (patch coordinates) rx + 2 d pos
       const int c0 = DMAX == 1 ? 2 * t_tx : (t_tx % d) + 2 * d * (t_tx / d);
@@ -239,28 +259,44 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if (nchunk > 2) issue_p(2);
   }
   __syncthreads();
-  for (int i = 0; i < nchunk; ++i) {
+  // The steady-state intervals carry no tail guards: with them every `if (i + k < nchunk)` is a branch whose join makes the
+  // compiler's waitcnt pass assume the worst of both paths (vmcnt(0) where a counted wait would do).
+#ifdef VSP_WINO_ABLATE  // tuning only (VSP_CONV_DBG): 0x400 no transform, 0x800 no U loads, 0x1000 no patch loads, 0x2000 no MFMAs, 0x4000 no commit
+  const int ab = p.dbg;
+#else
+  constexpr int ab = 0;
+#endif
+  auto interval = [&](int i, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int cur = i & 1, nxt = cur ^ 1;
-    if (KS == 2 && KS * i + 1 < nchunk4) load_u(KS * i + 1, ub);
-    if (i + 2 < nchunk) {
+    if (KS == 2 && (FULL || KS * i + 1 < nchunk4) && !(ab & 0x800)) load_u(KS * i + 1, ub);
+    if (FULL || i + 2 < nchunk) {
 #pragma unroll
       for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one interval ago
     }
-    if (i + 3 < nchunk) issue_p(i + 3);
-    if (i + 1 < nchunk) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
+    if ((FULL || i + 3 < nchunk) && !(ab & 0x1000)) issue_p(i + 3);
+    if ((FULL || i + 1 < nchunk) && !(ab & 0x400)) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
     if (KS == 2) {
-      multiply(Vl + cur * LDS_V, 0, ua);
-      if (KS * i + 2 < nchunk4) load_u(KS * i + 2, ua);     // next interval's first k-step (the MFMAs above have read ua)
-      if (KS * i + 1 < nchunk4) multiply(Vl + cur * LDS_V, 1, ub);
+      if (!(ab & 0x2000)) multiply(Vl + cur * LDS_V, 0, ua);
+      if ((FULL || KS * i + 2 < nchunk4) && !(ab & 0x800)) load_u(KS * i + 2, ua);  // next interval's first k-step (the MFMAs above have read ua)
+      if ((FULL || KS * i + 1 < nchunk4) && !(ab & 0x2000)) multiply(Vl + cur * LDS_V, 1, ub);
     } else {
-      if (i + 1 < nchunk4) load_u(i + 1, ub);
-      multiply(Vl + cur * LDS_V, 0, ua);
+      if ((FULL || i + 1 < nchunk4) && !(ab & 0x800)) load_u(i + 1, ub);
+      if (!(ab & 0x2000)) multiply(Vl + cur * LDS_V, 0, ua);
 #pragma unroll
       for (int q = 0; q < UF; ++q) ua[q] = ub[q];
     }
-    if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P, i + 2); // Pl[cur] held patch(i): consumed one interval ago
+    if ((FULL || i + 2 < nchunk) && !(ab & 0x4000)) commit_p(Pl + cur * LDS_P, i + 2);  // Pl[cur] held patch(i): consumed one interval ago
     __syncthreads();
-  }
+  };
+  int iv = 0;
+  // FULL needs i + 3 < nchunk and every 4-channel U chunk of intervals i, i + 1 present (Cin a multiple of IVC)
+  const int n_full = (p.Cin % IVC == 0) ? nchunk - 3 : 0;
+  for (; iv < n_full; ++iv) interval(iv, std::true_type{});
+  for (; iv < nchunk; ++iv) interval(iv, std::false_type{});
+#ifdef VSP_WINO_ABLATE
+  if (ab & 0x8000) return;
+#endif
 
   // ---- epilogue: per 16-channel block and (at most) 64 tiles, all sixteen positions through LDS, one thread per
   //      (channel, tile): Y = A^T M A, then the fused operand chain of the direct kernel
@@ -370,6 +406,13 @@ int launch_variant(ConvK q, hipStream_t stream) {
     const int n = ((q.W + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((SH + 2 * Gm::TLY - 1) / (2 * Gm::TLY)) * d;
     blocks = n > blocks ? n : blocks;
   }
+  // work order (see the kernel): channel-tile-major once the launch's U no longer fits an L2 beside the patches
+  const int64_t u_bytes = (int64_t)q.G * q.co_tiles * Gm::WCO * ((q.Cin + 3) / 4 * 4) * 16 * 4;
+  (void)u_bytes;  // measured: the order makes no difference on the big-U layers (512 -> 512 at 64^2: 772 us either way), pixel-major
+                  // wins on 32 -> 32 at 1024^2 (1613 -> 1502 us) and on the dilation groups of small maps (512 -> 4 x 128 at 32^2: 437 -> 341 us)
+  q.wg_order = (DMAX == 1 && q.G == 1) || q.H * q.W <= 1024 ? 1 : 0;
+  if (q.dbg & 0x300) q.wg_order = (q.dbg >> 8) & 3;  // tuning: VSP_CONV_DBG = 256 / 512 / 768 forces order 1 / 2 / dispatch (0)
+  if (q.wg_order == 3) q.wg_order = 0;
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
   conv_wino_kernel<MBW, DMAX><<<grid, NTHR, lds, stream>>>(q);
   return VSP_OK;

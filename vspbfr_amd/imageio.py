@@ -27,22 +27,43 @@ def list_images(root):
     return out
 
 
+def _to_tensor(img):
+    """ToTensor + Normalize(0.5, 0.5) (restoration_test.py:89-94): uint8 HWC -> float32 CHW in [-1, 1]."""
+    a = np.asarray(img, dtype=np.uint8)
+    t = torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div_(255.0)
+    return t.sub_(0.5).div_(0.5)
+
+
+def _cover_and_crop(imgs, size_of, im_size):
+    """LANCZOS resize so that the image `size_of` covers im_size (h, w), then the same centre crop for every image in
+    `imgs` (dataset.py:410-429, 470-492: the resize target and the crop window come from ONE image's size)."""
+    from PIL import Image
+    w, h = size_of.size
+    if h == im_size[0] and w == im_size[1]:
+        return imgs
+    ratio = max(1.0 * im_size[0] / h, 1.0 * im_size[1] / w)
+    new_w, new_h = int(ratio * w), int(ratio * h)
+    h_idx = (new_h - im_size[0]) // 2 if new_h - im_size[0] > 0 else 0
+    w_idx = (new_w - im_size[1]) // 2 if new_w - im_size[1] > 0 else 0
+    box = (w_idx, h_idx, int(w_idx + im_size[1]), int(h_idx + im_size[0]))
+    return [im.resize((new_w, new_h), Image.Resampling.LANCZOS).crop(box) for im in imgs]
+
+
 def load_image(path, im_size=(512, 512)):
     """PIL RGB -> LANCZOS resize so the image covers im_size (h, w) -> centre crop -> float32 CHW in [-1, 1]
     (dataset.py:470-495 followed by ToTensor + Normalize(0.5, 0.5), restoration_test.py:89-94)."""
     from PIL import Image
     img = Image.open(path).convert("RGB")
-    w, h = img.size
-    if h != im_size[0] or w != im_size[1]:
-        ratio = max(1.0 * im_size[0] / h, 1.0 * im_size[1] / w)
-        new_w, new_h = int(ratio * w), int(ratio * h)
-        img = img.resize((new_w, new_h), Image.Resampling.LANCZOS)
-        h_idx = (new_h - im_size[0]) // 2 if new_h - im_size[0] > 0 else 0
-        w_idx = (new_w - im_size[1]) // 2 if new_w - im_size[1] > 0 else 0
-        img = img.crop((w_idx, h_idx, int(w_idx + im_size[1]), int(h_idx + im_size[0])))
-    a = np.asarray(img, dtype=np.uint8)
-    t = torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div_(255.0)
-    return t.sub_(0.5).div_(0.5)
+    return _to_tensor(_cover_and_crop([img], img, im_size)[0])
+
+
+def load_pair(lq_path, hq_path, im_size=(512, 512)):
+    """ImageFolder_restore_test.__getitem__ (dataset.py:408-436): the HQ image's size decides the resize and the crop of BOTH
+    images (an LQ file of another size is stretched to the HQ's scaled size)."""
+    from PIL import Image
+    lq, hq = Image.open(lq_path).convert("RGB"), Image.open(hq_path).convert("RGB")
+    lq, hq = _cover_and_crop([lq, hq], hq, im_size)
+    return _to_tensor(lq), _to_tensor(hq)
 
 
 class RestoreTestSet:
@@ -58,10 +79,9 @@ class RestoreTestSet:
         return len(self.lq)
 
     def __getitem__(self, idx):
-        lq = load_image(self.lq[idx], self.im_size)
         if self.hq is None:
-            return lq
-        return lq, load_image(self.hq[idx], self.im_size)
+            return load_image(self.lq[idx], self.im_size)
+        return load_pair(self.lq[idx], self.hq[idx], self.im_size)
 
 
 def output_name(eval_dir, index, rank, data_name, kind):
