@@ -109,9 +109,17 @@ def cpu_baseline(T, threads, sample_steps=2):
     per_step = st["diffuser"] / sample_steps
     total = st["encoder"] + st["prior_decoder"] + st["restorenet"] + per_step * T
     measured = sum(st.values())
+    ref = None
+    ref_path = os.path.join(ROOT, "profiles", "r02_reference_cpu_timing.json")
+    if os.path.exists(ref_path):  # the reference ITSELF, timed in the build container (tools/time_reference_cpu.py; it cannot travel here)
+        with open(ref_path) as f:
+            r = json.load(f)
+        ref = {"what": r["what"], "threads": r["threads"],
+               "B4_T10_img_per_s": r.get("c1", {}).get("img_per_s"), "B1_T50_img_per_s": r.get("b1t50", {}).get("img_per_s")}
     return {"value": round(1.0 / total, 5), "unit": "img/s", "cores": threads, "kind": "port",
             "sample": f"1 image 512x512: stages A, C (to 1024^2), D in full + {sample_steps} of {T} DDPM steps ({measured:.1f} s "
                       f"measured), chain extrapolated linearly to T={T} -> {total:.1f} s/image",
+            "reference_in_build_container": ref,
             "stage_seconds": {"encoder": round(st["encoder"], 2), "diffuser_per_step": round(per_step, 3),
                               "prior_decoder": round(st["prior_decoder"], 2), "restorenet": round(st["restorenet"], 2)}}
 

@@ -316,6 +316,15 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
     static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
     q.dbg = dbg;
   }
+  {
+    const float* kc = device_consts();
+    const bool affine = p.in_shift != nullptr;
+    q.wtp = (p.in_scale && !affine) ? p.in_scale : kc;             q.wt_cs = (p.in_scale && !affine) ? 1 : 0;
+    q.wt_bs = (p.in_scale && !affine) ? p.in_scale_bstride : 0;
+    q.wcp = (p.in_scale && affine) ? p.in_scale : kc;              q.wc_cs = (p.in_scale && affine) ? 1 : 0;
+    q.wc_bs = (p.in_scale && affine) ? p.in_scale_bstride : 0;
+    q.wshp = affine ? p.in_shift : kc + 1;                         q.wsh_cs = affine ? 1 : 0;
+  }
   if (int rc = vspconv::wino_launch(q, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_winograd");
 }

@@ -62,6 +62,12 @@ struct ConvK {
   int bf_pitch, bf_plane;                        // conv_bf16.hip: patch row pitch and plane size in positions
   int bf_isc_s, bf_ish_s;                        // conv_bf16.hip: channel stride of in_scale / in_shift (0: absent -> constant)
   int wg_order;                                  // conv_wino.hip: 0 = dispatch order, 1 = pixel-tile-major per XCD, 2 = channel-tile-major per XCD
+  // conv_wino.hip: per-input-channel operands resolved to pointer + strides (absent -> a device constant, strides 0), so that the
+  // interval body is branch-free: wt* = style scale applied on V (in_scale without in_shift); wc* / wsh* = the affine input of
+  // folded BatchNorm layers, applied to in-image pixels when the patch is committed (in_shift given)
+  const float* wtp; int wt_cs, wt_bs;
+  const float* wcp; int wc_cs, wc_bs;
+  const float* wshp; int wsh_cs;
 };
 
 __device__ __forceinline__ int round_pitch(int n, int odd) {

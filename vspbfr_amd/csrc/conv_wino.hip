@@ -148,17 +148,14 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 #pragma unroll
     for (int e = 0; e < PLD; ++e) pnext[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, p_voff[e], soff, 0));
   };
-  auto commit_p = [&](float* Pdst, int c) {  // preg = chunk c
-    const int ci = c * IVC + p_ch;
+  auto commit_p = [&](float* Pdst, int c) {  // preg = chunk c.  Affine input (folded BatchNorm): the shift belongs to in-image
+    const int ci = c * IVC + p_ch;             // pixels only, so it is applied here (plain layers: scale 1, shift 0 from the constants)
     const bool chok = ci < p.Cin;
-    float sc = 1.f, sh = 0.f;
-    if (p.in_shift && chok) {  // affine input (folded BatchNorm): the shift belongs to in-image pixels only, so it is applied here
-      sc = p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci] : 1.f;
-      sh = p.in_shift[ci];
-    }
+    const int cc = chok ? ci : p.Cin - 1;
+    const float sc = p.wcp[(int64_t)b * p.wc_bs + cc * p.wc_cs], sh = p.wshp[cc * p.wsh_cs];
 #pragma unroll
     for (int e = 0; e < PLD; ++e)
-      if (p_t + PTH * e < PLANE) Pdst[p_ch * PPITCH + p_t + PTH * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
+      if (PLD * PTH == PLANE || p_t + PTH * e < PLANE) Pdst[p_ch * PPITCH + p_t + PTH * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
   };
 
   // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
@@ -180,27 +177,36 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   // ---- transform: task = (channel, tile, half); half h produces V rows 2h, 2h+1 of the tile's 4x4 window
   constexpr int TASKS = 2 * IVC * NTILE;
   constexpr int TPT = (TASKS + NTHR - 1) / NTHR;
-  auto transform = [&](const float* Psrc, float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
+  static_assert(TASKS % NTHR == 0, "every thread runs TPT transform tasks");
+  float tdd[TPT][3][4];  // rows h, h+1, h+2 of each task's 4x4 window (columns d apart)
+  auto transform_read = [&](const float* Psrc) {  // the LDS reads of the transform: issued early, consumed under the MFMAs
 #pragma unroll
     for (int it = 0; it < TPT; ++it) {
       const int task = tid + it * NTHR;
-      if (task >= TASKS) break;
       const int th = task & 1, tq = task >> 1;
-      // (2 NTILE tasks per channel, a multiple of 64: the channel is wave-uniform -> the style scale comes through the scalar
-      //  cache on lgkmcnt; as a per-lane global load it put a vmcnt(0) -- i.e. the latency of the patch and U prefetches just
-      //  issued -- into every interval)
       const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
       const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
       // tile column t_tx: column residue t_tx % d, position t_tx / d -> first window column (patch coordinates) rx + 2 d pos
       const int c0 = DMAX == 1 ? 2 * t_tx : (t_tx % d) + 2 * d * (t_tx / d);
       const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + c0;
-      float dd[3][4];  // rows h, h+1, h+2 of the 4x4 window (columns d apart)
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc * d];
-      float sc = 1.f;
-      if (p.in_scale && !p.in_shift && c * IVC + t_ch < p.Cin) sc = p.in_scale[(int64_t)b * p.in_scale_bstride + c * IVC + t_ch];
+        for (int cc = 0; cc < 4; ++cc) tdd[it][r][cc] = src[r * PC + cc * d];
+    }
+  };
+  auto transform_write = [&](float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
+#pragma unroll
+    for (int it = 0; it < TPT; ++it) {
+      const int task = tid + it * NTHR;
+      const int th = task & 1, tq = task >> 1;
+      // (2 NTILE tasks per channel, a multiple of 64: the channel is wave-uniform -> the style scale comes through the scalar
+      //  cache on lgkmcnt; as a per-lane global load it put a vmcnt(0) -- i.e. the latency of the patch and U prefetches just
+      //  issued -- into every interval)
+      const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
+      const int ci = c * IVC + t_ch;
+      const float sc = p.wtp[(int64_t)b * p.wt_bs + (ci < p.Cin ? ci : p.Cin - 1) * p.wt_cs];
+      const auto& dd = tdd[it];
       float w0[4], w1[4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
@@ -217,6 +223,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         dst[((2 * th + 1) * 4 + nu) * (IVC * VPITCH)] = v1[nu];
       }
     }
+  };
+  auto transform = [&](const float* Psrc, float* Vdst, int c) {
+    transform_read(Psrc);
+    transform_write(Vdst, c);
   };
 
   f32x4 acc[2][MBW][NBW];
@@ -275,14 +285,22 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one interval ago
     }
     if ((FULL || i + 3 < nchunk) && !(ab & 0x1000)) issue_p(i + 3);
-    if ((FULL || i + 1 < nchunk) && !(ab & 0x400)) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
+    // program order inside the wave: the transform's LDS reads go out first, its arithmetic and LDS writes follow the first
+    // k-step's MFMAs -- an in-order wave overlaps only what sits between its own MFMAs (the matrix pipe takes one every 32 cycles)
+    // (the 128-tile geometry runs two tasks per thread: 24 window registers across the MFMAs would spill -- it transforms first)
+    constexpr bool SPLIT = TPT == 1;
+    const bool tr = (FULL || i + 1 < nchunk) && !(ab & 0x400);
+    if (tr) transform_read(Pl + nxt * LDS_P);
+    if (tr && !SPLIT) transform_write(Vl + nxt * LDS_V, i + 1);
     if (KS == 2) {
       if (!(ab & 0x2000)) multiply(Vl + cur * LDS_V, 0, ua);
+      if (tr && SPLIT) transform_write(Vl + nxt * LDS_V, i + 1);
       if ((FULL || KS * i + 2 < nchunk4) && !(ab & 0x800)) load_u(KS * i + 2, ua);  // next interval's first k-step (the MFMAs above have read ua)
       if ((FULL || KS * i + 1 < nchunk4) && !(ab & 0x2000)) multiply(Vl + cur * LDS_V, 1, ub);
     } else {
       if ((FULL || i + 1 < nchunk4) && !(ab & 0x800)) load_u(i + 1, ub);
       if (!(ab & 0x2000)) multiply(Vl + cur * LDS_V, 0, ua);
+      if (tr && SPLIT) transform_write(Vl + nxt * LDS_V, i + 1);
 #pragma unroll
       for (int q = 0; q < UF; ++q) ua[q] = ub[q];
     }
