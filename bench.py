@@ -48,7 +48,7 @@ def self_launch(n):
 
 PRESETS = {  # BASELINE.json configs[1..3]
     "c2": dict(batch=8, timesteps=50, sampler="ddpm", conv_dtype="f32"),
-    "c3": dict(batch=16, timesteps=50, sampler="ddim", ddim_steps=25, conv_dtype="bf16"),
+    "c3": dict(batch=16, timesteps=50, sampler="ddim", ddim_steps=25, conv_dtype="bf16", act_bf16=True),
     "c4": dict(batch=16, timesteps=50, sampler="ddpm", conv_dtype="f32"),
 }
 
@@ -125,14 +125,26 @@ def cpu_baseline(T, threads, sample_steps=2):
 
 
 def conv_traffic(B, args):
-    """HBM bytes per conv launch from the committed PMC passes (profiles/r01_conv_traffic_pmc.json: FETCH_SIZE x2 per the
-    gfx950 calibration, WRITE_SIZE x1, separate passes, tools/pmc_bench.sh).  PMC collection cannot run inside the timed
-    process, so the figure is only reported for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_conv_traffic_pmc.json" if args.conv_dtype == "f32" else "r01_conv_traffic_pmc_bf16.json")
-    if args.conv_dtype == "bf16x3" or B != 8 or args.timesteps != 50 or args.no_sample or args.sampler != "ddpm" or not os.path.exists(path):
+    """HBM bytes per conv launch from the committed PMC passes (FETCH_SIZE x2 per the gfx950 calibration, WRITE_SIZE x1, separate
+    passes: tools/pmc_bench.sh -> tools/pmc_traffic_summary.py).  PMC collection cannot run inside the timed process, so the
+    figure is only reported for the configurations it was measured on: C2 (batch 8, T = 50 DDPM, fp32) and C3 (batch 16, DDIM 25,
+    bf16 kernels + bf16 activations)."""
+    if args.no_sample:
         return None
-    with open(path) as f:
-        return round(json.load(f)["conv_hbm_bytes_per_launch"])
+    tag = None
+    if args.conv_dtype == "f32" and B == 8 and args.timesteps == 50 and args.sampler == "ddpm":
+        tag = "c2_f32"
+    elif args.conv_dtype == "bf16" and args.act_bf16 and B == 16 and args.sampler == "ddim" and args.ddim_steps == 25:
+        tag = "c3_bf16act"
+    elif args.conv_dtype == "bf16" and not args.act_bf16 and B == 8 and args.timesteps == 50 and args.sampler == "ddpm":
+        tag = "b8_bf16"
+    for name in ({"c2_f32": ["r02_conv_traffic_pmc_c2_f32.json", "r01_conv_traffic_pmc.json"], "c3_bf16act": ["r02_conv_traffic_pmc_c3_bf16act.json"],
+                  "b8_bf16": ["r01_conv_traffic_pmc_bf16.json"]}.get(tag, [])):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return round(json.load(f)["conv_hbm_bytes_per_launch"])
+    return None
 
 
 def main():
@@ -154,6 +166,9 @@ def main():
                     help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
                          "fp32 activations in HBM); not the parity configuration.  bf16x3 = the same kernels with hi + lo bf16 "
                          "operand pairs and three MFMAs per product (vsp_conv2d_bf16x3): fp32-grade results on the bf16 pipe")
+    ap.add_argument("--act-bf16", action="store_true",
+                    help="with --conv-dtype bf16: bf16 ACTIVATIONS in HBM between the kernels of stages C + D (every map of 32^2 and "
+                         "larger; vsp_conv2d_bf16 io_bf16, vsp_upfirdn2d_bf16, vsp_pointwise_bf16) -- BASELINE configs[2] as specified")
     ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
                     help="BASELINE.json configuration: c2 = batch 8, 50-step DDPM, fp32 (the default); c3 = batch 16, DDIM 25, bf16 "
                          "kernels; c4 = batch 16 per GPU (128 on 8 GPUs), 50-step DDPM, fp32")
@@ -185,7 +200,10 @@ def main():
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
     hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
+    if args.act_bf16 and args.conv_dtype != "bf16":
+        raise SystemExit("--act-bf16 needs --conv-dtype bf16")
     pipe = build_pipeline(dev, args.timesteps, not args.no_sample, None if args.torch_rng else args.seed)
+    pipe.act_bf16 = bool(args.act_bf16)
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
         ddpm, S = pipe.diffusion, args.ddim_steps
@@ -259,6 +277,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     conv_flops, conv_ms, conv_launches = prof.summary()
+    conv_bytes = prof.algorithmic_bytes()
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -277,7 +296,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.conv_dtype, "data": "synthetic",
             "config": {"workload": f"restoration_test.py hot path A+B+C+D, batch {B}/GPU, 512x512, {args.timesteps}-step DDPM "
                                    f"CodeDiffuser + StyleGAN2 prior{'' if not args.no_sample else ' (no 1024^2 tail)'} + RestoreNet "
-                                   "forward, " + {"f32": "fp32", "bf16": "bf16-MFMA convolutions (fp32 accumulate, fp32 activations), rest fp32",
+                                   "forward, " + {"f32": "fp32", "bf16": "bf16-MFMA convolutions (fp32 accumulate), " + (
+                                       "bf16 activations in HBM for stages C + D" if args.act_bf16 else "fp32 activations") + ", rest fp32",
                                                  "bf16x3": "split-precision bf16-MFMA convolutions (hi + lo operand pairs, 3 MFMAs per product, fp32 "
                                                            "accumulate; transposed and small-map layers fp32), rest fp32"}[args.conv_dtype] + ", random-init weights",
                        "batch_per_gpu": B, "timesteps": args.timesteps, "with_style_sample": not args.no_sample,
@@ -294,7 +314,25 @@ def main():
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
                          "pipeline_frac_of_fp32_peak": round(imgs / dt * ALGO_GFLOP_PER_IMAGE(args.timesteps) / 1e3 / (PEAK * world), 4)},
         }
-        if iso is not None:
+        if args.conv_dtype == "bf16":
+            # BASELINE configs[2] / SURVEY 8d: with the bf16 matrix pipe (2.5 PFLOP/s) the conv family is bound by HBM, not by MFMA.
+            # achieved = ALGORITHMIC bytes (every operand of a launch crosses HBM once at its element size: input, output, weights,
+            # noise, residuals) / kernel time, against the 8 TB/s HBM3E peak; the MFMA figure stays in the line as `mfma`.
+            src = iso if iso is not None else prof
+            fl, ms, n = src.summary()
+            by = src.algorithmic_bytes()
+            if iso is None:  # the timed region holds K steps
+                fl, ms, n, by = fl / args.steps, ms / args.steps, n // args.steps, by / args.steps
+            rl = line["roofline"]
+            rl["mfma"] = {"achieved_tflops": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK, "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK, 4)}
+            rl.update({"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4), "algorithmic_gb_per_step": round(by / 1e9, 2),
+                       "launches_per_step": n, "kernel_ms_per_step": round(ms, 2),
+                       "activations": "bf16 in HBM (2 B per element)" if args.act_bf16 else "fp32 in HBM (converted while staged)",
+                       "measured": "HIP events per launch on the launch stream over one serial step inside bench.py" if iso is not None
+                       else "HIP events per launch inside the timed region (no second stream: --no-overlap)"})
+            rl.pop("algorithmic_gflop_per_step", None)
+        elif iso is not None:
             fl, ms, n = iso.summary()
             # The roofline figures of the kernel are the per-launch HIP-event durations of the serial step: in the timed region
             # two streams run at once, so an event interval there also contains the other stream's kernels (and a graph replay

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 1
+#define VSP_ABI_VERSION 2
 
 #define VSP_OK 0
 #define VSP_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported combination) */
@@ -77,8 +77,8 @@ typedef struct vsp_fir_epilogue {
   const float* noise;       /* [major/channels, out_h, out_w] or NULL */
   const float* noise_w;     /* device scalar, required iff noise != NULL */
   const float* act_bias;    /* [channels] or NULL (treated as 0) */
-  const float* res1;        /* [major, out_h, out_w] or NULL */
-  const float* res2;        /* [major, out_h, out_w] or NULL */
+  const void* res1;         /* [major, out_h, out_w] or NULL; element type of out (float, or bf16 with vsp_upfirdn2d_bf16) */
+  const void* res2;         /* likewise */
   int channels;             /* C (>=1) */
   int act;                  /* 0 none, 1 leaky-relu */
   float slope;              /* 0.2 */
@@ -163,6 +163,10 @@ typedef struct vsp_conv_params {
    * stride / dilation / padding / OH / OW / os* / oo* fields are ignored; prologue scaling and the epilogue's
    * per-channel terms apply, noise and residuals are not available (they follow the blur in the reference). */
   int transposed;
+  /* io_bf16 = 1 (vsp_conv2d_bf16 only): x, y, res1 and res2 hold bf16 elements (raw 16-bit words, same dense NCHW shapes) --
+   * the bf16-ACTIVATION configuration of BASELINE configs[2]: 2 B per element through HBM instead of 4.  Every other operand
+   * (noise, scales, biases) and the accumulation stay fp32; y is rounded to nearest even once, after the epilogue chain. */
+  int io_bf16;
 } vsp_conv_params;
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
@@ -357,6 +361,24 @@ typedef struct vsp_tacc_chain_params {
 
 size_t vsp_tacc_chain_work_floats(int B);
 int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 activations in HBM (BASELINE configs[2] "bf16 kernels"; the fp32 path above is the parity path).  A bf16 tensor is
+ * the raw 16-bit words of its fp32 twin rounded to nearest even, same dense NCHW shape.  Arithmetic stays fp32.
+ *   vsp_convert_*      tensor conversion at the boundary between bf16-I/O kernels and fp32 ones (maps of 16^2 and smaller)
+ *   vsp_upfirdn2d_bf16 the `Blur` form of vsp_upfirdn2d_f32 (up = down = 1, minor = 1, 2x2 / 3x3 / 4x4 taps, out_w >= 16) with
+ *                      x, out and the epilogue's res1 / res2 in bf16 (kernel taps, noise, scales, biases fp32); VSP_ENOTSUP otherwise
+ *   vsp_pointwise_bf16 vsp_pointwise_f32 with the WIDE side in bf16: x when Cout <= 4 (ToRGB reads bf16 features, writes the
+ *                      fp32 image), y when Cin <= 4 (the 3 -> 64 input layer reads the fp32 image, writes bf16 features)
+ * ---------------------------------------------------------------------------------------------- */
+int vsp_convert_f32_to_bf16(uint16_t* out, const float* x, int64_t n, vsp_stream_t stream);
+int vsp_convert_bf16_to_f32(float* out, const uint16_t* x, int64_t n, vsp_stream_t stream);
+int vsp_upfirdn2d_bf16(uint16_t* out, const uint16_t* x, const float* kernel, int major, int in_h, int in_w, int minor,
+                       int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                       int pad_y1, const vsp_fir_epilogue* epilogue, vsp_stream_t stream);
+int vsp_pointwise_bf16(void* y, const void* x, const float* w, const float* in_scale, const float* ch_bias,
+                       const float* bias1, int act1, const float* bias2, int act2, const float* res, const float* up_src,
+                       const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keyed random tensors -- replaces the path's global-RNG draws: one `image.new_empty(B,1,H,W).normal_()` per NoiseInjection

@@ -458,22 +458,30 @@ def test_config_c3_full_size():
     x_T = torch.from_numpy(R.keyed_fill((B, 18, 512), H.SEG_XT, seed, i0))
     e_chain = maxerr(ref["pre_latent"], OM.ddim_sample(sd, ref["latent"].cpu(), x_T, T, S))
     H.BF16_CONV = True
+    pipe.act_bf16 = True                                              # bf16 activations in HBM for stages C + D
     try:
         out = pipe(lq, image_index0=i0)
+        pipe.act_bf16 = False
+        out_f32act = pipe(lq, image_index0=i0)                        # same bf16 kernels, fp32 activations in HBM (round 1's form)
     finally:
         H.BF16_CONV = False
+        pipe.act_bf16 = False
     assert out["restored"].shape == (B, 3, 512, 512) and torch.isfinite(out["restored"]).all()
+    assert out["restored"].dtype == torch.float32 and out["style_sample"].dtype == torch.float32
     d = (out["restored"] - ref["restored"]).float()
+    d32 = (out_f32act["restored"] - ref["restored"]).float()
     std = float(ref["restored"].std())
     q = OM.save_image_quantize(out["restored"][:, :, ::4, ::4].cpu()).int() - OM.save_image_quantize(ref["restored"][:, :, ::4, ::4].cpu()).int()
     rep = {"ddim_chain_vs_oracle": e_chain, "restored_std": std, "bf16_restored_rms": float(d.pow(2).mean().sqrt()),
            "bf16_restored_max": float(d.abs().max()), "bf16_codes_max": maxerr(out["latent"], ref["latent"]),
            "bf16_pre_latent_max": maxerr(out["pre_latent"], ref["pre_latent"]), "lsb_mean": float(q.abs().float().mean()),
-           "lsb_max": int(q.abs().max())}
+           "lsb_max": int(q.abs().max()), "fp32_activations_restored_rms": float(d32.pow(2).mean().sqrt()),
+           "fp32_activations_restored_max": float(d32.abs().max())}
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/parity_c3_b16_ddim25_bf16.json", "w"), indent=1)
     print("C3:", rep)
     assert e_chain < 3e-4
+    assert rep["bf16_restored_rms"] < 2.0 * rep["fp32_activations_restored_rms"] + 1e-3   # storing activations in bf16 adds little
     assert rep["bf16_restored_rms"] < 0.03 * std and rep["bf16_restored_max"] < 0.25 * std and rep["lsb_mean"] < 2.0

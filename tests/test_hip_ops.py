@@ -698,3 +698,96 @@ def test_keyed_fill_matches_restatement_and_is_shard_invariant(H):
         H.keyed_fill([(2, 4)] * 65, list(range(65)), 1, 0)                    # more segments than one launch takes
     with pytest.raises(RuntimeError):
         H.keyed_fill([(2, 7), (2, 8)], [1, 2], 1, 0)                          # a vector segment behind an odd-sized one
+
+
+# ------------------------------------------------------------------------------------------------ bf16 activations in HBM
+def _b16(t):
+    return t.to(torch.bfloat16)
+
+
+def test_convert_roundtrip_and_unaligned(H):
+    """vsp_convert_*: RNE to bf16 (== torch's), exact back; tensors that start at an odd element (2-byte aligned bf16 / 4-byte
+    aligned fp32 storage offsets) go through the same 8- / 16-byte accesses."""
+    x = torch.randn(4099, device=DEV) * 3
+    for off in (0, 1, 2, 3):
+        xs = x[off:]
+        b = H.to_bf16(xs)
+        assert b.dtype == torch.bfloat16 and torch.equal(b, xs.to(torch.bfloat16))
+        base = torch.zeros(4200, device=DEV, dtype=torch.bfloat16)
+        base[off:off + b.numel()] = b
+        bs = base[off:off + b.numel()]                       # bf16 view at element offset `off`
+        assert torch.equal(H.to_f32(bs), b.float())
+    assert H.to_bf16(None) is None and H.to_f32(x) is x and H.to_bf16(H.to_bf16(x)).dtype == torch.bfloat16
+    e = torch.empty(0, device=DEV)
+    assert H.to_bf16(e).numel() == 0
+
+
+@pytest.mark.parametrize("C_,Hh,Ww,k,pad", [(3, 65, 65, 4, (1, 1)), (2, 64, 64, 4, (2, 2)), (5, 33, 129, 4, (1, 1)), (2, 40, 70, 3, (1, 1))])
+def test_blur_bf16_io_matches_fp32_kernel(H, C_, Hh, Ww, k, pad):
+    """vsp_upfirdn2d_bf16 = the fp32 blur on the same (bf16-representable) operands, rounded once at the store: bit-identical
+    to rounding the fp32 kernel's output.  Odd widths make every plane start on a 2-byte boundary."""
+    B = 2
+    x = _b16(torch.randn(B, C_, Hh, Ww, device=DEV))
+    kern = dev(cases.fir_kernel("blur4" if k == 4 else "rand3x3", "bf16io"))
+    oh, ow = Hh + 2 * pad[0] - k + 1, Ww + 2 * pad[0] - k + 1
+    nz = torch.randn(B, 1, oh, ow, device=DEV)
+    nw, ab = torch.full((1,), 0.3, device=DEV), torch.randn(C_, device=DEV)
+    r1, r2 = _b16(torch.randn(B, C_, oh, ow, device=DEV)), _b16(torch.randn(B, C_, oh, ow, device=DEV))
+    got = H.blur_fused(x, kern, pad, noise=nz, noise_w=nw, act_bias=ab, act=True, res1=r1, res2=r2)
+    ref = H.blur_fused(x.float(), kern, pad, noise=nz, noise_w=nw, act_bias=ab, act=True, res1=r1.float(), res2=r2.float())
+    assert got.dtype == torch.bfloat16 and ref.dtype == torch.float32
+    assert torch.equal(got, _b16(ref))
+    assert torch.equal(H.blur_fused(x, kern, pad), _b16(H.blur_fused(x.float(), kern, pad)))      # plain blur
+    got2 = H.blur_fused(x, kern, pad, res1=r1.float())                                          # fp32 residual: converted
+    assert torch.equal(got2, _b16(H.blur_fused(x.float(), kern, pad, res1=r1.float())))
+    small = _b16(torch.randn(1, 2, 9, 9, device=DEV))                                            # narrower than 16: fp32 kernel
+    assert H.blur_fused(small, kern, pad).dtype == torch.float32
+
+
+def test_pointwise_bf16_wide_side(H):
+    B, Cin, S = 2, 64, 64
+    x = _b16(torch.randn(B, Cin, S, S, device=DEV))
+    w, sc, cb = torch.randn(3, Cin, device=DEV) / 8, torch.rand(B, Cin, device=DEV) + 0.5, torch.randn(3, device=DEV)
+    skip, kern = torch.randn(B, 3, S // 2, S // 2, device=DEV), dev(cases.fir_kernel("blur4", "x"))
+    got = H.pointwise(x, w, in_scale=sc, ch_bias=cb, up_src=skip, up_kernel=kern)
+    ref = H.pointwise(x.float(), w, in_scale=sc, ch_bias=cb, up_src=skip, up_kernel=kern)
+    assert got.dtype == torch.float32 and torch.equal(got, ref)       # same fp32 arithmetic on the same values
+    img = torch.rand(B, 3, S, S, device=DEV) * 2 - 1
+    w2, b1, b2 = torch.randn(64, 3, device=DEV), torch.randn(64, device=DEV), torch.randn(64, device=DEV)
+    ref2 = H.pointwise(img, w2, bias1=b1, bias2=b2)
+    H.ACT_BF16, H.BF16_CONV = True, True
+    try:
+        got2 = H.pointwise(img, w2, bias1=b1, bias2=b2)
+    finally:
+        H.ACT_BF16, H.BF16_CONV = False, False
+    assert got2.dtype == torch.bfloat16 and torch.equal(got2, _b16(ref2))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 32, 64, 64, 64), (1, 64, 32, 33, 70), (2, 128, 128, 32, 32)])
+def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww):
+    """io_bf16: the bf16 conv kernel with bf16 x / y / residuals equals the same kernel with fp32 I/O on the same
+    (bf16-representable) operands, rounded once at the store -- stride 1 with the whole epilogue, the four dilation groups,
+    stride 2 and the one-pass transposed form (whose (2H+1)^2 planes are only 2-byte aligned)."""
+    x = _b16(torch.randn(B, Cin, Hh, Ww, device=DEV))
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(Cin * 9)
+    s_in, demod, bias = torch.rand(B, Cin, device=DEV) + 0.5, torch.rand(B, Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+    nz, nw = torch.randn(B, 1, Hh, Ww, device=DEV), torch.full((1,), 0.2, device=DEV)
+    r1, r2 = _b16(torch.randn(B, Cout, Hh, Ww, device=DEV)), _b16(torch.randn(B, Cout, Hh, Ww, device=DEV))
+    pc = H.PackedConv(H.pack_weight(w), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    kw = dict(in_scale=s_in, out_scale=demod, act2=1, bias2=bias, noise=nz, noise_w=nw)
+    got = H.conv2d_packed(x, pc, bf16=True, res1=r1, res2=r2, **kw)
+    ref = H.conv2d_packed(x.float(), pc, bf16=True, res1=r1.float(), res2=r2.float(), **kw)
+    assert got.dtype == torch.bfloat16 and ref.dtype == torch.float32 and torch.equal(got, _b16(ref))
+    pc2 = H.PackedConv(H.pack_weight(w), 1, Cout, Cin, 3, 3, 2, (1,), (1,))
+    assert torch.equal(H.conv2d_packed(x, pc2, bf16=True), _b16(H.conv2d_packed(x.float(), pc2, bf16=True)))
+    yt = H.conv_transpose2d_s2_fused(x, pc, in_scale=s_in, out_scale=demod, bf16=True)
+    assert yt.dtype == torch.bfloat16 and yt.shape[-1] == 2 * Ww + 1
+    assert torch.equal(yt, _b16(H.conv_transpose2d_s2_fused(x.float(), pc, in_scale=s_in, out_scale=demod, bf16=True)))
+    if Cout % 4 == 0 and Cout // 4 >= 8:
+        wp = torch.stack([H.pack_weight(torch.randn(Cout // 4, Cin, 3, 3, device=DEV) / math.sqrt(Cin * 9))[0] for _ in range(4)]).contiguous()
+        pc4 = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+        assert torch.equal(H.conv2d_packed(x, pc4, bf16=True, in_scale=s_in), _b16(H.conv2d_packed(x.float(), pc4, bf16=True, in_scale=s_in)))
+    # a bf16 tensor handed to a layer that runs on an fp32 kernel is converted, the result is fp32
+    assert H.conv2d_packed(x, pc, bf16=False, winograd=False).dtype == torch.float32
+    o32 = torch.empty(B, Cout, Hh, Ww, device=DEV)                    # an fp32 `out` keeps the launch on fp32 I/O
+    assert H.conv2d_packed(x, pc, bf16=True, out=o32, **kw) is o32 and torch.equal(o32, H.conv2d_packed(x.float(), pc, bf16=True, **kw))

@@ -29,7 +29,7 @@ def measure(force, reps=3):
             pipe(lq)
             hip_ops.PROFILER = None
             torch.cuda.synchronize()
-            for fl, s, e, tag in prof.records:
+            for fl, s, e, tag, _nb in prof.records:
                 if tag[7] in ("bf16", "bf16x3"):
                     agg[tag[8]] += s.elapsed_time(e) / reps
     hip_ops.BF16_FORCE = 0

@@ -17,7 +17,7 @@ def step(bf):
         hip_ops.PROFILER = None
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
-    for fl, s, e, tag in prof.records:
+    for fl, s, e, tag, _nb in prof.records:
         k = tag[:7]
         a = agg.setdefault(k, [0, 0.0, 0.0, set()])
         a[0] += 1; a[1] += s.elapsed_time(e); a[2] += fl; a[3].add(tag[7])

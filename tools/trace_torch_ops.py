@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda", 0)
-pipe = bench.build_pipeline(dev, 4, True)
-lq = torch.rand(2, 3, 512, 512, device=dev) * 2 - 1
+pipe = bench.build_pipeline(dev, int(os.environ.get("T", 50)), True, noise_seed=None if os.environ.get("TORCH_RNG") else 123)
+lq = torch.rand(int(os.environ.get("B", 8)), 3, 512, 512, device=dev) * 2 - 1
 with torch.no_grad():
     pipe(lq)
 torch.cuda.synchronize()
@@ -26,9 +26,10 @@ for ev in prof.events():
     site = "?"
     for fr in (ev.stack or []):
         if "vspbfr_amd" in fr or "bench.py" in fr:
-            site = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
+            site = "vspbfr_amd/" + fr.split("vspbfr_amd/")[-1] if "vspbfr_amd/" in fr else fr
             break
     shp = str([tuple(s_) for s_ in (ev.input_shapes or []) if s_][:2])
     cnt[(ev.name, site + " " + shp)] += 1
-for (name, site), n in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
+print("ATen ops per batch (excluding views / allocations):", sum(cnt.values()))
+for (name, site), n in sorted(cnt.items(), key=lambda kv: -kv[1])[:80]:
     print(f"{n:5d}  {name:28s} {site}")

@@ -15,6 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSPBFR_HIP_LIB", os.path.join(_HERE, "lib", "libvspbfr_hip.so"))
 
+ABI_VERSION = 2  # include/vspbfr_hip.h VSP_ABI_VERSION
 c_float_p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 
 
@@ -44,6 +45,7 @@ class ConvParams(C.Structure):
         ("act2", C.c_int), ("bias2", C.c_void_p), ("prelu", C.c_void_p), ("slope2", C.c_float), ("gain2", C.c_float),
         ("res1", C.c_void_p), ("res2", C.c_void_p), ("res_ch", C.c_int), ("res_coff", C.c_int),
         ("tile_hint", C.c_int), ("x_ch", C.c_int), ("x_group_stride", C.c_int), ("transposed", C.c_int),
+        ("io_bf16", C.c_int),
     ]
 
 
@@ -107,6 +109,10 @@ SIGNATURES = {
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
+    "vsp_convert_f32_to_bf16": [_p, _p, _i64, _p],
+    "vsp_convert_bf16_to_f32": [_p, _p, _i64, _p],
+    "vsp_upfirdn2d_bf16": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
+    "vsp_pointwise_bf16": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i64, _p],
     "vsp_keyed_fill_f32": [_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _i, C.c_uint64, _i64, _p, _i, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
@@ -133,8 +139,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_size_t
-    if lib.vsp_abi_version() != 1:
-        raise ImportError(f"vspbfr_amd: ABI version {lib.vsp_abi_version()} != 1")
+    if lib.vsp_abi_version() != ABI_VERSION:
+        raise ImportError(f"vspbfr_amd: ABI version {lib.vsp_abi_version()} != {ABI_VERSION}")
     for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams), (3, TaccBlock), (4, TaccChainParams)):
         if lib.vsp_struct_size(which) != C.sizeof(st):
             raise ImportError(f"vspbfr_amd: struct layout mismatch for {st.__name__}: "

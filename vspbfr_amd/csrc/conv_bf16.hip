@@ -29,6 +29,7 @@
 // Numerics: operands rounded to bf16 (RNE, 8 significant bits), products exact, accumulation fp32; the epilogue chain is
 // the fp32 one of the direct kernel.  Not a parity path: tests bound its error against the fp32 kernels.
 #include "conv_kernel.h"
+#include "vsp_bf16.h"
 #include <type_traits>
 
 namespace vspconv {
@@ -56,9 +57,15 @@ enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 // SPLIT ("bf16x3"): both operands are carried as hi + lo bf16 pairs (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a
 // product is a_hi b_hi + a_hi b_lo + a_lo b_hi on the same fp32 accumulator -- fp32-grade results (relative error ~2^-16 per
 // product instead of 2^-8) at three MFMAs per tile pair; the LDS images and the weight DMA double ([part][...]).
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false>
+// IOB: the activations are bf16 IN HBM (x, y and the two residuals; 2 B per element instead of 4: the bf16-activation
+// configuration, hip_ops.ACT_BF16): the patch is fetched as 16-bit loads (same instruction count, half the bytes: the 512^2 and
+// 256^2 layers are bound by what the fabric delivers), the epilogue reads / writes four bf16 per 8-byte access.
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false>
 __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(!(SPLIT && IOB), "the split-precision form keeps fp32 activations");
+  using AT = typename std::conditional<IOB, vsp::bf16_t, float>::type;  // activation element in HBM
+  constexpr unsigned ES = sizeof(AT);
   constexpr int NPART = SPLIT ? 2 : 1;
   constexpr bool S2 = MODE == M_S2, TCV = MODE == M_TC;
   constexpr int NACC = TCV ? 4 * NB : NB;  // accumulator blocks per 32-channel block: transposed = four phases per position block
@@ -152,15 +159,15 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
       in = wr && sy >= 0 && sx >= 0 && iy < p.H && ix < p.W;
       pdst[e] = idx;
     }
-    poff[e] = in ? (unsigned)(iy * p.W + ix) * 4u : 0u;
+    poff[e] = in ? (unsigned)(iy * p.W + ix) * ES : 0u;
     pin |= in ? (1u << e) : 0u;
     pwr |= wr ? (1u << e) : 0u;
   }
-  const float* xb = p.x + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * chw;
+  const AT* xb = reinterpret_cast<const AT*>(p.x) + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * chw;
   // Two register sets: chunk k lives in set k & 1.  Its loads are issued TWO intervals before its MFMAs (top of interval
   // k - 2), its conversion + LDS write is spread over the tap loop of interval k - 1 (VALU work in the shadow of the MFMAs).
   float pregA[PT][8], pregB[PT][8];
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<AT*>(xb), 0, 0x7fffffff, 0x00020000);
   const float* iscp = p.in_scale + (int64_t)b * p.in_scale_bstride;
   const float* ishp = p.in_shift;
   // Cin is a multiple of 8 (host): a wave's channel octet is either wholly inside or wholly past Cin
@@ -169,13 +176,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     if (cib >= p.Cin) return;                                  // wave-uniform; the octet is committed as zeros
     // buffer loads: resource = this image, scalar offset = the channel plane (wave-uniform), vector offset = the lane's 32-bit
     // byte offset inside a plane.  (With flat pointers hipcc hoists 24 loop-invariant 64-bit per-lane addresses = 48 VGPRs.)
-    int soff = cib * chw * 4;
+    int soff = cib * chw * (int)ES;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int e = 0; e < PT; ++e)  // (tasks past the plane read element 0 and are never written)
-        pr[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)poff[e], soff, 0));
-      soff += chw * 4;
+      for (int e = 0; e < PT; ++e) {  // (tasks past the plane read element 0 and are never written)
+        if constexpr (IOB)  // the raw 16 bits (sign-extended by the load); widened to fp32 when the value is committed
+          pr[e][j] = __builtin_bit_cast(float, (int)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (int)poff[e], soff, 0));
+        else
+          pr[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)poff[e], soff, 0));
+      }
+      soff += chw * (int)ES;
     }
   };
   auto load_scales = [&](int c, float (&sc)[8], float (&sh)[8]) -> bool {  // wave-uniform: scalar loads
@@ -197,7 +208,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     const bool in = ((pin >> e) & 1u) && oct_ok;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = in ? fmaf(pr[e][j], sc[j], sh[j]) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const float xv = IOB ? __builtin_bit_cast(float, __builtin_bit_cast(unsigned, pr[e][j]) << 16) : pr[e][j];
+      v[j] = in ? fmaf(xv, sc[j], sh[j]) : 0.f;
+    }
     const u32x4 hi = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
     Pdst[oct * NPL * PLANE + pdst[e]] = hi;
     if constexpr (SPLIT) {  // lo = bf16(v - hi): the next eight significant bits
@@ -380,12 +394,12 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW;
   const float nw = p.nwp[0];
   const float s1 = p.s1, g1 = p.g1, g2 = p.g2;
-  float* yb = p.y + ((int64_t)b * p.y_ch + p.y_coff) * p.y_h * p.y_w;
-  const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
-  const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
+  AT* yb = reinterpret_cast<AT*>(p.y) + ((int64_t)b * p.y_ch + p.y_coff) * p.y_h * p.y_w;
+  const AT* r1b = reinterpret_cast<const AT*>(p.r1p) + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
+  const AT* r2b = reinterpret_cast<const AT*>(p.r2p) + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w;
   const bool has_nz = p.nzs != 0, has_r1 = p.r1s != 0, has_r2 = p.r2s != 0;
   const int y_plane = p.y_h * p.y_w;
-  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  using vsp::f32x4u;
   constexpr int Q = NPIX / 4;                 // pixel quads per channel row
   constexpr int EROWS = 32 * WM;              // channel rows per pass
   constexpr int EIT = EROWS * Q / BNT;
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           const int co = g * p.cout_g + cg;
           const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
           const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
-          float* yc = yb + (int64_t)co * y_plane;
+          AT* yc = yb + (int64_t)co * y_plane;
           auto fin = [&](float v) {
             v = v * os + cb;
             v = (v > 0.f ? v : v * s1) * g1 + b2;
@@ -420,10 +434,18 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
             if (m + py > p.H) continue;  // row 2m + 1 exists only for m < H
             const int yo = (2 * m + py) * p.y_w + 2 * c;
             const float v0 = fin(acc[mb][nb * 4 + py * 2][i]), v1 = fin(acc[mb][nb * 4 + py * 2 + 1][i]);
-            if (pair)
-              *reinterpret_cast<f32x2u*>(yc + yo) = f32x2u{v0, v1};
-            else
-              yc[yo] = v0;
+            if constexpr (IOB) {
+              typedef unsigned u32h __attribute__((aligned(2)));
+              if (pair)
+                *reinterpret_cast<u32h*>(yc + yo) = vsp::bf16_pack(v0, v1);
+              else
+                vsp::Elem<AT>::store1(yc + yo, v0);
+            } else {
+              if (pair)
+                *reinterpret_cast<f32x2u*>(yc + yo) = f32x2u{v0, v1};
+              else
+                yc[yo] = v0;
+            }
           }
         }
       }
@@ -479,16 +501,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
         if (ox + 3 < p.OW) {
           f32x4u nzv = {0.f, 0.f, 0.f, 0.f}, r1v = nzv, r2v = nzv;
           if (has_nz) nzv = *reinterpret_cast<const f32x4u*>(nzp + oy * p.OW + ox);
-          if (has_r1) r1v = *reinterpret_cast<const f32x4u*>(r1b + ro);
-          if (has_r2) r2v = *reinterpret_cast<const f32x4u*>(r2b + ro);
+          if (has_r1) r1v = vsp::Elem<AT>::load4(r1b + ro);
+          if (has_r2) r2v = vsp::Elem<AT>::load4(r2b + ro);
           const f32x4u o4 = {fin(av[0], nzv[0], r1v[0], r2v[0]), fin(av[1], nzv[1], r1v[1], r2v[1]),
                              fin(av[2], nzv[2], r1v[2], r2v[2]), fin(av[3], nzv[3], r1v[3], r2v[3])};
-          *reinterpret_cast<f32x4u*>(yb + ro) = o4;
+          vsp::Elem<AT>::store4(yb + ro, o4);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (ox + j >= p.OW) continue;
-            yb[ro + j] = fin(av[j], has_nz ? nzp[oy * p.OW + ox + j] : 0.f, has_r1 ? r1b[ro + j] : 0.f, has_r2 ? r2b[ro + j] : 0.f);
+            vsp::Elem<AT>::store1(yb + ro + j, fin(av[j], has_nz ? nzp[oy * p.OW + ox + j] : 0.f, has_r1 ? vsp::Elem<AT>::load1(r1b + ro + j) : 0.f,
+                                                   has_r2 ? vsp::Elem<AT>::load1(r2b + ro + j) : 0.f));
           }
         }
       }
@@ -539,12 +562,15 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
   return r;
 }
 
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false>
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
+  if constexpr (!SPLIT && !IOB) {
+    if (q.io_bf16) return launch_bf<MB, NB, WM, WN, PT, MODE, false, true>(q, gm, stream);
+  }
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_bf16: cannot reserve LDS: %s", hipGetErrorString(e));
     attr_set = true;
@@ -567,7 +593,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
     blocks = ((EW + TW - 1) / TW) * ((EH + TH - 1) / TH);
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT><<<grid, BNT, gm.lds, stream>>>(q);
+  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB><<<grid, BNT, gm.lds, stream>>>(q);
   return VSP_OK;
 }
 

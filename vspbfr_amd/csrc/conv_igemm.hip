@@ -300,6 +300,7 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
     VSP_REQUIRE((p.dil[g] == 1 || p.dil[g] == 2 || p.dil[g] == 4 || p.dil[g] == 8) && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
                 "conv2d_winograd: group %d needs dilation 1, 2, 4 or 8 and padding = dilation (got dilation %d, padding %d/%d)", g,
                 p.dil[g], p.pad_y[g], p.pad_x[g]);
+  VSP_REQUIRE(p.io_bf16 == 0, "conv2d_winograd: fp32 activations only (io_bf16 is served by vsp_conv2d_bf16)");
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
   VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd: transformed weights must be 16-byte aligned");
@@ -386,6 +387,9 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
     if (!q.in_scale) { q.in_scale = kc; q.in_scale_bstride = 0; }
     if (!q.in_shift) q.in_shift = kc + 1;
   }
+  VSP_REQUIRE(!(split && p.io_bf16), "conv2d_bf16x3: the split-precision form keeps fp32 activations (io_bf16 = 0)");
+  VSP_REQUIRE(p.io_bf16 == 0 || p.io_bf16 == 1, "conv2d_bf16: io_bf16 must be 0 or 1");
+  q.io_bf16 = p.io_bf16;
   if (split) {
     if (int rc = vspconv::bf16_launch_split(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
     return vsp::check_launch("conv2d_bf16x3");
@@ -396,6 +400,7 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
 
 extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d: null params");
+  VSP_REQUIRE(pp->io_bf16 == 0, "conv2d: fp32 activations only (io_bf16 is served by vsp_conv2d_bf16)");
   build_table();
   vsp_conv_params pcopy = *pp;
   if (pcopy.transposed) {  // normalise the ignored fields: the launch grid runs over input positions m = 0..H, n = 0..W

@@ -68,6 +68,7 @@ struct ConvK {
   const float* wtp; int wt_cs, wt_bs;
   const float* wcp; int wc_cs, wc_bs;
   const float* wshp; int wsh_cs;
+  int io_bf16;                                   // conv_bf16.hip: x, y, res1, res2 are bf16 in HBM
 };
 
 __device__ __forceinline__ int round_pitch(int n, int odd) {

@@ -4,10 +4,11 @@
 // (measured 2.0-2.3 TB/s on the conv kernel).  Here each thread owns 4 consecutive pixels, every plane is touched with
 // 16-byte accesses issued in batches, the (style-scaled) weights sit in LDS and are read as wave-uniform broadcasts.
 #include "vsp_common.h"
+#include "vsp_bf16.h"
 
 namespace {
 
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+using vsp::f32x4u;
 
 __device__ __forceinline__ float lrelu2(float v, float bias, int act) {
   if (!act) return v;
@@ -16,8 +17,9 @@ __device__ __forceinline__ float lrelu2(float v, float bias, int act) {
 }
 
 // Cout <= 4:  y[b,co,p] = sum_ci x[b,ci,p] * (w[co,ci] * s[b,ci]) + bias[co] + res[b,co,p]
-template <int CO>
-__global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, const float* __restrict__ x,
+// TX = float or vsp::bf16_t: element type of the WIDE side (the Cin input planes); the 3-channel image side stays fp32
+template <int CO, typename TX>
+__global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, const TX* __restrict__ x,
                                                          const float* __restrict__ w, const float* __restrict__ in_scale,
                                                          const float* __restrict__ ch_bias, const float* __restrict__ res,
                                                          const float* __restrict__ up_src, const float* __restrict__ up_k,
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
   const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (p0 >= HW) return;
   const bool full = p0 + 3 < HW;
-  const float* xb = x + (int64_t)b * Cin * HW + p0;
+  const TX* xb = x + (int64_t)b * Cin * HW + p0;
   f32x4u acc[CO];
 #pragma unroll
   for (int co = 0; co < CO; ++co) acc[co] = f32x4u{0.f, 0.f, 0.f, 0.f};
@@ -43,11 +45,11 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
     for (int u = 0; u < UN; ++u) {
       v[u] = f32x4u{0.f, 0.f, 0.f, 0.f};
       if (c0 + u < Cin) {
-        const float* src = xb + (int64_t)(c0 + u) * HW;
+        const TX* src = xb + (int64_t)(c0 + u) * HW;
         if (full) {
-          v[u] = *reinterpret_cast<const f32x4u*>(src);
+          v[u] = vsp::Elem<TX>::load4(src);
         } else {
-          for (int j = 0; j < 4 && p0 + j < HW; ++j) v[u][j] = src[j];
+          for (int j = 0; j < 4 && p0 + j < HW; ++j) v[u][j] = vsp::Elem<TX>::load1(src + j);
         }
       }
     }
@@ -100,8 +102,9 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
 }
 
 // Cin <= 4:  y[b,co,p] = act2(act1(sum_ci x[b,ci,p] * w[co,ci] * s[b,ci] + ch_bias[co]))   (bias + leaky-ReLU(0.2)*sqrt2 each)
-template <int CI>
-__global__ __launch_bounds__(256) void pw_few_in_kernel(float* __restrict__ y, const float* __restrict__ x,
+// TY = float or vsp::bf16_t: element type of the WIDE side (the Cout output planes)
+template <int CI, typename TY>
+__global__ __launch_bounds__(256) void pw_few_in_kernel(TY* __restrict__ y, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ in_scale,
                                                         const float* __restrict__ ch_bias, const float* __restrict__ bias1,
                                                         int act1, const float* __restrict__ bias2, int act2, int Cout,
@@ -138,18 +141,20 @@ __global__ __launch_bounds__(256) void pw_few_in_kernel(float* __restrict__ y, c
       a = lrelu2(a, wr[CI + 1], act1);
       out[j] = lrelu2(a, wr[CI + 2], act2);
     }
-    float* dst = y + ((int64_t)b * Cout + co) * HW + p0;
-    if (full) *reinterpret_cast<f32x4u*>(dst) = out;
-    else for (int j = 0; j < 4 && p0 + j < HW; ++j) dst[j] = out[j];
+    TY* dst = y + ((int64_t)b * Cout + co) * HW + p0;
+    if (full) vsp::Elem<TY>::store4(dst, out);
+    else for (int j = 0; j < 4 && p0 + j < HW; ++j) vsp::Elem<TY>::store1(dst + j, out[j]);
   }
 }
 
 }  // namespace
 
-extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const float* in_scale, const float* ch_bias,
-                                 const float* bias1, int act1, const float* bias2, int act2, const float* res,
-                                 const float* up_src, const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW,
-                                 vsp_stream_t stream) {
+// W = element type of the wide side: x when Cout <= 4, y when Cin <= 4 (the other side and every operand are fp32)
+template <typename TW>
+static int pointwise_impl(void* y, const void* x, const float* w, const float* in_scale, const float* ch_bias,
+                          const float* bias1, int act1, const float* bias2, int act2, const float* res,
+                          const float* up_src, const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW,
+                          vsp_stream_t stream) {
   VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && HW >= 0, "pointwise: bad dims");
   if (B == 0 || HW == 0) return VSP_OK;
   VSP_REQUIRE(y && x && w, "pointwise: null pointer");
@@ -165,22 +170,41 @@ extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const
     VSP_REQUIRE(!act1 && !act2, "pointwise: activations are only implemented on the few-input-channels form");
     VSP_REQUIRE(Cin <= 8192, "pointwise: too many input channels");
     const size_t lds = (size_t)Cout * Cin * sizeof(float);
+    float* yf = static_cast<float*>(y);
+    const TW* xw = static_cast<const TW*>(x);
     switch (Cout) {
-      case 1: pw_few_out_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
-      case 2: pw_few_out_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
-      case 3: pw_few_out_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
-      default: pw_few_out_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      case 1: pw_few_out_kernel<1, TW><<<grid, 256, lds, s>>>(yf, xw, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      case 2: pw_few_out_kernel<2, TW><<<grid, 256, lds, s>>>(yf, xw, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      case 3: pw_few_out_kernel<3, TW><<<grid, 256, lds, s>>>(yf, xw, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
+      default: pw_few_out_kernel<4, TW><<<grid, 256, lds, s>>>(yf, xw, w, in_scale, ch_bias, res, up_src, up_kernel, W, Cin, HW); break;
     }
   } else {
     VSP_REQUIRE(!res, "pointwise: a residual is only implemented on the few-output-channels form");
     VSP_REQUIRE(Cout <= 4096, "pointwise: too many output channels");
     const size_t lds = (size_t)Cout * (Cin + 3) * sizeof(float);
+    TW* yw = static_cast<TW*>(y);
+    const float* xf = static_cast<const float*>(x);
     switch (Cin) {
-      case 1: pw_few_in_kernel<1><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
-      case 2: pw_few_in_kernel<2><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
-      case 3: pw_few_in_kernel<3><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
-      default: pw_few_in_kernel<4><<<grid, 256, lds, s>>>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      case 1: pw_few_in_kernel<1, TW><<<grid, 256, lds, s>>>(yw, xf, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      case 2: pw_few_in_kernel<2, TW><<<grid, 256, lds, s>>>(yw, xf, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      case 3: pw_few_in_kernel<3, TW><<<grid, 256, lds, s>>>(yw, xf, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
+      default: pw_few_in_kernel<4, TW><<<grid, 256, lds, s>>>(yw, xf, w, in_scale, ch_bias, bias1, act1, bias2, act2, Cout, HW); break;
     }
   }
   return vsp::check_launch("pointwise");
+}
+
+extern "C" int vsp_pointwise_f32(float* y, const float* x, const float* w, const float* in_scale, const float* ch_bias,
+                                 const float* bias1, int act1, const float* bias2, int act2, const float* res,
+                                 const float* up_src, const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW,
+                                 vsp_stream_t stream) {
+  return pointwise_impl<float>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, res, up_src, up_kernel, W, B, Cin, Cout, HW, stream);
+}
+
+extern "C" int vsp_pointwise_bf16(void* y, const void* x, const float* w, const float* in_scale, const float* ch_bias,
+                                  const float* bias1, int act1, const float* bias2, int act2, const float* res,
+                                  const float* up_src, const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW,
+                                  vsp_stream_t stream) {
+  return pointwise_impl<vsp::bf16_t>(y, x, w, in_scale, ch_bias, bias1, act1, bias2, act2, res, up_src, up_kernel, W, B, Cin, Cout, HW,
+                                     stream);
 }

@@ -14,6 +14,8 @@
 //    Roofline: HBM, 4 B read + 4 B written per output element (+ epilogue operands).
 //  * fir_generic_kernel: any up/down/tap count/minor (RGB-skip Upsample: 3 channels, negligible bytes).
 #include "vsp_common.h"
+#include "vsp_bf16.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,8 +24,8 @@ struct Epi {
   const float* noise;
   const float* noise_w;
   const float* act_bias;
-  const float* res1;
-  const float* res2;
+  const void* res1;   // same element type as the output (fp32, or bf16 through vsp_upfirdn2d_bf16)
+  const void* res2;
   int channels;
   int act;
   float slope;
@@ -42,8 +44,8 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int
     v = (v > 0.f ? v : v * e.slope) * e.gain;
   }
   const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
-  if (e.res1) v += e.res1[o];
-  if (e.res2) v += e.res2[o];
+  if (e.res1) v += static_cast<const float*>(e.res1)[o];
+  if (e.res2) v += static_cast<const float*>(e.res2)[o];
   return v;
 }
 
@@ -65,15 +67,17 @@ constexpr int NTB = VSP_FIR_NTB;          // tiles per block
 constexpr int TOH = RPT * (256 / (TOW / 4)); // output tile rows
 
 // 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+using vsp::f32x4u;
 
 // One 256-thread block produces a 32x64 output tile of one plane.  Throughput shape: (1) the (32+KH-1) x 68 input window is
 // fetched as three 16-byte loads per thread, ALL issued before the first LDS write (the first version ran ten dependent
 // load -> LDS round trips per block); (2) each thread owns a 2x4 output patch: (KH+1) x 2 ds_read_b128 feed 8 outputs;
 // (3) the epilogue operands (noise, two residuals) are fetched as 16-byte vectors before the FMAs, the result leaves as
 // 16-byte stores.
-template <int KH, int KW>
-__global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, const float* __restrict__ x,
+// T = float or vsp::bf16_t: element type of x, out and the two residuals (arithmetic is fp32 either way; bf16: 2 B read + 2 B
+// written per output element, four elements per 8-byte access at halfword alignment).
+template <int KH, int KW, typename T>
+__global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, const T* __restrict__ x,
                                                         const float* __restrict__ kern, int in_h, int in_w,
                                                         int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
                                                         int tiles_y, int total_tiles, Epi epi) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
     int plane, oy0, ox0;
     decode(t, plane, oy0, ox0);
     const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-    const float* xp = x + (int64_t)plane * in_h * in_w;
+    const T* xp = x + (int64_t)plane * in_h * in_w;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
       const int idx = threadIdx.x + 256 * it;
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
       const int iy = iy0 + r, ix = ix0 + 4 * c4;
       v[it] = f32x4u{0.f, 0.f, 0.f, 0.f};
       if (idx < TIH * TIW4 && iy >= 0 && iy < in_h) {
-        const float* src = xp + (int64_t)iy * in_w + ix;
+        const T* src = xp + (int64_t)iy * in_w + ix;
         if (ix >= 0 && ix + 3 < in_w) {
-          v[it] = *reinterpret_cast<const f32x4u*>(src);
+          v[it] = vsp::Elem<T>::load4(src);
         } else {  // window crosses the left/right image border
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (ix + j >= 0 && ix + j < in_w) v[it][j] = src[j];
+            if (ix + j >= 0 && ix + j < in_w) v[it][j] = vsp::Elem<T>::load1(src + j);
         }
       }
     }
@@ -136,17 +140,19 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
       if (!epi.enabled || oy >= out_h || ox >= out_w) continue;
       const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
       const int64_t on = ((int64_t)b * out_h + oy) * out_w + ox;
+      const T* res1 = static_cast<const T*>(epi.res1);
+      const T* res2 = static_cast<const T*>(epi.res2);
       if (full) {
         if (epi.noise) nz[rr] = *reinterpret_cast<const f32x4u*>(epi.noise + on);
-        if (epi.res1) r1[rr] = *reinterpret_cast<const f32x4u*>(epi.res1 + o);
-        if (epi.res2) r2[rr] = *reinterpret_cast<const f32x4u*>(epi.res2 + o);
+        if (res1) r1[rr] = vsp::Elem<T>::load4(res1 + o);
+        if (res2) r2[rr] = vsp::Elem<T>::load4(res2 + o);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (ox + j < out_w) {
             if (epi.noise) nz[rr][j] = epi.noise[on + j];
-            if (epi.res1) r1[rr][j] = epi.res1[o + j];
-            if (epi.res2) r2[rr][j] = epi.res2[o + j];
+            if (res1) r1[rr][j] = vsp::Elem<T>::load1(res1 + o + j);
+            if (res2) r2[rr][j] = vsp::Elem<T>::load1(res2 + o + j);
           }
       }
     }
@@ -204,13 +210,13 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(float* __restrict__ out, 
         }
         o4[j] = a;
       }
-      float* dst = out + ((int64_t)plane * out_h + oy) * out_w + ox;
+      T* dst = out + ((int64_t)plane * out_h + oy) * out_w + ox;
       if (full) {
-        *reinterpret_cast<f32x4u*>(dst) = o4;
+        vsp::Elem<T>::store4(dst, o4);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (ox + j < out_w) dst[j] = o4[j];
+          if (ox + j < out_w) vsp::Elem<T>::store1(dst + j, o4[j]);
       }
     }
   };
@@ -272,10 +278,11 @@ __global__ __launch_bounds__(256) void fir_generic_kernel(float* __restrict__ ou
 
 }  // namespace
 
-extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major, int in_h, int in_w,
-                                  int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, const vsp_fir_epilogue* epi_in,
-                                  vsp_stream_t stream) {
+template <typename T>
+static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, int in_h, int in_w, int minor, int kh, int kw,
+                          int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                          const vsp_fir_epilogue* epi_in, vsp_stream_t stream) {
+  constexpr bool BF = !std::is_same<T, float>::value;
   VSP_REQUIRE(major >= 0 && in_h >= 0 && in_w >= 0 && minor >= 0, "upfirdn2d: negative dimension");
   VSP_REQUIRE(kh >= 1 && kw >= 1 && kh * kw <= 1024, "upfirdn2d: unsupported kernel size %dx%d", kh, kw);
   VSP_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d: up/down factors must be >= 1");
@@ -313,19 +320,39 @@ extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
     VSP_REQUIRE(blocks < ((int64_t)1 << 31), "upfirdn2d: grid too large");
     if (kh == 4)
-      fir_tile_kernel<4, 4><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
+      fir_tile_kernel<4, 4, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
     else if (kh == 3)
-      fir_tile_kernel<3, 3><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
+      fir_tile_kernel<3, 3, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
     else
-      fir_tile_kernel<2, 2><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                         pad_y0, tiles_x, tiles_y, (int)blocks, e);
+      fir_tile_kernel<2, 2, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
+                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
     return vsp::check_launch("upfirdn2d(tile)");
   }
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > vsp::kMaxStreamBlocks) blocks = vsp::kMaxStreamBlocks;
-  fir_generic_kernel<<<(unsigned)blocks, 256, kh * kw * sizeof(float), s>>>(
-      out, x, kernel, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, e);
-  return vsp::check_launch("upfirdn2d(generic)");
+  if constexpr (BF) {
+    return vsp::fail(VSP_ENOTSUP, "upfirdn2d_bf16: only the blur form (up = down = 1, minor = 1, 2x2 / 3x3 / 4x4 taps, width >= 16) has a bf16 kernel");
+  } else {
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > vsp::kMaxStreamBlocks) blocks = vsp::kMaxStreamBlocks;
+    fir_generic_kernel<<<(unsigned)blocks, 256, kh * kw * sizeof(float), s>>>(
+        out, x, kernel, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, out_h, out_w, e);
+    return vsp::check_launch("upfirdn2d(generic)");
+  }
+}
+
+extern "C" int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major, int in_h, int in_w,
+                                  int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, const vsp_fir_epilogue* epi_in,
+                                  vsp_stream_t stream) {
+  return upfirdn2d_impl<float>(out, x, kernel, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                               pad_y1, epi_in, stream);
+}
+
+extern "C" int vsp_upfirdn2d_bf16(uint16_t* out, const uint16_t* x, const float* kernel, int major, int in_h, int in_w,
+                                   int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, const vsp_fir_epilogue* epi_in,
+                                   vsp_stream_t stream) {
+  return upfirdn2d_impl<vsp::bf16_t>(out, x, kernel, major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1,
+                                     pad_y0, pad_y1, epi_in, stream);
 }

@@ -27,16 +27,21 @@ class ConvProfiler:
         ev.record()
         return ev
 
-    def end(self, start, flops, tag):
+    def end(self, start, flops, tag, nbytes=0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.append((flops, start, ev, tag))
+        self.records.append((flops, start, ev, tag, nbytes))
 
     def summary(self):
         """-> (total algorithmic FLOPs, total ms, launches); call after a device synchronize."""
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return fl, ms, len(self.records)
+
+    def algorithmic_bytes(self):
+        """Sum over the launches of the bytes a convolution must move when every operand crosses HBM exactly once: input image,
+        output, weights, noise map and residuals at their element sizes (the unit of the HBM roofline)."""
+        return sum(r[4] for r in self.records)
 
 
 PROFILER = None
@@ -90,16 +95,48 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _req(t, name):
+def _req(t, name, bf16_ok=False):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f"{name} must be a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA tensor")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
+        raise RuntimeError(f"{name} must be float32{' or bfloat16' if bf16_ok else ''} (got {t.dtype})")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     return t
+
+
+# bf16 ACTIVATIONS in HBM (BASELINE configs[2]; needs BF16_CONV = True).  Off: every tensor is fp32.  On: a layer that runs on a
+# bf16-I/O kernel (vsp_conv2d_bf16 with io_bf16, vsp_upfirdn2d_bf16, vsp_pointwise_bf16) reads and writes bf16 tensors; the dtype
+# simply follows the kernel, and a consumer whose kernel wants the other type converts its (small-map) input first -- the
+# transitions sit at the 16^2 maps, where the bf16 conv kernel hands over to the fp32 ones.
+ACT_BF16 = False
+BF = torch.bfloat16
+
+
+def to_bf16(t):
+    """fp32 -> bf16 (round to nearest even) through vsp_convert_f32_to_bf16; bf16 tensors pass through."""
+    if t is None or t.dtype == BF:
+        return t
+    t = _req(t, "tensor")
+    out = torch.empty(t.shape, device=t.device, dtype=BF)
+    check(lib.vsp_convert_f32_to_bf16(_ptr(out), _ptr(t), t.numel(), _stream()), "convert_f32_to_bf16")
+    return out
+
+
+def to_f32(t):
+    """bf16 -> fp32 (exact) through vsp_convert_bf16_to_f32; fp32 tensors pass through."""
+    if t is None or t.dtype == torch.float32:
+        return t
+    t = _req(t, "tensor", bf16_ok=True)
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    check(lib.vsp_convert_bf16_to_f32(_ptr(out), _ptr(t), t.numel(), _stream()), "convert_bf16_to_f32")
+    return out
+
+
+def as_dtype(t, dtype):
+    return to_bf16(t) if dtype == BF else to_f32(t)
 
 
 def _ptr(t):
@@ -137,7 +174,7 @@ def fir_out_size(in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, px0, px1, py0, 
 def upfirdn2d_native_layout(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, epilogue=None):
     """Same contract as the reference's native `upfirdn2d_op.upfirdn2d` (op/upfirdn2d.cpp:17-31):
     input [major, in_h, in_w, minor] -> new tensor [major, out_h, out_w, minor]."""
-    x = _req(input, "input")
+    x = _req(input, "input", bf16_ok=True)
     k = _req(kernel, "kernel")
     if x.dim() != 4 or k.dim() != 2:
         raise RuntimeError("upfirdn2d expects input [major,H,W,minor] and a 2-D kernel")
@@ -148,19 +185,30 @@ def upfirdn2d_native_layout(input, kernel, up_x, up_y, down_x, down_y, pad_x0, p
         raise RuntimeError(f"upfirdn2d: negative output size {out_h}x{out_w}")
     out = torch.empty((major, out_h, out_w, minor), device=x.device, dtype=x.dtype)
     epi = C.byref(epilogue) if epilogue is not None else None
-    check(lib.vsp_upfirdn2d_f32(_ptr(out), _ptr(x), _ptr(k), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x,
-                                down_y, pad_x0, pad_x1, pad_y0, pad_y1, epi, _stream()), "upfirdn2d")
+    fn = lib.vsp_upfirdn2d_bf16 if x.dtype == BF else lib.vsp_upfirdn2d_f32
+    check(fn(_ptr(out), _ptr(x), _ptr(k), major, in_h, in_w, minor, kh, kw, up_x, up_y, down_x,
+             down_y, pad_x0, pad_x1, pad_y0, pad_y1, epi, _stream()), "upfirdn2d")
     return out
+
+
+def fir_bf16_ok(kh, kw, up, down, minor, out_w):
+    """What vsp_upfirdn2d_bf16 serves: the blur form."""
+    return up == 1 and down == 1 and minor == 1 and out_w >= 16 and (kh, kw) in ((4, 4), (3, 3), (2, 2))
 
 
 def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_bias=None, act=False, res1=None,
                res2=None, slope=0.2, gain=SQRT2):
-    """NCHW blur (up=down=1) with the fused demod/noise/bias/leaky-relu/residual epilogue of the C ABI."""
-    x = _req(x, "x")
+    """NCHW blur (up=down=1) with the fused demod/noise/bias/leaky-relu/residual epilogue of the C ABI.  The element type of
+    x decides the kernel (fp32 / bf16 activations); residuals are converted to it when they differ (small maps only)."""
+    x = _req(x, "x", bf16_ok=True)
     B, Cc, H, W = x.shape
+    kh, kw = kernel.shape
+    if x.dtype == BF and not fir_bf16_ok(kh, kw, 1, 1, 1, fir_out_size(H, W, kh, kw, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1])[1]):
+        x = to_f32(x)
+    res1, res2 = as_dtype(res1, x.dtype), as_dtype(res2, x.dtype)
     epi = FirEpilogue()
     keep = [_opt(plane_scale, "plane_scale"), _opt(noise, "noise"), _opt(noise_w, "noise_w"), _opt(act_bias, "act_bias"),
-            _opt(res1, "res1"), _opt(res2, "res2")]
+            _req(res1, "res1", True) if res1 is not None else None, _req(res2, "res2", True) if res2 is not None else None]
     epi.plane_scale, epi.noise, epi.noise_w, epi.act_bias, epi.res1, epi.res2 = [
         (t.data_ptr() if t is not None else None) for t in keep]
     epi.channels, epi.act, epi.slope, epi.gain = Cc, 1 if act else 0, slope, gain
@@ -327,41 +375,13 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     compute (defaults to the standard conv output size).  `winograd`: True / False forces / forbids the F(2x2,3x3) kernel
     (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape.  `bf16`: True runs the
     layer on vsp_conv2d_bf16 (tile_hint = its variant), None = the module switch BF16_CONV on eligible layers."""
-    x = _req(x, "x")
+    x = _req(x, "x", bf16_ok=True)
     B, x_ch, H, W = x.shape
     Cin = pc.cin
     if (pc.G - 1) * pc.x_group_stride + Cin != x_ch:
         raise RuntimeError(f"conv2d: input has {x_ch} channels, weight expects {(pc.G - 1) * pc.x_group_stride + Cin}")
     OH, OW = n_out if n_out is not None else ((H + 1, W + 1) if transposed else conv2d_out_size(H, W, pc))
-    if out is None and transposed:
-        out = torch.empty((B, pc.cout, 2 * H + 1, 2 * W + 1), device=x.device, dtype=x.dtype)
-    if out is None:
-        yh, yw = out_hw if out_hw is not None else (OH, OW)
-        out = torch.empty((B, pc.cout, yh, yw), device=x.device, dtype=x.dtype)
-    _req(out, "out")
-    if B == 0:  # empty batch: nothing to enqueue (an empty tensor has no device pointer to hand to the C ABI)
-        return out
-    p = ConvParams()
-    keep = [x, pc.w, out, _opt(in_scale, "in_scale"), _opt(in_shift, "in_shift"), _opt(out_scale, "out_scale"),
-            _opt(ch_scale, "ch_scale"), _opt(ch_bias, "ch_bias"), _opt(bias1, "bias1"), _opt(noise, "noise"),
-            _opt(noise_w, "noise_w"), _opt(bias2, "bias2"), _opt(prelu, "prelu"), _opt(res1, "res1"), _opt(res2, "res2")]
-    dp = [(t.data_ptr() if t is not None else None) for t in keep]
-    (p.x, p.w, p.y, p.in_scale, p.in_shift, p.out_scale, p.ch_scale, p.ch_bias, p.bias1, p.noise, p.noise_w, p.bias2,
-     p.prelu, p.res1, p.res2) = dp
-    p.B, p.Cin, p.H, p.W = B, Cin, H, W
-    p.G, p.cout_g, p.OH, p.OW, p.KH, p.KW = pc.G, pc.cout_g, OH, OW, pc.kh, pc.kw
-    p.stride_y = p.stride_x = pc.stride
-    for g in range(4):
-        p.dil[g], p.pad_y[g], p.pad_x[g] = pc.dil[g], pc.pad_y[g], pc.pad_x[g]
-    p.y_ch, p.y_coff, p.y_h, p.y_w = out.shape[1], y_coff, out.shape[2], out.shape[3]
-    p.osy, p.osx = out_stride
-    p.ooy, p.oox = out_offset
-    p.in_scale_bstride = Cin if (in_scale is not None and in_scale_per_sample) else 0
-    p.act1, p.slope1, p.gain1 = (1 if act1 else 0), 0.2, SQRT2
-    p.act2, p.slope2, p.gain2 = int(act2), float(slope2), float(gain2)
-    rt = res1 if res1 is not None else res2
-    p.res_ch = rt.shape[1] if rt is not None else 0
-    p.res_coff = res_coff
+    # ---- which kernel family serves this launch (decided before anything is allocated: it fixes the activation dtype)
     key = conv_key(B, Cin, H, W, pc, OH, OW) + (",t" if transposed else "") + (",s" if in_shift is not None else "")
     if tile_hint == 0 and TUNE:
         pref = TUNE.get(key, 0)
@@ -377,6 +397,45 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
                 pc.stride == 1 or (pc.stride == 2 and pc.G == 1 and OW >= 32)))
     elif bf16 and not bf_ok:
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
+    # bf16 activations: the bf16 kernel (not its split-precision form) reads and writes bf16 when the configuration asks for it or
+    # the caller hands it a bf16 tensor; every other kernel is fp32 on both sides
+    io_bf = bool(bf16) and not x3 and (x.dtype == BF or (ACT_BF16 and out is None)) and (out is None or out.dtype == BF)
+    act_dt = BF if io_bf else torch.float32
+    x = as_dtype(x, act_dt)
+    res1, res2 = as_dtype(res1, act_dt), as_dtype(res2, act_dt)
+    if out is None and transposed:
+        out = torch.empty((B, pc.cout, 2 * H + 1, 2 * W + 1), device=x.device, dtype=act_dt)
+    if out is None:
+        yh, yw = out_hw if out_hw is not None else (OH, OW)
+        out = torch.empty((B, pc.cout, yh, yw), device=x.device, dtype=act_dt)
+    _req(out, "out", bf16_ok=io_bf)
+    if out.dtype != act_dt:
+        raise RuntimeError(f"conv2d: `out` is {out.dtype} but this launch writes {act_dt}")
+    if B == 0:  # empty batch: nothing to enqueue (an empty tensor has no device pointer to hand to the C ABI)
+        return out
+    p = ConvParams()
+    keep = [x, pc.w, out, _opt(in_scale, "in_scale"), _opt(in_shift, "in_shift"), _opt(out_scale, "out_scale"),
+            _opt(ch_scale, "ch_scale"), _opt(ch_bias, "ch_bias"), _opt(bias1, "bias1"), _opt(noise, "noise"),
+            _opt(noise_w, "noise_w"), _opt(bias2, "bias2"), _opt(prelu, "prelu"),
+            _req(res1, "res1", io_bf) if res1 is not None else None, _req(res2, "res2", io_bf) if res2 is not None else None]
+    dp = [(t.data_ptr() if t is not None else None) for t in keep]
+    (p.x, p.w, p.y, p.in_scale, p.in_shift, p.out_scale, p.ch_scale, p.ch_bias, p.bias1, p.noise, p.noise_w, p.bias2,
+     p.prelu, p.res1, p.res2) = dp
+    p.io_bf16 = 1 if io_bf else 0
+    p.B, p.Cin, p.H, p.W = B, Cin, H, W
+    p.G, p.cout_g, p.OH, p.OW, p.KH, p.KW = pc.G, pc.cout_g, OH, OW, pc.kh, pc.kw
+    p.stride_y = p.stride_x = pc.stride
+    for g in range(4):
+        p.dil[g], p.pad_y[g], p.pad_x[g] = pc.dil[g], pc.pad_y[g], pc.pad_x[g]
+    p.y_ch, p.y_coff, p.y_h, p.y_w = out.shape[1], y_coff, out.shape[2], out.shape[3]
+    p.osy, p.osx = out_stride
+    p.ooy, p.oox = out_offset
+    p.in_scale_bstride = Cin if (in_scale is not None and in_scale_per_sample) else 0
+    p.act1, p.slope1, p.gain1 = (1 if act1 else 0), 0.2, SQRT2
+    p.act2, p.slope2, p.gain2 = int(act2), float(slope2), float(gain2)
+    rt = res1 if res1 is not None else res2
+    p.res_ch = rt.shape[1] if rt is not None else 0
+    p.res_coff = res_coff
     if bf16:
         winograd = False
         if tile_hint < 0:
@@ -436,7 +495,11 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     else:
         check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
     if prof is not None:
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else "bf16") if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct")), key))
+        es = 2 if io_bf else 4
+        n_out_el = B * pc.cout * ((2 * H + 1) * (2 * W + 1) if transposed else OH * OW)
+        nbytes = (x.numel() + n_out_el * (1 + (res1 is not None) + (res2 is not None))) * es + pc.cout * Cin * pc.kh * pc.kw * (2 if bf16 else 4) + (
+            B * OH * OW * 4 if noise is not None else 0)
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else "bf16") if bf16 else ("wino" if winograd else ("tconv" if transposed else "direct")), key), nbytes)
     return out
 
 
@@ -696,14 +759,20 @@ def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=Non
     """1x1 convolution with <= 4 channels on one side as an HBM stream (see vsp_pointwise_f32): x (B,Cin,H,W), w (Cout,Cin);
     bias1 / bias2 switch on the two FusedLeakyReLU stages (few-input form), res is added last (few-output form);
     up_src (B,Cout,H/2,W/2) + up_kernel (4,4): the 2x FIR-upsampled skip is evaluated inside the kernel and added."""
-    x = _req(x, "x")
+    x = _req(x, "x", bf16_ok=True)
     B, Cin, Hh, Ww = x.shape
     Cout = w.shape[0]
-    y = torch.empty((B, Cout, Hh, Ww), device=x.device, dtype=x.dtype)
-    check(lib.vsp_pointwise_f32(_ptr(y), _ptr(x), _ptr(_req(w, "w")), _ptr(_opt(in_scale, "in_scale")), _ptr(_opt(ch_bias, "ch_bias")),
-                                _ptr(_opt(bias1, "bias1")), 1 if bias1 is not None else 0, _ptr(_opt(bias2, "bias2")),
-                                1 if bias2 is not None else 0, _ptr(_opt(res, "res")), _ptr(_opt(up_src, "up_src")),
-                                _ptr(_opt(up_kernel, "up_kernel")), Ww, B, Cin, Cout, Hh * Ww, _stream()), "pointwise")
+    # bf16 on the WIDE side only: few outputs (ToRGB) read bf16 features and write the fp32 image; few inputs (the 3 -> 64 input
+    # layer) read the fp32 image and, in the bf16-activation configuration, write bf16 features
+    if Cout > 4 and x.dtype == BF:
+        x = to_f32(x)
+    wide_bf = (x.dtype == BF) if Cout <= 4 else bool(ACT_BF16 and BF16_CONV is True and min(Hh, Ww) >= 32)
+    y = torch.empty((B, Cout, Hh, Ww), device=x.device, dtype=BF if (wide_bf and Cout > 4) else torch.float32)
+    fn = lib.vsp_pointwise_bf16 if wide_bf else lib.vsp_pointwise_f32
+    check(fn(_ptr(y), _ptr(x), _ptr(_req(w, "w")), _ptr(_opt(in_scale, "in_scale")), _ptr(_opt(ch_bias, "ch_bias")),
+             _ptr(_opt(bias1, "bias1")), 1 if bias1 is not None else 0, _ptr(_opt(bias2, "bias2")),
+             1 if bias2 is not None else 0, _ptr(_opt(res, "res")), _ptr(_opt(up_src, "up_src")),
+             _ptr(_opt(up_kernel, "up_kernel")), Ww, B, Cin, Cout, Hh * Ww, _stream()), "pointwise")
     return y
 
 

@@ -58,6 +58,9 @@ class RestorationPipeline:
         self.generator, self.psp, self.diffusion = generator.eval(), psp_embedding.eval(), diffusion.eval()
         self.mixing, self.with_sample, self.noise_seed = mixing, with_sample, noise_seed
         self._index_tensor = None  # device int64 base index (graph replays)
+        # bf16 ACTIVATIONS in HBM for stages C + D (BASELINE configs[2]; only with hip_ops.BF16_CONV = True): every map of 32^2
+        # and larger travels between the kernels as bf16, the 3-channel images, the latents, the noise maps and stage A + B stay fp32
+        self.act_bf16 = False
         # option for the split-precision configuration: keep the encoder on the fp32 kernels.  Off: measured on the pinned case the
         # free-running result is the same either way (codes 2.5e-5 vs 4e-6, restored 3.0e-3 vs 3.6e-3 from the reference -- the
         # sampler chain's own fp32 conditioning dominates), and it costs 5 % throughput (tools/x3_free_running.py)
@@ -111,9 +114,15 @@ class RestorationPipeline:
             gen_noise = kg if gen_noise is None else gen_noise
             enc_noise, dec_noise = (ke if enc_noise is None else enc_noise), (kd if dec_noise is None else dec_noise)
         noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
-        sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
-        restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
-                                  dec_noise=dec_noise)
+        from . import hip_ops
+        prev = hip_ops.ACT_BF16
+        hip_ops.ACT_BF16 = bool(self.act_bf16 and hip_ops.BF16_CONV is True)
+        try:
+            sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
+            restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
+                                      dec_noise=dec_noise)
+        finally:
+            hip_ops.ACT_BF16 = prev
         return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
 
     @torch.no_grad()
