@@ -33,6 +33,14 @@ namespace vspconv {
 
 namespace {
 
+// Wave-uniform operand through the scalar cache, whatever the compiler can prove about the index: the constant address space
+// makes the load an s_load (lgkmcnt).  As a per-lane global load it joins vmcnt and drags the latency of every prefetch in
+// flight into the interval (measured: 674 -> 802 us on 512 -> 512 at 64^2 when an unrelated edit flipped the compiler's choice).
+__device__ __forceinline__ float uload(const float* base, int idx) {
+  typedef const float __attribute__((address_space(4))) * cfp4;
+  return ((cfp4)(uintptr_t)base)[__builtin_amdgcn_readfirstlane(idx)];
+}
+
 constexpr int WCK = 4;      // input channels per chunk = one MFMA k-step
 constexpr int NTHR = 512;
 
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     const int ci = c * IVC + p_ch;             // pixels only, so it is applied here (plain layers: scale 1, shift 0 from the constants)
     const bool chok = ci < p.Cin;
     const int cc = chok ? ci : p.Cin - 1;
-    const float sc = p.wcp[(int64_t)b * p.wc_bs + cc * p.wc_cs], sh = p.wshp[cc * p.wsh_cs];
+    const float sc = uload(p.wcp, b * p.wc_bs + cc * p.wc_cs), sh = uload(p.wshp, cc * p.wsh_cs);
 #pragma unroll
     for (int e = 0; e < PLD; ++e)
       if (PLD * PTH == PLANE || p_t + PTH * e < PLANE) Pdst[p_ch * PPITCH + p_t + PTH * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
       //  issued -- into every interval)
       const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
       const int ci = c * IVC + t_ch;
-      const float sc = p.wtp[(int64_t)b * p.wt_bs + (ci < p.Cin ? ci : p.Cin - 1) * p.wt_cs];
+      const float sc = uload(p.wtp, b * p.wt_bs + (ci < p.Cin ? ci : p.Cin - 1) * p.wt_cs);
       const auto& dd = tdd[it];
       float w0[4], w1[4];
 #pragma unroll
@@ -236,19 +244,20 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     for (int mb = 0; mb < MBW; ++mb)
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply_pp = [&](const float* Vsrc, int ks, int pp, const float (&u)[UF]) {  // one position of k-step ks: MBW x NBW MFMAs
+    const float* vp = Vsrc + (2 * wave + pp) * (IVC * VPITCH) + (4 * ks + kq) * VPITCH + lr;
+    float bv[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) bv[nb] = vp[nb * 16];
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb)
+        acc[pp][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pp * MBW + mb], bv[nb], acc[pp][mb][nb], 0, 0, 0);
+  };
   auto multiply = [&](const float* Vsrc, int ks, const float (&u)[UF]) {  // k-step ks of the interval: channels 4 ks + kq
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-      const float* vp = Vsrc + (2 * wave + pp) * (IVC * VPITCH) + (4 * ks + kq) * VPITCH + lr;
-      float bv[NBW];
-#pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) bv[nb] = vp[nb * 16];
-#pragma unroll
-      for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb)
-          acc[pp][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pp * MBW + mb], bv[nb], acc[pp][mb][nb], 0, 0, 0);
-    }
+    multiply_pp(Vsrc, ks, 0, u);
+    multiply_pp(Vsrc, ks, 1, u);
   };
 
   // ---- pipeline.  State at the top of interval i:  Vl[i&1] = V(i), Pl[(i+1)&1] = patch(i+1), ua = U chunk KS*i (registers,
@@ -287,7 +296,11 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     if ((FULL || i + 3 < nchunk) && !(ab & 0x1000)) issue_p(i + 3);
     // program order inside the wave: the transform's LDS reads go out first, its arithmetic and LDS writes follow the first
     // k-step's MFMAs -- an in-order wave overlaps only what sits between its own MFMAs (the matrix pipe takes one every 32 cycles)
-    // (the 128-tile geometry runs two tasks per thread: 24 window registers across the MFMAs would spill -- it transforms first)
+    // (the 128-tile geometry runs two tasks per thread: 24 window registers across the MFMAs would spill -- it transforms first).
+    // Tried on top of this order and dropped: groups of MBW x NBW MFMAs with the transform pinned between them by scheduling
+    // fences (718 us on 512 -> 512 at 64^2 against 688: a fenced block of VALU work leaves the pipe to the other waves only) and
+    // sched_group_barrier patterns (one MFMA : two VALU), which the scheduler does not honour across the LDS waits; an
+    // anti-phase start of the two workgroups of a CU (s_sleep of half an interval for every other group of 32): no effect.
     constexpr bool SPLIT = TPT == 1;
     const bool tr = (FULL || i + 1 < nchunk) && !(ab & 0x400);
     if (tr) transform_read(Pl + nxt * LDS_P);

@@ -1,7 +1,8 @@
 """conv2d_gradfix: signature mirror of reference op/conv2d_gradfix.py:22-92 (which, on every torch other than
 1.7/1.8, is a pass-through to F.conv2d / F.conv_transpose2d, :78-92) routed to the gfx950 implicit-GEMM kernel.
-Forward only.  `groups > 1` is served group by group (the model code in this package never needs it: it uses the
-modulate-input / demodulate-output form, see vspbfr_amd/layers.py)."""
+Forward only.  `groups > 1` (the reference's `groups=batch` modulated form, models/RestoreNet.py:373-383) is ONE launch: the kernel's
+true-group mode (x_group_stride) gives every group its own input-channel slice; the model code in this package does not need it
+(it uses the modulate-input / demodulate-output form, see vspbfr_amd/layers.py)."""
 import contextlib
 
 import torch
@@ -32,12 +33,12 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if groups == 1:
         return hip_ops.conv2d(input.contiguous(), weight.contiguous(), bias, sy, py, dy)
     B, C, H, W = input.shape
-    cg, og = C // groups, weight.shape[0] // groups
-    outs = []
-    for g in range(groups):
-        outs.append(hip_ops.conv2d(input[:, g * cg:(g + 1) * cg].contiguous(), weight[g * og:(g + 1) * og].contiguous(),
-                                   None if bias is None else bias[g * og:(g + 1) * og].contiguous(), sy, py, dy))
-    return torch.cat(outs, dim=1)
+    cout, cg, kh, kw = weight.shape
+    if C != cg * groups or cout % groups:
+        raise RuntimeError(f"conv2d_gradfix.conv2d: input has {C} channels, weight expects {cg} x {groups} groups")
+    pc = hip_ops.PackedConv(hip_ops.pack_weight(weight.contiguous(), groups), groups, cout // groups, cg, kh, kw, sy, (dy,), (py,),
+                            x_group_stride=cg)
+    return hip_ops.conv2d_packed(input.contiguous(), pc, ch_bias=None if bias is None else bias.contiguous())
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
