@@ -40,7 +40,7 @@ const char* vsp_last_error(void);
 /* number of HIP devices visible, or a negative VSP_E* code (used by the loader's self-check). */
 int vsp_device_count(void);
 /* sizeof of an ABI struct (0 = vsp_fir_epilogue, 1 = vsp_conv_params, 2 = vsp_gemm_params,
- * 3 = vsp_tacc_block, 4 = vsp_tacc_chain_params): lets a binding in
+ * 3 = vsp_tacc_block, 4 = vsp_tacc_chain_params, 5 = vsp_conv_wgrad_params): lets a binding in
  * another language check its own struct layout when it loads the library. */
 int vsp_struct_size(int which);
 
@@ -379,6 +379,31 @@ int vsp_upfirdn2d_bf16(uint16_t* out, const uint16_t* x, const float* kernel, in
 int vsp_pointwise_bf16(void* y, const void* x, const float* w, const float* in_scale, const float* ch_bias,
                        const float* bias1, int act1, const float* bias2, int act2, const float* res, const float* up_src,
                        const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW, vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution backward (the training step; reference op/conv2d_gradfix.py:104-227, which on current torch is
+ * autograd of F.conv2d / F.conv_transpose2d, :78-92).
+ *   data gradient   = the forward kernels: conv with the flipped, channel-transposed weight (stride 1), the one-pass
+ *                     transposed conv (adjoint of the stride-2 conv) and the stride-2 conv (adjoint of the transposed conv)
+ *   weight gradient = vsp_conv2d_wgrad_f32:
+ *     dw[g][co][ci][ky][kx] = sum_{b,oy,ox} dy[b, g*Cout_g+co, oy, ox] * dy_scale[b, .] * x[b, g*Cin_g+ci, oy*stride+ky*dil-pad, ox*stride+kx*dil-pad] * x_scale[b, .]
+ *     dw is (G*Cout_g, Cin_g, KH, KW) dense (torch's weight layout), overwritten; x (B, G*Cin_g, H, W), dy (B, G*Cout_g, OH, OW);
+ *     x_scale (B, G*Cin_g) / dy_scale (B, G*Cout_g) may be NULL (the per-sample style / demodulation vectors of a
+ *     modulated layer in its modulate-input / demodulate-output form); 3x3 or 1x1, stride 1 or 2.  G = B with batch 1 is
+ *     the reference's groups=batch form (models/RestoreNet.py:373-383).  A transposed conv's weight gradient is the same
+ *     call with x and dy exchanged (and the result read as (ci, co)).
+ *   vsp_plane_dot_f32: out[p] = sum_i a[p,i]*b[p,i] -- the gradients of the two per-sample scale vectors.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct vsp_conv_wgrad_params {
+  const float* x;
+  const float* dy;
+  float* dw;
+  const float* x_scale;
+  const float* dy_scale;
+  int B, Cin_g, H, W, G, Cout_g, OH, OW, KH, KW, stride, dil, pad;
+} vsp_conv_wgrad_params;
+int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* p, vsp_stream_t stream);
+int vsp_plane_dot_f32(float* out, const float* a, const float* b, int64_t planes, int64_t n, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keyed random tensors -- replaces the path's global-RNG draws: one `image.new_empty(B,1,H,W).normal_()` per NoiseInjection

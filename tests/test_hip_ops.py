@@ -791,3 +791,82 @@ def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww):
     assert H.conv2d_packed(x, pc, bf16=False, winograd=False).dtype == torch.float32
     o32 = torch.empty(B, Cout, Hh, Ww, device=DEV)                    # an fp32 `out` keeps the launch on fp32 I/O
     assert H.conv2d_packed(x, pc, bf16=True, out=o32, **kw) is o32 and torch.equal(o32, H.conv2d_packed(x.float(), pc, bf16=True, **kw))
+
+
+# ------------------------------------------------------------------------------------------------ convolution backward
+def _grads(fn, *tensors):
+    with torch.enable_grad():   # (this module switches autograd off globally)
+        ts = [t.clone().requires_grad_(True) for t in tensors]
+        y = fn(*ts)
+        g = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(y.device, y.dtype)
+        y.backward(g)
+    return [y.detach()] + [t.grad for t in ts]
+
+
+@pytest.mark.parametrize("case", [
+    dict(cin=24, cout=40, hw=(19, 23), k=3, stride=1, pad=1, dil=1, groups=1, bias=True),
+    dict(cin=16, cout=24, hw=(21, 18), k=3, stride=1, pad=2, dil=2, groups=1, bias=False),
+    dict(cin=18, cout=12, hw=(12, 12), k=3, stride=1, pad=1, dil=1, groups=3, bias=False),      # the groups=batch form
+    dict(cin=32, cout=3, hw=(16, 16), k=1, stride=1, pad=0, dil=1, groups=1, bias=True),        # ToRGB
+    dict(cin=16, cout=32, hw=(17, 17), k=3, stride=2, pad=0, dil=1, groups=1, bias=False),      # StyledConv_down after its blur
+    dict(cin=16, cout=16, hw=(18, 20), k=3, stride=2, pad=0, dil=1, groups=2, bias=False),
+    dict(cin=80, cout=72, hw=(70, 66), k=3, stride=1, pad=1, dil=1, groups=1, bias=False),      # several tiles, ragged channel tiles
+])
+def test_conv2d_gradfix_autograd(case):
+    """conv2d_gradfix.conv2d with autograd against torch autograd of F.conv2d in float64: forward, data gradient (forward
+    kernels on the adjoint geometry), weight gradient (vsp_conv2d_wgrad_f32), bias gradient."""
+    from vspbfr_amd.op import conv2d_gradfix
+    c = case
+    B = 2
+    g_ = torch.Generator().manual_seed(11)
+    x = torch.randn(B, c["cin"], *c["hw"], generator=g_)
+    w = torch.randn(c["cout"], c["cin"] // c["groups"], c["k"], c["k"], generator=g_) / math.sqrt(c["cin"] // c["groups"] * c["k"] ** 2)
+    b = torch.randn(c["cout"], generator=g_) if c["bias"] else None
+    kw = dict(stride=c["stride"], padding=c["pad"], dilation=c["dil"], groups=c["groups"])
+    ts = [x, w] + ([b] if b is not None else [])
+    ref = _grads(lambda x_, w_, *b_: F.conv2d(x_, w_, b_[0] if b_ else None, **kw), *[t.double() for t in ts])
+    got = _grads(lambda x_, w_, *b_: conv2d_gradfix.conv2d(x_, w_, b_[0] if b_ else None, **kw), *[dev(t) for t in ts])
+    for name, a, r in zip(("y", "dx", "dw", "db"), got, ref):
+        close(a, r.float(), 3e-5, 3e-5, name)
+    with conv2d_gradfix.no_weight_gradients(), torch.enable_grad():
+        xs, ws = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+        conv2d_gradfix.conv2d(xs, ws, None, **kw).sum().backward()
+        assert ws.grad is None and xs.grad is not None
+    with torch.no_grad():
+        assert not conv2d_gradfix.conv2d(dev(x), dev(w), None, **kw).requires_grad
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_conv_transpose2d_gradfix_autograd(groups):
+    from vspbfr_amd.op import conv2d_gradfix
+    B, cin, cout, Hh, Ww = 2, 16 * groups, 12, 9, 11
+    g_ = torch.Generator().manual_seed(3)
+    x = torch.randn(B, cin, Hh, Ww, generator=g_)
+    w = torch.randn(cin, cout, 3, 3, generator=g_) / math.sqrt(cin // groups * 9)
+    ref = _grads(lambda x_, w_: F.conv_transpose2d(x_, w_, stride=2, groups=groups), x.double(), w.double())
+    got = _grads(lambda x_, w_: conv2d_gradfix.conv_transpose2d(x_, w_, stride=2, padding=0, groups=groups), dev(x), dev(w))
+    for name, a, r in zip(("y", "dx", "dw"), got, ref):
+        close(a, r.float(), 3e-5, 3e-5, name)
+
+
+def test_conv2d_wgrad_scales_and_plane_dot(H):
+    """The fused form of a modulated layer: y = demod[b,co] * conv(x * s[b,ci], W).  dW with both per-sample scales inside the
+    kernel, and the two scale gradients through vsp_plane_dot_f32, against float64 autograd."""
+    B, cin, cout, S = 3, 20, 28, 14
+    g_ = torch.Generator().manual_seed(9)
+    x, w = torch.randn(B, cin, S, S, generator=g_), torch.randn(cout, cin, 3, 3, generator=g_) / math.sqrt(cin * 9)
+    s, dm = torch.rand(B, cin, generator=g_) + 0.5, torch.rand(B, cout, generator=g_) + 0.5
+    gy = torch.randn(B, cout, S, S, generator=g_)
+    with torch.enable_grad():
+        xd, wd, sd, dd = (t.double().requires_grad_(True) for t in (x, w, s, dm))
+        y = F.conv2d(xd * sd[:, :, None, None], wd, padding=1) * dd[:, :, None, None]
+        y.backward(gy.double())
+    dw = H.conv2d_wgrad(dev(x), dev(gy), w.shape, 1, 1, 1, 1, x_scale=dev(s), dy_scale=dev(dm))
+    close(dw, wd.grad.float(), 3e-5, 3e-5, "dw")
+    # d demod[b,co] = <gy, y> / demod;  d s[b,ci] = <dxs, x> with dxs = the data gradient w.r.t. the scaled input
+    close(H.plane_dot(dev(gy), dev(y.detach().float())) / dev(dm), dd.grad.float(), 3e-5, 3e-5, "d demod")
+    dxs = F.conv_transpose2d(gy.double() * dm.double()[:, :, None, None], w.double(), padding=1).float()
+    close(H.plane_dot(dev(dxs), dev(x)), sd.grad.float(), 3e-5, 3e-5, "d style")
+    assert H.conv2d_wgrad(dev(x[:0]), dev(gy[:0]), w.shape, 1, 1).abs().max().item() == 0.0     # empty batch: zeros
+    with pytest.raises(RuntimeError):
+        H.conv2d_wgrad(dev(x), dev(gy), (cout, cin, 5, 5), 1, 2)

@@ -49,6 +49,11 @@ class ConvParams(C.Structure):
     ]
 
 
+class ConvWgradParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("x_scale", C.c_void_p), ("dy_scale", C.c_void_p)] + [
+        (n, C.c_int) for n in ("B", "Cin_g", "H", "W", "G", "Cout_g", "OH", "OW", "KH", "KW", "stride", "dil", "pad")]
+
+
 class TaccBlock(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("wcat", "eQ", "ek", "wq", "wk", "gamma", "beta")]
 
@@ -109,6 +114,8 @@ SIGNATURES = {
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
+    "vsp_conv2d_wgrad_f32": [C.POINTER(ConvWgradParams), _p],
+    "vsp_plane_dot_f32": [_p, _p, _p, _i64, _i64, _p],
     "vsp_convert_f32_to_bf16": [_p, _p, _i64, _p],
     "vsp_convert_bf16_to_f32": [_p, _p, _i64, _p],
     "vsp_upfirdn2d_bf16": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
@@ -141,7 +148,8 @@ def _load():
         fn.restype = C.c_size_t
     if lib.vsp_abi_version() != ABI_VERSION:
         raise ImportError(f"vspbfr_amd: ABI version {lib.vsp_abi_version()} != {ABI_VERSION}")
-    for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams), (3, TaccBlock), (4, TaccChainParams)):
+    for which, st in ((0, FirEpilogue), (1, ConvParams), (2, GemmParams), (3, TaccBlock), (4, TaccChainParams),
+                      (5, ConvWgradParams)):
         if lib.vsp_struct_size(which) != C.sizeof(st):
             raise ImportError(f"vspbfr_amd: struct layout mismatch for {st.__name__}: "
                               f"C {lib.vsp_struct_size(which)} vs ctypes {C.sizeof(st)}")

@@ -33,6 +33,7 @@ int vsp_struct_size(int which) {
     case 2: return (int)sizeof(vsp_gemm_params);
     case 3: return (int)sizeof(vsp_tacc_block);
     case 4: return (int)sizeof(vsp_tacc_chain_params);
+    case 5: return (int)sizeof(vsp_conv_wgrad_params);
     default: return -1;
   }
 }

@@ -30,7 +30,13 @@ class ConstantInput(nn.Module):
         self.input = nn.Parameter(torch.randn(1, channel, size, size))
 
     def forward(self, batch):
-        return self.input.repeat(batch, 1, 1, 1)
+        # a constant: the batch copy is built once per (parameter version, batch size), not once per call
+        stamp = (self.input.data_ptr(), self.input._version, self.input.device, batch)
+        hit = self.__dict__.get("_rep")
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, self.input.detach().repeat(batch, 1, 1, 1))
+            self.__dict__["_rep"] = hit
+        return hit[1]
 
 
 class Generator(nn.Module):

@@ -854,3 +854,34 @@ def keyed_fill(shapes, ids, seed, image_index0, dist="normal", device=None, inde
         out.append(flat[off:off + B * e].view(s))
         off += B * e
     return out
+
+
+# ----------------------------------------------------------------------------------------------- convolution backward
+def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1, x_scale=None, dy_scale=None):
+    """dL/dW of y = conv2d(x * x_scale, W, stride, padding, dilation, groups) * dy_scale given dL/dy (vsp_conv2d_wgrad_f32):
+    x (B, G*Cin_g, H, W), dy (B, G*Cout_g, OH, OW) -> (G*Cout_g, Cin_g, KH, KW); the scales are optional (B, channels)."""
+    from ._lib import ConvWgradParams
+    x, dy = _req(x, "x"), _req(dy, "dy")
+    cout, cin_g, kh, kw = (int(v) for v in weight_shape)
+    B, xc, H, W = x.shape
+    if dy.shape[0] != B or dy.shape[1] != cout or xc != cin_g * groups or cout % groups:
+        raise RuntimeError(f"conv2d_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} do not match weight {tuple(weight_shape)} with {groups} groups")
+    dw = torch.empty((cout, cin_g, kh, kw), device=x.device, dtype=torch.float32)
+    p = ConvWgradParams()
+    keep = [x, dy, dw, _opt(x_scale, "x_scale"), _opt(dy_scale, "dy_scale")]
+    p.x, p.dy, p.dw, p.x_scale, p.dy_scale = [(t.data_ptr() if t is not None else None) for t in keep]
+    p.B, p.Cin_g, p.H, p.W, p.G, p.Cout_g = B, cin_g, H, W, groups, cout // groups
+    p.OH, p.OW, p.KH, p.KW, p.stride, p.dil, p.pad = dy.shape[2], dy.shape[3], kh, kw, int(stride), int(dilation), int(padding)
+    check(lib.vsp_conv2d_wgrad_f32(C.byref(p), _stream()), "conv2d_wgrad")
+    return dw
+
+
+def plane_dot(a, b):
+    """(B, C, H, W) x (B, C, H, W) -> (B, C): sum over the plane of a * b."""
+    a, b = _req(a, "a"), _req(b, "b")
+    if a.shape != b.shape or a.dim() < 3:
+        raise RuntimeError("plane_dot: two tensors of the same (B, C, ...) shape")
+    out = torch.empty(a.shape[:2], device=a.device, dtype=torch.float32)
+    planes = a.shape[0] * a.shape[1]
+    check(lib.vsp_plane_dot_f32(_ptr(out), _ptr(a), _ptr(b), planes, a.numel() // max(planes, 1), _stream()), "plane_dot")
+    return out

@@ -1,11 +1,17 @@
-"""conv2d_gradfix: signature mirror of reference op/conv2d_gradfix.py:22-92 (which, on every torch other than
-1.7/1.8, is a pass-through to F.conv2d / F.conv_transpose2d, :78-92) routed to the gfx950 implicit-GEMM kernel.
-Forward only.  `groups > 1` (the reference's `groups=batch` modulated form, models/RestoreNet.py:373-383) is ONE launch: the kernel's
-true-group mode (x_group_stride) gives every group its own input-channel slice; the model code in this package does not need it
-(it uses the modulate-input / demodulate-output form, see vspbfr_amd/layers.py)."""
+"""conv2d_gradfix: signature mirror of reference op/conv2d_gradfix.py:22-92 (which, on every torch other than 1.7/1.8, is a
+pass-through to F.conv2d / F.conv_transpose2d, :78-92, i.e. plain autograd) over the gfx950 kernels.
+
+Forward: the implicit-GEMM / Winograd kernels; `groups > 1` (the reference's `groups=batch` modulated form,
+models/RestoreNet.py:373-383) is ONE launch through the kernel's true-group mode.  With autograd enabled the two functions are
+differentiable (first order) in input, weight and bias, as the training step needs (restoration_train.py:153-255):
+    data gradient    stride 1: the forward kernel with the flipped, channel-transposed weight; stride 2 (padding 0): the one-pass
+                     transposed conv; transposed conv: the stride-2 conv
+    weight gradient  vsp_conv2d_wgrad_f32 (skipped inside `no_weight_gradients()`, reference :12-19)
+Under torch.no_grad() (the restoration path) they are plain calls."""
 import contextlib
 
 import torch
+from torch.autograd import Function
 
 from .. import hip_ops
 
@@ -26,19 +32,96 @@ def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
+def _conv_fwd(x, weight, bias, stride, padding, dilation, groups):
+    cout, cg, kh, kw = weight.shape
+    if x.shape[1] != cg * groups or cout % groups:
+        raise RuntimeError(f"conv2d_gradfix.conv2d: input has {x.shape[1]} channels, weight expects {cg} x {groups} groups")
+    if groups == 1:
+        return hip_ops.conv2d(x.contiguous(), weight.contiguous(), bias, stride, padding, dilation)
+    pc = hip_ops.PackedConv(hip_ops.pack_weight(weight.contiguous(), groups), groups, cout // groups, cg, kh, kw, stride, (dilation,),
+                            (padding,), x_group_stride=cg)
+    return hip_ops.conv2d_packed(x.contiguous(), pc, ch_bias=None if bias is None else bias.contiguous())
+
+
+def _convT_fwd(x, weight, groups):
+    """conv_transpose2d(stride 2, padding 0), 3x3; weight (G*Cin_g, Cout_g, 3, 3)."""
+    cg = x.shape[1] // groups
+    outs = []
+    for g in range(groups):
+        w_io = weight[g * cg:(g + 1) * cg]  # (Cin_g, Cout_g, 3, 3)
+        phases = hip_ops.pack_transposed_s2(w_io.transpose(0, 1).contiguous())
+        outs.append(hip_ops.conv_transpose2d_s2(x[:, g * cg:(g + 1) * cg].contiguous(), phases))
+    return outs[0] if groups == 1 else torch.cat(outs, dim=1)
+
+
+class _Conv2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, dilation, groups, bias is not None)
+        return _conv_fwd(x, weight, bias, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, groups, has_bias = ctx.cfg
+        g = g.contiguous()
+        cout, cg, kh, kw = weight.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
+                wt = weight.detach().view(groups, cout // groups, cg, kh, kw).transpose(1, 2).flip(3, 4).reshape(groups * cg, cout // groups, kh, kw)
+                dx = _conv_fwd(g, wt.contiguous(), None, 1, dilation * (kh - 1) - padding, dilation, groups)
+            elif stride == 2 and padding == 0 and dilation == 1 and (kh, kw) == (3, 3):
+                # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2, zero rows beyond when H is even
+                wt = weight.detach().view(groups, cout // groups, cg, 3, 3).reshape(cout, cg, 3, 3)   # (G*Cout_g = "in" of the transpose, Cin_g, 3, 3)
+                dx = _convT_fwd(g, wt, groups)
+                ph, pw = x.shape[2] - dx.shape[2], x.shape[3] - dx.shape[3]
+                if ph < 0 or pw < 0 or ph > 1 or pw > 1:
+                    raise RuntimeError("conv2d_gradfix: stride-2 data gradient needs H in {2 OH + 1, 2 OH + 2}")
+                if ph or pw:
+                    dx = torch.nn.functional.pad(dx, (0, pw, 0, ph))
+            else:
+                raise RuntimeError("conv2d_gradfix: the data gradient is implemented for stride 1 and for stride 2 with padding 0, 3x3 "
+                                   "(the forms of restoration_train.py)")
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = hip_ops.conv2d_wgrad(x.detach().contiguous(), g, weight.shape, stride, padding, dilation, groups)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = g.sum((0, 2, 3))
+        return dx, dw, db, None, None, None, None
+
+
+class _ConvTranspose2d(Function):
+    @staticmethod
+    def forward(ctx, x, weight, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.groups = groups
+        return _convT_fwd(x, weight, groups)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        groups = ctx.groups
+        g = g.contiguous()
+        dx = dw = None
+        cin, cog = weight.shape[0], weight.shape[1]
+        if ctx.needs_input_grad[0]:
+            # x[ci, m, n] meets g[co, 2m + ky, 2n + kx] through W[ci][co][ky][kx]: a stride-2 conv of g with W read as (out = ci, in = co)
+            dx = _conv_fwd(g, weight.detach().contiguous(), None, 2, 0, 1, groups)
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            # the same sum with the roles exchanged: "input" = g (Cout_g channels per group), "output gradient" = x
+            dw = hip_ops.conv2d_wgrad(g, x.detach().contiguous(), (cin, cog, 3, 3), 2, 0, 1, groups)
+        return dx, dw, None
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     (sy, sx), (py, px), (dy, dx) = _pair(stride), _pair(padding), _pair(dilation)
     if sy != sx or py != px or dy != dx:
         raise RuntimeError("conv2d_gradfix.conv2d: only square stride/padding/dilation are supported")
-    if groups == 1:
-        return hip_ops.conv2d(input.contiguous(), weight.contiguous(), bias, sy, py, dy)
-    B, C, H, W = input.shape
-    cout, cg, kh, kw = weight.shape
-    if C != cg * groups or cout % groups:
-        raise RuntimeError(f"conv2d_gradfix.conv2d: input has {C} channels, weight expects {cg} x {groups} groups")
-    pc = hip_ops.PackedConv(hip_ops.pack_weight(weight.contiguous(), groups), groups, cout // groups, cg, kh, kw, sy, (dy,), (py,),
-                            x_group_stride=cg)
-    return hip_ops.conv2d_packed(input.contiguous(), pc, ch_bias=None if bias is None else bias.contiguous())
+    if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _Conv2d.apply(input, weight, bias, sy, py, dy, groups)
+    return _conv_fwd(input, weight, bias, sy, py, dy, groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
@@ -47,11 +130,8 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
             or tuple(weight.shape[2:]) != (3, 3) or bias is not None:
         raise RuntimeError("conv2d_gradfix.conv_transpose2d: the restoration path only uses stride=2, padding=0, 3x3, "
                            "no bias (models/RestoreNet.py:530-532); other forms are not implemented")
-    B, C, H, W = input.shape
-    cg = C // groups
-    outs = []
-    for g in range(groups):
-        w_io = weight[g * cg:(g + 1) * cg]  # (Cin_g, Cout_g, 3, 3)
-        phases = hip_ops.pack_transposed_s2(w_io.transpose(0, 1).contiguous())
-        outs.append(hip_ops.conv_transpose2d_s2(input[:, g * cg:(g + 1) * cg].contiguous(), phases))
-    return outs[0] if groups == 1 else torch.cat(outs, dim=1)
+    if input.shape[1] != weight.shape[0]:
+        raise RuntimeError("conv2d_gradfix.conv_transpose2d: weight is (G*Cin_g, Cout_g, 3, 3)")
+    if torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad):
+        return _ConvTranspose2d.apply(input, weight, groups)
+    return _convT_fwd(input, weight, groups)

@@ -85,9 +85,11 @@ class RestorationPipeline:
     def encode(self, low_imgs, x_T=None, image_index0=0):
         """Stages A + B: (low_latent, pre_dic_latent).  Small-map convolutions and the latency-bound sampler chain."""
         from . import hip_ops
+        owned = False
         if x_T is None and self.noise_seed is not None:
             x_T = hip_ops.keyed_fill([(low_imgs.shape[0], 18, 512)], [hip_ops.SEG_XT], self.noise_seed, image_index0,
                                      device=low_imgs.device, index_tensor=self._index_tensor)[0]
+            owned = True
         mode = hip_ops.BF16_CONV
         if mode == "x3" and self.encoder_fp32_under_x3:
             # the sampler chain amplifies a perturbation of its condition ~2000x with random weights (DESIGN 2): the encoder that
@@ -97,7 +99,8 @@ class RestorationPipeline:
             low_latent = self.psp.get_w_plus(low_imgs)
         finally:
             hip_ops.BF16_CONV = mode
-        pre = self.diffusion(x=low_latent, condi_in=low_latent, training=False, x_T=x_T)
+        kw = {"x_T_owned": True} if (owned and isinstance(self.diffusion, My_DDPM)) else {}
+        pre = self.diffusion(x=low_latent, condi_in=low_latent, training=False, x_T=x_T, **kw)
         return low_latent, pre
 
     @torch.no_grad()
