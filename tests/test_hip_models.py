@@ -485,3 +485,79 @@ def test_config_c3_full_size():
     assert e_chain < 3e-4
     assert rep["bf16_restored_rms"] < 2.0 * rep["fp32_activations_restored_rms"] + 1e-3   # storing activations in bf16 adds little
     assert rep["bf16_restored_rms"] < 0.03 * std and rep["bf16_restored_max"] < 0.25 * std and rep["lsb_mean"] < 2.0
+
+
+# ---------------------------------------------------------------------------------------- training row
+def test_restorenet64_training_gradients(golden):
+    """The generator half of the training step at size 64, batch 2: vspbfr_amd.training.restoration_net_forward (every
+    convolution through conv2d_gradfix -> the gfx950 forward / data-gradient kernels and vsp_conv2d_wgrad_f32, activations
+    through fused_leaky_relu, blurs through upfirdn2d) + loss.backward() against the REFERENCE's forward + backward
+    (tests/golden/restorenet64_grad.npz): image, loss, and a strided sample + norm of the gradient of all 184 parameters,
+    of pre_styles and of the prior's features.  Also: the training forward equals the fused inference forward."""
+    from vspbfr_amd.restorenet import Restoration_net
+    from vspbfr_amd.training import restoration_net_forward
+    g = golden("restorenet64_grad")
+    case, size, B = "restorenet64_grad", 64, 2
+    sd = weights.synth_state_dict("restorenet", weights.load_specs()["restorenet64"], cases.SEED)
+    net = load(Restoration_net(size, 512, 8), "restorenet", sd=sd)
+    imgs = dev(cases.image_batch(case, B, size))
+    enc_s, dec_s = OM.restoration_noise_shapes(size, B)
+    en, dn = [dev(n) for n in cases.noise_list(case, "enc", enc_s)], [dev(n) for n in cases.noise_list(case, "dec", dec_s)]
+    z, R = dev(cases.tensor(case, "z", (B, 512))), dev(cases.tensor(case, "R", (B, 3, size, size)))
+
+    def sample(t):
+        f = t.detach().reshape(-1)
+        return f[::max(1, f.numel() // 2048)][:2048]
+
+    with torch.enable_grad():
+        de = [dev(cases.tensor(case, f"de_feat{k}", (B, 512, 2 ** (k + 2), 2 ** (k + 2)), 0.5)).requires_grad_(True) for k in range(5)]
+        pre = dev(cases.tensor(case, "pre_styles", (B, 18, 512))).requires_grad_(True)
+        for p_ in net.parameters():
+            p_.requires_grad_(True)
+            p_.grad = None
+        img = restoration_net_forward(net, imgs, de, pre, [z], en, dn)
+        loss = (img * R).sum()
+        loss.backward()
+    assert maxerr(img, g["image"]) < 2e-4
+    assert abs(loss.item() - float(g["loss"][0])) < 2e-3 * max(1.0, abs(float(g["loss"][0])))
+    # gradients: compared on the scale of each tensor's own gradient (max |g| of the sample).  They are fp32 sums of up to
+    # 2 * 64^2 * 9 * 512 terms THROUGH leaky-ReLU masks: an activation within rounding of zero takes the other slope in one of
+    # the two implementations and moves its term by 0.8 sqrt2 |g| -- measured worst case 3.3e-3 (a bias gradient), bound 1e-2;
+    # the norms agree to 2e-3
+    worst = {}
+
+    def check_grad(name, got, ref, ref_norm=None):
+        ref = torch.from_numpy(ref)
+        if ref.numel() == 1:
+            # NoiseInjection.weight: d/dw = <dL/dout, noise> over B*C*H*W zero-mean terms (up to 5e5 of them, ~1e-2 each: natural
+            # scale ~7) -- the value is what survives the cancellation, so it is held to an ABSOLUTE bound (measured 0.04)
+            worst[name] = abs(float(got) - float(ref))
+            assert worst[name] < 0.15, (name, float(got), float(ref))
+            return
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((sample(got).cpu() - ref).abs().max()) / scale
+        worst[name] = err
+        assert err < 1e-2, (name, err, scale)
+        if ref_norm is not None:
+            assert abs(float(got.norm()) - float(ref_norm[0])) < 2e-3 * float(ref_norm[0]) + 1e-6, name
+
+    check_grad("pre_styles", pre.grad, g["d_pre_styles"], g["d_pre_styles_norm"])
+    assert de[0].grad is None                     # never used by the decoder (models/RestoreNet.py:1030-1035)
+    for k in range(1, 5):
+        check_grad(f"de_feat{k}", de[k].grad, g[f"d_de_feat{k}"])
+    params = dict(net.named_parameters())
+    names = [str(n) for n in g["param_names"]]
+    assert len(names) == 184
+    for n in names:
+        assert params[n].grad is not None, n
+        check_grad(n, params[n].grad, g["g/" + n], g["n/" + n])
+    unused = [n for n, p_ in params.items() if p_.grad is not None and n not in names]
+    assert not unused, unused
+    print("training gradients: worst relative errors", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
+    for p_ in net.parameters():
+        p_.requires_grad_(False)
+        p_.grad = None
+    # the un-fused training forward and the fused inference forward are the same function
+    with torch.no_grad():
+        inf = net(imgs, [d.detach() for d in de], pre.detach(), [z], enc_noise=en, dec_noise=dn)
+    assert maxerr(inf, img.detach()) < 2e-4

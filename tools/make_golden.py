@@ -200,6 +200,56 @@ def gen_restorenet64():
     print("restorenet64.npz:", tuple(img.shape), "std %.3f absmax %.3f" % (img.std(), img.abs().max()), "%.1fs" % (time.time() - t))
 
 
+GRAD_SAMPLES = 2048
+
+
+def grad_sample(g):
+    """A strided sample of a gradient tensor (fixtures stay small) -- the test takes the same sample of its own gradient."""
+    f = g.detach().reshape(-1)
+    return f[::max(1, f.numel() // GRAD_SAMPLES)][:GRAD_SAMPLES]
+
+
+def gen_restorenet64_grad():
+    """The generator half of the training step (restoration_train.py:153-255) at size 64: forward + backward of the REFERENCE
+    Restoration_net in eval mode (Dropout2d off, so the pass is deterministic) for the scalar loss <image, R>, R a keyed random
+    tensor: the image, the loss and a strided sample of the gradient of every parameter and of the differentiable inputs
+    (pre_styles, the prior's features).  B = 2 so that the groups = batch convolutions really carry two groups."""
+    t = time.time()
+    case, size, B = "restorenet64_grad", 64, 2
+    net = RN.Restoration_net(size, 512, 8)
+    load_synth(net, "restorenet", cases.SEED)
+    imgs = cases.image_batch(case, B, size)
+    enc_s, dec_s = omodels.restoration_noise_shapes(size, B)
+    enc_noise, dec_noise = cases.noise_list(case, "enc", enc_s), cases.noise_list(case, "dec", dec_s)
+    de_feats = [cases.tensor(case, f"de_feat{k}", (B, net.channels[2 ** (k + 2)], 2 ** (k + 2), 2 ** (k + 2)), 0.5).requires_grad_(True)
+                for k in range(5)]
+    pre = cases.tensor(case, "pre_styles", (B, 18, 512)).requires_grad_(True)
+    z = cases.tensor(case, "z", (B, 512))
+    R = cases.tensor(case, "R", (B, 3, size, size))
+    NOISE_QUEUE.clear()
+    NOISE_QUEUE.extend(enc_noise + dec_noise)
+    with torch.enable_grad():
+        img = net(imgs, de_feats, pre, [z])
+        loss = (img * R).sum()
+        loss.backward()
+    assert not NOISE_QUEUE
+    out = {"image": np_(img), "loss": np.array([loss.item()], dtype=np.float64), "d_pre_styles": np_(grad_sample(pre.grad)),
+           "d_pre_styles_norm": np.array([pre.grad.norm().item()])}
+    for k, f in enumerate(de_feats):   # (de_feats[0] never enters the decoder: models/RestoreNet.py:1030-1035 start at k = 1)
+        if f.grad is not None:
+            out[f"d_de_feat{k}"] = np_(grad_sample(f.grad))
+    names = []
+    for name, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        names.append(name)
+        out["g/" + name] = np_(grad_sample(p_.grad))
+        out["n/" + name] = np.array([p_.grad.norm().item()])
+    out["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "restorenet64_grad.npz"), **out)
+    print("restorenet64_grad.npz: loss %.4f, %d parameter gradients, |d pre| %.3e, %.1fs" % (loss.item(), len(names), pre.grad.norm().item(), time.time() - t))
+
+
 def gen_generator64():
     g = SG.Generator(64, 512, 8, channel_multiplier=2)
     load_synth(g, "e4e_decoder", cases.SEED)
@@ -315,7 +365,7 @@ def gen_loader():
 
 
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
