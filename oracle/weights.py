@@ -45,6 +45,8 @@ def synth_tensor(model, name, shape, dtype, seed):
         k = make_kernel([1, 3, 3, 1])
         down = "encoder_convs" in name  # StyledConv_down blurs are not gain-compensated (models/RestoreNet.py:451-457)
         return k if down else k * 4
+    if model == "discriminator" and leaf == "kernel":   # the Blur of every down-sampling ConvLayer (models/RestoreNet.py:1150-1156)
+        return make_kernel([1, 3, 3, 1])
     if name.startswith("noises.") or ".noises." in name:
         return N()
     if name == "latent_avg":

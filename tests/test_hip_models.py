@@ -561,3 +561,66 @@ def test_restorenet64_training_gradients(golden):
     with torch.no_grad():
         inf = net(imgs, [d.detach() for d in de], pre.detach(), [z], enc_noise=en, dec_noise=dn)
     assert maxerr(inf, img.detach()) < 2e-4
+
+
+def test_discriminator64_losses_and_double_backward(golden):
+    """The discriminator half of the training step (restoration_train.py:176-218) at size 64, batch 4, against the REFERENCE's
+    own pass (tests/golden/discriminator64.npz): predictions, logistic loss + parameter gradients, the R1 penalty -- the input
+    gradient under no_weight_gradients() with create_graph, squared, then backward: a DOUBLE backward through every
+    conv2d_gradfix / fused_leaky_relu / upfirdn2d of the network -- with its parameter gradients, and the generator's
+    non-saturating loss with its gradient w.r.t. the fake image."""
+    from vspbfr_amd.discriminator import Discriminator, d_logistic_loss, d_r1_loss, g_nonsaturating_loss
+    g = golden("discriminator64")
+    case, size, B = "discriminator64", 64, 4
+    D = load(Discriminator(size), "discriminator", "discriminator64")
+    real, fake = dev(cases.image_batch(case + "/real", B, size)), dev(cases.image_batch(case + "/fake", B, size))
+    names = [str(n) for n in g["param_names"]]
+    params = dict(D.named_parameters())
+    assert sorted(names) == sorted(params)
+
+    def sample(t):
+        f = t.detach().reshape(-1)
+        return f[::max(1, f.numel() // 2048)][:2048]
+
+    def rel(got, ref):
+        ref = torch.from_numpy(ref)
+        return float((sample(got).cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-20)
+
+    worst = {}
+    with torch.enable_grad():
+        for p_ in D.parameters():
+            p_.requires_grad_(True)
+        D.zero_grad()
+        rp, fp = D(real), D(fake)
+        d_loss = d_logistic_loss(rp, fp)
+        d_loss.backward()
+        assert maxerr(rp, g["real_pred"]) < 2e-5 and maxerr(fp, g["fake_pred"]) < 2e-5
+        assert abs(d_loss.item() - float(g["d_loss"][0])) < 1e-5
+        for n in names:
+            worst["d/" + n] = rel(params[n].grad, g["gd/" + n])
+            assert abs(float(params[n].grad.norm()) - float(g["nd/" + n][0])) < 5e-3 * float(g["nd/" + n][0]) + 1e-9, n
+        D.zero_grad()
+        x = real.detach().clone().requires_grad_(True)
+        pred = D(x)
+        r1 = d_r1_loss(pred, x)
+        (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()
+        assert abs(r1.item() - float(g["r1"][0])) < 5e-3 * float(g["r1"][0])
+        for n in names:
+            worst["r1/" + n] = rel(params[n].grad, g["gr/" + n])
+            assert abs(float(params[n].grad.norm()) - float(g["nr/" + n][0])) < 1e-2 * float(g["nr/" + n][0]) + 1e-9, n
+        D.zero_grad()
+        xf = fake.detach().clone().requires_grad_(True)
+        g_loss = g_nonsaturating_loss(D(xf))
+        g_loss.backward()
+        assert abs(g_loss.item() - float(g["g_loss"][0])) < 1e-5
+        worst["d_fake_image"] = rel(xf.grad, g["d_fake_image"])
+        assert abs(float(xf.grad.norm()) - float(g["d_fake_image_norm"][0])) < 5e-3 * float(g["d_fake_image_norm"][0])
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    print("discriminator: worst relative gradient errors", top)
+    # leaky-ReLU mask flips (see test_restorenet64_training_gradients) bound the element-wise agreement
+    assert top[0][1] < 2e-2, top
+    for p_ in D.parameters():
+        p_.requires_grad_(False)
+        p_.grad = None
+    with torch.no_grad():
+        assert maxerr(D(real), g["real_pred"]) < 2e-5        # the same module under no_grad (plain kernel calls)

@@ -13,6 +13,7 @@ SPECS = json.load(open(os.path.join(ROOT, "tests", "golden", "state_specs.json")
 
 def build(name):
     from vspbfr_amd.diffusion import Code_diffuser
+    from vspbfr_amd.discriminator import Discriminator
     from vspbfr_amd.e4e import Encoder4Editing, Generator
     from vspbfr_amd.restorenet import Restoration_net
     return {
@@ -22,6 +23,8 @@ def build(name):
         "e4e_encoder": lambda: Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024)),
         "e4e_decoder1024": lambda: Generator(1024, 512, 8, channel_multiplier=2),
         "e4e_decoder64": lambda: Generator(64, 512, 8, channel_multiplier=2),
+        "discriminator512": lambda: Discriminator(512),
+        "discriminator64": lambda: Discriminator(64),
     }[name]()
 
 

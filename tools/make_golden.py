@@ -78,6 +78,8 @@ def gen_specs():
         "e4e_encoder": spec_of(Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))),
         "e4e_decoder1024": spec_of(SG.Generator(1024, 512, 8, channel_multiplier=2)),
         "e4e_decoder64": spec_of(SG.Generator(64, 512, 8, channel_multiplier=2)),
+        "discriminator512": spec_of(RN.Discriminator(512)),
+        "discriminator64": spec_of(RN.Discriminator(64)),
     }
     with open(os.path.join(GOLD, "state_specs.json"), "w") as f:
         json.dump(specs, f)
@@ -250,6 +252,49 @@ def gen_restorenet64_grad():
     print("restorenet64_grad.npz: loss %.4f, %d parameter gradients, |d pre| %.3e, %.1fs" % (loss.item(), len(names), pre.grad.norm().item(), time.time() - t))
 
 
+def gen_discriminator64():
+    """The discriminator half of the training step (restoration_train.py:176-218, 60-79) at size 64, batch 4 (= the minibatch
+    stddev group): the REFERENCE Discriminator's predictions on a "real" and a "fake" keyed batch, the logistic loss with its
+    parameter gradients, the R1 penalty (a double backward through every layer) with its parameter gradients, and the
+    generator's non-saturating loss with its gradient w.r.t. the fake image."""
+    import torch.nn.functional as F
+    from torch import autograd
+    import op.conv2d_gradfix as ref_gradfix
+    t = time.time()
+    case, size, B = "discriminator64", 64, 4
+    D = RN.Discriminator(size)
+    load_synth(D, "discriminator", cases.SEED)
+    real, fake = cases.image_batch(case + "/real", B, size), cases.image_batch(case + "/fake", B, size)
+    out = {}
+    with torch.enable_grad():
+        D.zero_grad()
+        rp, fp = D(real), D(fake)
+        d_loss = F.softplus(-rp).mean() + F.softplus(fp).mean()
+        d_loss.backward()
+        out.update(real_pred=np_(rp), fake_pred=np_(fp), d_loss=np.array([d_loss.item()]))
+        names = [n for n, p_ in D.named_parameters() if p_.grad is not None]
+        for n, p_ in D.named_parameters():
+            out["gd/" + n], out["nd/" + n] = np_(grad_sample(p_.grad)), np.array([p_.grad.norm().item()])
+        D.zero_grad()
+        x = real.detach().clone().requires_grad_(True)
+        pred = D(x)
+        with ref_gradfix.no_weight_gradients():
+            grad_real, = autograd.grad(outputs=pred.sum(), inputs=x, create_graph=True)
+        r1 = grad_real.pow(2).reshape(B, -1).sum(1).mean()
+        (10.0 / 2 * r1 * 16 + 0 * pred[0]).backward()          # restoration_train.py:211 with r1 = 10, d_reg_every = 16
+        out.update(r1=np.array([r1.item()]), grad_real=np_(grad_sample(grad_real)))
+        for n, p_ in D.named_parameters():
+            out["gr/" + n], out["nr/" + n] = np_(grad_sample(p_.grad)), np.array([p_.grad.norm().item()])
+        D.zero_grad()
+        xf = fake.detach().clone().requires_grad_(True)
+        g_loss = F.softplus(-D(xf)).mean()
+        g_loss.backward()
+        out.update(g_loss=np.array([g_loss.item()]), d_fake_image=np_(grad_sample(xf.grad)), d_fake_image_norm=np.array([xf.grad.norm().item()]))
+    out["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "discriminator64.npz"), **out)
+    print("discriminator64.npz: d_loss %.4f r1 %.4e g_loss %.4f, %d parameters, %.1fs" % (d_loss.item(), r1.item(), g_loss.item(), len(names), time.time() - t))
+
+
 def gen_generator64():
     g = SG.Generator(64, 512, 8, channel_multiplier=2)
     load_synth(g, "e4e_decoder", cases.SEED)
@@ -365,7 +410,7 @@ def gen_loader():
 
 
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,0 +1,112 @@
+"""`Discriminator` of the restoration GAN (reference models/RestoreNet.py:1137-1265) and the adversarial losses of the training
+step (restoration_train.py:60-79) over the gfx950 operators -- SURVEY 8f rows 2 and 4.
+
+Same constructor signature, same state-dict keys / shapes as the reference (`ConvLayer` = Sequential[Blur?, EqualConv2d,
+FusedLeakyReLU?], `ResBlock` = conv1 / conv2 / skip: pinned by tests/test_layout.py against the reference's own module).  The
+forward is differentiable to second order -- the R1 penalty differentiates the input gradient again -- because every operator on
+the way is: op.conv2d_gradfix (forward / data-gradient kernels + vsp_conv2d_wgrad_f32), op.fused_leaky_relu, op.upfirdn2d, and
+torch tensor algebra for the minibatch-stddev statistic and the two linear layers (plain library GEMMs).
+ADA augmentation (non_leaking.py) is not part of this module."""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .layers import Blur, EqualConv2d, EqualLinear, LeakyBias
+from .op import conv2d_gradfix, fused_leaky_relu, upfirdn2d
+from .training import equal_linear
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur,] EqualConv2d [, FusedLeakyReLU] with the reference's child indices (models/RestoreNet.py:1137-1179)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=(1, 3, 3, 1), bias=True, activate=True):
+        layers = []
+        if downsample:
+            p = (len(blur_kernel) - 2) + (kernel_size - 1)
+            layers.append(Blur(list(blur_kernel), pad=((p + 1) // 2, p // 2)))
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=0 if downsample else kernel_size // 2,
+                                  stride=2 if downsample else 1, bias=bias and not activate))
+        if activate:
+            layers.append(LeakyBias(out_channel))
+        super().__init__(*layers)
+
+    def forward(self, x):
+        for m in self:
+            if isinstance(m, Blur):
+                x = upfirdn2d(x, m.kernel, pad=m.pad)
+            elif isinstance(m, EqualConv2d):
+                x = conv2d_gradfix.conv2d(x, m.weight * m.scale, bias=m.bias, stride=m.stride, padding=m.padding)
+            else:
+                x = fused_leaky_relu(x, m.bias)
+        return x
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True, blur_kernel=blur_kernel)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, blur_kernel=blur_kernel, activate=False, bias=False)
+
+    def forward(self, x):
+        return (self.conv2(self.conv1(x)) + self.skip(x)) / math.sqrt(2)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, size, input_channel=3, channel_multiplier=2, blur_kernel=(1, 3, 3, 1)):
+        super().__init__()
+        cm = channel_multiplier
+        channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
+        self.encoder_input_convs = ConvLayer(input_channel, channels[size], 1)
+        self.log_size = int(math.log(size, 2))
+        in_channel = channels[size]
+        self.encoder_convs = nn.ModuleList()
+        for i in range(self.log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            self.encoder_convs.append(ResBlock(in_channel, out_channel, blur_kernel))
+            in_channel = out_channel
+        self.stddev_group, self.stddev_feat = 4, 1
+        self.final_conv = ConvLayer(in_channel + 1, channels[4], 3)
+        self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation="fused_lrelu"),
+                                          EqualLinear(channels[4], 1))
+
+    def forward(self, x):
+        out = self.encoder_input_convs(x.contiguous())
+        for blk in self.encoder_convs:
+            out = blk(out)
+        batch, channel, height, width = out.shape
+        group = min(batch, self.stddev_group)                    # minibatch standard deviation (models/RestoreNet.py:1249-1256)
+        sd = out.view(group, -1, self.stddev_feat, channel // self.stddev_feat, height, width)
+        sd = torch.sqrt(sd.var(0, unbiased=False) + 1e-8).mean([2, 3, 4], keepdims=True).squeeze(2)
+        out = torch.cat([out, sd.repeat(group, 1, height, width)], 1)
+        out = self.final_conv(out)
+        out = equal_linear(out.view(batch, -1), self.final_linear[0])
+        return equal_linear(out, self.final_linear[1])
+
+
+# ---------------------------------------------------------------------------------------------------- adversarial losses
+def d_logistic_loss(real_pred, fake_pred):
+    """restoration_train.py:60-64"""
+    return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+
+def d_r1_loss(real_pred, real_img):
+    """restoration_train.py:66-73: the input gradient is taken without weight gradients and kept differentiable."""
+    with conv2d_gradfix.no_weight_gradients():
+        grad_real, = torch.autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+
+def g_nonsaturating_loss(fake_pred):
+    """restoration_train.py:76-79"""
+    return F.softplus(-fake_pred).mean()
+
+
+def accumulate(model1, model2, decay=0.999):
+    """EMA of the generator (restoration_train.py:46-51)."""
+    par1, par2 = dict(model1.named_parameters()), dict(model2.named_parameters())
+    with torch.no_grad():
+        for k in par1:
+            par1[k].mul_(decay).add_(par2[k].detach(), alpha=1 - decay)

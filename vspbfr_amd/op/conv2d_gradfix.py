@@ -3,10 +3,12 @@ pass-through to F.conv2d / F.conv_transpose2d, :78-92, i.e. plain autograd) over
 
 Forward: the implicit-GEMM / Winograd kernels; `groups > 1` (the reference's `groups=batch` modulated form,
 models/RestoreNet.py:373-383) is ONE launch through the kernel's true-group mode.  With autograd enabled the two functions are
-differentiable (first order) in input, weight and bias, as the training step needs (restoration_train.py:153-255):
+differentiable in input, weight and bias, as the training step needs (restoration_train.py:153-255):
     data gradient    stride 1: the forward kernel with the flipped, channel-transposed weight; stride 2 (padding 0): the one-pass
-                     transposed conv; transposed conv: the stride-2 conv
+                     transposed conv (3x3) or the 1x1 adjoint on the even pixels; transposed conv: the stride-2 conv
     weight gradient  vsp_conv2d_wgrad_f32 (skipped inside `no_weight_gradients()`, reference :12-19)
+Both are written over these same public functions, so a backward pass run with create_graph=True can be differentiated again
+(the reference's double backward, :104-227; the R1 penalty of the discriminator needs it).
 Under torch.no_grad() (the restoration path) they are plain calls."""
 import contextlib
 
@@ -54,6 +56,53 @@ def _convT_fwd(x, weight, groups):
     return outs[0] if groups == 1 else torch.cat(outs, dim=1)
 
 
+def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
+    """Data gradient of conv2d as a composition of the PUBLIC (differentiable) entry points, so that a backward pass run with
+    create_graph=True (the R1 penalty, restoration_train.py:66-73) can be differentiated again: it is linear in g and in weight."""
+    cout, cg, kh, kw = weight.shape
+    if stride == 1:
+        # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
+        wt = weight.reshape(groups, cout // groups, cg, kh, kw).transpose(1, 2).flip(3, 4).reshape(groups * cg, cout // groups, kh, kw)
+        return conv2d(g, wt, None, 1, dilation * (kh - 1) - padding, dilation, groups)
+    if stride == 2 and padding == 0 and dilation == 1 and (kh, kw) == (3, 3):
+        # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2, zero rows beyond when H is even
+        dx = conv_transpose2d(g, weight, stride=2, padding=0, groups=groups)
+        ph, pw = x_shape[2] - dx.shape[2], x_shape[3] - dx.shape[3]
+        if ph < 0 or pw < 0 or ph > 1 or pw > 1:
+            raise RuntimeError("conv2d_gradfix: stride-2 data gradient needs H in {2 OH + 1, 2 OH + 2}")
+        return torch.nn.functional.pad(dx, (0, pw, 0, ph)) if (ph or pw) else dx
+    if stride == 2 and padding == 0 and (kh, kw) == (1, 1):
+        # 1x1, stride 2 (the skip branch of the discriminator's ResBlock): the 1x1 adjoint lands on the even pixels
+        wt = weight.reshape(groups, cout // groups, cg, 1, 1).transpose(1, 2).reshape(groups * cg, cout // groups, 1, 1)
+        d = conv2d(g, wt, None, 1, 0, 1, groups)
+        dx = d.new_zeros(x_shape)
+        dx[:, :, 0:2 * d.shape[2]:2, 0:2 * d.shape[3]:2] = d
+        return dx
+    raise RuntimeError("conv2d_gradfix: the data gradient is implemented for stride 1, and for stride 2 with padding 0 and 3x3 / 1x1 "
+                       "kernels (the forms of restoration_train.py)")
+
+
+class _Wgrad(Function):
+    """dW = wgrad(x, g) of conv2d -- bilinear in (x, g), so its own backward is a conv (w.r.t. g) and a data gradient (w.r.t. x)."""
+
+    @staticmethod
+    def forward(ctx, x, g, weight_shape, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (tuple(weight_shape), stride, padding, dilation, groups)
+        return hip_ops.conv2d_wgrad(x.detach().contiguous(), g.detach().contiguous(), weight_shape, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, g = ctx.saved_tensors
+        _, stride, padding, dilation, groups = ctx.cfg
+        dx = dg = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(g, ggw, x.shape, stride, padding, dilation, groups)
+        if ctx.needs_input_grad[1]:
+            dg = conv2d(x, ggw, None, stride, padding, dilation, groups)
+        return dx, dg, None, None, None, None, None
+
+
 class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
@@ -66,30 +115,35 @@ class _Conv2d(Function):
         x, weight = ctx.saved_tensors
         stride, padding, dilation, groups, has_bias = ctx.cfg
         g = g.contiguous()
-        cout, cg, kh, kw = weight.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            if stride == 1:
-                # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
-                wt = weight.detach().view(groups, cout // groups, cg, kh, kw).transpose(1, 2).flip(3, 4).reshape(groups * cg, cout // groups, kh, kw)
-                dx = _conv_fwd(g, wt.contiguous(), None, 1, dilation * (kh - 1) - padding, dilation, groups)
-            elif stride == 2 and padding == 0 and dilation == 1 and (kh, kw) == (3, 3):
-                # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2, zero rows beyond when H is even
-                wt = weight.detach().view(groups, cout // groups, cg, 3, 3).reshape(cout, cg, 3, 3)   # (G*Cout_g = "in" of the transpose, Cin_g, 3, 3)
-                dx = _convT_fwd(g, wt, groups)
-                ph, pw = x.shape[2] - dx.shape[2], x.shape[3] - dx.shape[3]
-                if ph < 0 or pw < 0 or ph > 1 or pw > 1:
-                    raise RuntimeError("conv2d_gradfix: stride-2 data gradient needs H in {2 OH + 1, 2 OH + 2}")
-                if ph or pw:
-                    dx = torch.nn.functional.pad(dx, (0, pw, 0, ph))
-            else:
-                raise RuntimeError("conv2d_gradfix: the data gradient is implemented for stride 1 and for stride 2 with padding 0, 3x3 "
-                                   "(the forms of restoration_train.py)")
+            dx = _dgrad(g, weight, x.shape, stride, padding, dilation, groups)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = hip_ops.conv2d_wgrad(x.detach().contiguous(), g, weight.shape, stride, padding, dilation, groups)
+            dw = _Wgrad.apply(x, g, weight.shape, stride, padding, dilation, groups)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum((0, 2, 3))
         return dx, dw, db, None, None, None, None
+
+
+class _WgradT(Function):
+    """dW of conv_transpose2d(x, W, stride 2): the stride-2 conv weight gradient with the roles of x and g exchanged."""
+
+    @staticmethod
+    def forward(ctx, x, g, weight_shape, groups):
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (tuple(weight_shape), groups)
+        return hip_ops.conv2d_wgrad(g.detach().contiguous(), x.detach().contiguous(), weight_shape, 2, 0, 1, groups)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, g = ctx.saved_tensors
+        _, groups = ctx.cfg
+        dx = dg = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d(g, ggw, None, 2, 0, 1, groups)
+        if ctx.needs_input_grad[1]:
+            dg = conv_transpose2d(x, ggw, stride=2, padding=0, groups=groups)
+        return dx, dg, None, None
 
 
 class _ConvTranspose2d(Function):
@@ -105,13 +159,12 @@ class _ConvTranspose2d(Function):
         groups = ctx.groups
         g = g.contiguous()
         dx = dw = None
-        cin, cog = weight.shape[0], weight.shape[1]
         if ctx.needs_input_grad[0]:
             # x[ci, m, n] meets g[co, 2m + ky, 2n + kx] through W[ci][co][ky][kx]: a stride-2 conv of g with W read as (out = ci, in = co)
-            dx = _conv_fwd(g, weight.detach().contiguous(), None, 2, 0, 1, groups)
+            dx = conv2d(g, weight, None, 2, 0, 1, groups)
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             # the same sum with the roles exchanged: "input" = g (Cout_g channels per group), "output gradient" = x
-            dw = hip_ops.conv2d_wgrad(g, x.detach().contiguous(), (cin, cog, 3, 3), 2, 0, 1, groups)
+            dw = _WgradT.apply(x, g, weight.shape, groups)
         return dx, dw, None
 
 
