@@ -120,3 +120,51 @@ def test_bench_self_launch_world2():
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["launch_check"] == "ok"
+
+
+GRAD_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from vspbfr_amd.train_step import allreduce_gradients
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 11), torch.nn.Linear(11, 5))
+    x = torch.randn(6, 37, generator=torch.Generator().manual_seed(100 + rank))
+    out = net[1](net[0](x))
+    out = net[2](out)                       # net[3] takes no part in the loss on any rank: its gradients are None
+    out.pow(2).mean().backward()
+    if rank == 1:
+        net[2].bias.grad = None             # a gradient missing on ONE rank only (find_unused_parameters): it contributes zeros
+    mine = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    nb = allreduce_gradients(list(net.parameters()), bucket_bytes=1024)      # two buckets
+    assert nb >= 2, nb
+    # reference: gather every rank's gradients and average by hand
+    for p, g in zip(net.parameters(), mine):
+        g = torch.zeros_like(p) if g is None else g
+        parts = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        want = sum(parts) / world
+        assert p.grad is not None and torch.allclose(p.grad, want, rtol=0, atol=1e-7), (rank, p.shape)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok", nb)
+""" % ROOT)
+
+
+def test_bucketed_gradient_allreduce_world2(tmp_path):
+    """train_step.allreduce_gradients (the training step's RCCL gradient exchange; gloo here): flat buckets in reverse
+    registration order, averaged, unpacked; parameters without a gradient -- on every rank, or on one rank only -- take part as
+    zeros so that all ranks issue the same collectives."""
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o

@@ -624,3 +624,42 @@ def test_discriminator64_losses_and_double_backward(golden):
         p_.grad = None
     with torch.no_grad():
         assert maxerr(D(real), g["real_pred"]) < 2e-5        # the same module under no_grad (plain kernel calls)
+
+
+def test_training_step_size64():
+    """RestorationTrainer.step (restoration_train.py:153-255) at size 64, batch 4, with the frozen front's outputs supplied:
+    iteration 0 (D step + R1 regulariser + G step + EMA) and iteration 1 (no regulariser): finite losses, the first iteration's
+    D / G losses equal the formulas on the pre-update networks, every optimiser moved its parameters, the other network stayed
+    untouched during each step, and the EMA copy moved by (1 - decay) of the generator's update."""
+    import copy
+    from vspbfr_amd.discriminator import Discriminator
+    from vspbfr_amd.restorenet import Restoration_net
+    from vspbfr_amd.train_step import RestorationTrainer
+    size, B = 64, 4
+    sd = weights.synth_state_dict("restorenet", weights.load_specs()["restorenet64"], cases.SEED)
+    G = load(Restoration_net(size, 512, 8), "restorenet", sd=sd)
+    G_ema = copy.deepcopy(G)
+    D = load(Discriminator(size), "discriminator", "discriminator64")
+    tr = RestorationTrainer(G, G_ema, D, mixing=0.0)
+    low, real = dev(cases.image_batch("train/low", B, size)), dev(cases.image_batch("train/real", B, size))
+    de = [dev(cases.tensor("train", f"de_feat{k}", (B, 512, 2 ** (k + 2), 2 ** (k + 2)), 0.5)) for k in range(5)]
+    lat = dev(cases.tensor("train", "latent", (B, 18, 512)))
+    g0 = {k: v.detach().clone() for k, v in G.named_parameters()}
+    d0 = {k: v.detach().clone() for k, v in D.named_parameters()}
+    with torch.enable_grad():
+        l0 = tr.step(0, low, real, de_feats=de, latent=lat)
+        l1 = tr.step(1, low, real, de_feats=de, latent=lat)
+    for l in (l0, l1):
+        assert all(torch.isfinite(torch.as_tensor(v)).all() for v in l.values()), l
+    assert "r1" in l0 and "r1" not in l1
+    assert 0.5 < float(l0["d"]) < 3.0 and 0.2 < float(l0["g"]) < 2.0           # 2 ln 2 and ln 2 for an uninformed discriminator
+    moved_g = [k for k, v in G.named_parameters() if not torch.equal(v, g0[k])]
+    moved_d = [k for k, v in D.named_parameters() if not torch.equal(v, d0[k])]
+    assert len(moved_d) == len(d0)
+    assert len(moved_g) >= len(g0) - 2, sorted(set(g0) - set(moved_g))         # every parameter that reaches the image is updated
+    k = "convs.7.fusion.0.weight"
+    ema = dict(G_ema.named_parameters())[k]
+    # two Adam steps of the generator, EMA with decay a after each: ema - g0 = (1-a) [a (g1 - g0) + (g2 - g0)] ~ (1-a) * O(step)
+    a = tr.accum
+    assert not torch.equal(ema, g0[k]) and float((ema - g0[k]).abs().max()) < 3 * (1 - a) * float((dict(G.named_parameters())[k] - g0[k]).abs().max()) + 1e-9
+    assert all(not p_.requires_grad for p_ in D.parameters()) and all(p_.requires_grad for p_ in G.parameters())   # state after a G step

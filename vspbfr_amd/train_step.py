@@ -1,0 +1,150 @@
+"""One iteration of the restoration GAN's training loop (reference restoration_train.py:153-255, optimisers :397-408) over the gfx950
+operators, data-parallel with a bucketed gradient all-reduce (SURVEY 8f row 2 / BASELINE configs[4]).
+
+    D step        d_logistic(D(real), D(G(low).detach()))                              every iteration
+    D regulariser r1 / 2 * R1(D, real) * d_reg_every  (double backward)                every d_reg_every iterations
+    G step        g_nonsaturating(D(G(low))) [+ percept_w * percept(fake, real)] [+ id_w * id(fake, real)]
+    EMA           g_ema <- decay * g_ema + (1 - decay) * G,  decay = 0.5 ** (32 / 10000)
+
+The frozen front of the path (stage A encoder, stage B sampler, stage C prior) runs through the INFERENCE kernels under no_grad
+exactly as in restoration_test; the generator runs `training.restoration_net_forward` (differentiable), the discriminator
+`discriminator.Discriminator`.  The perceptual (LPIPS-VGG) and identity (ArcFace) terms of the reference need their pretrained
+networks (my_lpips/, Loss/id_loss.py: out of scope): they enter as optional callables with weight 0 by default.
+
+Data parallelism: one process per GPU, every rank owns the same parameters and its shard of the batch; after each backward the
+gradients are averaged with `allreduce_gradients`: parameters are packed into flat buckets in REVERSE registration order (the
+order backward produces them), each bucket is one asynchronous all-reduce (RCCL over xGMI through torch.distributed "nccl"; gloo
+in the CPU tests), unpacked after the last wait.  xGMI is point-to-point -- a ring all-reduce moves 2 (N-1)/N of a bucket over
+the slowest link -- so buckets are large (64 MB default: the generator's 450 MB of fp32 gradients = 7 collectives) rather than the
+25 MB that suits NVSwitch; parameters without a gradient (find_unused_parameters in the reference's DDP) contribute zeros so that
+every rank issues identical collectives."""
+import random
+
+import torch
+
+from . import training
+from .discriminator import accumulate, d_logistic_loss, d_r1_loss, g_nonsaturating_loss
+from .restorenet import mixing_noise
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20, group=None):
+    """Average .grad over the ranks of `group` in flat buckets; a no-op without an initialised process group or with one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    world = dist.get_world_size(group)
+    params = [p for p in params if p.requires_grad]
+    buckets, cur, size = [], [], 0
+    for p in reversed(params):
+        cur.append(p)
+        size += p.numel() * p.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        pending.append((bucket, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    for bucket, flat, work in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+    return len(buckets)
+
+
+def requires_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad_(flag)
+
+
+class RestorationTrainer:
+    def __init__(self, generator, g_ema, discriminator, psp_embedding=None, diffusion=None, lr=0.002, g_reg_every=4, d_reg_every=16,
+                 r1=10.0, mixing=0.9, percept_loss=None, percept_weight=0.0, id_loss=None, id_weight=0.0, bucket_bytes=64 << 20):
+        self.G, self.G_ema, self.D = generator, g_ema, discriminator
+        self.psp, self.diffusion = psp_embedding, diffusion
+        self.d_reg_every, self.r1, self.mixing = d_reg_every, r1, mixing
+        self.percept_loss, self.percept_weight, self.id_loss, self.id_weight = percept_loss, percept_weight, id_loss, id_weight
+        self.bucket_bytes = bucket_bytes
+        g_ratio, d_ratio = g_reg_every / (g_reg_every + 1), d_reg_every / (d_reg_every + 1)   # restoration_train.py:397-408
+        self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
+        self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio))
+        self.accum = 0.5 ** (32 / (10 * 1000))
+        accumulate(g_ema, generator, 0)
+        self.generator_bytes = sum(p.numel() * p.element_size() for p in generator.parameters())
+
+    @torch.no_grad()
+    def front(self, low_img):
+        """Stages A, B, C of the path (frozen): W+ codes -> denoised latent -> prior features (restoration_train.py:167-171)."""
+        low_latent = self.psp.get_w_plus(low_img)
+        latent = self.diffusion(x=low_latent, condi_in=low_latent, training=False)
+        _, de_feats = self.psp.get_stylegan_feats(latent, with_sample=False)
+        return de_feats, latent
+
+    def generate(self, low_img, de_feats, latent, noise, enc_noise=None, dec_noise=None):
+        B, size = low_img.shape[0], self.G.size
+        if enc_noise is None:
+            from .pipeline import noise_map_shapes
+            _, es, ds = noise_map_shapes(size, B)
+            enc_noise = [torch.randn(s, device=low_img.device) for s in es]
+            dec_noise = [torch.randn(s, device=low_img.device) for s in ds]
+        inject = None if len(noise) < 2 else random.randint(1, self.G.n_latent - 1)
+        return training.restoration_net_forward(self.G, low_img, de_feats, latent, noise, enc_noise, dec_noise, inject_index=inject)
+
+    def step(self, i, low_img, real_img, de_feats=None, latent=None):
+        """Iteration i on this rank's shard (images in [-1, 1] on the device).  de_feats / latent: precomputed outputs of the
+        frozen front (tests); default = run it.  Returns the loss dict of the reference's logger."""
+        dev, B = low_img.device, low_img.shape[0]
+        if de_feats is None:
+            de_feats, latent = self.front(low_img)
+        de_feats = [f.detach().float() if f.dtype != torch.float32 else f.detach() for f in de_feats]
+        latent = latent.detach()
+        losses = {}
+        # ---- discriminator
+        requires_grad(self.G, False)
+        requires_grad(self.D, True)
+        with torch.no_grad():
+            fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
+        fake_pred, real_pred = self.D(fake.detach()), self.D(real_img)
+        d_loss = d_logistic_loss(real_pred, fake_pred)
+        self.D.zero_grad(set_to_none=True)
+        d_loss.backward()
+        allreduce_gradients(list(self.D.parameters()), self.bucket_bytes)
+        self.d_optim.step()
+        losses.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
+        if i % self.d_reg_every == 0:
+            x = real_img.detach().clone().requires_grad_(True)
+            pred = self.D(x)
+            r1_loss = d_r1_loss(pred, x)
+            self.D.zero_grad(set_to_none=True)
+            (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * pred[0]).backward()
+            allreduce_gradients(list(self.D.parameters()), self.bucket_bytes)
+            self.d_optim.step()
+            losses["r1"] = r1_loss.detach()
+        # ---- generator
+        requires_grad(self.G, True)
+        requires_grad(self.D, False)
+        fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
+        g_loss = g_nonsaturating_loss(self.D(fake))
+        losses["g"] = g_loss.detach()
+        if self.percept_loss is not None and self.percept_weight > 0:
+            t = self.percept_loss(fake, real_img.detach()).sum() * self.percept_weight
+            losses["g_percept_loss"], g_loss = t.detach(), g_loss + t
+        if self.id_loss is not None and self.id_weight > 0:
+            t = self.id_loss(fake, real_img.detach()) * self.id_weight
+            losses["g_id_loss"], g_loss = t.detach(), g_loss + t
+        self.G.zero_grad(set_to_none=True)
+        g_loss.backward()
+        losses["grad_buckets"] = allreduce_gradients(list(self.G.parameters()), self.bucket_bytes)
+        self.g_optim.step()
+        accumulate(self.G_ema, self.G, self.accum)
+        return losses
+
