@@ -1,0 +1,40 @@
+"""One training iteration (restoration_train.py:153-255 without the LPIPS / ID terms, whose pretrained networks are out of scope) at
+the real size: Restoration_net(512) + Discriminator(512), batch B per GPU, frozen front (stages A, B, C) through the inference
+kernels.  usage: python tools/bench_train_step.py [B] [iters]   -> JSON line with ms per iteration and the phase split."""
+import copy, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from vspbfr_amd.discriminator import Discriminator
+from vspbfr_amd.train_step import RestorationTrainer
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda", 0)
+pipe = bench.build_pipeline(dev, 4, False)                 # T = 4 sampler as restoration_train.py's load_ddpm default
+G = pipe.generator
+torch.manual_seed(1)
+D = Discriminator(512).to(dev)
+G_ema = copy.deepcopy(G)
+tr = RestorationTrainer(G, G_ema, D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9)
+low = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
+real = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
+G.train()
+times = []
+for i in range(iters + 1):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = tr.step(i + 1, low, real)                       # i + 1: no R1 step (every 16th iteration carries one)
+    torch.cuda.synchronize()
+    times.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+tr.step(16, low, real)                                       # an iteration with the R1 regulariser (double backward)
+torch.cuda.synchronize()
+t_r1 = time.perf_counter() - t0
+ms = sum(times[1:]) / iters * 1e3
+print(json.dumps({"what": "restoration_train step, 512x512, Restoration_net + Discriminator fwd/bwd + Adam + EMA, frozen front, no LPIPS/ID",
+                  "batch_per_gpu": B, "ms_per_iteration": round(ms, 1), "img_per_s": round(B / ms * 1e3, 2),
+                  "ms_iteration_with_r1": round(t_r1 * 1e3, 1), "losses": {k: float(v) for k, v in losses.items()},
+                  "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                  "generator_param_mb": round(tr.generator_bytes / 2 ** 20, 1)}))

@@ -8,6 +8,8 @@ G = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 B = 8
 x = torch.randn(B, Cin, S, S, device="cuda")
+if os.environ.get("IO_BF16"):
+    x = x.to(torch.bfloat16)
 if G == 1:
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") / math.sqrt(Cin * 9)
     pc = H.PackedConv(H.pack_weight(w), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
@@ -15,7 +17,7 @@ else:
     wp = torch.randn(4, 9, Cin, Cout // 4, device="cuda") / math.sqrt(Cin * 9)
     pc = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
 sc = torch.rand(B, Cin, device="cuda") + 0.5
-out = torch.empty(B, Cout, S, S, device="cuda")
+out = torch.empty(B, Cout, S, S, device="cuda", dtype=x.dtype)
 for _ in range(iters):
     H.conv2d_packed(x, pc, out=out, in_scale=sc, bf16=True, tile_hint=v)
 torch.cuda.synchronize()

@@ -172,6 +172,9 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   const float* ishp = p.in_shift;
   // Cin is a multiple of 8 (host): a wave's channel octet is either wholly inside or wholly past Cin
   auto issue_p = [&](float (&pr)[PT][8], int c) {
+#ifdef VSP_BF16_ABLATE  // 0x200000 no patch loads after the prologue
+    if ((p.dbg & 0x200000) && c > 0) return;
+#endif
     const int cib = c * BCK + 8 * oct;
     if (cib >= p.Cin) return;                                  // wave-uniform; the octet is committed as zeros
     // buffer loads: resource = this image, scalar offset = the channel plane (wave-uniform), vector offset = the lane's 32-bit
@@ -230,6 +233,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   constexpr int NDMA = WSLAB / 64;
   const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)g * nchunk * (NPART * T * 2) * co_pad;
   auto issue_w = [&](u32x4* Wdst, int c) {
+#ifdef VSP_BF16_ABLATE  // tuning only (VSP_CONV_DBG): 0x100000 no weight DMA after the prologue, 0x400000 every chunk re-reads chunk 0's slab
+    if ((p.dbg & 0x100000) && c > 0) return;
+    if (p.dbg & 0x400000) c = 0;
+#endif
     const u32x4* src = wsrc + (int64_t)c * (NPART * T * 2) * co_pad;
 #pragma unroll
     for (int k = 0; k < (NDMA + 3) / 4; ++k) {

@@ -390,6 +390,10 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   VSP_REQUIRE(!(split && p.io_bf16), "conv2d_bf16x3: the split-precision form keeps fp32 activations (io_bf16 = 0)");
   VSP_REQUIRE(p.io_bf16 == 0 || p.io_bf16 == 1, "conv2d_bf16: io_bf16 must be 0 or 1");
   q.io_bf16 = p.io_bf16;
+  {
+    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
+    q.dbg = dbg;
+  }
   if (split) {
     if (int rc = vspconv::bf16_launch_split(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;
     return vsp::check_launch("conv2d_bf16x3");
