@@ -95,16 +95,39 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   // pixel tile (same patch), then neighbouring tiles (shared halo), then images.  Dilation-group launches keep the launch
   // order (residue-major): there the column residues of a tile, which read the same 32-byte sectors, already follow each other
   // on one XCD two slots apart, and packing them into the same instant instead measured 25 % slower.
+  // Shared-input dilation groups (wg_order 3, round 2): the four SMART branches read the SAME image region with different row
+  // strides, and in launch order no two of them ever meet in one L2 -- measured 13-15x the input fetched (8.1 GB for a 0.54 GB
+  // input on 64 -> 4x16 at 512^2), the launch fabric-bound at 4 TB/s.  Region-major order: a region = one image band of 8 TH
+  // rows x 4 column tiles; for every dilation d | 8 exactly 8 workgroups per column tile cover it (d residues x 8/d row tiles),
+  // so a region is G x co_tiles x 32 workgroups that one XCD runs back to back on ~1.3 MB of input.
   const int GX = gridDim.x, GY = gridDim.y, GN = GX * GY, GT = GN * gridDim.z;
   int b = blockIdx.z, xl = blockIdx.x, yy = blockIdx.y;
-  if (p.G == 1) {
+  int reg_ry = -1, reg_ty = 0, reg_tx = 0;
+  if (p.G == 1 || (MODE == M_CONV && p.wg_order == 3)) {
     const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
     const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
-    b = lid / GN;
-    const int lrem = lid - b * GN;
-    xl = lrem / GY;
-    yy = lrem - xl * GY;
+    if (p.G == 1) {
+      b = lid / GN;
+      const int lrem = lid - b * GN;
+      xl = lrem / GY;
+      yy = lrem - xl * GY;
+    } else {
+      constexpr int CGX = 4;
+      const int nb = p.tiles_y, ncg = p.tiles_x;               // (host: bands per image, column groups per band)
+      const int per_region = GY * 8 * CGX;
+      const int region = lid / per_region, w = lid - region * per_region;
+      b = region / (nb * ncg);
+      const int rr = region - b * (nb * ncg);
+      const int band = rr / ncg, cg = rr - band * ncg;
+      const int slot = w / (GY * CGX), w2 = w - slot * (GY * CGX);
+      const int cx = w2 / GY;
+      yy = w2 - cx * GY;
+      const int dg = p.dil[yy / p.co_tiles];
+      reg_ry = slot % dg;
+      reg_ty = band * (8 / dg) + slot / dg;
+      reg_tx = cg * CGX + cx;
+    }
   }
   const int g = yy / p.co_tiles, ct = yy - g * p.co_tiles;
   const int d = MODE == M_CONV ? p.dil[p.G > 4 ? 0 : g] : 1;
@@ -113,9 +136,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   const int twl = p.tw_log2, TW = 1 << twl, TH = NPIX >> twl;
   const int tiles_x = (SW + TW - 1) >> twl, tiles_y = (SH + TH - 1) / TH;
   const int per_res = tiles_x * tiles_y;
-  if (xl >= per_res * d) return;                               // (row counts that d does not divide leave a few spare blocks)
-  const int ry = xl / per_res, tile_i = xl - ry * per_res;
-  const int ty_i = tile_i / tiles_x, tx_i = tile_i - ty_i * tiles_x;
+  int ry, ty_i, tx_i;
+  if (reg_ry >= 0) {
+    if (reg_ty >= tiles_y || reg_tx >= tiles_x) return;          // (bands / column groups that the image does not fill)
+    ry = reg_ry; ty_i = reg_ty; tx_i = reg_tx;
+  } else {
+    if (xl >= per_res * d) return;                               // (row counts that d does not divide leave a few spare blocks)
+    ry = xl / per_res;
+    const int tile_i = xl - ry * per_res;
+    ty_i = tile_i / tiles_x;
+    tx_i = tile_i - ty_i * tiles_x;
+  }
   const int oy0 = ty_i * TH, ox0 = tx_i << twl;                // sub-image coordinates
   const int co0 = ct * CO_T;
   const int co_pad = (p.cout_g + 31) & ~31;
@@ -598,6 +629,17 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   } else {
     const int EH = MODE == M_TC ? q.H + 1 : q.OH, EW = MODE == M_TC ? q.W + 1 : q.OW;
     blocks = ((EW + TW - 1) / TW) * ((EH + TH - 1) / TH);
+  }
+  q.wg_order = 0;
+  if (MODE == M_CONV && q.G >= 2 && q.G <= 4 && q.x_gs == 0 && !(q.dbg & 0x800000)) {
+    bool ok = true;
+    for (int g = 0; g < q.G; ++g) ok = ok && (q.dil[g] == 1 || q.dil[g] == 2 || q.dil[g] == 4 || q.dil[g] == 8);
+    if (ok) {  // region-major order over bands of 8 TH rows x 4 column tiles (see the kernel)
+      q.wg_order = 3;
+      q.tiles_y = (q.H + 8 * TH - 1) / (8 * TH);
+      q.tiles_x = ((q.W + TW - 1) / TW + 3) / 4;
+      blocks = q.tiles_y * q.tiles_x * 32;
+    }
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
   conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB><<<grid, BNT, gm.lds, stream>>>(q);

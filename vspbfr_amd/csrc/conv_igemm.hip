@@ -484,6 +484,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
       raised[best.cfg] = true;
     }
   }
+  q.wg_order = (q.dbg & 0x1000000) ? 0 : 1;   // XCD-aware order (conv_kernel.h); VSP_CONV_DBG = 16777216 keeps the dispatch order
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y + (best.strip_col > 0 ? best.strip_col + best.strip_row : 0)), (unsigned)gy,
             (unsigned)p.B);
   dim3 block(64 * k.WM * k.WN * k.WK);

@@ -116,11 +116,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
   const int lr = lane & 15;  // MFMA row (A) / column (B, D) index inside a 16x16 block
   const int kq = lane >> 4;  // MFMA k slot (A, B); D row group
 
-  const int tile = blockIdx.x;
+  // XCD-aware work order (round 2).  In dispatch order a workgroup's neighbours are other PIXEL tiles of the same channel
+  // tile, the dispatcher deals them round-robin over the 8 XCDs, and the channel tiles that re-read a patch come a whole grid
+  // row later: no L2 ever sees a patch twice (the e4e style-head stem, 44 channel tiles x 64 pixel tiles, fetched 6.8 GB for a
+  // 67 MB input).  Bijective remap: every XCD walks a contiguous range of (image, pixel tile, channel tile) with the channel
+  // tiles of one pixel tile adjacent -- they read the same patch back to back out of one L2.
+  int tile = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.wg_order == 1) {
+    const int GX = gridDim.x, GY = gridDim.y, GN = GX * GY, GT = GN * gridDim.z;
+    const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
+    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+    bz = lid / GN;
+    const int lrem = lid - bz * GN;
+    tile = lrem / GY;
+    by = lrem - tile * GY;
+  }
   const int tx_i = tile % p.tiles_x, ty_i = tile / p.tiles_x;
-  const int g = DG ? 0 : blockIdx.y / p.co_tiles;
-  const int co0 = DG ? blockIdx.y * 16 : (blockIdx.y % p.co_tiles) * CO_T;  // within the group
-  const int b = blockIdx.z;
+  const int g = DG ? 0 : by / p.co_tiles;
+  const int co0 = DG ? by * 16 : (by % p.co_tiles) * CO_T;  // within the group
+  const int b = bz;
 
   // Transposed mode, H and W multiples of the tile: the main tiles cover positions [0,H) x [0,W) exactly and the odd
   // edge (column n = W, row m = H of the (H+1) x (W+1) position grid) is served by strip blocks -- 1 x NPIX column

@@ -92,8 +92,31 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   //       (32 KB per 8-channel interval against 5.8 KB of patch: 4.3 GB per 512 -> 512 launch at 64^2, ~5 TB/s).  In
   //       pixel-major order all 8 channel tiles (16.8 MB) compete for one 4 MB L2 and U streams from MALL / HBM; in
   //       channel-major order an XCD works on one or two channel tiles at a time and U stays L2-resident.
+  //   4 = region-major (shared-input dilation groups, as in conv_bf16.hip): a region = one image band of 8 x 2 TLY rows x 4 column
+  //       tiles; for every dilation d | 8 exactly 8 workgroups per column tile cover it (d residues x 8/d row tiles), and the four
+  //       groups of a region run back to back on one XCD instead of never meeting in an L2.
   int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (p.wg_order) {
+  int reg_ry = -1, reg_ty = 0, reg_tx = 0;
+  if (DMAX > 1 && p.wg_order == 4) {
+    constexpr int CGX = 4;
+    const int GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z, GT = GX * GY * GZ;
+    const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
+    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+    const int nb = p.tiles_y, ncg = p.tiles_x;                 // (host: bands per image, column groups per band)
+    const int per_region = GY * 8 * CGX;
+    const int region = lid / per_region, w = lid - region * per_region;
+    b = region / (nb * ncg);
+    const int rr = region - b * (nb * ncg);
+    const int band = rr / ncg, cg = rr - band * ncg;
+    const int slot = w / (GY * CGX), w2 = w - slot * (GY * CGX);
+    const int cx = w2 / GY;
+    by = w2 - cx * GY;
+    const int dg = p.dil[by / p.co_tiles];
+    reg_ry = slot % dg;
+    reg_ty = band * (8 / dg) + slot / dg;
+    reg_tx = cg * CGX + cx;
+  } else if (p.wg_order) {
     const int GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z, GT = GX * GY * GZ;
     const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
     const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
@@ -117,9 +140,17 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   const int SH = (p.H + d - 1) / d;                           // rows of one residue class
   const int tiles_x = (p.W + 2 * TLX - 1) / (2 * TLX), tiles_y = (SH + 2 * TLY - 1) / (2 * TLY);
   const int per_res = tiles_x * tiles_y;
-  if (bx >= per_res * d) return;                              // (row counts that d does not divide leave a few spare blocks)
-  const int ry = bx / per_res, tile_i = bx - ry * per_res;
-  const int tx_i = tile_i % tiles_x, ty_i = tile_i / tiles_x;
+  int ry, tx_i, ty_i;
+  if (reg_ry >= 0) {
+    if (reg_ty >= tiles_y || reg_tx >= tiles_x) return;       // (bands / column groups that the image does not fill)
+    ry = reg_ry; ty_i = reg_ty; tx_i = reg_tx;
+  } else {
+    if (bx >= per_res * d) return;                            // (row counts that d does not divide leave a few spare blocks)
+    ry = bx / per_res;
+    const int tile_i = bx - ry * per_res;
+    tx_i = tile_i % tiles_x;
+    ty_i = tile_i / tiles_x;
+  }
   const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);   // sub-image rows, image columns
   const int PC = 2 * TLX + 2 * d;                             // patch row of this group
   const int co0 = ct * WCO;                                   // within the group
@@ -444,6 +475,16 @@ int launch_variant(ConvK q, hipStream_t stream) {
   q.wg_order = (DMAX == 1 && q.G == 1) || q.H * q.W <= 1024 ? 1 : 0;
   if (q.dbg & 0x300) q.wg_order = (q.dbg >> 8) & 3;  // tuning: VSP_CONV_DBG = 256 / 512 / 768 forces order 1 / 2 / dispatch (0)
   if (q.wg_order == 3) q.wg_order = 0;
+  if (DMAX > 1 && q.G >= 2 && q.x_gs == 0 && !(q.dbg & 0x800000)) {
+    bool ok = true;
+    for (int g = 0; g < q.G; ++g) ok = ok && (q.dil[g] == 1 || q.dil[g] == 2 || q.dil[g] == 4 || q.dil[g] == 8);
+    if (ok) {  // region-major order over bands of 8 x 2 TLY rows x 4 column tiles
+      q.wg_order = 4;
+      q.tiles_y = (q.H + 16 * Gm::TLY - 1) / (16 * Gm::TLY);
+      q.tiles_x = ((q.W + 2 * Gm::TLX - 1) / (2 * Gm::TLX) + 3) / 4;
+      blocks = q.tiles_y * q.tiles_x * 32;
+    }
+  }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
   conv_wino_kernel<MBW, DMAX><<<grid, NTHR, lds, stream>>>(q);
   return VSP_OK;
