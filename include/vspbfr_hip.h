@@ -285,6 +285,9 @@ int vsp_subsample_f32(float* out, const float* x, int64_t planes, int IH, int IW
  *   t = (clamp(x, lo, hi) - lo) / max(hi - lo, 1e-5);  out[b,y,x,c] = (uint8) clamp(t * 255 + 0.5, 0, 255) */
 int vsp_quantize_u8_nhwc(uint8_t* out, const float* x, int B, int C, int H, int W, float lo, float hi,
                          vsp_stream_t stream);
+/* F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False) on `planes` = B*C planes (the resize to 256^2 in front of the
+ * e4e encoder, reference Loss/e4e_embedding.py:91-100, for inputs that are not 512^2 -- there it is the 2x2 mean above). */
+int vsp_resize_bilinear_f32(float* out, const float* x, int64_t planes, int IH, int IW, int OH, int OW, vsp_stream_t stream);
 /* out = a + b + c (c may be NULL). */
 int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream);
 
@@ -404,6 +407,20 @@ typedef struct vsp_conv_wgrad_params {
 } vsp_conv_wgrad_params;
 int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* p, vsp_stream_t stream);
 int vsp_plane_dot_f32(float* out, const float* a, const float* b, int64_t planes, int64_t n, vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ADA augmentation primitives (reference non_leaking.py:857-934).
+ *   vsp_affine_sample_f32      out = F.grid_sample(x, F.affine_grid(theta, (B,C,OH,OW), align_corners=False), "bilinear", "zeros",
+ *                              align_corners=False); theta (B, 2, 3) fp32 on the device; the grid is never materialised
+ *   vsp_affine_sample_bwd_f32  gx = adjoint of the above w.r.t. x applied to gout (gx (B,C,IH,IW) is overwritten)
+ *   vsp_color_affine_f32       y[b,c,p] = sum_k M[b,c,k] x[b,k,p] + t[b,c] on 3-channel images (apply_color, :910-918); M (B,3,3),
+ *                              t (B,3) or NULL
+ * ---------------------------------------------------------------------------------------------- */
+int vsp_affine_sample_f32(float* out, const float* x, const float* theta, int B, int C, int IH, int IW, int OH, int OW,
+                          vsp_stream_t stream);
+int vsp_affine_sample_bwd_f32(float* gx, const float* gout, const float* theta, int B, int C, int IH, int IW, int OH, int OW,
+                              vsp_stream_t stream);
+int vsp_color_affine_f32(float* y, const float* x, const float* M, const float* t, int B, int64_t HW, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keyed random tensors -- replaces the path's global-RNG draws: one `image.new_empty(B,1,H,W).normal_()` per NoiseInjection

@@ -663,3 +663,47 @@ def test_training_step_size64():
     a = tr.accum
     assert not torch.equal(ema, g0[k]) and float((ema - g0[k]).abs().max()) < 3 * (1 - a) * float((dict(G.named_parameters())[k] - g0[k]).abs().max()) + 1e-9
     assert all(not p_.requires_grad for p_ in D.parameters()) and all(p_.requires_grad for p_ in G.parameters())   # state after a G step
+    # the same iteration with ADA on (fixed p): gradients reach the generator THROUGH the augmentation, R1 through it twice
+    tr2 = RestorationTrainer(G, G_ema, D, mixing=0.0, augment=True, augment_p=0.7)
+    gk = dict(G.named_parameters())[k].detach().clone()
+    torch.manual_seed(5)
+    with torch.enable_grad():
+        l2 = tr2.step(0, low, real, de_feats=de, latent=lat)
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in l2.values()) and "r1" in l2
+    assert not torch.equal(dict(G.named_parameters())[k], gk)
+
+
+def test_ada_augment_golden(golden):
+    """vspbfr_amd.non_leaking.augment against the reference's ADA pipeline (tests/golden/ada.npz) with the transformation
+    matrices pinned: geometric part (reflect pad, sym6 2x up, fused affine grid + bilinear sampling, 2x down), colour part, and
+    the gradient w.r.t. the input image; then the random path (matrices drawn here) and the probability controller."""
+    from vspbfr_amd import non_leaking as NL
+    g = golden("ada")
+    case, B, size = "ada", 4, 64
+    G, C = torch.from_numpy(g["G"]), torch.from_numpy(g["C"])
+    R = dev(cases.tensor(case, "R", (B, 3, size, size)))
+    geo, _ = NL.random_apply_affine(dev(cases.image_batch(case, B, size)), 0.8, G)
+    assert maxerr(geo, g["geometric"]) < 2e-5
+    with torch.enable_grad():
+        img = dev(cases.image_batch(case, B, size)).requires_grad_(True)
+        out, (G2, C2) = NL.augment(img, 0.8, (G, C))
+        (out * R).sum().backward()
+    assert out.shape == (B, 3, size, size) and maxerr(out, g["out"]) < 2e-5
+    assert maxerr(img.grad, g["d_img"]) < 1e-4 * max(1.0, float(np.abs(g["d_img"]).max()))   # scatter-add order (atomics), measured 3.2e-5
+    # affine sampler alone against torch's own affine_grid + grid_sample on the host, and second-order consistency
+    x = torch.randn(2, 3, 20, 17)
+    th = torch.tensor([[[0.9, 0.2, 0.05], [-0.15, 1.1, -0.1]], [[1.2, 0.0, 0.3], [0.0, 0.7, 0.0]]])
+    ref = torch.nn.functional.grid_sample(x, torch.nn.functional.affine_grid(th, (2, 3, 24, 30), align_corners=False),
+                                          mode="bilinear", padding_mode="zeros", align_corners=False)
+    assert maxerr(NL.affine_sample(dev(x), dev(th), (24, 30)), ref) < 1e-5
+    # drawn matrices: shapes, finiteness, p = 0 is the identity up to the filters' pass band
+    torch.manual_seed(3)
+    rnd, (Gr, Cr) = NL.augment(dev(cases.image_batch(case, B, size)), 0.6)
+    assert rnd.shape == (B, 3, size, size) and torch.isfinite(rnd).all() and Gr.shape == (B, 3, 3) and Cr.shape == (B, 4, 4)
+    same, _ = NL.augment(dev(cases.image_batch(case, B, size)), 0.0)
+    smooth = dev(torch.linspace(-1, 1, size).view(1, 1, 1, size).expand(B, 3, size, size).contiguous())
+    ident, _ = NL.augment(smooth, 0.0)
+    assert maxerr(ident[:, :, 8:-8, 8:-8], smooth[:, :, 8:-8, 8:-8].cpu()) < 2e-3      # a ramp passes the sym6 up / down pair
+    ada = NL.AdaptiveAugment(0.6, 1000, 2, DEV)
+    assert ada.tune(dev(torch.ones(8, 1))) == 0 and abs(ada.tune(dev(torch.ones(8, 1))) - 16 / 1000) < 1e-9   # r_t = 1 > target: p up
+    assert ada.tune(dev(-torch.ones(8, 1))) == 16 / 1000 and ada.tune(dev(-torch.ones(8, 1))) == 0.0          # r_t = -1: p down

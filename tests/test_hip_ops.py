@@ -870,3 +870,13 @@ def test_conv2d_wgrad_scales_and_plane_dot(H):
     assert H.conv2d_wgrad(dev(x[:0]), dev(gy[:0]), w.shape, 1, 1).abs().max().item() == 0.0     # empty batch: zeros
     with pytest.raises(RuntimeError):
         H.conv2d_wgrad(dev(x), dev(gy), (cout, cin, 5, 5), 1, 2)
+
+
+@pytest.mark.parametrize("ish,osh", [((512, 512), (256, 256)), ((300, 420), (256, 256)), ((128, 96), (256, 256)), ((7, 5), (3, 11))])
+def test_resize_bilinear_matches_interpolate(H, ish, osh):
+    """vsp_resize_bilinear_f32 = F.interpolate(mode="bilinear", align_corners=False) (the reference's resize in front of the e4e
+    encoder, Loss/e4e_embedding.py:91-100) for down- and up-scaling; from 512^2 to 256^2 it equals the 2x2 mean get_w_plus uses."""
+    x = torch.randn(2, 3, *ish)
+    close(H.resize_bilinear(dev(x), osh), F.interpolate(x, osh, mode="bilinear", align_corners=False), 1e-6, 2e-6)
+    if ish == (512, 512):
+        close(H.resize_bilinear(dev(x), osh), H.avgpool2x2(dev(x)), 1e-6, 1e-6)

@@ -295,6 +295,30 @@ def gen_discriminator64():
     print("discriminator64.npz: d_loss %.4f r1 %.4e g_loss %.4f, %d parameters, %.1fs" % (d_loss.item(), r1.item(), g_loss.item(), len(names), time.time() - t))
 
 
+def gen_ada():
+    """ADA augmentation (non_leaking.py:857-934) of the REFERENCE with pinned transformation matrices: G = the inverse of a
+    sample_affine draw, C = a sample_color draw (both stored), the augmented batch, and the gradient of <augmented, R> w.r.t.
+    the input image (the path the generator's gradient takes when augmentation is on)."""
+    import non_leaking as NL
+    import torch.nn.functional as F
+    # GridSampleBackward (non_leaking.py:826-846) fetches aten::grid_sampler_2d_backward through torch._C._jit_get_operation, which
+    # returns a tuple on this torch (2.10): the reference's own backward cannot run.  Its forward is exactly this call (:811-813);
+    # in-process replacement by the plain op, whose backward autograd knows (no reference file is edited)
+    NL.grid_sample = lambda inp, grid: F.grid_sample(inp, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    case, B, size, p_aug = "ada", 4, 64, 0.8
+    img = cases.image_batch(case, B, size).requires_grad_(True)
+    R = cases.tensor(case, "R", (B, 3, size, size))
+    torch.manual_seed(11)
+    G = torch.inverse(NL.sample_affine(p_aug, B, size, size))
+    C = NL.sample_color(p_aug, B)
+    with torch.enable_grad():
+        out, _ = NL.augment(img, p_aug, (G, C))
+        (out * R).sum().backward()
+    geo, _ = NL.random_apply_affine(img.detach(), p_aug, G)
+    np.savez_compressed(os.path.join(GOLD, "ada.npz"), G=np_(G), C=np_(C), out=np_(out), geometric=np_(geo), d_img=np_(img.grad))
+    print("ada.npz:", tuple(out.shape), "std %.3f" % out.std(), "G[0]", G[0].tolist())
+
+
 def gen_generator64():
     g = SG.Generator(64, 512, 8, channel_multiplier=2)
     load_synth(g, "e4e_decoder", cases.SEED)
@@ -410,7 +434,7 @@ def gen_loader():
 
 
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

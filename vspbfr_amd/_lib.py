@@ -100,6 +100,7 @@ SIGNATURES = {
     "vsp_demod_f32": [_p, _p, _p, _i, _i, _i, _f, _f, _p],
     "vsp_avgpool2x2_f32": [_p, _p, _i64, _i, _i, _p],
     "vsp_upsample_add_f32": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "vsp_resize_bilinear_f32": [_p, _p, _i64, _i, _i, _i, _i, _p],
     "vsp_plane_mean_f32": [_p, _p, _i64, _i, _p],
     "vsp_scale_add_f32": [_p, _p, _p, _p, _i64, _i, _p],
     "vsp_subsample_f32": [_p, _p, _i64, _i, _i, _i, _p],
@@ -114,6 +115,9 @@ SIGNATURES = {
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
+    "vsp_affine_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "vsp_affine_sample_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "vsp_color_affine_f32": [_p, _p, _p, _p, _i, _i64, _p],
     "vsp_conv2d_wgrad_f32": [C.POINTER(ConvWgradParams), _p],
     "vsp_plane_dot_f32": [_p, _p, _p, _i64, _i64, _p],
     "vsp_convert_f32_to_bf16": [_p, _p, _i64, _p],

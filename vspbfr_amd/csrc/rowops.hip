@@ -165,6 +165,28 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(float* out, const flo
   }
 }
 
+// bilinear, align_corners=False, no antialiasing (F.interpolate(mode="bilinear"), the 256^2 resize in front of the e4e encoder,
+// Loss/e4e_embedding.py:91-100): src = (dst + 0.5) * I / O - 0.5 clamped at 0, neighbours clamped at I - 1
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(float* out, const float* x, int64_t planes, int IH, int IW, int OH,
+                                                               int OW, float sy, float sx) {
+  const int64_t total = planes * OH * OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const int64_t t = i / OW;
+    const int oy = (int)(t % OH);
+    const int64_t pl = t / OH;
+    const float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > IH - 1) y0 = IH - 1;
+    if (x0 > IW - 1) x0 = IW - 1;
+    const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* xp = x + pl * IH * IW;
+    out[i] = hy * (hx * xp[y0 * IW + x0] + lx * xp[y0 * IW + x1]) + ly * (hx * xp[y1 * IW + x0] + lx * xp[y1 * IW + x1]);
+  }
+}
+
 // one wave per plane
 __global__ __launch_bounds__(256) void plane_mean_kernel(float* out, const float* x, int64_t planes, int hw) {
   const int lane = threadIdx.x & 63;
@@ -310,6 +332,15 @@ int vsp_upsample_add_f32(float* out, const float* x, const float* y, int64_t pla
   const float rx = OW > 1 ? (float)(IW - 1) / (float)(OW - 1) : 0.f;
   VSP_LAUNCH_1D(upsample_add_kernel, n, stream, out, x, y, planes, IH, IW, OH, OW, ry, rx);
   return vsp::check_launch("upsample_add");
+}
+
+int vsp_resize_bilinear_f32(float* out, const float* x, int64_t planes, int IH, int IW, int OH, int OW, vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && IH >= 1 && IW >= 1 && OH >= 1 && OW >= 1, "resize_bilinear: bad dims");
+  const int64_t n = planes * OH * OW;
+  if (n == 0) return VSP_OK;
+  VSP_REQUIRE(out && x, "resize_bilinear: null pointer");
+  VSP_LAUNCH_1D(resize_bilinear_kernel, n, stream, out, x, planes, IH, IW, OH, OW, (float)IH / (float)OH, (float)IW / (float)OW);
+  return vsp::check_launch("resize_bilinear");
 }
 
 int vsp_plane_mean_f32(float* out, const float* x, int64_t planes, int hw, vsp_stream_t stream) {

@@ -6,7 +6,7 @@ FusedLeakyReLU?], `ResBlock` = conv1 / conv2 / skip: pinned by tests/test_layout
 forward is differentiable to second order -- the R1 penalty differentiates the input gradient again -- because every operator on
 the way is: op.conv2d_gradfix (forward / data-gradient kernels + vsp_conv2d_wgrad_f32), op.fused_leaky_relu, op.upfirdn2d, and
 torch tensor algebra for the minibatch-stddev statistic and the two linear layers (plain library GEMMs).
-ADA augmentation (non_leaking.py) is not part of this module."""
+ADA augmentation lives in vspbfr_amd/non_leaking.py."""
 import math
 
 import torch

@@ -360,9 +360,12 @@ class E4e_embedding(nn.Module):
 
     @torch.no_grad()
     def get_w_plus(self, img, weight_map=None):
-        if img.shape[-1] != 512 or img.shape[-2] != 512:
-            raise RuntimeError("get_w_plus: the restoration path feeds 512x512 images (bilinear 512->256 == 2x2 mean)")
-        return self.E4Enet(H.avgpool2x2(img.contiguous()))
+        # F.interpolate(img, (256, 256), mode="bilinear") of the reference: from 512^2 it is exactly the 2x2 mean
+        if img.shape[-1] == 512 and img.shape[-2] == 512:
+            return self.E4Enet(H.avgpool2x2(img.contiguous()))
+        if img.shape[-1] == 256 and img.shape[-2] == 256:
+            return self.E4Enet(img.contiguous())
+        return self.E4Enet(H.resize_bilinear(img.contiguous(), (256, 256)))
 
     @torch.no_grad()
     def get_stylegan_feats(self, styles, noise=None, with_sample=True):

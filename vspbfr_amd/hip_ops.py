@@ -687,6 +687,16 @@ def upsample_add(x, y):
     return out
 
 
+def resize_bilinear(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) for NCHW fp32."""
+    x = _req(x, "x")
+    B, Cc, IH, IW = x.shape
+    OH, OW = size
+    out = torch.empty((B, Cc, OH, OW), device=x.device, dtype=x.dtype)
+    check(lib.vsp_resize_bilinear_f32(_ptr(out), _ptr(x), B * Cc, IH, IW, OH, OW, _stream()), "resize_bilinear")
+    return out
+
+
 def plane_mean(x):
     x = _req(x, "x")
     B, Cc, H, W = x.shape

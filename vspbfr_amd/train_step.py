@@ -68,12 +68,18 @@ def requires_grad(model, flag=True):
 
 class RestorationTrainer:
     def __init__(self, generator, g_ema, discriminator, psp_embedding=None, diffusion=None, lr=0.002, g_reg_every=4, d_reg_every=16,
-                 r1=10.0, mixing=0.9, percept_loss=None, percept_weight=0.0, id_loss=None, id_weight=0.0, bucket_bytes=64 << 20):
+                 r1=10.0, mixing=0.9, percept_loss=None, percept_weight=0.0, id_loss=None, id_weight=0.0, bucket_bytes=64 << 20,
+                 augment=False, augment_p=0.0, ada_target=0.6, ada_length=500 * 1000, ada_every=256):
         self.G, self.G_ema, self.D = generator, g_ema, discriminator
         self.psp, self.diffusion = psp_embedding, diffusion
         self.d_reg_every, self.r1, self.mixing = d_reg_every, r1, mixing
         self.percept_loss, self.percept_weight, self.id_loss, self.id_weight = percept_loss, percept_weight, id_loss, id_weight
         self.bucket_bytes = bucket_bytes
+        # ADA (restoration_train.py:144-148, 173-180, 194-196): fixed probability augment_p, or adaptive when it is 0
+        self.augment_on, self.ada_aug_p, self.ada = augment, augment_p, None
+        if augment and augment_p == 0:
+            from .non_leaking import AdaptiveAugment
+            self.ada = AdaptiveAugment(ada_target, ada_length, ada_every, next(discriminator.parameters()).device)
         g_ratio, d_ratio = g_reg_every / (g_reg_every + 1), d_reg_every / (d_reg_every + 1)   # restoration_train.py:397-408
         self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
         self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio))
@@ -99,6 +105,12 @@ class RestorationTrainer:
         inject = None if len(noise) < 2 else random.randint(1, self.G.n_latent - 1)
         return training.restoration_net_forward(self.G, low_img, de_feats, latent, noise, enc_noise, dec_noise, inject_index=inject)
 
+    def _aug(self, img):
+        if not self.augment_on:
+            return img
+        from .non_leaking import augment
+        return augment(img, self.ada_aug_p)[0]
+
     def step(self, i, low_img, real_img, de_feats=None, latent=None):
         """Iteration i on this rank's shard (images in [-1, 1] on the device).  de_feats / latent: precomputed outputs of the
         frozen front (tests); default = run it.  Returns the loss dict of the reference's logger."""
@@ -113,16 +125,18 @@ class RestorationTrainer:
         requires_grad(self.D, True)
         with torch.no_grad():
             fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
-        fake_pred, real_pred = self.D(fake.detach()), self.D(real_img)
+        fake_pred, real_pred = self.D(self._aug(fake.detach())), self.D(self._aug(real_img.detach().clone()))
         d_loss = d_logistic_loss(real_pred, fake_pred)
         self.D.zero_grad(set_to_none=True)
         d_loss.backward()
         allreduce_gradients(list(self.D.parameters()), self.bucket_bytes)
         self.d_optim.step()
         losses.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
+        if self.ada is not None:
+            self.ada_aug_p = self.ada.tune(real_pred)
         if i % self.d_reg_every == 0:
             x = real_img.detach().clone().requires_grad_(True)
-            pred = self.D(x)
+            pred = self.D(self._aug(x))
             r1_loss = d_r1_loss(pred, x)
             self.D.zero_grad(set_to_none=True)
             (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * pred[0]).backward()
@@ -133,7 +147,7 @@ class RestorationTrainer:
         requires_grad(self.G, True)
         requires_grad(self.D, False)
         fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
-        g_loss = g_nonsaturating_loss(self.D(fake))
+        g_loss = g_nonsaturating_loss(self.D(self._aug(fake)))
         losses["g"] = g_loss.detach()
         if self.percept_loss is not None and self.percept_weight > 0:
             t = self.percept_loss(fake, real_img.detach()).sum() * self.percept_weight
