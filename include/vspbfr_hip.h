@@ -288,6 +288,15 @@ int vsp_quantize_u8_nhwc(uint8_t* out, const float* x, int B, int C, int H, int 
 /* F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False) on `planes` = B*C planes (the resize to 256^2 in front of the
  * e4e encoder, reference Loss/e4e_embedding.py:91-100, for inputs that are not 512^2 -- there it is the 2x2 mean above). */
 int vsp_resize_bilinear_f32(float* out, const float* x, int64_t planes, int IH, int IW, int OH, int OW, vsp_stream_t stream);
+/* Latent plumbing of a batch as single launches (the reference runs it as repeat / cat / flip / add on (B, 18, 512) tensors):
+ *   e4e_codes:   codes[b,t,:] = heads[t,b,:] + (t > 0 ? heads[0,b,:] : 0) + latent_avg[t,:]  -- the 18 map2style outputs (T, B, D) to
+ *                W+ codes (B, T, D) (psp_encoders.py:188-199 w0 + delta_i, psp.py:159-165 latent_avg; latent_avg may be NULL)
+ *   rows_concat: out[b,t,:] = [seg_0 | seg_1 | seg_2], seg_k = src_k[b*batch_stride_k + tt*token_stride_k + 0..width_k), tt = t or
+ *                T-1-t (flip_k); token_stride 0 broadcasts one row over the tokens (Restoration_net's latent = [W+ code | mapped z],
+ *                its flipped copy and the decoder styles [latent | x_global], models/RestoreNet.py:1000-1025).  Host arrays. */
+int vsp_e4e_codes_f32(float* out, const float* heads, const float* latent_avg, int B, int T, int D, vsp_stream_t stream);
+int vsp_rows_concat_f32(float* out, int B, int T, int nseg, const float* const* src, const int* batch_stride, const int* token_stride,
+                        const int* width, const int* flip, vsp_stream_t stream);
 /* out = a + b + c (c may be NULL). */
 int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream);
 

@@ -100,6 +100,8 @@ SIGNATURES = {
     "vsp_demod_f32": [_p, _p, _p, _i, _i, _i, _f, _f, _p],
     "vsp_avgpool2x2_f32": [_p, _p, _i64, _i, _i, _p],
     "vsp_upsample_add_f32": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
+    "vsp_e4e_codes_f32": [_p, _p, _p, _i, _i, _i, _p],
+    "vsp_rows_concat_f32": [_p, _i, _i, _i, C.POINTER(C.c_void_p), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _p],
     "vsp_resize_bilinear_f32": [_p, _p, _i64, _i, _i, _i, _i, _p],
     "vsp_plane_mean_f32": [_p, _p, _i64, _i, _p],
     "vsp_scale_add_f32": [_p, _p, _p, _p, _i64, _i, _p],

@@ -245,6 +245,54 @@ __global__ __launch_bounds__(256) void add3_kernel(float* out, const float* a, c
 
 }  // namespace
 
+// The latent plumbing of a batch (a few hundred KB; the reference runs it as repeat / cat / flip / add on (B, 18, 512) tensors):
+//   e4e codes: codes[b, t, :] = heads[t, b, :] + (t > 0 ? heads[0, b, :] : 0) + latent_avg[t, :]     (psp_encoders.py:188-199, psp.py:159-165)
+//   row concat: out[b, t, :] = [seg0 | seg1 | seg2], seg k = src_k[b * bs_k + tt * ts_k + j], tt = t or T-1-t (flip), ts_k = 0 broadcasts
+__global__ __launch_bounds__(256) void e4e_codes_kernel(float* __restrict__ out, const float* __restrict__ heads,
+                                                         const float* __restrict__ avg, int B, int T, int D) {
+  const int64_t total = (int64_t)B * T * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % D);
+    const int64_t r = i / D;
+    const int t = (int)(r % T), b = (int)(r / T);
+    float v = heads[((int64_t)t * B + b) * D + j];
+    if (t > 0) v += heads[(int64_t)b * D + j];
+    if (avg) v += avg[t * D + j];
+    out[i] = v;
+  }
+}
+
+struct ConcatSeg {
+  const float* src;
+  int bs, ts, width, flip;
+};
+struct ConcatArgs {
+  ConcatSeg seg[3];
+  int nseg, B, T, W;
+};
+
+__global__ __launch_bounds__(256) void rows_concat_kernel(float* __restrict__ out, ConcatArgs a) {
+  const int64_t total = (int64_t)a.B * a.T * a.W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int j = (int)(i % a.W);
+    const int64_t r = i / a.W;
+    const int t = (int)(r % a.T), b = (int)(r / a.T);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k >= a.nseg) break;
+      const ConcatSeg sg = a.seg[k];
+      if (j < sg.width) {
+        const int tt = sg.flip ? a.T - 1 - t : t;
+        v = sg.src[(int64_t)b * sg.bs + (int64_t)tt * sg.ts + j];
+        break;
+      }
+      j -= sg.width;
+    }
+    out[i] = v;
+  }
+}
+
 #define VSP_LAUNCH_1D(kern, n, s, ...)                                         \
   do {                                                                         \
     kern<<<stream_blocks(n), 256, 0, vsp::as_stream(s)>>>(__VA_ARGS__);        \
@@ -377,6 +425,30 @@ int vsp_quantize_u8_nhwc(uint8_t* out, const float* x, int B, int C, int H, int 
   const float range = hi - lo > 1e-5f ? hi - lo : 1e-5f;
   VSP_LAUNCH_1D(quantize_u8_nhwc_kernel, n, stream, out, x, B, C, H, W, lo, hi, range);
   return vsp::check_launch("quantize_u8_nhwc");
+}
+
+int vsp_e4e_codes_f32(float* out, const float* heads, const float* latent_avg, int B, int T, int D, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && T >= 1 && D >= 1, "e4e_codes: bad dims");
+  if (B == 0) return VSP_OK;
+  VSP_REQUIRE(out && heads, "e4e_codes: null pointer");
+  VSP_LAUNCH_1D(e4e_codes_kernel, (int64_t)B * T * D, stream, out, heads, latent_avg, B, T, D);
+  return vsp::check_launch("e4e_codes");
+}
+
+int vsp_rows_concat_f32(float* out, int B, int T, int nseg, const float* const* src, const int* batch_stride, const int* token_stride,
+                        const int* width, const int* flip, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && T >= 1 && nseg >= 1 && nseg <= 3, "rows_concat: 1..3 segments");
+  if (B == 0) return VSP_OK;
+  VSP_REQUIRE(out && src && batch_stride && token_stride && width && flip, "rows_concat: null pointer");
+  ConcatArgs a{};
+  a.nseg = nseg; a.B = B; a.T = T; a.W = 0;
+  for (int k = 0; k < nseg; ++k) {
+    VSP_REQUIRE(src[k] && width[k] >= 1, "rows_concat: bad segment %d", k);
+    a.seg[k] = ConcatSeg{src[k], batch_stride[k], token_stride[k], width[k], flip[k]};
+    a.W += width[k];
+  }
+  VSP_LAUNCH_1D(rows_concat_kernel, (int64_t)B * T * a.W, stream, out, a);
+  return vsp::check_launch("rows_concat");
 }
 
 int vsp_add3_f32(float* out, const float* a, const float* b, const float* c, int64_t n, vsp_stream_t stream) {

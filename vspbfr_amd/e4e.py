@@ -223,7 +223,8 @@ class Encoder4Editing(_Cached):
         self.latlayer2 = nn.Conv2d(128, 512, kernel_size=1, stride=1, padding=0)
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, latent_avg=None):
+        """`latent_avg` (extension): added to the codes in the same launch that assembles them (My_pSp.forward does it)."""
         il = self.input_layer
         src = [il[0].weight, il[1].weight, il[1].bias, il[1].running_mean, il[1].running_var, self.latlayer1.weight,
                self.latlayer2.weight]
@@ -239,16 +240,15 @@ class Encoder4Editing(_Cached):
         p2 = H.upsample_add(c3, H.conv2d_packed(c2, c["l1"], ch_bias=self.latlayer1.bias))
         p1 = H.upsample_add(p2, H.conv2d_packed(c1, c["l2"], ch_bias=self.latlayer2.bias))
         B = x.shape[0]
-        outs = [self._heads(lo, hi, f) for (lo, hi), f in zip(self._head_classes(), (c3, p2, p1))]
-        w = torch.cat(outs, 0).permute(1, 0, 2).contiguous()  # (B, 18, 512): [w0, delta_1, ..., delta_17]
-        w[:, 1:] += w[:, :1]                                   # w[:, i] = w0 + delta_i (psp_encoders.py:188-199)
-        assert w.shape == (B, self.style_count, 512)
-        return w
+        heads = torch.empty((self.style_count, B, 512), device=x.device, dtype=torch.float32)   # [w0, delta_1, ..., delta_17]
+        for (lo, hi), f in zip(self._head_classes(), (c3, p2, p1)):
+            self._heads(lo, hi, f, out=heads[lo:hi])
+        return H.e4e_codes(heads, latent_avg)                  # w[:, i] = w0 + delta_i (psp_encoders.py:188-199), (B, 18, 512)
 
     def _head_classes(self):
         return ((0, self.coarse_ind), (self.coarse_ind, self.middle_ind), (self.middle_ind, self.style_count))
 
-    def _heads(self, lo, hi, feat):
+    def _heads(self, lo, hi, feat, out=None):
         """All map2style heads fed by one feature map (same depth) as ONE launch per stage: the first conv is a plain conv
         with the heads' output channels concatenated, the following ones are true grouped convs (one group per head), the
         final EqualLinear a batched GEMM.  Returns (hi - lo, B, 512)."""
@@ -280,7 +280,7 @@ class Encoder4Editing(_Cached):
             x = H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
         B = x.shape[0]
         lin = heads[0].linear
-        return H.gemm_nt(x, lw, dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
+        return H.gemm_nt(x, lw, out=out, dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
                          alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
 
 
@@ -324,10 +324,11 @@ class My_pSp(nn.Module):
 
     @torch.no_grad()
     def forward(self, x):
-        codes = self.encoder(x)
-        if self.opts.start_from_latent_avg:
-            codes = codes + self.latent_avg.to(codes.device).unsqueeze(0)
-        return codes[:, :self.n_latent]
+        avg = self.latent_avg if self.opts.start_from_latent_avg else None
+        if avg is not None and (avg.device != x.device or not avg.is_contiguous()):
+            avg = self.latent_avg = avg.to(x.device).contiguous()
+        codes = self.encoder(x, latent_avg=avg)
+        return codes if codes.shape[1] == self.n_latent else codes[:, :self.n_latent]
 
     @torch.no_grad()
     def stylegan2_feat_forward(self, codes, resize=True, randomize_noise=True, return_features=True, noise=None,

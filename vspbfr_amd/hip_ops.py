@@ -687,6 +687,30 @@ def upsample_add(x, y):
     return out
 
 
+def e4e_codes(heads, latent_avg=None):
+    """(T, B, D) map2style outputs -> (B, T, D) W+ codes: w0 + delta_i (+ latent_avg), one launch."""
+    heads = _req(heads, "heads")
+    T, B, D = heads.shape
+    out = torch.empty((B, T, D), device=heads.device, dtype=torch.float32)
+    check(lib.vsp_e4e_codes_f32(_ptr(out), _ptr(heads), _ptr(_opt(latent_avg, "latent_avg")), B, T, D, _stream()), "e4e_codes")
+    return out
+
+
+def rows_concat(B, T, segments):
+    """out (B, T, sum widths) from up to three segments (tensor, width, per_token, flip): per_token=True reads tensor[b, t (or T-1-t),
+    :width] of a (B, >= T, >= width) contiguous tensor, per_token=False broadcasts tensor[b, :width] over the tokens."""
+    n = len(segments)
+    keep = [_req(t, "segment") for t, _, _, _ in segments]
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in keep])
+    bs = (C.c_int * n)(*[t.stride(0) for t in keep])
+    ts = (C.c_int * n)(*[(t.stride(1) if per_tok else 0) for (t, _, per_tok, _) in segments])
+    wd = (C.c_int * n)(*[int(w) for _, w, _, _ in segments])
+    fl = (C.c_int * n)(*[1 if f else 0 for _, _, _, f in segments])
+    out = torch.empty((B, T, sum(int(w) for _, w, _, _ in segments)), device=keep[0].device, dtype=torch.float32)
+    check(lib.vsp_rows_concat_f32(_ptr(out), B, T, n, src, bs, ts, wd, fl, _stream()), "rows_concat")
+    return out
+
+
 def resize_bilinear(x, size):
     """F.interpolate(x, size, mode="bilinear", align_corners=False) for NCHW fp32."""
     x = _req(x, "x")

@@ -124,9 +124,17 @@ class Restoration_net(nn.Module):
             noise_styles = [self.style(s.contiguous()) for s in noise_styles]
         if truncation < 1:
             noise_styles = [truncation_latent + truncation * (s - truncation_latent) for s in noise_styles]
-        noise_latent = self._noise_latent(noise_styles, inject_index)
-        latent = torch.cat([pre_styles[:, :noise_latent.shape[1], :], noise_latent], dim=-1)
-        latent_cp = torch.flip(latent, dims=[1])
+        B, nl, sd = images.shape[0], self.n_latent, self.style_dim
+        pre_styles = pre_styles.contiguous()
+        if len(noise_styles) == 1 and noise_styles[0].ndim == 2 and pre_styles.shape[2] == sd and pre_styles.shape[1] >= nl:
+            # latent = [W+ code | mapped z], and its token-flipped copy for the encoder: two launches instead of repeat + cat + flip
+            z = noise_styles[0].contiguous()
+            latent = H.rows_concat(B, nl, [(pre_styles, sd, True, False), (z, sd, False, False)])
+            latent_cp = H.rows_concat(B, nl, [(pre_styles, sd, True, True), (z, sd, False, False)])   # token t <- token nl - 1 - t
+        else:
+            noise_latent = self._noise_latent(noise_styles, inject_index)
+            latent = torch.cat([pre_styles[:, :noise_latent.shape[1], :], noise_latent], dim=-1)
+            latent_cp = torch.flip(latent, dims=[1])
         n_enc = len(self.encoder_convs)
         enc_noise = list(enc_noise) if enc_noise is not None else [None] * n_enc
         dec_noise = list(dec_noise) if dec_noise is not None else [None] * self.num_layers
@@ -136,7 +144,8 @@ class Restoration_net(nn.Module):
         x_global, feats = self.encoder_forward(images, latent_cp, enc_noise)
 
         # decoder styles cat[latent_i, x_global] for all layers in ONE concatenation; sty(i) is then a strided row view
-        sty_all = torch.cat([latent, x_global.unsqueeze(1).expand(-1, latent.shape[1], -1)], dim=2)
+        sty_all = H.rows_concat(latent.shape[0], latent.shape[1], [(latent, latent.shape[2], True, False),
+                                                                    (x_global.contiguous(), x_global.shape[1], False, False)])
 
         def sty(i):
             return sty_all[:, i]
