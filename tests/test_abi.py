@@ -71,3 +71,19 @@ def test_product_does_not_import_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "from oracle" in txt:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_torch_extension_modules_load_and_keep_the_reference_signatures():
+    """The AOT pybind11 modules `fused` / `upfirdn2d` (what the reference's `load(...)` calls return, op/fused_act.py:13-20,
+    op/upfirdn2d.py:13-20) import without a GPU, expose the reference's function names with its argument counts, and refuse CPU
+    tensors the way TORCH_CHECK does (op/fused_bias_act.cpp:10-16)."""
+    import pytest
+    import torch
+    from vspbfr_amd.op import native
+    fused, upfirdn2d_op = native.load()
+    assert fused.fused_bias_act.__doc__.count("arg") == 7          # input, bias, refer, act, grad, alpha, scale
+    assert upfirdn2d_op.upfirdn2d.__doc__.count("arg") == 10       # input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.zeros(0), 3, 0, 0.2, 1.0)
+    with pytest.raises(RuntimeError):
+        upfirdn2d_op.upfirdn2d(torch.zeros(1, 4, 4, 1), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0)

@@ -880,3 +880,22 @@ def test_resize_bilinear_matches_interpolate(H, ish, osh):
     close(H.resize_bilinear(dev(x), osh), F.interpolate(x, osh, mode="bilinear", align_corners=False), 1e-6, 2e-6)
     if ish == (512, 512):
         close(H.resize_bilinear(dev(x), osh), H.avgpool2x2(dev(x)), 1e-6, 1e-6)
+
+
+def test_torch_extension_modules(golden):
+    """The AOT pybind11 modules `fused` / `upfirdn2d` (vspbfr_amd/csrc/torch_ext) with the reference's native signatures
+    (op/fused_bias_act.cpp:18-31, op/upfirdn2d.cpp:17-31) against the reference's golden outputs and the ctypes path."""
+    from vspbfr_amd.op import native
+    fused, upfirdn2d_op = native.load()
+    e = torch.empty(0, device=DEV)
+    for name in cases.LRELU_CASES:
+        x, b = cases.lrelu_inputs(name)
+        y = fused.fused_bias_act(dev(x), dev(b) if b is not None else e, e, 3, 0, 0.2, math.sqrt(2))
+        close(y, golden("ops")[name], 1e-6, 1e-6, name)
+    for name in ("fir_blur_after_up", "fir_upsample_rgb", "fir_generic_asym", "fir_tiles_129"):
+        x, k, up, down, pad = cases.fir_inputs(name)
+        B, C_, Hh, Ww = x.shape
+        y = upfirdn2d_op.upfirdn2d(dev(x).reshape(-1, Hh, Ww, 1), dev(k), up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3])
+        close(y.view(B, C_, y.shape[1], y.shape[2]), golden("ops")[name], 1e-6, 1e-6, name)
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.zeros(0), 3, 0, 0.2, 1.0)      # CPU tensor: TORCH_CHECK
