@@ -41,6 +41,9 @@ __device__ __forceinline__ float uload(const float* base, int idx) {
   return ((cfp4)(uintptr_t)base)[__builtin_amdgcn_readfirstlane(idx)];
 }
 
+#ifndef VSP_WINO_PIN
+#define VSP_WINO_PIN 1   // pinned steady-state schedule for the undilated kernel (measured +1.5..3.5 %); dilated: slower, off
+#endif
 constexpr int WCK = 4;      // input channels per chunk = one MFMA k-step
 constexpr int NTHR = 512;
 
@@ -320,6 +323,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     constexpr bool FULL = decltype(full_tag)::value;
     const int cur = i & 1, nxt = cur ^ 1;
     if (KS == 2 && (FULL || KS * i + 1 < nchunk4) && !(ab & 0x800)) load_u(KS * i + 1, ub);
+#if VSP_WINO_PIN
+    if constexpr (FULL && KS == 2 && TPT == 1 && DMAX == 1) __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200);
+#endif
     if (FULL || i + 2 < nchunk) {
 #pragma unroll
       for (int e = 0; e < PLD; ++e) preg[e] = pnext[e];   // patch(i+2), issued one interval ago
@@ -333,6 +339,27 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     // sched_group_barrier patterns (one MFMA : two VALU), which the scheduler does not honour across the LDS waits; an
     // anti-phase start of the two workgroups of a CU (s_sleep of half an interval for every other group of 32): no effect.
     constexpr bool SPLIT = TPT == 1;
+#if VSP_WINO_PIN
+    if constexpr (FULL && KS == 2 && SPLIT && DMAX == 1) {
+      // Steady state with the vector-memory issue points pinned INSIDE the MFMA stream (mask 0x386: VALU, SALU and LDS operations
+      // may cross a fence, MFMAs and vector-memory instructions may not): the U loads of the second k-step and the patch loads of
+      // interval i + 3 leave after the first MFMA groups instead of all before the first one.
+      constexpr int M_ = 0x2 | 0x4 | 0x80 | 0x100 | 0x200;
+      multiply_pp(Vl + cur * LDS_V, 0, 0, ua);
+      __builtin_amdgcn_sched_barrier(M_);
+      transform_read(Pl + nxt * LDS_P);
+      multiply_pp(Vl + cur * LDS_V, 0, 1, ua);
+      __builtin_amdgcn_sched_barrier(M_);
+      load_u(KS * i + 2, ua);
+      transform_write(Vl + nxt * LDS_V, i + 1);
+      multiply_pp(Vl + cur * LDS_V, 1, 0, ub);
+      __builtin_amdgcn_sched_barrier(M_);
+      multiply_pp(Vl + cur * LDS_V, 1, 1, ub);
+      commit_p(Pl + cur * LDS_P, i + 2);
+      __syncthreads();
+      return;
+    }
+#endif
     const bool tr = (FULL || i + 1 < nchunk) && !(ab & 0x400);
     if (tr) transform_read(Pl + nxt * LDS_P);
     if (tr && !SPLIT) transform_write(Vl + nxt * LDS_V, i + 1);
