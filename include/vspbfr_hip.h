@@ -432,6 +432,26 @@ int vsp_affine_sample_bwd_f32(float* gx, const float* gout, const float* theta, 
 int vsp_color_affine_f32(float* y, const float* x, const float* M, const float* t, int B, int64_t HW, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Operators of the training losses (BASELINE configs[4]: LPIPS-VGG + ArcFace identity; reference restoration_train.py:236-245).
+ *   vsp_maxpool2d_f32 / _bwd   F.max_pool2d(x, k, s, p) in floor mode on `planes` = B*C planes (torchvision 0.13 vgg16.features
+ *                              2x2/2, resnet101 3x3/2 pad 1); the backward recomputes each window's arg-max (first maximum in
+ *                              row-major order, ATen's rule) from x; dx is overwritten
+ *   vsp_lpips_layer_f32        out[b] = mean_p sum_c w[c] (f0/(|f0|_c + 1e-10) - f1/(|f1|_c + 1e-10))^2  -- normalize_tensor,
+ *                              squared difference, the 1x1 `lin` layer and spatial_average of one LPIPS level in one stream
+ *                              (my_lpips/networks_basic.py:73-83, my_lpips/__init__.py:44-46); f0, f1 (B,C,HW), w (C), out (B)
+ *   vsp_lpips_layer_bwd_f32    df1 = gout[b] * d out[b] / d f1   (the reference calls forward(target, pred): my_lpips/__init__.py:42)
+ *   vsp_resize_bilinear_bwd_f32  adjoint of vsp_resize_bilinear_f32 (F.interpolate(size=112) in Loss/id_loss.py:37-41); dx overwritten
+ * ---------------------------------------------------------------------------------------------- */
+int vsp_maxpool2d_f32(float* out, const float* x, int64_t planes, int H, int W, int OH, int OW, int k, int s, int p,
+                      vsp_stream_t stream);
+int vsp_maxpool2d_bwd_f32(float* dx, const float* dy, const float* x, int64_t planes, int H, int W, int OH, int OW, int k, int s,
+                          int p, vsp_stream_t stream);
+int vsp_lpips_layer_f32(float* out, const float* f0, const float* f1, const float* w, int B, int C, int HW, vsp_stream_t stream);
+int vsp_lpips_layer_bwd_f32(float* df1, const float* f0, const float* f1, const float* w, const float* gout, int B, int C, int HW,
+                            vsp_stream_t stream);
+int vsp_resize_bilinear_bwd_f32(float* dx, const float* dy, int64_t planes, int IH, int IW, int OH, int OW, vsp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Keyed random tensors -- replaces the path's global-RNG draws: one `image.new_empty(B,1,H,W).normal_()` per NoiseInjection
  * (reference models/RestoreNet.py:564-569, e4e/models/stylegan2/model.py:287-292), `torch.randn(shape)` for x_T
  * (ldm/ddpm.py:423), `torch.randn(batch, latent_dim)` for z (restoration_test.py:77-82) and the synthetic LQ batch of the

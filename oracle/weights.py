@@ -69,6 +69,25 @@ def synth_tensor(model, name, shape, dtype, seed):
             return N(0.1)
         return N(1.0 / math.sqrt(_fan_in(shape)))
 
+    # ---- loss networks (torchvision architectures, oracle/tv_models.py): He-init convs keep the ReLU activations O(1)
+    if model == "lpips_vgg":
+        return N(0.1) if leaf == "bias" else N(math.sqrt(2.0 / _fan_in(shape)))
+    if model == "arcface_resnet101":
+        if leaf == "running_mean":
+            return N(0.1)
+        if leaf == "running_var":
+            return U(0.5, 1.5)
+        if re.search(r"(bn\d|downsample\.1)\.(weight|bias)$", name):
+            if leaf == "bias":
+                return N(0.1)
+            # the last BatchNorm of a residual branch at 0.1-0.3: 33 stacked blocks keep the trunk O(1) instead of growing 6x
+            return U(0.1, 0.3) if ".bn3." in name else U(0.5, 1.5)
+        if name == "fc.bias":
+            return N(0.1)
+        if name == "fc.weight":
+            return N(1.0 / math.sqrt(_fan_in(shape)))
+        return N(math.sqrt(2.0 / _fan_in(shape)))
+
     # ---- Code_diffuser (nn.Linear / LayerNorm)
     if model == "diffuser":
         if re.search(r"(gamma_|beta_)\.1\.(weight|bias)$", name):  # LayerNorm affine

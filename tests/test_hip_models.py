@@ -707,3 +707,61 @@ def test_ada_augment_golden(golden):
     ada = NL.AdaptiveAugment(0.6, 1000, 2, DEV)
     assert ada.tune(dev(torch.ones(8, 1))) == 0 and abs(ada.tune(dev(torch.ones(8, 1))) - 16 / 1000) < 1e-9   # r_t = 1 > target: p up
     assert ada.tune(dev(-torch.ones(8, 1))) == 16 / 1000 and ada.tune(dev(-torch.ones(8, 1))) == 0.0          # r_t = -1: p down
+
+
+def test_lpips_vgg_golden(golden):
+    """The perceptual term (restoration_train.py:236-239) against the REFERENCE's my_lpips.PerceptualLoss(net-lin, vgg) run on a
+    keyed VGG16 with the reference's own v0.1 `lin` weights (tests/golden/lpips64.npz; the torchvision VGG16 architecture is
+    restated in oracle/tv_models.py): per-image distance, the five levels, the loss and its gradient w.r.t. the predicted image."""
+    from vspbfr_amd.lpips import PerceptualLoss
+    g = golden("lpips64")
+    case, size, B = "lpips64", 64, 3
+    pl = PerceptualLoss(model="net-lin", net="vgg")
+    spec = weights.load_specs()["lpips_vgg"]
+    sd = weights.synth_state_dict("lpips_vgg", [e for e in spec if e[0].startswith("net.")], cases.SEED)
+    sd.update({k[4:]: torch.from_numpy(g[k]) for k in g if k.startswith("lin/")})
+    missing = pl.net.load_state_dict(sd, strict=False)
+    assert sorted(missing.missing_keys) == ["scaling_layer.scale", "scaling_layer.shift"] and not missing.unexpected_keys
+    pl = pl.to(DEV).eval()
+    pred, target = dev(cases.image_batch(case + "/pred", B, size)), dev(cases.image_batch(case + "/target", B, size))
+    with torch.no_grad():
+        val, res = pl.net(target, pred, retPerLayer=True)
+    assert val.shape == (B, 1, 1, 1)
+    assert maxerr(val.reshape(-1), g["dist"]) < 2e-6
+    # (the reference accumulates in place, `val = res[0]; val += res[l]`, networks_basic.py:88-90: its res[0] IS the total)
+    assert np.array_equal(g["level0"], g["dist"])
+    ref0 = g["dist"] - sum(g[f"level{i}"] for i in range(1, 5))
+    for i, r in enumerate(res):
+        assert maxerr(r.reshape(-1), g[f"level{i}"] if i else ref0) < 1e-6, i
+    with torch.enable_grad():
+        x = pred.clone().requires_grad_(True)
+        loss = pl(x, target).sum() * 0.5
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"][0])) < 2e-6
+    ref = g["d_pred"]
+    assert maxerr(x.grad, ref) < 2e-3 * float(np.abs(ref).max()), (maxerr(x.grad, ref), float(np.abs(ref).max()))
+    assert abs(float(x.grad.norm()) - float(np.linalg.norm(ref))) < 1e-3 * float(np.linalg.norm(ref))
+
+
+def test_id_loss_golden(golden):
+    """The identity term (restoration_train.py:242-245) against the REFERENCE's Loss.id_loss.IDLoss on a keyed ResNet-101 with
+    calibrated BatchNorm statistics (tests/golden/idloss128.npz): embeddings, loss, gradient w.r.t. the generated image through
+    the bilinear resize, 104 folded conv + BN layers, both max-pool forms and the L2 normalisation."""
+    from vspbfr_amd.id_loss import IDLoss
+    g = golden("idloss128")
+    case, size, B = "idloss128", 128, 2
+    sd = weights.synth_state_dict("arcface_resnet101", weights.load_specs()["arcface_resnet101"], cases.SEED)
+    sd.update({k[3:]: torch.from_numpy(g[k]) for k in g if k.startswith("bn/")})
+    idl = IDLoss(sd, device=DEV)
+    pred, target = dev(cases.image_batch(case + "/pred", B, size)), dev(cases.image_batch(case + "/target", B, size))
+    with torch.no_grad():
+        assert maxerr(idl.get_id(pred), g["z_pred"]) < 2e-5
+        assert maxerr(idl.get_id(target), g["z_target"]) < 2e-5
+    with torch.enable_grad():
+        x = pred.clone().requires_grad_(True)
+        loss = idl(x, target)
+        (loss * 0.1).backward()
+    assert abs(loss.item() - float(g["loss"][0])) < 2e-5
+    ref = g["d_pred"]
+    assert maxerr(x.grad, ref) < 1e-2 * float(np.abs(ref).max()), (maxerr(x.grad, ref), float(np.abs(ref).max()))
+    assert abs(float(x.grad.norm()) - float(np.linalg.norm(ref))) < 3e-3 * float(np.linalg.norm(ref))

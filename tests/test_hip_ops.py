@@ -811,6 +811,8 @@ def _grads(fn, *tensors):
     dict(cin=16, cout=32, hw=(17, 17), k=3, stride=2, pad=0, dil=1, groups=1, bias=False),      # StyledConv_down after its blur
     dict(cin=16, cout=16, hw=(18, 20), k=3, stride=2, pad=0, dil=1, groups=2, bias=False),
     dict(cin=80, cout=72, hw=(70, 66), k=3, stride=1, pad=1, dil=1, groups=1, bias=False),      # several tiles, ragged channel tiles
+    dict(cin=16, cout=24, hw=(28, 28), k=3, stride=2, pad=1, dil=1, groups=1, bias=False),      # ResNet bottleneck (identity loss), even size
+    dict(cin=16, cout=16, hw=(15, 17), k=3, stride=2, pad=1, dil=1, groups=1, bias=True),       # ... odd sizes
 ])
 def test_conv2d_gradfix_autograd(case):
     """conv2d_gradfix.conv2d with autograd against torch autograd of F.conv2d in float64: forward, data gradient (forward
@@ -899,3 +901,85 @@ def test_torch_extension_modules(golden):
         close(y.view(B, C_, y.shape[1], y.shape[2]), golden("ops")[name], 1e-6, 1e-6, name)
     with pytest.raises(RuntimeError):
         fused.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.zeros(0), 3, 0, 0.2, 1.0)      # CPU tensor: TORCH_CHECK
+
+
+# ------------------------------------------------------------------------------------------------ loss-network operators
+@pytest.mark.parametrize("k,s,p,hw", [(2, 2, 0, (20, 14)), (2, 2, 0, (9, 7)), (3, 2, 1, (56, 56)), (3, 2, 1, (13, 10))])
+def test_maxpool2d_forward_backward(H, k, s, p, hw):
+    """vsp_maxpool2d_f32 / _bwd against F.max_pool2d and its autograd (VGG16 2x2/2, ResNet 3x3/2 pad 1), ties included: the
+    input is quantised to a few levels so that many windows hold their maximum more than once."""
+    from vspbfr_amd.lpips import max_pool2d
+    x = (torch.randn(2, 5, *hw, generator=torch.Generator().manual_seed(1)) * 2).round() / 2
+    ref = _grads(lambda t: F.max_pool2d(t, k, s, p), x.double())
+    got = _grads(lambda t: max_pool2d(t, k, s, p), dev(x))
+    close(got[0], ref[0].float(), 0, 0, "y")
+    close(got[1], ref[1].float(), 1e-6, 1e-6, "dx")
+    assert torch.equal(H.maxpool2d(dev(x), k, s, p), got[0])
+
+
+@pytest.mark.parametrize("C_,hw", [(64, (24, 20)), (512, (5, 3)), (7, (33, 1))])
+def test_lpips_layer_forward_backward(H, C_, hw):
+    """vsp_lpips_layer_f32 / _bwd against the reference's formula (my_lpips/__init__.py:44-46, networks_basic.py:73-83) evaluated by
+    torch autograd in float64, including a pixel whose features are all zero (ReLU outputs) in either map."""
+    from vspbfr_amd.lpips import _LayerDistance
+    g_ = torch.Generator().manual_seed(2)
+    f0, f1 = torch.randn(3, C_, *hw, generator=g_).relu(), torch.randn(3, C_, *hw, generator=g_).relu()
+    f0[0, :, 0, 0] = 0
+    f1[1, :, -1, -1] = 0
+    w = torch.rand(C_, generator=g_)
+
+    def ref_fn(a, b, w_):
+        na = a / (torch.sqrt((a ** 2).sum(1, keepdim=True)) + 1e-10)
+        nb = b / (torch.sqrt((b ** 2).sum(1, keepdim=True)) + 1e-10)
+        return ((na - nb) ** 2 * w_.view(1, -1, 1, 1)).sum(1).mean([1, 2])
+    with torch.enable_grad():
+        a, b = f0.double().requires_grad_(True), f1.double().requires_grad_(True)
+        r = ref_fn(a, b, w.double())
+        gout = torch.randn(3, generator=g_)
+        r.backward(gout.double())
+        a2, b2 = dev(f0).requires_grad_(True), dev(f1).requires_grad_(True)
+        y = _LayerDistance.apply(a2, b2, dev(w))
+        y.backward(dev(gout))
+    close(y, r.float(), 1e-6, 1e-5, "dist")
+    # d/df at an all-zero pixel: sqrt'(0) * 0 is NaN in autograd; the kernel drops that term (the pixel's own gradient is g r)
+    mask0, mask1 = torch.isfinite(a.grad), torch.isfinite(b.grad)
+    close(torch.where(mask0, a2.grad.cpu(), torch.zeros(())), torch.nan_to_num(a.grad).float(), 1e-7, 2e-5, "df0")
+    close(torch.where(mask1, b2.grad.cpu(), torch.zeros(())), torch.nan_to_num(b.grad).float(), 1e-7, 2e-5, "df1")
+    assert torch.isfinite(a2.grad).all() and torch.isfinite(b2.grad).all()
+
+
+@pytest.mark.parametrize("ish,osh", [((128, 128), (112, 112)), ((512, 512), (112, 112)), ((20, 31), (45, 17))])
+def test_resize_bilinear_backward(H, ish, osh):
+    from vspbfr_amd.id_loss import interpolate_bilinear
+    x = torch.randn(2, 3, *ish, generator=torch.Generator().manual_seed(4))
+    # (fp32 reference: the source coordinates are fp32 in both implementations; in float64 they differ by ~1e-5 of a pixel)
+    ref = _grads(lambda t: F.interpolate(t, osh, mode="bilinear", align_corners=False), x)
+    got = _grads(lambda t: interpolate_bilinear(t, osh), dev(x))
+    close(got[0], ref[0], 1e-6, 2e-6, "y")
+    close(got[1], ref[1], 1e-6, 1e-5, "dx")
+
+
+def test_conv4x4_phase_stem_gradient():
+    """The 7x7 stride-2 stem of the identity network as a 4x4 stride-1 convolution over sub-pixel phases (vspbfr_amd/id_loss.py):
+    output and input gradient against F.conv2d(x, w, stride=2, padding=3) in float64."""
+    from vspbfr_amd.id_loss import ResNet101
+    net = ResNet101(num_classes=8, layers=(1, 1, 1, 1)).to(DEV).eval()
+    g_ = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 3, 36, 28, generator=g_)
+    with torch.no_grad():
+        net.bn1.weight.copy_(torch.rand(64, generator=g_) + 0.5)
+        net.bn1.bias.copy_(torch.randn(64, generator=g_) * 0.1)
+        net.bn1.running_mean.copy_(torch.randn(64, generator=g_) * 0.1)
+        net.bn1.running_var.copy_(torch.rand(64, generator=g_) + 0.5)
+    w, bn = net.conv1.weight.detach().cpu().double(), net.bn1
+
+    def ref_fn(t):
+        y = F.conv2d(t, w, None, 2, 3)
+        return F.relu(F.batch_norm(y, bn.running_mean.cpu().double(), bn.running_var.cpu().double(), bn.weight.detach().cpu().double(),
+                                   bn.bias.detach().cpu().double(), False, 0.0, bn.eps))
+    ref = _grads(ref_fn, x.double())
+    got = _grads(lambda t: net._stem(t), dev(x))
+    close(got[0], ref[0].float(), 2e-5, 2e-5, "y")
+    close(got[1], ref[1].float(), 3e-5, 3e-5, "dx")
+    with torch.no_grad():
+        close(net._stem(dev(x)), ref[0].float(), 2e-5, 2e-5, "y (fused epilogue)")

@@ -15,8 +15,12 @@ def build(name):
     from vspbfr_amd.diffusion import Code_diffuser
     from vspbfr_amd.discriminator import Discriminator
     from vspbfr_amd.e4e import Encoder4Editing, Generator
+    from vspbfr_amd.id_loss import ResNet101
+    from vspbfr_amd.lpips import PNetLin
     from vspbfr_amd.restorenet import Restoration_net
     return {
+        "lpips_vgg": lambda: PNetLin(),                      # my_lpips PNetLin(vgg) over torchvision vgg16().features
+        "arcface_resnet101": lambda: ResNet101(256),         # torchvision resnet101(num_classes=256) of Loss/id_loss.py:13
         "restorenet512": lambda: Restoration_net(512, 512, 8, channel_multiplier=2),
         "restorenet64": lambda: Restoration_net(64, 512, 8),
         "diffuser": lambda: Code_diffuser(timesteps=4),

@@ -1,6 +1,7 @@
-"""One training iteration (restoration_train.py:153-255 without the LPIPS / ID terms, whose pretrained networks are out of scope) at
-the real size: Restoration_net(512) + Discriminator(512), batch B per GPU, frozen front (stages A, B, C) through the inference
-kernels.  usage: python tools/bench_train_step.py [B] [iters]   -> JSON line with ms per iteration and the phase split."""
+"""One training iteration (restoration_train.py:153-255) at the real size: Restoration_net(512) + Discriminator(512), batch B per GPU,
+frozen front (stages A, B, C) through the inference kernels; with `losses` also the LPIPS-VGG (x 0.5) and ArcFace identity (x 0.1)
+terms of BASELINE configs[4] (random-init VGG16 / ResNet-101: there is no network for checkpoints).
+usage: python tools/bench_train_step.py [B] [iters] [losses]   -> JSON line with ms per iteration."""
 import copy, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +17,14 @@ G = pipe.generator
 torch.manual_seed(1)
 D = Discriminator(512).to(dev)
 G_ema = copy.deepcopy(G)
-tr = RestorationTrainer(G, G_ema, D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9)
+LOSSES = len(sys.argv) > 3 and sys.argv[3] == "losses"
+kw = {}
+if LOSSES:
+    from vspbfr_amd.id_loss import IDLoss
+    from vspbfr_amd.lpips import PerceptualLoss
+    kw = dict(percept_loss=PerceptualLoss(model="net-lin", net="vgg").to(dev), percept_weight=0.5, id_loss=IDLoss(None, device=dev),
+              id_weight=0.1)
+tr = RestorationTrainer(G, G_ema, D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9, **kw)
 low = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
 real = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
 G.train()
@@ -33,7 +41,8 @@ tr.step(16, low, real)                                       # an iteration with
 torch.cuda.synchronize()
 t_r1 = time.perf_counter() - t0
 ms = sum(times[1:]) / iters * 1e3
-print(json.dumps({"what": "restoration_train step, 512x512, Restoration_net + Discriminator fwd/bwd + Adam + EMA, frozen front, no LPIPS/ID",
+print(json.dumps({"what": "restoration_train step, 512x512, Restoration_net + Discriminator fwd/bwd + Adam + EMA, frozen front, "
+                          + ("LPIPS-VGG x0.5 + ArcFace ID x0.1" if LOSSES else "no LPIPS/ID"),
                   "batch_per_gpu": B, "ms_per_iteration": round(ms, 1), "img_per_s": round(B / ms * 1e3, 2),
                   "ms_iteration_with_r1": round(t_r1 * 1e3, 1), "losses": {k: float(v) for k, v in losses.items()},
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),

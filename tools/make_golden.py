@@ -81,7 +81,11 @@ def gen_specs():
         "discriminator512": spec_of(RN.Discriminator(512)),
         "discriminator64": spec_of(RN.Discriminator(64)),
     }
-    with open(os.path.join(GOLD, "state_specs.json"), "w") as f:
+    path = os.path.join(GOLD, "state_specs.json")
+    if os.path.exists(path):   # entries other generators add (gen_lpips, gen_idloss) survive a re-run of this one
+        with open(path) as f:
+            specs = {**{k: v for k, v in json.load(f).items() if k in ("lpips_vgg", "arcface_resnet101")}, **specs}
+    with open(path, "w") as f:
         json.dump(specs, f)
     print("state_specs.json:", {k: len(v) for k, v in specs.items()})
 
@@ -433,8 +437,97 @@ def gen_loader():
     print("loader.npz:", list(out["no_gt/files"]), {k: v.shape for k, v in out.items() if not k.endswith("files")})
 
 
+def gen_lpips():
+    """The perceptual term of the generator loss (restoration_train.py:143, 236-239): the REFERENCE's
+    my_lpips.PerceptualLoss(model="net-lin", net="vgg") -- ScalingLayer, five VGG16 slices, normalize_tensor, squared difference,
+    the `lin` layers with the reference's OWN v0.1 weights (my_lpips/weights/v0.1/vgg.pth, stored in the fixture), spatial
+    average -- on keyed 64x64 batches with a keyed VGG16 (torchvision is absent: architecture from oracle/tv_models.py):
+    per-image distances, the five levels, and the gradient of 0.5 * sum w.r.t. the predicted image."""
+    refshim.install_loss_networks()
+    import my_lpips
+    t = time.time()
+    case, size, B = "lpips64", 64, 3
+    pl = my_lpips.PerceptualLoss(model="net-lin", net="vgg", use_gpu=False)
+    net = pl.model.net
+    spec = spec_of(net)
+    lin = {k: v.clone() for k, v in net.state_dict().items() if k.startswith("lin")}
+    sd = weights.synth_state_dict("lpips_vgg", [e for e in spec if e[0].startswith("net.")], cases.SEED)
+    net.load_state_dict(sd, strict=False)
+    net.eval()
+    pred, target = cases.image_batch(case + "/pred", B, size), cases.image_batch(case + "/target", B, size)
+    out = {"lin/" + k: np_(v) for k, v in lin.items()}
+    with torch.enable_grad():
+        x = pred.clone().requires_grad_(True)
+        val, res = net.forward(target, x, retPerLayer=True)
+        out["dist"] = np_(pl(x, target)).reshape(-1)
+        for i, r in enumerate(res):
+            out[f"level{i}"] = np_(r).reshape(-1)
+        loss = pl(x, target).sum() * 0.5
+        loss.backward()
+        out["loss"], out["d_pred"] = np.array([loss.item()]), np_(x.grad)
+    with open(os.path.join(GOLD, "state_specs.json")) as f:
+        specs = json.load(f)
+    specs["lpips_vgg"] = spec
+    with open(os.path.join(GOLD, "state_specs.json"), "w") as f:
+        json.dump(specs, f)
+    np.savez_compressed(os.path.join(GOLD, "lpips64.npz"), **out)
+    print("lpips64.npz: dist", out["dist"], "|d_pred| max %.3e, %d state entries, %.1fs" % (np.abs(out["d_pred"]).max(), len(spec), time.time() - t))
+
+
+def gen_idloss():
+    """The identity term (restoration_train.py:116-117, 242-245): the REFERENCE's Loss.id_loss.IDLoss -- bilinear resize to 112,
+    ResNet-101 (256 outputs, eval), L2-normalise, 1 - <z_src, z_out> averaged -- with a keyed ResNet-101 (architecture from
+    oracle/tv_models.py; the checkpoint file is written to a temporary directory and read back by the reference's own
+    torch.load call).  128x128 inputs so that the resize interpolates."""
+    import tempfile
+    refshim.install_loss_networks()
+    from oracle import tv_models
+    t = time.time()
+    case, size, B = "idloss128", 128, 2
+    z = tv_models.resnet101(num_classes=256)
+    spec = spec_of(z)
+    sd = weights.synth_state_dict("arcface_resnet101", spec, cases.SEED)
+    # A random 101-layer ReLU network maps every image to (almost) the same direction.  Calibrate the BatchNorm running statistics on
+    # a keyed batch, as training would have (cumulative average of one pass in train mode), so that the embedding depends on the
+    # image; the calibrated statistics are part of the fixture (bn/<name>), everything else regenerates from names.
+    z.load_state_dict(sd)
+    z.train()
+    for m in z.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.reset_running_stats()
+            m.momentum = None
+    z(torch.nn.functional.interpolate(cases.image_batch(case + "/calib", 8, size), size=112, mode="bilinear"))
+    z.eval()
+    bn = {k: v.clone() for k, v in z.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    sd.update(bn)
+    real_cuda = torch.nn.Module.cuda
+    torch.nn.Module.cuda = lambda self, *a, **k: self       # IDLoss.__init__ moves the network to the GPU (Loss/id_loss.py:15)
+    try:
+        from Loss.id_loss import IDLoss
+        with tempfile.TemporaryDirectory() as d:
+            torch.save(sd, os.path.join(d, "arcface.pth"))
+            idl = IDLoss(os.path.join(d, "arcface.pth"))
+    finally:
+        torch.nn.Module.cuda = real_cuda
+    pred, target = cases.image_batch(case + "/pred", B, size), cases.image_batch(case + "/target", B, size)
+    out = {"bn/" + k: np_(v) for k, v in bn.items()}
+    with torch.enable_grad():
+        x = pred.clone().requires_grad_(True)
+        loss = idl(x, target)
+        (loss * 0.1).backward()
+        out.update(loss=np.array([loss.item()]), d_pred=np_(x.grad), z_pred=np_(idl.get_id(pred)), z_target=np_(idl.get_id(target)))
+    with open(os.path.join(GOLD, "state_specs.json")) as f:
+        specs = json.load(f)
+    specs["arcface_resnet101"] = spec
+    with open(os.path.join(GOLD, "state_specs.json"), "w") as f:
+        json.dump(specs, f)
+    np.savez_compressed(os.path.join(GOLD, "idloss128.npz"), **out)
+    print("idloss128.npz: loss %.5f |d_pred| max %.3e |z| %.3f, %d state entries, %.1fs" % (loss.item(), np.abs(out["d_pred"]).max(),
+          np.linalg.norm(out["z_pred"][0]), len(spec), time.time() - t))
+
+
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "lpips": gen_lpips, "idloss": gen_idloss}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -10,6 +10,11 @@ The three shims, none of which edits a reference file:
   2. a dummy `cv2` module (op/__init__.py:6 -> op/utils.py:6).
   3. sys.modules aliases op.fused_act_cpu / op.upfirdn2d_cpu -> op.fused_act / op.upfirdn2d
      (e4e/models/stylegan2/model.py:7-12 imports them when torch.cuda.is_available() is False).
+install_loss_networks() (LPIPS / ArcFace goldens only) adds
+  4. `torchvision.models.vgg16 / resnet101` from oracle/tv_models.py -- torchvision (requirements.txt:27, 0.13.0) is an un-vendored
+     third-party dependency absent here; the two published architectures are restated there -- and empty stand-ins for
+     `skimage` / `IPython` (my_lpips/__init__.py:6, networks_basic.py:10-11 import them at module level for metrics the loss
+     never calls).
 """
 import os
 import sys
@@ -53,3 +58,29 @@ def install():
     sys.modules["op.fused_act_cpu"] = sys.modules["op.fused_act"]
     sys.modules["op.upfirdn2d_cpu"] = sys.modules["op.upfirdn2d"]
     install._done = True
+
+
+def install_loss_networks():
+    """torchvision.models (vgg16, resnet101) + skimage / IPython stand-ins for `import my_lpips` and `Loss.id_loss`."""
+    install()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from oracle import tv_models
+    tv = sys.modules.get("torchvision") or types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+    models.vgg16, models.resnet101 = tv_models.vgg16, tv_models.resnet101
+    tv.models = models
+    sys.modules["torchvision"], sys.modules["torchvision.models"] = tv, models
+    for name, attrs in (("skimage", ()), ("skimage.metrics", ("structural_similarity",)), ("skimage.color", ()),
+                        ("skimage.transform", ()), ("IPython", ("embed",))):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = []          # importable as a package (`import skimage.transform`)
+            for a in attrs:
+                setattr(mod, a, None)
+            sys.modules[name] = mod
+    if not hasattr(sys.modules["IPython"], "get_ipython"):
+        sys.modules["IPython"].get_ipython = lambda: None   # matplotlib.pyplot asks once it finds an IPython module
+    sys.modules["skimage"].color = sys.modules["skimage.color"]
+    sys.modules["skimage"].transform = sys.modules["skimage.transform"]

@@ -120,6 +120,11 @@ SIGNATURES = {
     "vsp_affine_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "vsp_affine_sample_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "vsp_color_affine_f32": [_p, _p, _p, _p, _i, _i64, _p],
+    "vsp_maxpool2d_f32": [_p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p],
+    "vsp_maxpool2d_bwd_f32": [_p, _p, _p, _i64, _i, _i, _i, _i, _i, _i, _i, _p],
+    "vsp_lpips_layer_f32": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "vsp_lpips_layer_bwd_f32": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "vsp_resize_bilinear_bwd_f32": [_p, _p, _i64, _i, _i, _i, _i, _p],
     "vsp_conv2d_wgrad_f32": [C.POINTER(ConvWgradParams), _p],
     "vsp_plane_dot_f32": [_p, _p, _p, _i64, _i64, _p],
     "vsp_convert_f32_to_bf16": [_p, _p, _i64, _p],

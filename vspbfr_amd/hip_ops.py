@@ -507,7 +507,18 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, **epi):
     """F.conv2d-shaped convenience entry (groups=1): packs the weight on the fly (tests, generic callers)."""
     weight = _req(weight, "weight")
     cout, cin, kh, kw = weight.shape
-    pc = PackedConv(pack_weight(weight), 1, cout, cin, kh, kw, stride, (dilation,), (padding,))
+    # The packed (and, on a Winograd layer, transformed) weight rides on the tensor object it was built from: a long-lived weight
+    # (frozen loss networks, folded BatchNorm weights) is packed once per version, a temporary dies with its packing.
+    key = (weight._version, weight.data_ptr(), stride, dilation, padding)
+    cached = getattr(weight, "_vsp_packed", None)
+    if cached is not None and cached[0] == key:
+        pc = cached[1]
+    else:
+        pc = PackedConv(pack_weight(weight), 1, cout, cin, kh, kw, stride, (dilation,), (padding,))
+        try:
+            weight._vsp_packed = (key, pc)
+        except (AttributeError, RuntimeError):
+            pass
     return conv2d_packed(x, pc, ch_bias=bias, **epi)
 
 
@@ -719,6 +730,54 @@ def resize_bilinear(x, size):
     out = torch.empty((B, Cc, OH, OW), device=x.device, dtype=x.dtype)
     check(lib.vsp_resize_bilinear_f32(_ptr(out), _ptr(x), B * Cc, IH, IW, OH, OW, _stream()), "resize_bilinear")
     return out
+
+
+def resize_bilinear_bwd(dy, in_size):
+    """Adjoint of resize_bilinear: gradient w.r.t. the (IH, IW) input."""
+    dy = _req(dy, "dy")
+    B, Cc, OH, OW = dy.shape
+    IH, IW = in_size
+    dx = torch.empty((B, Cc, IH, IW), device=dy.device, dtype=dy.dtype)
+    check(lib.vsp_resize_bilinear_bwd_f32(_ptr(dx), _ptr(dy), B * Cc, IH, IW, OH, OW, _stream()), "resize_bilinear_bwd")
+    return dx
+
+
+def maxpool2d(x, k, s, p=0):
+    """F.max_pool2d(x, k, s, p) (floor mode) for NCHW fp32."""
+    x = _req(x, "x")
+    B, Cc, H, W = x.shape
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((B, Cc, OH, OW), device=x.device, dtype=x.dtype)
+    check(lib.vsp_maxpool2d_f32(_ptr(out), _ptr(x), B * Cc, H, W, OH, OW, k, s, p, _stream()), "maxpool2d")
+    return out
+
+
+def maxpool2d_bwd(dy, x, k, s, p=0):
+    x, dy = _req(x, "x"), _req(dy, "dy")
+    B, Cc, H, W = x.shape
+    OH, OW = dy.shape[-2:]
+    dx = torch.empty_like(x)
+    check(lib.vsp_maxpool2d_bwd_f32(_ptr(dx), _ptr(dy), _ptr(x), B * Cc, H, W, OH, OW, k, s, p, _stream()), "maxpool2d_bwd")
+    return dx
+
+
+def lpips_layer(f0, f1, w):
+    """One LPIPS level: (B,) = spatial mean of sum_c w_c (unit(f0) - unit(f1))^2 over NCHW fp32 features."""
+    f0, f1, w = _req(f0, "f0"), _req(f1, "f1"), _req(w, "w")
+    B, Cc, H, W = f0.shape
+    if f1.shape != f0.shape or w.numel() != Cc:
+        raise RuntimeError("lpips_layer: f0 / f1 / w shapes do not match")
+    out = torch.empty((B,), device=f0.device, dtype=torch.float32)
+    check(lib.vsp_lpips_layer_f32(_ptr(out), _ptr(f0), _ptr(f1), _ptr(w), B, Cc, H * W, _stream()), "lpips_layer")
+    return out
+
+
+def lpips_layer_bwd(gout, f0, f1, w):
+    f0, f1, w, gout = _req(f0, "f0"), _req(f1, "f1"), _req(w, "w"), _req(gout, "gout")
+    B, Cc, H, W = f0.shape
+    df1 = torch.empty_like(f1)
+    check(lib.vsp_lpips_layer_bwd_f32(_ptr(df1), _ptr(f0), _ptr(f1), _ptr(w), _ptr(gout), B, Cc, H * W, _stream()), "lpips_layer_bwd")
+    return df1
 
 
 def plane_mean(x):

@@ -62,15 +62,30 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
     cout, cg, kh, kw = weight.shape
     if stride == 1:
         # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
+        if not weight.requires_grad and not torch.is_grad_enabled():
+            # frozen weight, first-order pass (the loss networks): the adjoint weight is built -- and packed -- once per version
+            key = (weight._version, weight.data_ptr(), groups)
+            cached = getattr(weight, "_vsp_adjoint", None)
+            if cached is None or cached[0] != key:
+                cached = (key, weight.reshape(groups, cout // groups, cg, kh, kw).transpose(1, 2).flip(3, 4)
+                          .reshape(groups * cg, cout // groups, kh, kw).contiguous())
+                try:
+                    weight._vsp_adjoint = cached
+                except (AttributeError, RuntimeError):
+                    pass
+            return conv2d(g, cached[1], None, 1, dilation * (kh - 1) - padding, dilation, groups)
         wt = weight.reshape(groups, cout // groups, cg, kh, kw).transpose(1, 2).flip(3, 4).reshape(groups * cg, cout // groups, kh, kw)
         return conv2d(g, wt, None, 1, dilation * (kh - 1) - padding, dilation, groups)
-    if stride == 2 and padding == 0 and dilation == 1 and (kh, kw) == (3, 3):
-        # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2, zero rows beyond when H is even
+    if stride == 2 and padding in (0, 1) and dilation == 1 and (kh, kw) == (3, 3):
+        # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2 rows of the PADDED input, zero rows beyond
+        # when H + 2 padding is even; padding 1 (the ResNet bottleneck of the identity loss) crops the border back off
         dx = conv_transpose2d(g, weight, stride=2, padding=0, groups=groups)
-        ph, pw = x_shape[2] - dx.shape[2], x_shape[3] - dx.shape[3]
+        ph, pw = x_shape[2] + 2 * padding - dx.shape[2], x_shape[3] + 2 * padding - dx.shape[3]
         if ph < 0 or pw < 0 or ph > 1 or pw > 1:
-            raise RuntimeError("conv2d_gradfix: stride-2 data gradient needs H in {2 OH + 1, 2 OH + 2}")
-        return torch.nn.functional.pad(dx, (0, pw, 0, ph)) if (ph or pw) else dx
+            raise RuntimeError("conv2d_gradfix: stride-2 data gradient needs H + 2 padding in {2 OH + 1, 2 OH + 2}")
+        if ph or pw:
+            dx = torch.nn.functional.pad(dx, (0, pw, 0, ph))
+        return dx[:, :, padding:padding + x_shape[2], padding:padding + x_shape[3]] if padding else dx
     if stride == 2 and padding == 0 and (kh, kw) == (1, 1):
         # 1x1, stride 2 (the skip branch of the discriminator's ResBlock): the 1x1 adjoint lands on the even pixels
         wt = weight.reshape(groups, cout // groups, cg, 1, 1).transpose(1, 2).reshape(groups * cg, cout // groups, 1, 1)
@@ -78,8 +93,8 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
         dx = d.new_zeros(x_shape)
         dx[:, :, 0:2 * d.shape[2]:2, 0:2 * d.shape[3]:2] = d
         return dx
-    raise RuntimeError("conv2d_gradfix: the data gradient is implemented for stride 1, and for stride 2 with padding 0 and 3x3 / 1x1 "
-                       "kernels (the forms of restoration_train.py)")
+    raise RuntimeError("conv2d_gradfix: the data gradient is implemented for stride 1, and for stride 2 with 3x3 (padding 0 / 1) and "
+                       "1x1 (padding 0) kernels (the forms of restoration_train.py and its loss networks)")
 
 
 class _Wgrad(Function):
