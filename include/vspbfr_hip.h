@@ -131,7 +131,7 @@ typedef struct vsp_conv_params {
   int y_ch, y_coff, y_h, y_w;
   int osy, osx, ooy, oox;
   /* prologue */
-  const float* in_scale; /* NULL or [.., Cin] */
+  const float* in_scale; /* NULL or [.., Cin]; grouped input (x_group_stride > 0): [.., x_ch], group g reads [g * x_group_stride, + Cin) */
   int in_scale_bstride;  /* Cin for per-sample styles, 0 for per-channel constants */
   const float* in_shift; /* NULL or [Cin] */
   /* epilogue */

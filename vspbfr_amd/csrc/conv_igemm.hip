@@ -207,7 +207,7 @@ static int validate_conv(const vsp_conv_params& p, int* x_ch_out, bool* empty) {
   VSP_REQUIRE(p.x_group_stride >= 0 && p.x_ch >= 0, "conv2d: negative x_ch / x_group_stride");
   const int x_ch = p.x_ch > 0 ? p.x_ch : p.Cin;
   VSP_REQUIRE((int64_t)(p.G - 1) * p.x_group_stride + p.Cin <= x_ch, "conv2d: group input channels exceed x_ch=%d", x_ch);
-  VSP_REQUIRE(p.x_group_stride == 0 || !p.in_scale, "conv2d: input scaling is not supported with grouped input");
+  VSP_REQUIRE(p.x_group_stride == 0 || !p.in_shift, "conv2d: an input shift is not supported with grouped input");
   VSP_REQUIRE(p.KH >= 1 && p.KW >= 1 && p.KH * p.KW <= 49, "conv2d: unsupported kernel %dx%d", p.KH, p.KW);
   VSP_REQUIRE(p.stride_y >= 1 && p.stride_x >= 1 && p.stride_x <= 2 && p.stride_y <= 2, "conv2d: stride must be 1 or 2");
   VSP_REQUIRE(p.OH >= 0 && p.OW >= 0, "conv2d: negative output size");

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
       const int ci = ci0 + cl;
       const bool chok = cl < CK && ci < p.Cin;  // wave-uniform
       const int cic = chok ? ci : 0;
-      psc[pc] = chok ? (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + cic] : 1.f) : 0.f;
+      psc[pc] = chok ? (p.in_scale ? p.in_scale[(int64_t)b * p.in_scale_bstride + g * p.x_gs + cic] : 1.f) : 0.f;
       psh[pc] = chok ? (p.in_shift ? p.in_shift[cic] : 0.f) : 0.f;
       const int xsoff = cic * chw * 4;
 #pragma unroll
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
       const int cl = row & (CK - 1);
       const bool ok = woff[w] >= 0 && ci0 + cl < p.Cin;
       const float4 v = *reinterpret_cast<const float4*>(wc + (ok ? woff[w] : 0));
-      const float sc = (ok && p.in_scale) ? p.in_scale[(int64_t)b * p.in_scale_bstride + ci0 + cl] : 1.f;
+      const float sc = (ok && p.in_scale) ? p.in_scale[(int64_t)b * p.in_scale_bstride + g * p.x_gs + ci0 + cl] : 1.f;
       wreg[w] = ok ? make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll

@@ -430,7 +430,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     p.y_ch, p.y_coff, p.y_h, p.y_w = out.shape[1], y_coff, out.shape[2], out.shape[3]
     p.osy, p.osx = out_stride
     p.ooy, p.oox = out_offset
-    p.in_scale_bstride = Cin if (in_scale is not None and in_scale_per_sample) else 0
+    p.in_scale_bstride = (in_scale.shape[-1] if pc.x_group_stride else Cin) if (in_scale is not None and in_scale_per_sample) else 0
     p.act1, p.slope1, p.gain1 = (1 if act1 else 0), 0.2, SQRT2
     p.act2, p.slope2, p.gain2 = int(act2), float(slope2), float(gain2)
     rt = res1 if res1 is not None else res2
@@ -965,7 +965,12 @@ def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1,
     p.x, p.dy, p.dw, p.x_scale, p.dy_scale = [(t.data_ptr() if t is not None else None) for t in keep]
     p.B, p.Cin_g, p.H, p.W, p.G, p.Cout_g = B, cin_g, H, W, groups, cout // groups
     p.OH, p.OW, p.KH, p.KW, p.stride, p.dil, p.pad = dy.shape[2], dy.shape[3], kh, kw, int(stride), int(dilation), int(padding)
+    prof = PROFILER
+    start = prof.begin() if prof is not None else None
     check(lib.vsp_conv2d_wgrad_f32(C.byref(p), _stream()), "conv2d_wgrad")
+    if prof is not None:
+        prof.end(start, 2.0 * B * cout * dy.shape[2] * dy.shape[3] * cin_g * kh * kw,
+                 (cin_g, cout // groups, dy.shape[2], dy.shape[3], kh, int(stride), groups, "wgrad", f"d{int(dilation)}"))
     return dw
 
 

@@ -48,6 +48,10 @@ def _conv_fwd(x, weight, bias, stride, padding, dilation, groups):
 def _convT_fwd(x, weight, groups):
     """conv_transpose2d(stride 2, padding 0), 3x3; weight (G*Cin_g, Cout_g, 3, 3)."""
     cg = x.shape[1] // groups
+    if groups == 1:   # the one-pass transposed kernel (all four sub-pixel phases from one staged patch), whole batch in one launch
+        w_oihw = weight.transpose(0, 1).contiguous()
+        pc = hip_ops.PackedConv(hip_ops.pack_weight(w_oihw), 1, w_oihw.shape[0], cg, 3, 3, 1, (1,), (1,))
+        return hip_ops.conv_transpose2d_s2_fused(x.contiguous(), pc)
     outs = []
     for g in range(groups):
         w_io = weight[g * cg:(g + 1) * cg]  # (Cin_g, Cout_g, 3, 3)

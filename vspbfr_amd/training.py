@@ -18,7 +18,10 @@ noise, bias and activation in the conv epilogue -- none of which records a graph
 reference's own backward pass (tests/golden/restorenet64_grad.npz, tools/make_golden.py::gen_restorenet64_grad)."""
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
+from . import hip_ops as H
 from .op import conv2d_gradfix, fused_leaky_relu, upfirdn2d
 
 
@@ -33,9 +36,11 @@ def _blur(x, blur):
     return upfirdn2d(x, blur.kernel, pad=blur.pad)
 
 
-def modulated_conv(x, conv, style, modulation=None):
-    """ModulatedConv2d.forward, fused branch (reference models/RestoreNet.py:373-416): per-sample weights
-    w[b] = scale * W * s[b], demodulated, applied as ONE grouped convolution with groups = batch."""
+def modulated_conv_grouped(x, conv, style, modulation=None):
+    """ModulatedConv2d.forward, fused branch, LITERALLY as the reference evaluates it (models/RestoreNet.py:373-416): per-sample
+    weights w[b] = scale * W * s[b], demodulated, applied as ONE grouped convolution with groups = batch.  Kept as the statement the
+    fused form below is checked against (tests); the training step does not use it: it materialises B weight copies per layer and
+    runs every layer at batch 1 per group."""
     B, cin, H, W = x.shape
     k, cout = conv.kernel_size, conv.out_channel
     s = equal_linear(style, modulation if modulation is not None else conv.modulation).view(B, 1, cin, 1, 1)
@@ -56,6 +61,159 @@ def modulated_conv(x, conv, style, modulation=None):
     return out.view(B, cout, out.shape[2], out.shape[3])
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Modulated convolution in the modulate-input / demodulate-output form:  y[b] = demod[b, co] * conv(x[b] * s[b, ci], scale * W).
+# Identical to the reference's per-sample weights w[b] = scale W s[b] demod[b] (the two scales commute with the convolution), but ONE
+# convolution over the whole batch with the SHARED weight: the tuned / Winograd kernels of the inference path with their fused
+# in_scale / out_scale operands, a data gradient on the same kernels (scales exchanged), and ONE weight gradient with K = B * pixels
+# (vsp_conv2d_wgrad_f32 folds both scales in) instead of B per-sample ones.  s and demod stay torch tensors, so the gradient reaches
+# the style MLP, the modulation layer and -- through demod -- the weight by plain autograd; the Function below supplies d/dx,
+# d/dW (direct term), d/ds (direct term) and d/d demod.  First order only: the generator is never differentiated twice
+# (the R1 penalty runs through the discriminator, which has no modulated layers).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _adjoint_pack(layer):
+    """Packed weight of the data gradient of `layer` (cached per weight version on the layer)."""
+    def build():
+        w = layer._w_scaled()                                         # (Cout, Cin, k, k), scale folded in
+        k, d = layer.kernel_size, layer.dilation
+        if layer.upsample:       # forward = transposed conv; adjoint = stride-2 conv of g, weight read as (out = ci, in = co)
+            return H.PackedConv(H.pack_weight(w.transpose(0, 1).contiguous()), 1, layer.in_channel, layer.out_channel, 3, 3, 2, (1,), (0,))
+        if layer.downsample:     # forward = stride-2 conv; adjoint = one-pass transposed conv (ordinary 3x3 packing of (out = ci, in = co))
+            return H.PackedConv(H.pack_weight(w.transpose(0, 1).contiguous()), 1, layer.in_channel, layer.out_channel, 3, 3, 1, (1,), (1,))
+        wt = w.transpose(0, 1).flip(2, 3).contiguous()                # stride 1: correlation with the flipped kernel, channels exchanged
+        return H.PackedConv(H.pack_weight(wt), 1, layer.in_channel, layer.out_channel, k, k, 1, (d,), (d * (k - 1) - layer.padding,))
+    return layer._derive("adjoint", [layer.weight], build)
+
+
+class _ModConv(Function):
+    @staticmethod
+    def forward(ctx, x, weight, s, demod, layer):
+        x, s = x.contiguous(), s.contiguous()
+        demod = None if demod is None else demod.contiguous()
+        if layer.upsample:
+            y = H.conv_transpose2d_s2_fused(x, layer.packed(), in_scale=s, out_scale=demod)
+        else:
+            y = H.conv2d_packed(x, layer.packed(), in_scale=s, out_scale=demod)
+        ctx.layer = layer
+        ctx.save_for_backward(x, s, demod, y if demod is not None else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, s, demod, y = ctx.saved_tensors
+        layer = ctx.layer
+        g = g.contiguous()
+        B, cin, cout, k = x.shape[0], layer.in_channel, layer.out_channel, layer.kernel_size
+        d_demod = None
+        if demod is not None:
+            d_demod = H.plane_dot(g, y) / demod                       # y = demod * raw  ->  d/d demod = <g, raw>
+        dx = ds = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            adj = _adjoint_pack(layer)
+            if layer.downsample:
+                dxs = H.conv_transpose2d_s2_fused(g, adj, in_scale=demod)       # (2 OH + 1)^2; one zero row / column more when H is even
+                ph, pw = x.shape[2] - dxs.shape[2], x.shape[3] - dxs.shape[3]
+                if ph or pw:
+                    dxs = F.pad(dxs, (0, pw, 0, ph))
+            else:
+                dxs = H.conv2d_packed(g, adj, in_scale=demod)
+            ds = H.plane_dot(dxs, x)                                  # dxs = d/d(x s)
+            dx = dxs.mul_(s.view(B, cin, 1, 1))
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            if layer.upsample:   # the stride-2 weight gradient with the roles of x and g exchanged; result in (Cin, Cout, 3, 3)
+                dw = H.conv2d_wgrad(g, x, (cin, cout, 3, 3), 2, 0, 1, 1, x_scale=demod, dy_scale=s).transpose(0, 1)
+            else:
+                dw = H.conv2d_wgrad(x, g, (cout, cin, k, k), 2 if layer.downsample else 1, 0 if layer.downsample else layer.padding,
+                                    layer.dilation, 1, x_scale=s, dy_scale=demod)
+            dw = (dw * layer.scale).unsqueeze(0)
+        return dx, dw, ds, d_demod, None
+
+
+def _demod(conv, s):
+    """rsqrt(sum_{ci,k} (scale W s)^2 + 1e-8) = rsqrt(s^2 @ (scale^2 sum_k W^2)^T + 1e-8): (B, Cout), differentiable in s and W."""
+    wsq = conv.weight[0].pow(2).sum((2, 3))
+    return torch.rsqrt(F.linear(s * s, wsq) * (conv.scale ** 2) + 1e-8)
+
+
+def modulated_conv(x, conv, style, modulation=None):
+    """ModulatedConv2d.forward (reference models/RestoreNet.py:373-416) in the fused form above."""
+    s = equal_linear(style, modulation if modulation is not None else conv.modulation)
+    demod = _demod(conv, s) if conv.demodulate else None
+    if conv.downsample:
+        x = _blur(x, conv.blur)
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or s.requires_grad):
+        out = _ModConv.apply(x, conv.weight, s, demod, conv)
+    else:
+        out = _ModConv.forward(_NoCtx(), x, conv.weight, s, demod, conv)
+    return _blur(out, conv.blur) if conv.upsample else out
+
+
+class _NoCtx:
+    def save_for_backward(self, *a):
+        pass
+
+
+# ---- the four dilated branches of a SMART layer as ONE launch (shared input and modulation, per-branch weight / demodulation)
+def _smart_adjoint_pack(layer):
+    ws = [m.weight for m in layer.ModulatedConv2ds]
+
+    def build():
+        m0 = layer.ModulatedConv2ds[0]
+        cg = layer.out_channel // len(ws)
+        # true grouped conv over g: group i reads its branch's cg channels, writes Cin channels, dilation / padding of branch i
+        wp = torch.stack([H.pack_weight((w[0] * m0.scale).transpose(0, 1).flip(2, 3).contiguous())[0] for w in ws]).contiguous()
+        dil = tuple(m.dilation for m in layer.ModulatedConv2ds)
+        pad = tuple(m.dilation * (m.kernel_size - 1) - m.padding for m in layer.ModulatedConv2ds)
+        return H.PackedConv(wp, len(ws), layer.in_channel, cg, 3, 3, 1, dil, pad, x_group_stride=cg)
+    return layer._derive("branches_adjoint", ws, build)
+
+
+class _SmartBranches(Function):
+    @staticmethod
+    def forward(ctx, x, s, demod, layer, *weights):
+        x, s, demod = x.contiguous(), s.contiguous(), demod.contiguous()
+        pc, _ = layer._branch_pack()
+        y = H.conv2d_packed(x, pc, in_scale=s, out_scale=demod)
+        ctx.layer = layer
+        ctx.save_for_backward(x, s, demod, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, s, demod, y = ctx.saved_tensors
+        layer = ctx.layer
+        g = g.contiguous()
+        B, cin, Hh, Ww = x.shape
+        nb = len(layer.ModulatedConv2ds)
+        cg = layer.out_channel // nb
+        d_demod = H.plane_dot(g, y) / demod
+        dx = ds = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            parts = H.conv2d_packed(g, _smart_adjoint_pack(layer), in_scale=demod)          # (B, nb * Cin, H, W)
+            dxs = parts.view(B, nb, cin, Hh, Ww).sum(1)
+            ds = H.plane_dot(dxs, x)
+            dx = dxs.mul_(s.view(B, cin, 1, 1))
+        dws = [None] * nb
+        if any(ctx.needs_input_grad[4:]) and not conv2d_gradfix.weight_gradients_disabled:
+            g5 = g.view(B, nb, cg, Hh, Ww)
+            for i, m in enumerate(layer.ModulatedConv2ds):
+                dw = H.conv2d_wgrad(x, g5[:, i].contiguous(), (cg, cin, 3, 3), 1, m.padding, m.dilation, 1, x_scale=s,
+                                    dy_scale=demod[:, i * cg:(i + 1) * cg].contiguous())
+                dws[i] = (dw * m.scale).unsqueeze(0)
+        return (dx, ds, d_demod, None, *dws)
+
+
+def smart_branches(x, layer, style):
+    s = equal_linear(style, layer.modulation)
+    demod = torch.cat([_demod(m, s) for m in layer.ModulatedConv2ds], 1)
+    ws = [m.weight for m in layer.ModulatedConv2ds]
+    if torch.is_grad_enabled() and (x.requires_grad or s.requires_grad or any(w.requires_grad for w in ws)):
+        return _SmartBranches.apply(x, s, demod, layer, *ws)
+    return _SmartBranches.forward(_NoCtx(), x, s, demod, layer, *ws)
+
+
 def styled_conv(x, layer, style, noise):
     """StyledConv.forward (reference models/RestoreNet.py:599-603): conv -> noise -> FusedLeakyReLU."""
     out = modulated_conv(x, layer.conv, style)
@@ -66,8 +224,7 @@ def styled_conv(x, layer, style, noise):
 def smart_layer(x, layer, style, noise):
     """SMART_layer.forward (reference models/RestoreNet.py:220-244): the four dilated branches share ONE modulation; fusion conv,
     FusedLeakyReLU, noise, FusedLeakyReLU."""
-    outs = [modulated_conv(x, m, style, modulation=layer.modulation) for m in layer.ModulatedConv2ds]
-    out = torch.cat(outs, dim=1)
+    out = smart_branches(x, layer, style)
     f = layer.fusion[0]
     out = conv2d_gradfix.conv2d(out, f.weight * f.scale, padding=1)
     out = fused_leaky_relu(out, layer.fusion[1].bias)
