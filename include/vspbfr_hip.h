@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 2
+#define VSP_ABI_VERSION 3
 
 #define VSP_OK 0
 #define VSP_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported combination) */
@@ -413,6 +413,14 @@ typedef struct vsp_conv_wgrad_params {
   const float* x_scale;
   const float* dy_scale;
   int B, Cin_g, H, W, G, Cout_g, OH, OW, KH, KW, stride, dil, pad;
+  /* ABI 3 (all zero = the plain call above): channel windows into larger tensors, a shared input with per-group geometry (the four
+   * dilated SMART branches: G = 4, x_shared = 1, per_group_geometry = 1, dil_g = pad_g = {1, 2, 4, 8}), accumulation into dw */
+  int x_ch, x_coff;        /* channels of the x tensor (0: G*Cin_g, or Cin_g when shared) and first channel used */
+  int dy_ch, dy_coff;      /* channels of the dy tensor (0: G*Cout_g) and first channel used */
+  int x_shared;            /* 1: every group reads the same Cin_g input channels */
+  int per_group_geometry;  /* 1: group g uses dil_g[g] / pad_g[g] (G <= 4) instead of dil / pad */
+  int dil_g[4], pad_g[4];
+  int accumulate;          /* 1: add to dw instead of overwriting it */
 } vsp_conv_wgrad_params;
 int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* p, vsp_stream_t stream);
 int vsp_plane_dot_f32(float* out, const float* a, const float* b, int64_t planes, int64_t n, vsp_stream_t stream);

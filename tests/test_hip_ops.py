@@ -983,3 +983,49 @@ def test_conv4x4_phase_stem_gradient():
     close(got[1], ref[1].float(), 3e-5, 3e-5, "dx")
     with torch.no_grad():
         close(net._stem(dev(x)), ref[0].float(), 2e-5, 2e-5, "y (fused epilogue)")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(cin=64, cout=64, hw=(40, 72), k=3, stride=1, pad=1, dil=1),          # 64 co x 32 ci tiles, two row segments
+    dict(cin=48, cout=32, hw=(33, 65), k=3, stride=1, pad=2, dil=2),          # 32 co x 64 ci tiles, ragged channels and columns
+    dict(cin=40, cout=16, hw=(20, 130), k=3, stride=1, pad=8, dil=8),         # 16 co x 64 ci tiles, widest halo
+    dict(cin=32, cout=24, hw=(37, 135), k=3, stride=2, pad=0, dil=1),         # stride 2: two staging items per lane
+    dict(cin=16, cout=3, hw=(24, 24), k=1, stride=1, pad=0, dil=1),           # ToRGB
+    dict(cin=16, cout=32, hw=(26, 26), k=1, stride=2, pad=0, dil=1),          # ResBlock skip
+])
+def test_conv2d_wgrad_tile_shapes(H, cfg):
+    """vsp_conv2d_wgrad_f32 over its tile shapes / staging forms against torch autograd in float64."""
+    c = cfg
+    g_ = torch.Generator().manual_seed(21)
+    B = 3
+    x = torch.randn(B, c["cin"], *c["hw"], generator=g_)
+    w = torch.zeros(c["cout"], c["cin"], c["k"], c["k"], dtype=torch.float64, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv2d(x.double(), w, None, c["stride"], c["pad"], c["dil"])
+        gy = torch.randn(y.shape, generator=g_)
+        y.backward(gy.double())
+    dw = H.conv2d_wgrad(dev(x), dev(gy), w.shape, c["stride"], c["pad"], c["dil"], 1)
+    close(dw, w.grad.float(), 2e-5, 2e-5 * float(w.grad.abs().max()), "dw")
+
+
+def test_conv2d_wgrad_shared_input_groups(H):
+    """The four dilated SMART branches as one weight-gradient launch: shared input, per-group dilation / padding, per-sample scales;
+    channel window into a wider dy; accumulation."""
+    g_ = torch.Generator().manual_seed(22)
+    B, cin, cg, Hh, Ww = 2, 24, 16, 30, 70
+    rates = (1, 2, 4, 8)
+    x, s = torch.randn(B, cin, Hh, Ww, generator=g_), torch.rand(B, cin, generator=g_) + 0.5
+    gy, dm = torch.randn(B, 4 * cg + 8, Hh, Ww, generator=g_), torch.rand(B, 4 * cg + 8, generator=g_) + 0.5
+    refs = []
+    for i, r in enumerate(rates):
+        w = torch.zeros(cg, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        with torch.enable_grad():
+            y = F.conv2d((x * s[:, :, None, None]).double(), w, None, 1, r, r) * dm[:, 8 + i * cg:8 + (i + 1) * cg, None, None].double()
+            y.backward(gy[:, 8 + i * cg:8 + (i + 1) * cg].double())
+        refs.append(w.grad.float())
+    ref = torch.cat(refs, 0)
+    dw = H.conv2d_wgrad(dev(x), dev(gy), (4 * cg, cin, 3, 3), 1, rates, rates, 4, x_scale=dev(s), dy_scale=dev(dm), x_shared=True, dy_coff=8)
+    close(dw, ref, 2e-5, 2e-5 * float(ref.abs().max()), "dw")
+    dw2 = H.conv2d_wgrad(dev(x), dev(gy), (4 * cg, cin, 3, 3), 1, rates, rates, 4, x_scale=dev(s), dy_scale=dev(dm), x_shared=True, dy_coff=8,
+                         out=dw.clone(), accumulate=True)
+    close(dw2, 2 * ref, 2e-5, 4e-5 * float(ref.abs().max()), "accumulated dw")

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSPBFR_HIP_LIB", os.path.join(_HERE, "lib", "libvspbfr_hip.so"))
 
-ABI_VERSION = 2  # include/vspbfr_hip.h VSP_ABI_VERSION
+ABI_VERSION = 3  # include/vspbfr_hip.h VSP_ABI_VERSION
 c_float_p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 
 
@@ -51,7 +51,9 @@ class ConvParams(C.Structure):
 
 class ConvWgradParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("x_scale", C.c_void_p), ("dy_scale", C.c_void_p)] + [
-        (n, C.c_int) for n in ("B", "Cin_g", "H", "W", "G", "Cout_g", "OH", "OW", "KH", "KW", "stride", "dil", "pad")]
+        (n, C.c_int) for n in ("B", "Cin_g", "H", "W", "G", "Cout_g", "OH", "OW", "KH", "KW", "stride", "dil", "pad", "x_ch", "x_coff", "dy_ch",
+                               "dy_coff", "x_shared", "per_group_geometry")] + [("dil_g", C.c_int * 4), ("pad_g", C.c_int * 4),
+                                                                                ("accumulate", C.c_int)]
 
 
 class TaccBlock(C.Structure):

@@ -950,21 +950,40 @@ def keyed_fill(shapes, ids, seed, image_index0, dist="normal", device=None, inde
 
 
 # ----------------------------------------------------------------------------------------------- convolution backward
-def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1, x_scale=None, dy_scale=None):
+def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1, x_scale=None, dy_scale=None, x_shared=False,
+                 dy_coff=0, out=None, accumulate=False):
     """dL/dW of y = conv2d(x * x_scale, W, stride, padding, dilation, groups) * dy_scale given dL/dy (vsp_conv2d_wgrad_f32):
-    x (B, G*Cin_g, H, W), dy (B, G*Cout_g, OH, OW) -> (G*Cout_g, Cin_g, KH, KW); the scales are optional (B, channels)."""
+    x (B, G*Cin_g, H, W), dy (B, G*Cout_g, OH, OW) -> (G*Cout_g, Cin_g, KH, KW); the scales are optional (B, channels).
+    `x_shared`: every group reads the same Cin_g channels of x; `dilation` / `padding` may then be per-group tuples (<= 4 groups: the
+    dilated SMART branches in one launch).  `dy_coff`: first channel of dy used (dy may hold more channels than G*Cout_g)."""
     from ._lib import ConvWgradParams
     x, dy = _req(x, "x"), _req(dy, "dy")
     cout, cin_g, kh, kw = (int(v) for v in weight_shape)
     B, xc, H, W = x.shape
-    if dy.shape[0] != B or dy.shape[1] != cout or xc != cin_g * groups or cout % groups:
+    if dy.shape[0] != B or dy.shape[1] < dy_coff + cout or xc != (cin_g if x_shared else cin_g * groups) or cout % groups:
         raise RuntimeError(f"conv2d_wgrad: x {tuple(x.shape)} / dy {tuple(dy.shape)} do not match weight {tuple(weight_shape)} with {groups} groups")
-    dw = torch.empty((cout, cin_g, kh, kw), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((cout, cin_g, kh, kw), device=x.device, dtype=torch.float32)
+    if out is not None and (_req(out, "out").shape != (cout, cin_g, kh, kw)):
+        raise RuntimeError("conv2d_wgrad: `out` must be (Cout, Cin_g, KH, KW)")
     p = ConvWgradParams()
     keep = [x, dy, dw, _opt(x_scale, "x_scale"), _opt(dy_scale, "dy_scale")]
     p.x, p.dy, p.dw, p.x_scale, p.dy_scale = [(t.data_ptr() if t is not None else None) for t in keep]
     p.B, p.Cin_g, p.H, p.W, p.G, p.Cout_g = B, cin_g, H, W, groups, cout // groups
-    p.OH, p.OW, p.KH, p.KW, p.stride, p.dil, p.pad = dy.shape[2], dy.shape[3], kh, kw, int(stride), int(dilation), int(padding)
+    p.OH, p.OW, p.KH, p.KW, p.stride = dy.shape[2], dy.shape[3], kh, kw, int(stride)
+    per_group = isinstance(dilation, (tuple, list)) or isinstance(padding, (tuple, list))
+    if per_group:
+        dl = tuple(dilation) if isinstance(dilation, (tuple, list)) else (dilation,) * groups
+        pd = tuple(padding) if isinstance(padding, (tuple, list)) else (padding,) * groups
+        if len(dl) != groups or len(pd) != groups or groups > 4:
+            raise RuntimeError("conv2d_wgrad: per-group dilation / padding need one value per group, at most 4 groups")
+        p.per_group_geometry = 1
+        for i in range(groups):
+            p.dil_g[i], p.pad_g[i] = int(dl[i]), int(pd[i])
+        p.dil, p.pad = int(dl[0]), int(pd[0])
+        dilation = dl[0]
+    else:
+        p.dil, p.pad = int(dilation), int(padding)
+    p.x_shared, p.dy_ch, p.dy_coff, p.accumulate = int(bool(x_shared)), dy.shape[1], int(dy_coff), int(bool(accumulate))
     prof = PROFILER
     start = prof.begin() if prof is not None else None
     check(lib.vsp_conv2d_wgrad_f32(C.byref(p), _stream()), "conv2d_wgrad")

@@ -197,11 +197,11 @@ class _SmartBranches(Function):
             dx = dxs.mul_(s.view(B, cin, 1, 1))
         dws = [None] * nb
         if any(ctx.needs_input_grad[4:]) and not conv2d_gradfix.weight_gradients_disabled:
-            g5 = g.view(B, nb, cg, Hh, Ww)
-            for i, m in enumerate(layer.ModulatedConv2ds):
-                dw = H.conv2d_wgrad(x, g5[:, i].contiguous(), (cg, cin, 3, 3), 1, m.padding, m.dilation, 1, x_scale=s,
-                                    dy_scale=demod[:, i * cg:(i + 1) * cg].contiguous())
-                dws[i] = (dw * m.scale).unsqueeze(0)
+            ms = layer.ModulatedConv2ds   # one launch: 4 groups over the shared input, each with its branch's dilation
+            dw = H.conv2d_wgrad(x, g, (nb * cg, cin, 3, 3), 1, tuple(m.padding for m in ms), tuple(m.dilation for m in ms), nb,
+                                x_scale=s, dy_scale=demod, x_shared=True)
+            for i, m in enumerate(ms):
+                dws[i] = (dw[i * cg:(i + 1) * cg] * m.scale).unsqueeze(0)
         return (dx, ds, d_demod, None, *dws)
 
 
