@@ -53,7 +53,8 @@ class ConvWgradParams(C.Structure):
     _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("x_scale", C.c_void_p), ("dy_scale", C.c_void_p)] + [
         (n, C.c_int) for n in ("B", "Cin_g", "H", "W", "G", "Cout_g", "OH", "OW", "KH", "KW", "stride", "dil", "pad", "x_ch", "x_coff", "dy_ch",
                                "dy_coff", "x_shared", "per_group_geometry")] + [("dil_g", C.c_int * 4), ("pad_g", C.c_int * 4),
-                                                                                ("accumulate", C.c_int)]
+                                                                                ("accumulate", C.c_int), ("work", C.c_void_p),
+                                                                                ("work_floats", C.c_size_t)]
 
 
 class TaccBlock(C.Structure):
@@ -138,7 +139,7 @@ SIGNATURES = {
     "vsp_conv2d_winograd_mbw": [_i],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
-_SIZET = {"vsp_tacc_chain_work_floats": [_i]}
+_SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)]}
 
 
 def _load():

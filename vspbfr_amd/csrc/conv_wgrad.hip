@@ -27,6 +27,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
 
+#ifndef VSP_WG_UNROLL
+#define VSP_WG_UNROLL 2
+#endif
+#ifndef VSP_WG_ABL   // tuning builds only: 1 no atomics, 2 no MFMAs, 4 no staging after the first chunk
+#define VSP_WG_ABL 0
+#endif
 constexpr int WG_PX = 64, WG_NT = 256;
 constexpr int DPITCH = WG_PX + 2;  // 66 = 2 (mod 32)
 constexpr size_t kMaxLds = 128 * 1024;
@@ -41,6 +47,8 @@ struct WgradK {
   int dil[4], pad[4], per_group;
   int x_ch, x_coff, x_gs, dy_ch, dy_coff;
   int xwp, plane, segs, chunks;
+  float* work;       // null: fp32 atomics into dw; else [gridDim.x][dw elements] partial copies, plain stores
+  int64_t dw_elems;
 };
 
 template <int NTAP, int WCO, int NB, int XJ>
@@ -62,13 +70,19 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   const int KW = NTAP == 1 ? 1 : p.KW, KH = NTAP == 1 ? 1 : p.KH;
   const int d = p.dil[p.per_group ? g : 0], pad = p.pad[p.per_group ? g : 0], s = p.stride;
   const int XWP = p.xwp, plane = p.plane;
-  const int xw = (WG_PX - 1) * s + (KW - 1) * d + 1;            // slab row of this group
+  const int xw = (WG_PX - 1) * s + (KW - 1) * d + 1 + ((4 - (pad & 3)) & 3);   // slab row of this group (aligned origin)
   const int xw4 = (xw + 3) >> 2;
   const int xc0 = p.x_coff + g * p.x_gs + ci0, yc0 = p.dy_coff + g * p.Cout_g + co0;
   const int64_t xplane = (int64_t)p.H * p.W, yplane = (int64_t)p.OH * p.OW;
 
   // ---- staging roles.  X: item = lane + 64 j -> (slab row, column quad), wave + 4 it -> channel (XJ = 2: slab rows of more than
-  //      64 / KH quads, i.e. stride 2).  dY: tid / 16 + 16 it -> channel, tid % 16 -> quad
+  //      64 / KH quads, i.e. stride 2).  dY: tid / 16 + 16 it -> channel, tid % 16 -> quad.
+  //      Every load is a 16-byte load at a CLAMPED address and every border case is arithmetic on its result -- no branch: a
+  //      divergent scalar-fallback path made the compiler wait for the loads in flight at each join (vmcnt(2) between the
+  //      loads of one prefetch: the staging alone took as long as all the MFMAs).  The slab starts at a column that is a
+  //      multiple of 4 in image coordinates, so a quad is either left of the image, inside it, or cut by the RIGHT border only:
+  //      that one loads the last four pixels of the row and shifts (sh = 1..3 pixels, zeros enter from the right).
+  const int xs_al = (4 - (pad & 3)) & 3;                         // slab column of input column ox0 s - pad (ox0 s is a multiple of 64)
   int x_row[XJ], x_q[XJ];
   bool x_on[XJ];
 #pragma unroll
@@ -80,30 +94,31 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   }
   const int d_row = tid >> 4, d_q = tid & 15;
   float4 xr[XJ][NITX], dr[NITD];
-  float xsc[NITX], dsc[NITD];
-  int x_mask[XJ], d_mask = 0;       // bit e: element e of the quad lies inside the image (and the row does)
-#pragma unroll
-  for (int j = 0; j < XJ; ++j) x_mask[j] = 0;
+  float xsc[NITX], dsc[NITD], x_okf[XJ];
+  int x_sh[XJ], d_sh = 0;
+  float d_okf = 0.f;
+  auto shifted = [](float4 v, int sh) {   // v holds pixels c .. c+3, the quad wants c+sh .. c+sh+3 (beyond the row: zero)
+    if (sh & 1) v = make_float4(v.y, v.z, v.w, 0.f);
+    if (sh & 2) v = make_float4(v.z, v.w, 0.f, 0.f);
+    return v;
+  };
   auto fetch = [&](int ch) {
     const int seg = ch % p.segs, row = ch / p.segs;
     const int oy = row % p.OH, b = row / p.OH;
     const int ox0 = seg * WG_PX;
     {  // dY
       const int ox = ox0 + 4 * d_q;
-      d_mask = (ox < p.OW ? 1 : 0) | (ox + 1 < p.OW ? 2 : 0) | (ox + 2 < p.OW ? 4 : 0) | (ox + 3 < p.OW ? 8 : 0);
+      const int oxc = min(ox, p.OW - 4);
+      d_sh = ox - oxc;
+      d_okf = ox < p.OW ? 1.f : 0.f;
 #pragma unroll
       for (int it = 0; it < NITD; ++it) {
         const int c = d_row + 16 * it;
         const bool cok = co0 + c < p.Cout_g;
         const int ch_ = yc0 + (cok ? c : 0);
         const float* src = p.dy + ((int64_t)b * p.dy_ch + ch_) * yplane + (int64_t)oy * p.OW;
-        if (d_mask == 15) {
-          const f32x4u v = *reinterpret_cast<const f32x4u*>(src + ox);
-          dr[it] = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          dr[it].x = src[min(ox, p.OW - 1)]; dr[it].y = src[min(ox + 1, p.OW - 1)];
-          dr[it].z = src[min(ox + 2, p.OW - 1)]; dr[it].w = src[min(ox + 3, p.OW - 1)];
-        }
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(src + oxc);
+        dr[it] = make_float4(v[0], v[1], v[2], v[3]);
         dsc[it] = cok ? (p.dys ? p.dys[(int64_t)b * p.dy_ch + ch_] : 1.f) : 0.f;
       }
     }
@@ -114,47 +129,39 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      if (!x_on[j]) continue;
-      const int iy = oy * s + x_row[j] * d - pad, ix = ox0 * s - pad + 4 * x_q[j];
-      const bool rok = iy >= 0 && iy < p.H;
-      x_mask[j] = rok ? ((ix >= 0 && ix < p.W ? 1 : 0) | (ix + 1 >= 0 && ix + 1 < p.W ? 2 : 0) | (ix + 2 >= 0 && ix + 2 < p.W ? 4 : 0) |
-                         (ix + 3 >= 0 && ix + 3 < p.W ? 8 : 0)) : 0;
-      const int iyc = min(max(iy, 0), p.H - 1);
-      const float* rowp = p.x + ((int64_t)b * p.x_ch + xc0) * xplane + (int64_t)iyc * p.W;
-      const int e0 = min(max(ix, 0), p.W - 1), e1 = min(max(ix + 1, 0), p.W - 1), e2 = min(max(ix + 2, 0), p.W - 1),
-                e3 = min(max(ix + 3, 0), p.W - 1);
+      const int iy = oy * s + x_row[j] * d - pad, ix = ox0 * s - pad - xs_al + 4 * x_q[j];
+      const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 4);
+      x_sh[j] = ix - ixc;                                   // > 0 only at the right border (>= 4: the quad is outside)
+      x_okf[j] = (x_on[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
+      const float* rowp = p.x + ((int64_t)b * p.x_ch + xc0) * xplane + (int64_t)iyc * p.W + ixc;
 #pragma unroll
       for (int it = 0; it < NITX; ++it) {
         const int c = wave + 4 * it;
         const bool cok = ci0 + c < p.Cin_g;   // wave-uniform
-        const float* src = rowp + (int64_t)(cok ? c : 0) * xplane;
-        if (x_mask[j] == 15) {
-          const f32x4u v = *reinterpret_cast<const f32x4u*>(src + ix);
-          xr[j][it] = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          xr[j][it] = make_float4(src[e0], src[e1], src[e2], src[e3]);
-        }
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(rowp + (int64_t)(cok ? c : 0) * xplane);
+        xr[j][it] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < NITD; ++it) {
-      const float sc = dsc[it];
+      const float sc = dsc[it] * d_okf;
+      const float4 v = shifted(dr[it], d_sh);
       float* dst = Dl + (d_row + 16 * it) * DPITCH + 4 * d_q;
-      *reinterpret_cast<f32x2a*>(dst) = f32x2a{(d_mask & 1) ? dr[it].x * sc : 0.f, (d_mask & 2) ? dr[it].y * sc : 0.f};
-      *reinterpret_cast<f32x2a*>(dst + 2) = f32x2a{(d_mask & 4) ? dr[it].z * sc : 0.f, (d_mask & 8) ? dr[it].w * sc : 0.f};
+      *reinterpret_cast<f32x2a*>(dst) = f32x2a{v.x * sc, v.y * sc};
+      *reinterpret_cast<f32x2a*>(dst + 2) = f32x2a{v.z * sc, v.w * sc};
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       if (!x_on[j]) continue;
-      const int m = x_mask[j];
 #pragma unroll
       for (int it = 0; it < NITX; ++it) {
-        const float sc = xsc[it];
+        const float sc = xsc[it] * x_okf[j];
+        const float4 v = shifted(xr[j][it], x_sh[j]);
         float* dst = Xl + (wave + 4 * it) * plane + x_row[j] * XWP + 4 * x_q[j];
-        *reinterpret_cast<f32x2a*>(dst) = f32x2a{(m & 1) ? xr[j][it].x * sc : 0.f, (m & 2) ? xr[j][it].y * sc : 0.f};
-        *reinterpret_cast<f32x2a*>(dst + 2) = f32x2a{(m & 4) ? xr[j][it].z * sc : 0.f, (m & 8) ? xr[j][it].w * sc : 0.f};
+        *reinterpret_cast<f32x2a*>(dst) = f32x2a{v.x * sc, v.y * sc};
+        *reinterpret_cast<f32x2a*>(dst + 2) = f32x2a{v.z * sc, v.w * sc};
       }
     }
   };
@@ -166,16 +173,23 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     for (int t = 0; t < NTAP; ++t) acc[nb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int wco = wave % WCO, wci = wave / WCO;
   const float* ap = Dl + (wco * 16 + r) * DPITCH + kq;
-  const float* bp = Xl + (wci * NB * 16 + r) * plane + kq * s;
+  const float* bp = Xl + (wci * NB * 16 + r) * plane + kq * s + xs_al;
 
   int ch = blockIdx.x;
   if (ch < p.chunks) fetch(ch);
   for (; ch < p.chunks; ch += gridDim.x) {
+#if VSP_WG_ABL & 4
+    if (ch == (int)blockIdx.x) { commit(); __syncthreads(); }
+#else
     __syncthreads();   // the MFMAs of the previous chunk have read the slabs
     commit();
     __syncthreads();
     if (ch + (int)gridDim.x < p.chunks) fetch(ch + gridDim.x);
-#pragma unroll 2
+#endif
+#if VSP_WG_ABL & 2
+    continue;
+#endif
+#pragma unroll VSP_WG_UNROLL
     for (int k0 = 0; k0 < WG_PX; k0 += 4) {
       const float a = ap[k0];
 #pragma unroll
@@ -197,10 +211,38 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     for (int j = 0; j < 4; ++j) {
       const int co = co0 + wco * 16 + 4 * kq + j;
       if (co >= p.Cout_g) continue;
-      float* dst = p.dw + (((int64_t)g * p.Cout_g + co) * p.Cin_g + ci) * NTAP;
+      const int64_t off = (((int64_t)g * p.Cout_g + co) * p.Cin_g + ci) * NTAP;
+#if VSP_WG_ABL & 1
+      if (p.chunks < 0)
+#endif
+      if (p.work) {   // this workgroup's private copy: every (split index, tile) pair is written exactly once
+        float* dst = p.work + (int64_t)blockIdx.x * p.dw_elems + off;
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t) unsafeAtomicAdd(dst + t, acc[nb][t][j]);
+        for (int t = 0; t < NTAP; ++t) dst[t] = acc[nb][t][j];
+      } else {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) unsafeAtomicAdd(p.dw + off + t, acc[nb][t][j]);
+      }
     }
+  }
+}
+
+// dw[i] (+)= sum over the split copies
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ work, int64_t n, int copies,
+                                                            int accumulate) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = accumulate ? reinterpret_cast<const float4*>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < copies; ++c) {
+      const float4 v = reinterpret_cast<const float4*>(work + (int64_t)c * n)[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = a;
+  }
+  for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float a = accumulate ? dw[i] : 0.f;
+    for (int c = 0; c < copies; ++c) a += work[(int64_t)c * n + i];
+    dw[i] = a;
   }
 }
 
@@ -223,7 +265,46 @@ int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st)
   return VSP_OK;
 }
 
+struct Plan {
+  int dmax, xw4, xj, wco, nb, tiles, segs;
+  int64_t chunks, split;
+};
+
+// tile shape and split of a (validated) parameter block
+Plan make_plan(const vsp_conv_wgrad_params& q) {
+  Plan pl{};
+  pl.dmax = 1;
+  for (int g = 0; g < (q.per_group_geometry ? (q.G < 4 ? q.G : 4) : 1); ++g) {
+    const int d = q.per_group_geometry ? q.dil_g[g] : q.dil;
+    pl.dmax = d > pl.dmax ? d : pl.dmax;
+  }
+  const int xw = (WG_PX - 1) * q.stride + (q.KW - 1) * pl.dmax + 1 + 3;   // + alignment slack of the slab origin
+  pl.xw4 = (xw + 3) / 4;
+  pl.xj = q.KH * pl.xw4 <= 64 ? 1 : 2;
+  // (two-item staging -- wide stride-2 slabs -- doubles the prefetch registers: it keeps to the 16 / 32-channel X tiles)
+  if (q.Cout_g > 32 || pl.xj == 2) { pl.wco = 4; pl.nb = q.Cin_g > 16 ? 2 : 1; }
+  else if (q.Cout_g > 16) { pl.wco = 2; pl.nb = q.Cin_g > 32 ? 2 : 1; }
+  else { pl.wco = 1; pl.nb = 1; }
+  const int co_t = 16 * pl.wco, ci_t = 16 * pl.nb * (4 / pl.wco);
+  pl.tiles = ((q.Cout_g + co_t - 1) / co_t) * ((q.Cin_g + ci_t - 1) / ci_t);
+  pl.segs = (q.OW + WG_PX - 1) / WG_PX;
+  pl.chunks = (int64_t)q.B * q.OH * pl.segs;
+  // split the pixel dimension so that ~3 workgroups per CU are in flight, every workgroup keeping >= 8 chunks when it can
+  pl.split = (3 * vsp::kNumCU + (int64_t)pl.tiles * q.G - 1) / ((int64_t)pl.tiles * q.G);
+  if (pl.split > pl.chunks / 8) pl.split = pl.chunks / 8;
+  if (pl.split < 1) pl.split = 1;
+  return pl;
+}
+
 }  // namespace
+
+extern "C" size_t vsp_conv2d_wgrad_work_floats(const vsp_conv_wgrad_params* pp) {
+  if (!pp) return 0;
+  const vsp_conv_wgrad_params& q = *pp;
+  if (q.B <= 0 || q.G < 1 || q.Cin_g < 1 || q.Cout_g < 1 || q.OH <= 0 || q.OW <= 0 || q.KH < 1 || q.KW < 1 || q.stride < 1) return 0;
+  const Plan pl = make_plan(q);
+  return (size_t)pl.split * (size_t)q.G * q.Cout_g * q.Cin_g * q.KH * q.KW;
+}
 
 extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d_wgrad: null params");
@@ -233,6 +314,7 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   VSP_REQUIRE((q.KH == 3 && q.KW == 3) || (q.KH == 1 && q.KW == 1), "conv2d_wgrad: 3x3 and 1x1 kernels only (got %dx%d)", q.KH, q.KW);
   VSP_REQUIRE(q.stride == 1 || q.stride == 2, "conv2d_wgrad: stride must be 1 or 2");
   VSP_REQUIRE(q.dw != nullptr, "conv2d_wgrad: null output");
+  VSP_REQUIRE(q.W >= 4 && (q.OW >= 4 || q.OW == 0), "conv2d_wgrad: rows shorter than 4 pixels are not supported (W %d, OW %d)", q.W, q.OW);
   VSP_REQUIRE(!q.per_group_geometry || q.G <= 4, "conv2d_wgrad: per-group dilation / padding for at most 4 groups");
   VSP_REQUIRE(q.x_ch >= 0 && q.dy_ch >= 0 && q.x_coff >= 0 && q.dy_coff >= 0, "conv2d_wgrad: negative channel count / offset");
   WgradK k{};
@@ -250,9 +332,12 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
     }
   }
   k.per_group = q.per_group_geometry ? 1 : 0;
-  const size_t dw_bytes = (size_t)q.G * q.Cout_g * q.Cin_g * q.KH * q.KW * sizeof(float);
+  const int64_t dw_elems = (int64_t)q.G * q.Cout_g * q.Cin_g * q.KH * q.KW;
+  const size_t dw_bytes = (size_t)dw_elems * sizeof(float);
   hipStream_t st = vsp::as_stream(stream);
-  if (!q.accumulate && hipMemsetAsync(q.dw, 0, dw_bytes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
+  const bool use_work = q.work != nullptr && q.work_floats > 0;
+  if (!q.accumulate && (!use_work || q.B == 0 || q.OH == 0 || q.OW == 0) && hipMemsetAsync(q.dw, 0, dw_bytes, st) != hipSuccess)
+    return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
   if (q.B == 0 || q.OH == 0 || q.OW == 0) return VSP_OK;
   VSP_REQUIRE(q.x && q.dy, "conv2d_wgrad: null input");
   k.x = q.x; k.dy = q.dy; k.dw = q.dw; k.xs = q.x_scale; k.dys = q.dy_scale;
@@ -265,31 +350,30 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   VSP_REQUIRE(k.x_coff + (q.G - 1) * k.x_gs + q.Cin_g <= k.x_ch && k.dy_coff + q.G * q.Cout_g <= k.dy_ch,
               "conv2d_wgrad: channel window exceeds the tensor (x %d+%d of %d, dy %d+%d of %d)", k.x_coff, (q.G - 1) * k.x_gs + q.Cin_g,
               k.x_ch, k.dy_coff, q.G * q.Cout_g, k.dy_ch);
-  const int xw = (WG_PX - 1) * q.stride + (q.KW - 1) * dmax + 1;
-  const int xw4 = (xw + 3) / 4;
+  const Plan pl = make_plan(q);
+  const int xw4 = pl.xw4, xj = pl.xj, wco = pl.wco, nb = pl.nb, tiles = pl.tiles;
+  const int64_t chunks = pl.chunks;
+  int64_t split = pl.split;
   VSP_REQUIRE(q.KH * xw4 <= 128, "conv2d_wgrad: row segment with halo too wide for the staging layout (stride %d, dilation %d)", q.stride, dmax);
-  const int xj = q.KH * xw4 <= 64 ? 1 : 2;
   k.xwp = 4 * xw4;
   int plane = q.KH * k.xwp;
   while (plane % 32 != 2) plane += 2;  // ci rows 2 (mod 32) words apart, 8-byte aligned
   k.plane = plane;
-  k.segs = (q.OW + WG_PX - 1) / WG_PX;
-  const int64_t chunks = (int64_t)q.B * q.OH * k.segs;
+  k.segs = pl.segs;
   VSP_REQUIRE(chunks < ((int64_t)1 << 31), "conv2d_wgrad: too many pixels");
   k.chunks = (int)chunks;
-  // tile shape by the group's channel counts
-  // (two-item staging -- wide stride-2 slabs -- doubles the prefetch registers: it keeps to the 16 / 32-channel X tiles)
-  int wco, nb;
-  if (q.Cout_g > 32 || xj == 2) { wco = 4; nb = q.Cin_g > 16 ? 2 : 1; }
-  else if (q.Cout_g > 16) { wco = 2; nb = q.Cin_g > 32 ? 2 : 1; }
-  else { wco = 1; nb = 1; }
   const int co_t = 16 * wco, ci_t = 16 * nb * (4 / wco);
-  const int tiles = ((q.Cout_g + co_t - 1) / co_t) * ((q.Cin_g + ci_t - 1) / ci_t);
   VSP_REQUIRE((int64_t)tiles <= 65535 && q.G <= 65535, "conv2d_wgrad: grid too large");
-  // split the pixel dimension so that ~3 workgroups per CU are in flight, every workgroup keeping >= 8 chunks when it can
-  int64_t split = (3 * vsp::kNumCU + (int64_t)tiles * q.G - 1) / ((int64_t)tiles * q.G);
-  if (split > chunks / 8) split = chunks / 8;
-  if (split < 1) split = 1;
+  if (use_work) {   // the copies must fit the caller's workspace; a workspace that is too small for even one copy is an error
+    VSP_REQUIRE(vsp::aligned16(q.work) && vsp::aligned16(q.dw), "conv2d_wgrad: dw and work must be 16-byte aligned");
+    VSP_REQUIRE((int64_t)q.work_floats >= dw_elems, "conv2d_wgrad: workspace holds %zu floats, one copy of dw needs %lld",
+                (size_t)q.work_floats, (long long)dw_elems);
+    if (split > (int64_t)q.work_floats / dw_elems) split = (int64_t)q.work_floats / dw_elems;
+    k.work = q.work;
+    k.dw_elems = dw_elems;
+    // a tile the channel counts do not fill leaves holes in a copy, as do blocks without a chunk: the copies start from zero
+    if (hipMemsetAsync(q.work, 0, (size_t)split * dw_bytes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
+  }
   const size_t lds = ((size_t)co_t * DPITCH + (size_t)ci_t * k.plane) * sizeof(float);
   VSP_REQUIRE(lds <= kMaxLds, "conv2d_wgrad: row segment with halo does not fit LDS (dilation %d)", dmax);
   dim3 grid((unsigned)split, (unsigned)tiles, (unsigned)q.G);
@@ -301,6 +385,11 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   else if (wco == 2) rc = k3 ? launch_wgrad<9, 2, 1>(k, xj, grid, lds, st) : launch_wgrad<1, 2, 1>(k, xj, grid, lds, st);
   else rc = k3 ? launch_wgrad<9, 1, 1>(k, xj, grid, lds, st) : launch_wgrad<1, 1, 1>(k, xj, grid, lds, st);
   if (rc != VSP_OK) return rc;
+  if (use_work) {
+    int blocks = (int)((dw_elems / 4 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > vsp::kMaxStreamBlocks ? vsp::kMaxStreamBlocks : blocks);
+    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(q.dw, q.work, dw_elems, (int)split, q.accumulate ? 1 : 0);
+  }
   return vsp::check_launch("conv2d_wgrad");
 }
 

@@ -44,6 +44,7 @@ class ConvProfiler:
         return sum(r[4] for r in self.records)
 
 
+WGRAD_WORKSPACE = True   # False: vsp_conv2d_wgrad_f32 reduces its split-K partial sums with atomics
 PROFILER = None
 RECORDER = None  # tools/autotune_conv.py: list collecting the shape key of every conv launch
 
@@ -984,6 +985,12 @@ def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1,
     else:
         p.dil, p.pad = int(dilation), int(padding)
     p.x_shared, p.dy_ch, p.dy_coff, p.accumulate = int(bool(x_shared)), dy.shape[1], int(dy_coff), int(bool(accumulate))
+    # split-K partial sums in private copies of dw (torch's caching allocator: stream-ordered) instead of fp32 atomics
+    wf = int(lib.vsp_conv2d_wgrad_work_floats(C.byref(p))) if WGRAD_WORKSPACE else 0
+    if wf > 0:
+        work = torch.empty((wf,), device=x.device, dtype=torch.float32)
+        keep.append(work)
+        p.work, p.work_floats = work.data_ptr(), wf
     prof = PROFILER
     start = prof.begin() if prof is not None else None
     check(lib.vsp_conv2d_wgrad_f32(C.byref(p), _stream()), "conv2d_wgrad")
