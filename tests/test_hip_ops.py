@@ -1029,3 +1029,14 @@ def test_conv2d_wgrad_shared_input_groups(H):
     dw2 = H.conv2d_wgrad(dev(x), dev(gy), (4 * cg, cin, 3, 3), 1, rates, rates, 4, x_scale=dev(s), dy_scale=dev(dm), x_shared=True, dy_coff=8,
                          out=dw.clone(), accumulate=True)
     close(dw2, 2 * ref, 2e-5, 4e-5 * float(ref.abs().max()), "accumulated dw")
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 64, 128, 128), (4, 3, 512, 512), (5, 16)])
+def test_channel_sum_and_plane_dot_split(H, shape):
+    """vsp_channel_sum_f32 and the split form of vsp_plane_dot_f32 (several workgroups per plane) against float64 sums."""
+    g_ = torch.Generator().manual_seed(8)
+    a, b = torch.randn(*shape, generator=g_), torch.randn(*shape, generator=g_)
+    dims = [0] + list(range(2, a.dim()))
+    close(H.channel_sum(dev(a)), a.double().sum(dims).float(), 1e-5, 1e-3, "channel_sum")
+    if a.dim() == 4:
+        close(H.plane_dot(dev(a), dev(b)), (a.double() * b.double()).sum((2, 3)).float(), 1e-5, 1e-3, "plane_dot")

@@ -394,22 +394,74 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
 }
 
 // out[plane] = sum_i a[plane, i] * b[plane, i]: the gradients of the per-sample input / output scales of a modulated convolution
-// (d in_scale[b, ci] = <dXs, x>, d out_scale[b, co] = <dY, y> / out_scale).  One workgroup per plane, HBM stream.
+// (d in_scale[b, ci] = <dXs, x>, d out_scale[b, co] = <dY, y> / out_scale); out[c] = sum_{b, i} x[b, c, i]: bias gradients.
+// HBM streams: a plane is split over several workgroups (16-byte loads, block reduction, one fp32 atomic per workgroup) so that a
+// handful of 512^2 planes still fills the chip.
 namespace {
+__device__ __forceinline__ float block_sum_256(float s) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out, const float* __restrict__ a,
-                                                         const float* __restrict__ b, int64_t n) {
+                                                         const float* __restrict__ b, int64_t n, int64_t per) {
   const float* ap = a + (int64_t)blockIdx.x * n;
   const float* bp = b + (int64_t)blockIdx.x * n;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < n ? lo + per : n;     // (per is a multiple of 4)
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s = fmaf(ap[i], bp[i], s);
-  __shared__ float red[256];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int w = 128; w > 0; w >>= 1) {
-    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-    __syncthreads();
+  if ((n & 3) == 0) {
+    for (int64_t i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+      const float4 u = *reinterpret_cast<const float4*>(ap + i), v = *reinterpret_cast<const float4*>(bp + i);
+      s = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, s))));
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s = fmaf(ap[i], bp[i], s);
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+  s = block_sum_256(s);
+  if (threadIdx.x == 0) {
+    if (gridDim.y == 1) out[blockIdx.x] = s;
+    else unsafeAtomicAdd(out + blockIdx.x, s);
+  }
+}
+
+// grid (C, splits): workgroup (c, sp) sums its share of the B planes of channel c
+__global__ __launch_bounds__(256) void channel_sum_kernel(float* __restrict__ out, const float* __restrict__ x, int B, int C, int64_t hw,
+                                                           int64_t per) {
+  const int c = blockIdx.x;
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < hw ? lo + per : hw;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + ((int64_t)b * C + c) * hw;
+    if ((hw & 3) == 0) {
+      for (int64_t i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+        const float4 u = *reinterpret_cast<const float4*>(xp + i);
+        s += (u.x + u.y) + (u.z + u.w);
+      }
+    } else {
+      for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += xp[i];
+    }
+  }
+  s = block_sum_256(s);
+  if (threadIdx.x == 0) {
+    if (gridDim.y == 1) out[c] = s;
+    else unsafeAtomicAdd(out + c, s);
+  }
+}
+
+// splits of an n-element plane so that planes * splits ~ 8 workgroups per CU, each at least 4096 elements (multiple of 4)
+inline int plane_splits(int64_t planes, int64_t n, int64_t* per) {
+  int64_t sp = (8 * vsp::kNumCU + planes - 1) / planes;
+  if (sp > n / 4096) sp = n / 4096;
+  if (sp < 1) sp = 1;
+  if (sp > 65535) sp = 65535;
+  int64_t p = (n + sp - 1) / sp;
+  p = (p + 3) / 4 * 4;
+  *per = p;
+  return (int)((n + p - 1) / p);
 }
 }  // namespace
 
@@ -418,6 +470,23 @@ extern "C" int vsp_plane_dot_f32(float* out, const float* a, const float* b, int
   if (planes == 0) return VSP_OK;
   VSP_REQUIRE(out && (n == 0 || (a && b)), "plane_dot: null pointer");
   VSP_REQUIRE(planes < ((int64_t)1 << 31), "plane_dot: too many planes");
-  plane_dot_kernel<<<(unsigned)planes, 256, 0, vsp::as_stream(stream)>>>(out, a, b, n);
+  hipStream_t st = vsp::as_stream(stream);
+  int64_t per;
+  const int sp = plane_splits(planes, n, &per);
+  if (sp > 1 && hipMemsetAsync(out, 0, sizeof(float) * planes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "plane_dot: memset failed");
+  plane_dot_kernel<<<dim3((unsigned)planes, (unsigned)sp), 256, 0, st>>>(out, a, b, n, per);
   return vsp::check_launch("plane_dot");
+}
+
+extern "C" int vsp_channel_sum_f32(float* out, const float* x, int B, int C, int64_t hw, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && C >= 0 && hw >= 0, "channel_sum: negative size");
+  if (C == 0) return VSP_OK;
+  VSP_REQUIRE(out && (B == 0 || hw == 0 || x), "channel_sum: null pointer");
+  VSP_REQUIRE(C <= 65535 * 32, "channel_sum: too many channels");
+  hipStream_t st = vsp::as_stream(stream);
+  int64_t per;
+  const int sp = plane_splits(C, hw, &per);
+  if (sp > 1 && hipMemsetAsync(out, 0, sizeof(float) * C, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "channel_sum: memset failed");
+  channel_sum_kernel<<<dim3((unsigned)C, (unsigned)sp), 256, 0, st>>>(out, x, B, C, hw, per);
+  return vsp::check_launch("channel_sum");
 }

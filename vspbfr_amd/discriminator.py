@@ -107,6 +107,7 @@ def g_nonsaturating_loss(fake_pred):
 def accumulate(model1, model2, decay=0.999):
     """EMA of the generator (restoration_train.py:46-51)."""
     par1, par2 = dict(model1.named_parameters()), dict(model2.named_parameters())
-    with torch.no_grad():
-        for k in par1:
-            par1[k].mul_(decay).add_(par2[k].detach(), alpha=1 - decay)
+    with torch.no_grad():   # two multi-tensor launches instead of two per parameter
+        a, b = [par1[k] for k in par1], [par2[k].detach() for k in par1]
+        torch._foreach_mul_(a, decay)
+        torch._foreach_add_(a, b, alpha=1 - decay)

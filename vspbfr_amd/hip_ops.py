@@ -1000,6 +1000,17 @@ def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1,
     return dw
 
 
+def channel_sum(x):
+    """(B, C, ...) -> (C,): sum over the batch and everything behind the channel dimension (bias gradients)."""
+    x = _req(x, "x")
+    if x.dim() < 2:
+        raise RuntimeError("channel_sum: (B, C, ...) tensor")
+    B, Cc = x.shape[0], x.shape[1]
+    out = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+    check(lib.vsp_channel_sum_f32(_ptr(out), _ptr(x), B, Cc, x.numel() // max(B * Cc, 1), _stream()), "channel_sum")
+    return out
+
+
 def plane_dot(a, b):
     """(B, C, H, W) x (B, C, H, W) -> (B, C): sum over the plane of a * b."""
     a, b = _req(a, "a"), _req(b, "b")

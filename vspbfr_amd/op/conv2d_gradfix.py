@@ -140,7 +140,7 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
             dw = _Wgrad.apply(x, g, weight.shape, stride, padding, dilation, groups)
         if has_bias and ctx.needs_input_grad[2]:
-            db = g.sum((0, 2, 3))
+            db = g.sum((0, 2, 3)) if torch.is_grad_enabled() else hip_ops.channel_sum(g)
         return dx, dw, db, None, None, None, None
 
 

@@ -42,7 +42,9 @@ class _SlopeMask(Function):
 
 
 def _channel_sum(t):
-    return t.sum([0] + list(range(2, t.ndim)))
+    if torch.is_grad_enabled() or t.dtype != torch.float32:     # (a double-backward pass differentiates through the sum)
+        return t.sum([0] + list(range(2, t.ndim)))
+    return hip_ops.channel_sum(t.contiguous())
 
 
 class _LeakyBias(Function):
