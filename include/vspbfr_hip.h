@@ -429,6 +429,8 @@ typedef struct vsp_conv_wgrad_params {
 size_t vsp_conv2d_wgrad_work_floats(const vsp_conv_wgrad_params* p);
 int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* p, vsp_stream_t stream);
 int vsp_plane_dot_f32(float* out, const float* a, const float* b, int64_t planes, int64_t n, vsp_stream_t stream);
+/* out[p] = sum_i a[p,i]*b[p,i] and, in the same pass, a[p,:] *= scale[p] (d/ds and d/dx of a modulated layer from d/d(x s)) */
+int vsp_plane_dot_scale_f32(float* out, float* a, const float* b, const float* scale, int64_t planes, int64_t n, vsp_stream_t stream);
 /* out[c] = sum over b and the plane of x[b, c, :] (x (B, C, hw) dense): bias gradients of the training step */
 int vsp_channel_sum_f32(float* out, const float* x, int B, int C, int64_t hw, vsp_stream_t stream);
 

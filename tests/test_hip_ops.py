@@ -992,6 +992,11 @@ def test_conv4x4_phase_stem_gradient():
     dict(cin=32, cout=24, hw=(37, 135), k=3, stride=2, pad=0, dil=1),         # stride 2: two staging items per lane
     dict(cin=16, cout=3, hw=(24, 24), k=1, stride=1, pad=0, dil=1),           # ToRGB
     dict(cin=16, cout=32, hw=(26, 26), k=1, stride=2, pad=0, dil=1),          # ResBlock skip
+    dict(cin=32, cout=64, hw=(16, 16), k=3, stride=1, pad=1, dil=1),          # small maps: 4 rows x 16 columns per chunk
+    dict(cin=32, cout=64, hw=(33, 33), k=3, stride=2, pad=0, dil=1),          # ... 16 x 16 outputs at stride 2 (dense slab rows)
+    dict(cin=16, cout=16, hw=(9, 8), k=3, stride=1, pad=1, dil=1),            # 8 x 8 chunks over a ragged map
+    dict(cin=16, cout=16, hw=(4, 4), k=3, stride=1, pad=1, dil=1),            # 4 x 4 map
+    dict(cin=24, cout=40, hw=(19, 30), k=3, stride=1, pad=2, dil=2),          # 2 rows x 32 columns, dilation 2
 ])
 def test_conv2d_wgrad_tile_shapes(H, cfg):
     """vsp_conv2d_wgrad_f32 over its tile shapes / staging forms against torch autograd in float64."""

@@ -47,6 +47,7 @@ struct WgradK {
   int dil[4], pad[4], per_group;
   int x_ch, x_coff, x_gs, dy_ch, dy_coff;
   int xwp, plane, segs, chunks;
+  int tcl, rbs, nrows, rstep, rmul;   // chunk = 2^tcl columns x (64 >> tcl) rows; slab rows, input-row step of a slab row, slab rows per tap row
   float* work;       // null: fp32 atomics into dw; else [gridDim.x][dw elements] partial copies, plain stores
   int64_t dw_elems;
 };
@@ -70,8 +71,11 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   const int KW = NTAP == 1 ? 1 : p.KW, KH = NTAP == 1 ? 1 : p.KH;
   const int d = p.dil[p.per_group ? g : 0], pad = p.pad[p.per_group ? g : 0], s = p.stride;
   const int XWP = p.xwp, plane = p.plane;
-  const int xw = (WG_PX - 1) * s + (KW - 1) * d + 1 + ((4 - (pad & 3)) & 3);   // slab row of this group (aligned origin)
+  const int TC = 1 << p.tcl, TR = WG_PX >> p.tcl;                 // chunk: TR output rows x TC columns (TR > 1: small maps)
+  const int xw = (TC - 1) * s + (KW - 1) * d + 1 + ((4 - (pad & 3)) & 3);   // slab row of this group (aligned origin)
   const int xw4 = (xw + 3) >> 2;
+  const int rstep = p.rstep ? p.rstep : d, rmul = p.rmul ? p.rmul : d;   // compact tap rows (step d) / dense rows (tap ky at row ky d)
+  const int NR = p.nrows;                                         // slab rows: KH (tap rows, one output row) or every input row of TR rows
   const int xc0 = p.x_coff + g * p.x_gs + ci0, yc0 = p.dy_coff + g * p.Cout_g + co0;
   const int64_t xplane = (int64_t)p.H * p.W, yplane = (int64_t)p.OH * p.OW;
 
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     const int item = lane + 64 * j;
     x_row[j] = item / xw4;
     x_q[j] = item - x_row[j] * xw4;
-    x_on[j] = x_row[j] < KH;
+    x_on[j] = x_row[j] < NR;
   }
   const int d_row = tid >> 4, d_q = tid & 15;
   float4 xr[XJ][NITX], dr[NITD];
@@ -104,19 +108,20 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   };
   auto fetch = [&](int ch) {
     const int seg = ch % p.segs, row = ch / p.segs;
-    const int oy = row % p.OH, b = row / p.OH;
-    const int ox0 = seg * WG_PX;
-    {  // dY
-      const int ox = ox0 + 4 * d_q;
-      const int oxc = min(ox, p.OW - 4);
+    const int rb = row % p.rbs, b = row / p.rbs;
+    const int oy0 = rb * TR, ox0 = seg * TC;
+    {  // dY: quad d_q = pixels 4 d_q .. + 3 of the chunk = row ty, columns tx .. tx + 3
+      const int ty = (4 * d_q) >> p.tcl, tx = (4 * d_q) & (TC - 1);
+      const int oy = oy0 + ty, ox = ox0 + tx;
+      const int oxc = min(ox, p.OW - 4), oyc = min(oy, p.OH - 1);
       d_sh = ox - oxc;
-      d_okf = ox < p.OW ? 1.f : 0.f;
+      d_okf = (ox < p.OW && oy < p.OH) ? 1.f : 0.f;
 #pragma unroll
       for (int it = 0; it < NITD; ++it) {
         const int c = d_row + 16 * it;
         const bool cok = co0 + c < p.Cout_g;
         const int ch_ = yc0 + (cok ? c : 0);
-        const float* src = p.dy + ((int64_t)b * p.dy_ch + ch_) * yplane + (int64_t)oy * p.OW;
+        const float* src = p.dy + ((int64_t)b * p.dy_ch + ch_) * yplane + (int64_t)oyc * p.OW;
         const f32x4u v = *reinterpret_cast<const f32x4u*>(src + oxc);
         dr[it] = make_float4(v[0], v[1], v[2], v[3]);
         dsc[it] = cok ? (p.dys ? p.dys[(int64_t)b * p.dy_ch + ch_] : 1.f) : 0.f;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      const int iy = oy * s + x_row[j] * d - pad, ix = ox0 * s - pad - xs_al + 4 * x_q[j];
+      const int iy = oy0 * s + x_row[j] * rstep - pad, ix = ox0 * s - pad - xs_al + 4 * x_q[j];
       const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 4);
       x_sh[j] = ix - ixc;                                   // > 0 only at the right border (>= 4: the quad is outside)
       x_okf[j] = (x_on[j] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 1.f : 0.f;
@@ -192,12 +197,13 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll VSP_WG_UNROLL
     for (int k0 = 0; k0 < WG_PX; k0 += 4) {
       const float a = ap[k0];
+      const int kb = ((k0 >> p.tcl) * s) * XWP + (k0 & (TC - 1)) * s;   // pixel k0 = chunk row k0 / TC, column k0 % TC
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
           const int ky = t / 3, kx = t - 3 * ky;   // (NTAP = 9: 3x3; NTAP = 1: the single tap)
-          const float bv = bp[nb * 16 * plane + ky * XWP + k0 * s + kx * d];
+          const float bv = bp[nb * 16 * plane + ky * rmul * XWP + kb + kx * d];
           acc[nb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[nb][t], 0, 0, 0);
         }
     }
@@ -266,7 +272,7 @@ int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st)
 }
 
 struct Plan {
-  int dmax, xw4, xj, wco, nb, tiles, segs;
+  int dmax, xw4, xj, wco, nb, tiles, segs, tcl, nrows, rbs;
   int64_t chunks, split;
 };
 
@@ -278,17 +284,28 @@ Plan make_plan(const vsp_conv_wgrad_params& q) {
     const int d = q.per_group_geometry ? q.dil_g[g] : q.dil;
     pl.dmax = d > pl.dmax ? d : pl.dmax;
   }
-  const int xw = (WG_PX - 1) * q.stride + (q.KW - 1) * pl.dmax + 1 + 3;   // + alignment slack of the slab origin
-  pl.xw4 = (xw + 3) / 4;
-  pl.xj = q.KH * pl.xw4 <= 64 ? 1 : 2;
+  // chunk shape: one row segment of 64 pixels, or -- maps narrower than 64 -- TR rows x TC columns (TC a power of two) when the dense
+  // slab of those rows (every input row between the first and the last tap row) still fits the staging layout
+  pl.tcl = 6;
+  for (int tcl = 2; tcl < 6; ++tcl)
+    if ((1 << tcl) >= q.OW) { pl.tcl = tcl; break; }
+  for (;; pl.tcl = 6) {
+    const int tc = 1 << pl.tcl, tr = WG_PX >> pl.tcl;
+    const int xw = (tc - 1) * q.stride + (q.KW - 1) * pl.dmax + 1 + 3;   // + alignment slack of the slab origin
+    pl.xw4 = (xw + 3) / 4;
+    pl.nrows = tr == 1 ? q.KH : (tr - 1) * q.stride + (q.KH - 1) * pl.dmax + 1;
+    if (tr == 1 || pl.nrows * pl.xw4 <= 128) break;
+  }
+  pl.xj = pl.nrows * pl.xw4 <= 64 ? 1 : 2;
   // (two-item staging -- wide stride-2 slabs -- doubles the prefetch registers: it keeps to the 16 / 32-channel X tiles)
   if (q.Cout_g > 32 || pl.xj == 2) { pl.wco = 4; pl.nb = q.Cin_g > 16 ? 2 : 1; }
   else if (q.Cout_g > 16) { pl.wco = 2; pl.nb = q.Cin_g > 32 ? 2 : 1; }
   else { pl.wco = 1; pl.nb = 1; }
   const int co_t = 16 * pl.wco, ci_t = 16 * pl.nb * (4 / pl.wco);
   pl.tiles = ((q.Cout_g + co_t - 1) / co_t) * ((q.Cin_g + ci_t - 1) / ci_t);
-  pl.segs = (q.OW + WG_PX - 1) / WG_PX;
-  pl.chunks = (int64_t)q.B * q.OH * pl.segs;
+  pl.segs = (q.OW + (1 << pl.tcl) - 1) >> pl.tcl;
+  pl.rbs = (q.OH + (WG_PX >> pl.tcl) - 1) / (WG_PX >> pl.tcl);
+  pl.chunks = (int64_t)q.B * pl.rbs * pl.segs;
   // split the pixel dimension so that ~3 workgroups per CU are in flight, every workgroup keeping >= 8 chunks when it can
   pl.split = (3 * vsp::kNumCU + (int64_t)pl.tiles * q.G - 1) / ((int64_t)pl.tiles * q.G);
   if (pl.split > pl.chunks / 8) pl.split = pl.chunks / 8;
@@ -354,9 +371,13 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   const int xw4 = pl.xw4, xj = pl.xj, wco = pl.wco, nb = pl.nb, tiles = pl.tiles;
   const int64_t chunks = pl.chunks;
   int64_t split = pl.split;
-  VSP_REQUIRE(q.KH * xw4 <= 128, "conv2d_wgrad: row segment with halo too wide for the staging layout (stride %d, dilation %d)", q.stride, dmax);
+  VSP_REQUIRE(pl.nrows * xw4 <= 128, "conv2d_wgrad: row segment with halo too wide for the staging layout (stride %d, dilation %d)", q.stride, dmax);
   k.xwp = 4 * xw4;
-  int plane = q.KH * k.xwp;
+  k.tcl = pl.tcl; k.rbs = pl.rbs; k.nrows = pl.nrows;
+  const bool dense = pl.tcl < 6;                  // dense slab rows: row r = input row r of the chunk; else row ky = tap row ky
+  k.rstep = dense ? 1 : 0;                        // 0: the group's dilation (set in the kernel)
+  k.rmul = dense ? 0 : 1;                         // 0: the group's dilation
+  int plane = pl.nrows * k.xwp;
   while (plane % 32 != 2) plane += 2;  // ci rows 2 (mod 32) words apart, 8-byte aligned
   k.plane = plane;
   k.segs = pl.segs;
@@ -428,6 +449,37 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(float* __restrict__ out,
   }
 }
 
+// out[plane] = <a, b> and a[plane, :] *= scale[plane] in the same pass (data gradient of a modulated layer: a = d/d(x s), b = x:
+// d/ds = <a, x>, d/dx = a s)
+__global__ __launch_bounds__(256) void plane_dot_scale_kernel(float* __restrict__ out, float* __restrict__ a, const float* __restrict__ b,
+                                                               const float* __restrict__ scale, int64_t n, int64_t per) {
+  float* ap = a + (int64_t)blockIdx.x * n;
+  const float* bp = b + (int64_t)blockIdx.x * n;
+  const float sc = scale[blockIdx.x];
+  const int64_t lo = (int64_t)blockIdx.y * per, hi = lo + per < n ? lo + per : n;
+  float s = 0.f;
+  if ((n & 3) == 0) {
+    for (int64_t i = lo + 4 * threadIdx.x; i < hi; i += 1024) {
+      float4 u = *reinterpret_cast<const float4*>(ap + i);
+      const float4 v = *reinterpret_cast<const float4*>(bp + i);
+      s = fmaf(u.x, v.x, fmaf(u.y, v.y, fmaf(u.z, v.z, fmaf(u.w, v.w, s))));
+      u.x *= sc; u.y *= sc; u.z *= sc; u.w *= sc;
+      *reinterpret_cast<float4*>(ap + i) = u;
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      const float u = ap[i];
+      s = fmaf(u, bp[i], s);
+      ap[i] = u * sc;
+    }
+  }
+  s = block_sum_256(s);
+  if (threadIdx.x == 0) {
+    if (gridDim.y == 1) out[blockIdx.x] = s;
+    else unsafeAtomicAdd(out + blockIdx.x, s);
+  }
+}
+
 // grid (C, splits): workgroup (c, sp) sums its share of the B planes of channel c
 __global__ __launch_bounds__(256) void channel_sum_kernel(float* __restrict__ out, const float* __restrict__ x, int B, int C, int64_t hw,
                                                            int64_t per) {
@@ -476,6 +528,20 @@ extern "C" int vsp_plane_dot_f32(float* out, const float* a, const float* b, int
   if (sp > 1 && hipMemsetAsync(out, 0, sizeof(float) * planes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "plane_dot: memset failed");
   plane_dot_kernel<<<dim3((unsigned)planes, (unsigned)sp), 256, 0, st>>>(out, a, b, n, per);
   return vsp::check_launch("plane_dot");
+}
+
+extern "C" int vsp_plane_dot_scale_f32(float* out, float* a, const float* b, const float* scale, int64_t planes, int64_t n,
+                                       vsp_stream_t stream) {
+  VSP_REQUIRE(planes >= 0 && n >= 0, "plane_dot_scale: negative size");
+  if (planes == 0) return VSP_OK;
+  VSP_REQUIRE(out && scale && (n == 0 || (a && b)), "plane_dot_scale: null pointer");
+  VSP_REQUIRE(planes < ((int64_t)1 << 31), "plane_dot_scale: too many planes");
+  hipStream_t st = vsp::as_stream(stream);
+  int64_t per;
+  const int sp = plane_splits(planes, n, &per);
+  if (sp > 1 && hipMemsetAsync(out, 0, sizeof(float) * planes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "plane_dot_scale: memset failed");
+  plane_dot_scale_kernel<<<dim3((unsigned)planes, (unsigned)sp), 256, 0, st>>>(out, a, b, scale, n, per);
+  return vsp::check_launch("plane_dot_scale");
 }
 
 extern "C" int vsp_channel_sum_f32(float* out, const float* x, int B, int C, int64_t hw, vsp_stream_t stream) {

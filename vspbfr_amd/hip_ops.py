@@ -1000,6 +1000,18 @@ def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1,
     return dw
 
 
+def plane_dot_scale_(a, b, scale):
+    """-> (B, C) = sum over the plane of a * b; `a` (B, C, H, W) is multiplied IN PLACE by scale (B, C)."""
+    a, b, scale = _req(a, "a"), _req(b, "b"), _req(scale, "scale")
+    if a.shape != b.shape or a.dim() < 3 or scale.numel() != a.shape[0] * a.shape[1]:
+        raise RuntimeError("plane_dot_scale_: a, b of the same (B, C, ...) shape and scale (B, C)")
+    out = torch.empty(a.shape[:2], device=a.device, dtype=torch.float32)
+    planes = a.shape[0] * a.shape[1]
+    check(lib.vsp_plane_dot_scale_f32(_ptr(out), _ptr(a), _ptr(b), _ptr(scale), planes, a.numel() // max(planes, 1), _stream()),
+          "plane_dot_scale")
+    return out
+
+
 def channel_sum(x):
     """(B, C, ...) -> (C,): sum over the batch and everything behind the channel dimension (bias gradients)."""
     x = _req(x, "x")

@@ -118,8 +118,8 @@ class _ModConv(Function):
                     dxs = F.pad(dxs, (0, pw, 0, ph))
             else:
                 dxs = H.conv2d_packed(g, adj, in_scale=demod)
-            ds = H.plane_dot(dxs, x)                                  # dxs = d/d(x s)
-            dx = dxs.mul_(s.view(B, cin, 1, 1))
+            ds = H.plane_dot_scale_(dxs, x, s)                        # dxs = d/d(x s): ds = <dxs, x>, then dxs *= s in the same pass
+            dx = dxs
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             if layer.upsample:   # the stride-2 weight gradient with the roles of x and g exchanged; result in (Cin, Cout, 3, 3)
                 dw = H.conv2d_wgrad(g, x, (cin, cout, 3, 3), 2, 0, 1, 1, x_scale=demod, dy_scale=s).transpose(0, 1)
@@ -193,8 +193,8 @@ class _SmartBranches(Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             parts = H.conv2d_packed(g, _smart_adjoint_pack(layer), in_scale=demod)          # (B, nb * Cin, H, W)
             dxs = parts.view(B, nb, cin, Hh, Ww).sum(1)
-            ds = H.plane_dot(dxs, x)
-            dx = dxs.mul_(s.view(B, cin, 1, 1))
+            ds = H.plane_dot_scale_(dxs, x, s)
+            dx = dxs
         dws = [None] * nb
         if any(ctx.needs_input_grad[4:]) and not conv2d_gradfix.weight_gradients_disabled:
             ms = layer.ModulatedConv2ds   # one launch: 4 groups over the shared input, each with its branch's dilation
