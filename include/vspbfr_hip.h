@@ -431,6 +431,12 @@ int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* p, vsp_stream_t stream);
 int vsp_plane_dot_f32(float* out, const float* a, const float* b, int64_t planes, int64_t n, vsp_stream_t stream);
 /* out[p] = sum_i a[p,i]*b[p,i] and, in the same pass, a[p,:] *= scale[p] (d/ds and d/dx of a modulated layer from d/d(x s)) */
 int vsp_plane_dot_scale_f32(float* out, float* a, const float* b, const float* scale, int64_t planes, int64_t n, vsp_stream_t stream);
+/* NoiseInjection + FusedLeakyReLU of a styled layer as one stream (training forward; reference models/RestoreNet.py:558-569 then
+ * op/fused_act.py:199-233):  y[b,c,p] = lrelu(x[b,c,p] + noise_w[0] * noise[b,p] + bias[c], slope) * gain;  bias may be NULL.
+ * vsp_noise_dot_f32: out[0] = sum_{b,c,p} gx[b,c,p] * noise[b,p] -- the gradient of the scalar noise weight. */
+int vsp_noise_bias_act_f32(float* y, const float* x, const float* noise, const float* noise_w, const float* bias, int B, int C,
+                           int64_t hw, float slope, float gain, vsp_stream_t stream);
+int vsp_noise_dot_f32(float* out, const float* gx, const float* noise, int B, int C, int64_t hw, vsp_stream_t stream);
 /* out[c] = sum over b and the plane of x[b, c, :] (x (B, C, hw) dense): bias gradients of the training step */
 int vsp_channel_sum_f32(float* out, const float* x, int B, int C, int64_t hw, vsp_stream_t stream);
 

@@ -1045,3 +1045,21 @@ def test_channel_sum_and_plane_dot_split(H, shape):
     close(H.channel_sum(dev(a)), a.double().sum(dims).float(), 1e-5, 1e-3, "channel_sum")
     if a.dim() == 4:
         close(H.plane_dot(dev(a), dev(b)), (a.double() * b.double()).sum((2, 3)).float(), 1e-5, 1e-3, "plane_dot")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 7), (3, 16, 64, 64)])
+def test_noise_bias_act_autograd(H, shape):
+    """NoiseInjection + FusedLeakyReLU as one op (vspbfr_amd/training.py) against the two-step torch statement in float64:
+    y, dx, d noise_weight, d bias."""
+    from vspbfr_amd.training import noise_bias_act
+    g_ = torch.Generator().manual_seed(9)
+    B, C_, Hh, Ww = shape
+    x, noise = torch.randn(*shape, generator=g_), torch.randn(B, 1, Hh, Ww, generator=g_)
+    nw, bias = torch.tensor([0.3]), torch.randn(C_, generator=g_) * 0.2
+
+    def ref_fn(x_, nw_, b_):
+        return F.leaky_relu(x_ + nw_ * noise.double() + b_.view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    ref = _grads(ref_fn, x.double(), nw.double(), bias.double())
+    got = _grads(lambda x_, nw_, b_: noise_bias_act(x_, dev(noise), nw_, b_), dev(x), dev(nw), dev(bias))
+    for name, a, r in zip(("y", "dx", "dnw", "db"), got, ref):
+        close(a, r.float(), 2e-5, 2e-5, name)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   const int ci_tiles = (p.Cin_g + CI_T - 1) / CI_T;
   const int cot = blockIdx.y / ci_tiles, cit = blockIdx.y - cot * ci_tiles;
   const int co0 = cot * CO_T, ci0 = cit * CI_T;
-  const int KW = NTAP == 1 ? 1 : p.KW, KH = NTAP == 1 ? 1 : p.KH;
+  const int KW = NTAP == 1 ? 1 : p.KW;
   const int d = p.dil[p.per_group ? g : 0], pad = p.pad[p.per_group ? g : 0], s = p.stride;
   const int XWP = p.xwp, plane = p.plane;
   const int TC = 1 << p.tcl, TR = WG_PX >> p.tcl;                 // chunk: TR output rows x TC columns (TR > 1: small maps)

@@ -95,3 +95,84 @@ extern "C" int vsp_fused_bias_act_f32(float* out, const float* x, const float* b
   }
   return vsp::check_launch("fused_bias_act");
 }
+
+
+// ---- NoiseInjection + FusedLeakyReLU of a styled layer in one stream (training forward; the inference path carries the same chain
+// in the conv / blur epilogues):  y[b,c,p] = lrelu(x[b,c,p] + nw * noise[b,p] + bias[c], slope) * gain
+// (reference models/RestoreNet.py:558-569 then op/fused_act.py:199-233), and the gradient of the scalar noise weight
+//   d nw = sum_{b,c,p} gx[b,c,p] * noise[b,p]        (gx = g * m(y), the slope mask of fused_bias_act act=3 grad=1)
+namespace {
+
+__global__ __launch_bounds__(256) void noise_bias_act_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                              const float* __restrict__ noise, const float* __restrict__ nw,
+                                                              const float* __restrict__ bias, int C, int64_t hw, float slope, float gain) {
+  const int64_t plane = blockIdx.y;                    // b * C + c
+  const int b = (int)(plane / C), c = (int)(plane - (int64_t)b * C);
+  const float w = nw[0], bc = bias ? bias[c] : 0.f;
+  const float* xp = x + plane * hw;
+  const float* np = noise + (int64_t)b * hw;
+  float* yp = y + plane * hw;
+  auto f = [&](float v, float n) { v = fmaf(w, n, v) + bc; return (v > 0.f ? v : v * slope) * gain; };
+  if ((hw & 3) == 0) {
+    for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < hw; i += 4 * 256 * (int64_t)gridDim.x) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + i), n = *reinterpret_cast<const float4*>(np + i);
+      *reinterpret_cast<float4*>(yp + i) = make_float4(f(v.x, n.x), f(v.y, n.y), f(v.z, n.z), f(v.w, n.w));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += 256 * (int64_t)gridDim.x) yp[i] = f(xp[i], np[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void noise_dot_kernel(float* __restrict__ out, const float* __restrict__ gx,
+                                                         const float* __restrict__ noise, int C, int64_t hw) {
+  const int64_t plane = blockIdx.y;
+  const int b = (int)(plane / C);
+  const float* gp = gx + plane * hw;
+  const float* np = noise + (int64_t)b * hw;
+  float s = 0.f;
+  if ((hw & 3) == 0) {
+    for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < hw; i += 4 * 256 * (int64_t)gridDim.x) {
+      const float4 v = *reinterpret_cast<const float4*>(gp + i), n = *reinterpret_cast<const float4*>(np + i);
+      s = fmaf(v.x, n.x, fmaf(v.y, n.y, fmaf(v.z, n.z, fmaf(v.w, n.w, s))));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += 256 * (int64_t)gridDim.x) s = fmaf(gp[i], np[i], s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+inline int plane_blocks(int64_t planes, int64_t hw) {   // blocks per plane: ~8 workgroups per CU in all, >= 4096 elements each
+  int64_t nb = (8 * vsp::kNumCU + planes - 1) / planes;
+  if (nb > hw / 4096) nb = hw / 4096;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace
+
+extern "C" int vsp_noise_bias_act_f32(float* y, const float* x, const float* noise, const float* noise_w, const float* bias, int B, int C,
+                                      int64_t hw, float slope, float gain, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && C >= 0 && hw >= 0, "noise_bias_act: negative size");
+  if ((int64_t)B * C * hw == 0) return VSP_OK;
+  VSP_REQUIRE(y && x && noise && noise_w, "noise_bias_act: null pointer");
+  VSP_REQUIRE((int64_t)B * C <= 65535, "noise_bias_act: too many planes for one grid");
+  noise_bias_act_kernel<<<dim3((unsigned)plane_blocks((int64_t)B * C, hw), (unsigned)(B * C)), 256, 0, vsp::as_stream(stream)>>>(
+      y, x, noise, noise_w, bias, C, hw, slope, gain);
+  return vsp::check_launch("noise_bias_act");
+}
+
+extern "C" int vsp_noise_dot_f32(float* out, const float* gx, const float* noise, int B, int C, int64_t hw, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && C >= 0 && hw >= 0, "noise_dot: negative size");
+  VSP_REQUIRE(out != nullptr, "noise_dot: null output");
+  hipStream_t st = vsp::as_stream(stream);
+  if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "noise_dot: memset failed");
+  if ((int64_t)B * C * hw == 0) return VSP_OK;
+  VSP_REQUIRE(gx && noise, "noise_dot: null pointer");
+  VSP_REQUIRE((int64_t)B * C <= 65535, "noise_dot: too many planes for one grid");
+  noise_dot_kernel<<<dim3((unsigned)plane_blocks((int64_t)B * C, hw), (unsigned)(B * C)), 256, 0, st>>>(out, gx, noise, C, hw);
+  return vsp::check_launch("noise_dot");
+}

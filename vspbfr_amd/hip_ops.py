@@ -1012,6 +1012,27 @@ def plane_dot_scale_(a, b, scale):
     return out
 
 
+def noise_bias_act(x, noise, noise_w, bias, slope=0.2, gain=SQRT2):
+    """lrelu(x + noise_w * noise + bias[c], slope) * gain for x (B, C, H, W), noise (B, 1, H, W), noise_w (1,), bias (C,) or None."""
+    x, noise, noise_w = _req(x, "x"), _req(noise, "noise"), _req(noise_w, "noise_w")
+    B, Cc, Hh, Ww = x.shape
+    if noise.numel() != B * Hh * Ww or noise_w.numel() != 1 or (bias is not None and bias.numel() != Cc):
+        raise RuntimeError("noise_bias_act: noise (B, 1, H, W), noise_w (1,), bias (C,)")
+    y = torch.empty_like(x)
+    check(lib.vsp_noise_bias_act_f32(_ptr(y), _ptr(x), _ptr(noise), _ptr(noise_w), _ptr(_opt(bias, "bias")), B, Cc, Hh * Ww, float(slope),
+                                     float(gain), _stream()), "noise_bias_act")
+    return y
+
+
+def noise_dot(gx, noise):
+    """(1,) = sum over everything of gx (B, C, H, W) * noise (B, 1, H, W)."""
+    gx, noise = _req(gx, "gx"), _req(noise, "noise")
+    B, Cc, Hh, Ww = gx.shape
+    out = torch.empty((1,), device=gx.device, dtype=torch.float32)
+    check(lib.vsp_noise_dot_f32(_ptr(out), _ptr(gx), _ptr(noise), B, Cc, Hh * Ww, _stream()), "noise_dot")
+    return out
+
+
 def channel_sum(x):
     """(B, C, ...) -> (C,): sum over the batch and everything behind the channel dimension (bias gradients)."""
     x = _req(x, "x")

@@ -214,11 +214,38 @@ def smart_branches(x, layer, style):
     return _SmartBranches.forward(_NoCtx(), x, s, demod, layer, *ws)
 
 
+class _NoiseBiasAct(Function):
+    """NoiseInjection + FusedLeakyReLU as one launch; backward = the slope mask of fused_bias_act (from y), the channel sum for
+    the bias and one dot product for the scalar noise weight.  First order (generator only)."""
+
+    @staticmethod
+    def forward(ctx, x, noise, noise_w, bias):
+        noise = noise.contiguous()
+        y = H.noise_bias_act(x.contiguous(), noise, noise_w.contiguous(), bias.contiguous())
+        ctx.save_for_backward(y, noise)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        y, noise = ctx.saved_tensors
+        gx = H.fused_bias_act(g.contiguous(), g.new_empty(0), y, 3, 1, 0.2, 2 ** 0.5)
+        dnw = H.noise_dot(gx, noise) if ctx.needs_input_grad[2] else None
+        db = H.channel_sum(gx) if ctx.needs_input_grad[3] else None
+        return gx, None, dnw, db
+
+
+def noise_bias_act(x, noise, noise_w, bias):
+    """out = x + noise_w * noise; fused_leaky_relu(out, bias)  (NoiseInjection.forward + FusedLeakyReLU.forward)."""
+    if torch.is_grad_enabled() and (x.requires_grad or noise_w.requires_grad or bias.requires_grad):
+        return _NoiseBiasAct.apply(x, noise, noise_w, bias)
+    return H.noise_bias_act(x.contiguous(), noise.contiguous(), noise_w.contiguous(), bias.contiguous())
+
+
 def styled_conv(x, layer, style, noise):
     """StyledConv.forward (reference models/RestoreNet.py:599-603): conv -> noise -> FusedLeakyReLU."""
     out = modulated_conv(x, layer.conv, style)
-    out = out + layer.noise.weight * noise
-    return fused_leaky_relu(out, layer.activate.bias)
+    return noise_bias_act(out, noise, layer.noise.weight, layer.activate.bias)
 
 
 def smart_layer(x, layer, style, noise):
@@ -228,8 +255,7 @@ def smart_layer(x, layer, style, noise):
     f = layer.fusion[0]
     out = conv2d_gradfix.conv2d(out, f.weight * f.scale, padding=1)
     out = fused_leaky_relu(out, layer.fusion[1].bias)
-    out = out + layer.noise.weight * noise
-    return fused_leaky_relu(out, layer.activate.bias)
+    return noise_bias_act(out, noise, layer.noise.weight, layer.activate.bias)
 
 
 def large_conv_layer(x, layer):
