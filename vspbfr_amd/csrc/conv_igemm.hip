@@ -410,7 +410,9 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   if (pcopy.transposed) {  // normalise the ignored fields: the launch grid runs over input positions m = 0..H, n = 0..W
     VSP_REQUIRE(pcopy.KH == 3 && pcopy.KW == 3 && pcopy.G == 1, "conv2d: transposed mode needs a 3x3 kernel and G = 1");
     VSP_REQUIRE(!pcopy.noise && !pcopy.res1 && !pcopy.res2, "conv2d: transposed mode has no noise / residual epilogue");
-    VSP_REQUIRE(pcopy.y_h == 2 * pcopy.H + 1 && pcopy.y_w == 2 * pcopy.W + 1, "conv2d: transposed output must be (2H+1)x(2W+1)");
+    // (a larger output plane is allowed: the adjoint of a stride-2 conv over an even-sized input is one row / column wider; the
+    //  kernel only writes the (2H+1) x (2W+1) positions, the caller zeroes the margin)
+    VSP_REQUIRE(pcopy.y_h >= 2 * pcopy.H + 1 && pcopy.y_w >= 2 * pcopy.W + 1, "conv2d: transposed output must hold (2H+1)x(2W+1)");
     pcopy.stride_y = pcopy.stride_x = 1;
     pcopy.dil[0] = 1;
     pcopy.pad_y[0] = pcopy.pad_x[0] = 1;

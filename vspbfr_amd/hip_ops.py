@@ -547,6 +547,21 @@ def conv_transpose2d_s2_fused(x, pc, **kw):
     return conv2d_packed(x, pc, transposed=True, **kw)
 
 
+def conv_transpose2d_s2_into(x, pc, out_hw, **kw):
+    """The same launch writing into a (B, Cout, OH, OW) tensor with OH in {2H+1, 2H+2} (the data gradient of a stride-2 conv over an
+    even-sized input has one zero row / column more): the margin is zeroed here, no padded copy is made."""
+    B, _, H, W = x.shape
+    OH, OW = out_hw
+    if not (0 <= OH - (2 * H + 1) <= 1 and 0 <= OW - (2 * W + 1) <= 1):
+        raise RuntimeError("conv_transpose2d_s2_into: out_hw must be (2H+1 or 2H+2, 2W+1 or 2W+2)")
+    out = torch.empty((B, pc.cout, OH, OW), device=x.device, dtype=torch.float32)
+    if OH > 2 * H + 1:
+        out[:, :, -1].zero_()
+    if OW > 2 * W + 1:
+        out[:, :, :, -1].zero_()
+    return conv2d_packed(x, pc, transposed=True, out=out, bf16=False, **kw)
+
+
 def conv_transpose2d_s2(x, phases, **kw):
     """(B, Cin, H, W) -> (B, Cout, 2H+1, 2W+1): conv_transpose2d(stride=2, padding=0) with a 3x3 kernel, as four
     sub-pixel phase launches (kept as the cross-check of the fused kernel)."""

@@ -83,6 +83,11 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
     if stride == 2 and padding in (0, 1) and dilation == 1 and (kh, kw) == (3, 3):
         # adjoint of the stride-2 conv = conv_transpose2d(g, W, stride 2): (2 OH + 1)^2 rows of the PADDED input, zero rows beyond
         # when H + 2 padding is even; padding 1 (the ResNet bottleneck of the identity loss) crops the border back off
+        if groups == 1 and padding == 0 and not torch.is_grad_enabled():
+            # first-order pass: the one-pass transposed kernel writes straight into the (H, W) gradient (no padded copy)
+            w_oihw = weight.transpose(0, 1).contiguous()       # conv_transpose2d reads (Cout, Cin, 3, 3) as (in, out): oihw = (Cin, Cout)
+            pc = hip_ops.PackedConv(hip_ops.pack_weight(w_oihw), 1, cg, cout, 3, 3, 1, (1,), (1,))
+            return hip_ops.conv_transpose2d_s2_into(g.contiguous(), pc, x_shape[2:])
         dx = conv_transpose2d(g, weight, stride=2, padding=0, groups=groups)
         ph, pw = x_shape[2] + 2 * padding - dx.shape[2], x_shape[3] + 2 * padding - dx.shape[3]
         if ph < 0 or pw < 0 or ph > 1 or pw > 1:

@@ -112,10 +112,7 @@ class _ModConv(Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
             adj = _adjoint_pack(layer)
             if layer.downsample:
-                dxs = H.conv_transpose2d_s2_fused(g, adj, in_scale=demod)       # (2 OH + 1)^2; one zero row / column more when H is even
-                ph, pw = x.shape[2] - dxs.shape[2], x.shape[3] - dxs.shape[3]
-                if ph or pw:
-                    dxs = F.pad(dxs, (0, pw, 0, ph))
+                dxs = H.conv_transpose2d_s2_into(g, adj, x.shape[2:], in_scale=demod)   # (2 OH + 1)^2 (+ a zero row / column: H even)
             else:
                 dxs = H.conv2d_packed(g, adj, in_scale=demod)
             ds = H.plane_dot_scale_(dxs, x, s)                        # dxs = d/d(x s): ds = <dxs, x>, then dxs *= s in the same pass
