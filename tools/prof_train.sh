@@ -8,4 +8,5 @@ rocprofv3 --kernel-trace --stats -d $OUT -o k -- python3 tools/bench_train_step.
 DB=$(ls $OUT/*.db $OUT/*/*.db 2>/dev/null | head -1)
 python3 tools/rocpd_summary.py $DB $OUT/kernel_stats.md > /dev/null
 grep "^{" $OUT/run.log | tail -1 > $OUT/line.json
+rm -f $OUT/*.db $OUT/*/*.db   # (tens of MB: gpurun copies at most 64 MiB back)
 ls $OUT

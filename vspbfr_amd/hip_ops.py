@@ -52,7 +52,7 @@ RECORDER = None  # tools/autotune_conv.py: list collecting the shape key of ever
 def _load_tune_table():
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune.json")
+    path = os.environ.get("VSPBFR_CONV_TUNE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv_tune.json")  # (override: tuning runs)
     if not os.path.exists(path):
         return {}
     with open(path) as f:
