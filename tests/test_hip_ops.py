@@ -1063,3 +1063,30 @@ def test_noise_bias_act_autograd(H, shape):
     got = _grads(lambda x_, nw_, b_: noise_bias_act(x_, dev(noise), nw_, b_), dev(x), dev(nw), dev(bias))
     for name, a, r in zip(("y", "dx", "dnw", "db"), got, ref):
         close(a, r.float(), 2e-5, 2e-5, name)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(cin=12, cout=64, hw=(27, 27), k=4, stride=1, pad=0),      # the sub-pixel stem of the identity network
+    dict(cin=40, cout=24, hw=(13, 18), k=3, stride=1, pad=1),      # ragged channels / tiles
+    dict(cin=32, cout=32, hw=(17, 17), k=3, stride=2, pad=0),
+    dict(cin=64, cout=48, hw=(8, 8), k=1, stride=1, pad=0),
+])
+def test_conv_every_config_agrees(H, cfg):
+    """Every tile configuration that accepts a shape must give the cost model's result (summation order aside): a variant that merely
+    RUNS on a shape nobody tried it on is how a tuned table would ship a wrong kernel."""
+    from vspbfr_amd._lib import lib
+    c = cfg
+    g_ = torch.Generator().manual_seed(31)
+    x = dev(torch.randn(2, c["cin"], *c["hw"], generator=g_))
+    w = dev(torch.randn(c["cout"], c["cin"], c["k"], c["k"], generator=g_) / math.sqrt(c["cin"] * c["k"] ** 2))
+    pc = H.PackedConv(H.pack_weight(w), 1, c["cout"], c["cin"], c["k"], c["k"], c["stride"], (1,), (c["pad"],))
+    ref = F.conv2d(x.cpu().double(), w.cpu().double(), None, c["stride"], c["pad"]).float()
+    ran = 0
+    for i in range(lib.vsp_conv2d_num_configs() + 1):
+        try:
+            y = H.conv2d_packed(x, pc, tile_hint=i, winograd=False)
+        except RuntimeError:
+            continue
+        ran += 1
+        close(y, ref, 2e-5, 2e-5, "auto" if i == 0 else lib.vsp_conv2d_config_name(i - 1).decode())
+    assert ran > 10
