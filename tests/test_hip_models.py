@@ -771,3 +771,55 @@ def test_id_loss_golden(golden):
     ref = g["d_pred"]
     assert maxerr(x.grad, ref) < 1e-2 * float(np.abs(ref).max()), (maxerr(x.grad, ref), float(np.abs(ref).max()))
     assert abs(float(x.grad.norm()) - float(np.linalg.norm(ref))) < 3e-3 * float(np.linalg.norm(ref))
+
+
+def test_code_diffuser_training_gradients(golden):
+    """Stage-B training (code_diffuser_train.py:153-190) against the REFERENCE's own pass (tests/golden/diffuser_train.npz): the
+    training-mode sampler (q_sample + 4 posterior-mean steps over the differentiable TACC blocks), KDLoss, the StyleGAN2 prior at
+    size 64 on the predicted codes, loss = l_abs + 0.1 <image, R>: predicted codes, both loss terms, the image, and the gradient of
+    all 72 Code_diffuser tensors (which reach the image through the modulated-convolution Functions' style gradients)."""
+    from vspbfr_amd import training
+    from vspbfr_amd.diffusion import Code_diffuser, My_DDPM
+    from vspbfr_amd.e4e import Generator
+    g = golden("diffuser_train")
+    case, B, T, size = "diffuser_train", 2, 4, 64
+    net = load(Code_diffuser(timesteps=T), "diffuser", "diffuser")
+    ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T).to(DEV)
+    gen = load(Generator(size, 512, 8, channel_multiplier=2), "e4e_decoder", "e4e_decoder64")
+    for p_ in gen.parameters():
+        p_.requires_grad_(False)
+    low, target = dev(cases.tensor(case, "low_latent", (B, 18, 512))), dev(cases.tensor(case, "target", (B, 18, 512)))
+    q_noise = dev(cases.tensor(case, "q_noise", (B, 18, 512)))
+    gnoise = [dev(n) for n in cases.noise_list(case, "n", OM.generator_noise_shapes(size, B))]
+    R = dev(cases.tensor(case, "R", (B, 3, size, size)))
+    names = [str(n) for n in g["param_names"]]
+    params = dict(net.named_parameters())
+    assert sorted(names) == sorted(params)
+    with torch.enable_grad():
+        for p_ in net.parameters():
+            p_.requires_grad_(True)
+        pred, seq = training.ddpm_training_forward(ddpm, low, low, q_noise)
+        l_kd, l_abs = training.KDLoss()([target], [seq[-1]])
+        img = training.generator_forward(gen, pred[:, :gen.n_latent], gnoise)
+        loss = l_abs + 0.1 * (img * R).sum()
+        loss.backward()
+    assert maxerr(seq[0], g["x_noisy"]) < 1e-5
+    assert maxerr(pred, g["pred"]) < 1e-4
+    assert abs(l_abs.item() - float(g["l_abs"][0])) < 1e-5 and abs(l_kd.item() - float(g["l_kd"][0])) < 2e-4 * float(g["l_kd"][0])
+    assert maxerr(img, g["image"]) < 2e-4
+    assert abs(loss.item() - float(g["loss"][0])) < 2e-3
+
+    def sample(t):
+        f = t.detach().reshape(-1)
+        return f[::max(1, f.numel() // 2048)][:2048]
+    worst = {}
+    for n in names:
+        ref = torch.from_numpy(g["g/" + n])
+        worst[n] = float((sample(params[n].grad).cpu() - ref).norm()) / (float(ref.norm()) + 1e-20)
+        assert abs(float(params[n].grad.norm()) - float(g["n/" + n][0])) < 1e-2 * float(g["n/" + n][0]) + 1e-9, n
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print("code diffuser: worst relative gradient errors", top)
+    assert top[0][1] < 2e-2, top
+    with torch.no_grad():      # the training-mode forward agrees with the fused inference chain from the same x_T
+        x_T = seq[0].detach()
+        assert maxerr(ddpm(x=None, condi_in=low, x_T=x_T), pred) < 2e-4

@@ -526,8 +526,72 @@ def gen_idloss():
           np.linalg.norm(out["z_pred"][0]), len(spec), time.time() - t))
 
 
+def gen_diffuser_train():
+    """One iteration of code_diffuser_train.py:153-190 without the two loss networks (pinned on their own: lpips64 / idloss128): the
+    REFERENCE's My_DDPM.forward(training=True) (q_sample of the low-quality codes at t = T-1 with a keyed noise, T p_sample steps,
+    ldm/ddpm.py:412-421), KDLoss (code_diffuser_train.py:64-90) against keyed target codes, the StyleGAN2 decoder at size 64 on the
+    predicted codes (stylegan2_feat_forward_v2: all 10 latents, explicit noise maps) and the scalar
+        loss = l_abs + 0.1 * <image, R>
+    whose backward reaches the 72 Code_diffuser tensors through the decoder's style path.  Stored: predicted codes, l_kd, l_abs,
+    image, loss, a strided sample + norm of every Code_diffuser gradient."""
+    t0 = time.time()
+    import torch.nn as nn   # (code_diffuser_train.py imports lmdb / tqdm / torchvision at module level: its KDLoss is restated here)
+    import torch.nn.functional as F
+
+    class KDLoss(nn.Module):                      # code_diffuser_train.py:64-90, verbatim semantics
+        def __init__(self, loss_weight=1.0, temperature=0.15):
+            super().__init__()
+            self.loss_weight, self.temperature = loss_weight, temperature
+
+        def forward(self, S1_fea, S2_fea):
+            dis = ab = 0
+            for i in range(len(S1_fea)):
+                S2d = F.log_softmax(S2_fea[i] / self.temperature, dim=1)
+                S1d = F.softmax(S1_fea[i].detach() / self.temperature, dim=1)
+                dis = dis + F.kl_div(S2d, S1d, reduction="batchmean")
+                ab = ab + nn.L1Loss()(S2_fea[i], S1_fea[i].detach())
+            return self.loss_weight * dis, self.loss_weight * ab
+
+    case, B, T, size = "diffuser_train", 2, 4, 64
+    net = Code_diffuser(timesteps=T)
+    load_synth(net, "diffuser", cases.SEED)
+    ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T)
+    g = SG.Generator(size, 512, 8, channel_multiplier=2)
+    load_synth(g, "e4e_decoder", cases.SEED)
+    n_lat = g.n_latent
+    low = cases.tensor(case, "low_latent", (B, 18, 512))
+    target = cases.tensor(case, "target", (B, 18, 512))
+    q_noise = cases.tensor(case, "q_noise", (B, 18, 512))
+    gnoise = cases.noise_list(case, "n", omodels.generator_noise_shapes(size, B))
+    R = cases.tensor(case, "R", (B, 3, size, size))
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: q_noise.to(x.dtype)            # the draw of ldm/ddpm.py:414
+    out = {}
+    try:
+        with torch.enable_grad():
+            for p_ in net.parameters():
+                p_.requires_grad_(True)
+            net.zero_grad()
+            pred, lst = ddpm(x=low, condi_in=low, training=True)
+            l_kd, l_abs = KDLoss()([target], [lst[-1]])
+            img, _ = g([pred[:, :n_lat]], input_is_latent=True, noise=gnoise, return_features=False)
+            loss = l_abs + 0.1 * (img * R).sum()
+            loss.backward()
+    finally:
+        torch.randn_like = real_randn_like
+    out.update(pred=np_(pred), x_noisy=np_(lst[0]), l_kd=np.array([l_kd.item()]), l_abs=np.array([l_abs.item()]), image=np_(img),
+               loss=np.array([loss.item()]))
+    names = []
+    for n, p_ in net.named_parameters():
+        names.append(n)
+        out["g/" + n], out["n/" + n] = np_(grad_sample(p_.grad)), np.array([p_.grad.norm().item()])
+    out["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "diffuser_train.npz"), **out)
+    print("diffuser_train.npz: l_kd %.4f l_abs %.4f loss %.4f, %d parameters, %.1fs" % (l_kd.item(), l_abs.item(), loss.item(), len(names), time.time() - t0))
+
+
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "lpips": gen_lpips, "idloss": gen_idloss}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "lpips": gen_lpips, "idloss": gen_idloss, "diffuser_train": gen_diffuser_train}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -372,3 +372,27 @@ class E4e_embedding(nn.Module):
     def get_stylegan_feats(self, styles, noise=None, with_sample=True):
         return self.E4Enet.stylegan2_feat_forward(styles.contiguous(), resize=True, randomize_noise=True, noise=noise,
                                                   with_sample=with_sample)
+
+    def get_stylegan_featsV2(self, styles, grad=False, return_feat=True, noise=None):
+        """reference Loss/e4e_embedding.py:139-155 -> psp.stylegan2_feat_forward_v2 (:265-281): the prior's picture (pooled to
+        out_size) from ALL the codes; grad=True keeps the graph to `styles` (code_diffuser_train.py:175 trains the Code_diffuser
+        through the frozen decoder) and runs the differentiable forward of vspbfr_amd/training.py."""
+        net = self.E4Enet
+        if not grad:
+            with torch.no_grad():
+                images, feats = net.decoder([styles.contiguous()], input_is_latent=True, randomize_noise=True, noise=noise,
+                                            return_features=True)
+                while images.shape[-1] > net.out_size:
+                    images = H.avgpool2x2(images)
+            return (images, feats[:net.out_n_latent]) if return_feat else images
+        if return_feat:
+            raise RuntimeError("get_stylegan_featsV2(grad=True): only the picture is differentiable here (return_feat=False), as "
+                               "code_diffuser_train.py:175 asks for it")
+        from . import training
+        return training.face_pool(training.generator_forward(net.decoder, styles[:, :net.decoder.n_latent], noise), net.out_size)
+
+    def open_stylegan_grad(self):      # (the reference flips the decoder's requires_grad around the step without ever stepping it:
+        pass                           #  the gradient to the codes does not need it, so these are no-ops here)
+
+    def close_stylegan_grad(self):
+        pass

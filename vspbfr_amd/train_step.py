@@ -162,3 +162,57 @@ class RestorationTrainer:
         accumulate(self.G_ema, self.G, self.accum)
         return losses
 
+
+
+class CodeDiffuserTrainer:
+    """One iteration of the stage-B training loop (reference code_diffuser_train.py:153-190, optimiser :307-311): the Code_diffuser
+    learns to map the e4e codes of the degraded image to those of the clean one, through the training-mode sampler
+    (q_sample at T - 1, T posterior-mean steps) and -- for the perceptual / identity terms -- through the frozen StyleGAN2 prior.
+
+        latent_loss = L1(pred_IPR_list[-1], target codes)            (KDLoss's second output; the KL term is only logged)
+                      + 0.1 * LPIPS(prior(pred codes), real).mean() + 0.1 * ID(prior(pred codes), real)
+
+    Encoder, prior and loss networks are frozen; gradients are averaged over the ranks with `allreduce_gradients` (72 tensors,
+    17 MB: one bucket)."""
+
+    def __init__(self, diffusion, psp_embedding, lr=0.002, g_reg_every=4, percept_loss=None, percept_weight=0.5, id_loss=None,
+                 id_weight=0.1, bucket_bytes=64 << 20):
+        self.diffusion, self.psp = diffusion, psp_embedding
+        self.percept_loss, self.percept_weight, self.id_loss, self.id_weight = percept_loss, percept_weight, id_loss, id_weight
+        self.bucket_bytes = bucket_bytes
+        self.cri_kd = training.KDLoss()
+        ratio = g_reg_every / (g_reg_every + 1)
+        self.params = list(diffusion.model.parameters())
+        for p in self.params:
+            p.requires_grad_(True)
+        self.optim = torch.optim.Adam(self.params, lr=lr * ratio, betas=(0 ** ratio, 0.99 ** ratio))
+
+    def step(self, low_img, real_img, low_latent=None, target=None, q_noise=None, gen_noise=None):
+        """low_img / real_img in [-1, 1] on the device.  low_latent / target: precomputed codes (tests); q_noise / gen_noise: the
+        random draws (tests).  Returns the loss dict of the reference's logger."""
+        with torch.no_grad():
+            if low_latent is None:
+                low_latent = self.psp.get_w_plus(low_img)
+            if target is None:
+                target = self.psp.get_w_plus(real_img)
+        pred, seq = training.ddpm_training_forward(self.diffusion, low_latent.detach(), low_latent.detach(), q_noise)
+        l_kd, l_abs = self.cri_kd([target.detach()], [seq[-1]])
+        loss = l_abs
+        losses = {"latent_loss": l_abs.detach(), "l_kd": l_kd.detach()}
+        use_p = self.percept_loss is not None and self.percept_weight > 0
+        use_i = self.id_loss is not None and self.id_weight > 0
+        if use_p or use_i:
+            restore = self.psp.get_stylegan_featsV2(pred, grad=True, return_feat=False, noise=gen_noise)
+            if use_p:
+                t = self.percept_loss(restore, real_img.detach()).mean() * 0.1
+                losses["latent_percept_loss"], loss = t.detach(), loss + t
+            if use_i:
+                t = self.id_loss(restore, real_img.detach()) * 0.1
+                losses["latent_id_loss"], loss = t.detach(), loss + t
+        for p in self.params:
+            p.grad = None
+        loss.backward()
+        allreduce_gradients(self.params, self.bucket_bytes)
+        self.optim.step()
+        losses["pred_latent"] = pred.detach()
+        return losses

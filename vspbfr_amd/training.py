@@ -321,3 +321,120 @@ def restoration_net_forward(net, images, de_feats, pre_styles, noise_styles, enc
         i += 2
     return skip
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Stage-B training (reference code_diffuser_train.py:153-190): the Code_diffuser is trained THROUGH the frozen StyleGAN2 prior.
+#   * the denoiser (four TACC blocks, 18 x 512 tokens, ~0.3 GFLOP per block) runs as torch tensor algebra -- F.linear / matmul are
+#     plain library GEMMs, the rest is a handful of row operations -- because every one of its 72 tensors needs a gradient and the
+#     arithmetic is negligible beside the decoder's; the fused chain of the inference path (tacc_chain.hip) records no graph;
+#   * the prior's synthesis network runs on the modulated-convolution Functions above (data gradient and style gradients only: the
+#     decoder is frozen -- the reference switches its requires_grad on, code_diffuser_train.py:166, but never steps it).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _scaled_lrelu(x):
+    return F.leaky_relu(x, 0.2) * (2 ** 0.5)
+
+
+def _head(head, c):
+    """gamma_ / beta_ of a TACC block (models/CodeDiffuser.py:77-78): Linear(513, 512), LayerNorm, ScaledLeakyReLU, Linear, Sigmoid | ScaledLeakyReLU."""
+    h = F.linear(c, head[0].weight, head[0].bias)
+    h = _scaled_lrelu(F.layer_norm(h, (h.shape[-1],), head[1].weight, head[1].bias, 1e-5))
+    h = F.linear(h, head[3].weight, head[3].bias)
+    return torch.sigmoid(h) if head.last == 2 else _scaled_lrelu(h)
+
+
+def tacc_block_forward(blk, x, embd, step):
+    """TACC_block.forward (models/CodeDiffuser.py:86-116) with spatial_attention.forward (:30-47), differentiable."""
+    d = x.shape[-1]
+    x = x * torch.rsqrt(torch.mean(x ** 2, dim=1, keepdim=True) + 1e-8)           # PixelNorm over the 18 tokens
+    K, V = F.linear(x, blk.k_matrix.weight), F.linear(x, blk.v_matrix.weight)
+    c = torch.cat([embd, step], dim=-1)
+    Q = F.linear(c, blk.q_matrix.weight).permute(0, 2, 1)
+    h = torch.matmul(F.softmax(torch.matmul(K, Q) / (blk.dk ** 0.5), dim=-1), V)
+    a = blk.attention_layer
+    q, v = F.linear(x, a.q_matrix.weight), F.linear(x, a.v_matrix.weight)
+    k = F.linear(c, a.k_matrix.weight).permute(0, 2, 1)
+    t = torch.matmul(v, F.softmax(torch.matmul(k, q) / (d ** 0.5), dim=1))
+    t = F.layer_norm(t, (d,), None, None, 1e-5)
+    h = F.layer_norm(h + t, (d,), None, None, 1e-5)
+    return h * (1.0 + _head(blk.gamma_, c)) + _head(blk.beta_, c)
+
+
+def code_diffuser_forward(net, x, embd, t):
+    """Code_diffuser.forward (models/CodeDiffuser.py:133-140)."""
+    step = (t.float() / net.max_period).view(-1, 1, 1).repeat(1, embd.shape[1], 1)
+    for blk in net.att_mapper:
+        x = tacc_block_forward(blk, x, embd, step)
+    return x
+
+
+def ddpm_training_forward(ddpm, x, condi_in, noise=None):
+    """My_DDPM.forward(training=True) (ldm/ddpm.py:412-421): q_sample at t = T - 1, then the T posterior-mean steps; returns the
+    last denoised codes and the list [x_noisy, x_{T-1}, ..., x_0].  `noise`: the q_sample draw (default torch.randn_like)."""
+    if ddpm.parameterization != "x0" or ddpm.clip_denoised:
+        raise RuntimeError("ddpm_training_forward: the x0-parameterised, unclipped sampler of code_diffuser_train.py")
+    B, T = condi_in.shape[0], ddpm.num_timesteps
+    noise = torch.randn_like(x) if noise is None else noise
+    last = ddpm.sqrt_alphas_cumprod[T - 1] * x + ddpm.sqrt_one_minus_alphas_cumprod[T - 1] * noise
+    seq = [last]
+    for i in reversed(range(T)):
+        t = torch.full((B,), i, device=x.device, dtype=torch.long)
+        x0 = code_diffuser_forward(ddpm.model, last, condi_in, t)
+        last = ddpm.posterior_mean_coef1[i] * x0 + ddpm.posterior_mean_coef2[i] * last
+        seq.append(last)
+    return last, seq
+
+
+class KDLoss(torch.nn.Module):
+    """code_diffuser_train.py:64-90: (KL(softmax(S1 / T) || softmax(S2 / T)) batch mean, L1(S2, S1)) summed over the list, S1 detached."""
+
+    def __init__(self, loss_weight=1.0, temperature=0.15):
+        super().__init__()
+        self.loss_weight, self.temperature = loss_weight, temperature
+
+    def forward(self, S1_fea, S2_fea):
+        dis = ab = 0
+        for s1, s2 in zip(S1_fea, S2_fea):
+            s1 = s1.detach()
+            dis = dis + F.kl_div(F.log_softmax(s2 / self.temperature, dim=1), F.softmax(s1 / self.temperature, dim=1), reduction="batchmean")
+            ab = ab + (s2 - s1).abs().mean()
+        return self.loss_weight * dis, self.loss_weight * ab
+
+
+def generator_forward(gen, latent, noise=None):
+    """e4e Generator.forward([latent], input_is_latent=True) (e4e/models/stylegan2/model.py:475-552) -> image, differentiable in
+    `latent` (B, n_latent, 512) (and in the decoder's parameters where they require a gradient).  noise: one map per layer
+    (default: fresh normal draws, randomize_noise=True)."""
+    B = latent.shape[0]
+    if noise is None:
+        noise = [torch.randn(B, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), device=latent.device) for i in range(gen.num_layers)]
+    out = gen.input.input.repeat(B, 1, 1, 1)
+    out = styled_conv(out, gen.conv1, latent[:, 0], noise[0])
+    skip = to_rgb(out, gen.to_rgb1, latent[:, 1])
+    i = 1
+    for j in range(gen.log_size - 2):
+        out = styled_conv(out, gen.convs[2 * j], latent[:, i], noise[1 + 2 * j])
+        out = styled_conv(out, gen.convs[2 * j + 1], latent[:, i + 1], noise[2 + 2 * j])
+        skip = to_rgb(out, gen.to_rgbs[j], latent[:, i + 2], skip)
+        i += 2
+    return skip
+
+
+class _AvgPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return H.avgpool2x2(x.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g.repeat_interleave(2, 2).repeat_interleave(2, 3).mul_(0.25)
+
+
+def face_pool(img, out_size):
+    """AdaptiveAvgPool2d((out_size, out_size)) of e4e/models/psp.py:101 for the power-of-two ratios the path uses (exact 2x2 means)."""
+    while img.shape[-1] > out_size:
+        if img.shape[-1] % 2 or img.shape[-1] // 2 < out_size:
+            raise RuntimeError("face_pool: output size must divide the image size by a power of two")
+        img = _AvgPool2.apply(img) if (torch.is_grad_enabled() and img.requires_grad) else H.avgpool2x2(img.contiguous())
+    return img
