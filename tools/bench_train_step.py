@@ -35,6 +35,23 @@ for i in range(iters + 1):
     losses = tr.step(i + 1, low, real)                       # i + 1: no R1 step (every 16th iteration carries one)
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
+# roofline leg: every convolution launch of one more iteration (forward, data gradient, weight gradient; loss networks included) with
+# HIP events on the launch stream: algorithmic FLOPs / time against the fp32 MFMA peak (the path is fp32-compute bound)
+from vspbfr_amd import hip_ops
+prof = hip_ops.ConvProfiler(); hip_ops.PROFILER = prof
+tr.step(iters + 2, low, real)
+hip_ops.PROFILER = None
+torch.cuda.synchronize()
+fl, conv_ms, n_launch = prof.summary()
+by_kind = {}
+for f_, s_, e_, tag, _ in prof.records:
+    k = "weight gradient" if tag[7] == "wgrad" else "forward + data gradient"
+    a = by_kind.setdefault(k, [0.0, 0.0]); a[0] += f_; a[1] += s_.elapsed_time(e_)
+roofline = {"bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(fl / conv_ms / 1e9 / 157.3, 3),
+            "traffic": None, "kernel": "conv family of one iteration: conv_wino / conv_igemm (forward, data gradient) + conv_wgrad",
+            "launches": n_launch, "kernel_ms": round(conv_ms, 1), "algorithmic_gflop": round(fl / 1e9, 1),
+            "split": {k: {"tflops": round(v[0] / v[1] / 1e9, 1), "ms": round(v[1], 1)} for k, v in by_kind.items()},
+            "measured": "HIP events per launch on the launch stream over one iteration (serialises nothing: one stream)"}
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 tr.step(16, low, real)                                       # an iteration with the R1 regulariser (double backward)
@@ -45,5 +62,6 @@ print(json.dumps({"what": "restoration_train step, 512x512, Restoration_net + Di
                           + ("LPIPS-VGG x0.5 + ArcFace ID x0.1" if LOSSES else "no LPIPS/ID"),
                   "batch_per_gpu": B, "ms_per_iteration": round(ms, 1), "img_per_s": round(B / ms * 1e3, 2),
                   "ms_iteration_with_r1": round(t_r1 * 1e3, 1), "losses": {k: float(v) for k, v in losses.items()},
+                  "roofline": roofline, "dtype": "f32",
                   "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                   "generator_param_mb": round(tr.generator_bytes / 2 ** 20, 1)}))
