@@ -476,304 +476,6 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the same kernel for the undilated 64-channel-tile geometry (MBW = 4: 64 co x 32 tiles, 8 input channels
-// per barrier interval).  In the kernel above all eight waves transform AND multiply behind one barrier per interval, two workgroups
-// per CU in lock step: the matrix pipe is 64 % busy.  Here ONE workgroup per CU (256 VGPRs per wave) splits the roles:
-//   waves 0-3 (one per SIMD)  CONSUMERS: positions 4c .. 4c+3, all 64 MFMAs of an interval per wave (2 k-steps x 4 positions x 4 x 2
-//                             blocks = 2048 pipe cycles), their U fragments straight from global one interval ahead (the fragment
-//                             order of the 8-wave layout already keeps a consumer's four positions in two adjacent 32-byte runs);
-//   waves 4-7 (one per SIMD)  PRODUCERS: patch prefetch (two channels per wave, wave-uniform), patch commit, the 512 transform tasks
-//                             (two per thread): ~600 cycles of VALU / LDS work per interval.
-// The barrier per interval stays, but the consumer is the critical path and reaches it last: the matrix pipe idles for a barrier
-// latency per 2048 cycles instead of waiting for transforms.  V and the patch are double-buffered exactly as above.
-// ---------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR, 2) void conv_wino_pc_kernel(const ConvK p) {
-  using Gm = WG<4, 1>;
-  constexpr int MBW = 4, NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR, PC = Gm::PC;
-  constexpr int PPITCH = Gm::PPITCH, VPITCH = Gm::VPITCH, LDS_V = Gm::LDS_V, LDS_P = Gm::LDS_P, IVC = Gm::IVC;
-  static_assert(IVC == 8 && NBW == 2, "producer / consumer form: 8 channels per interval, 32 tiles");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Vl = smem;               // 2 x [16][IVC][VPITCH]
-  float* Pl = smem + 2 * LDS_V;   // 2 x [IVC][PPITCH]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool consumer = wave < 4;
-  const int lr = lane & 15, kq = lane >> 4;
-  int b = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
-  if (p.wg_order) {   // pixel-tile-major XCD order (see the kernel above)
-    const int GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z, GT = GX * GY * GZ;
-    const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
-    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
-    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
-    const int GN = GX * GY;
-    b = lid / GN;
-    const int lrem = lid - b * GN;
-    bx = lrem / GY;
-    by = lrem - bx * GY;
-  }
-  const int ct = by;   // (G = 1)
-  const int tiles_x = (p.W + 2 * TLX - 1) / (2 * TLX);
-  const int tx_i = bx % tiles_x, ty_i = bx / tiles_x;
-  const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);
-  const int co0 = ct * WCO;
-  const int chw = p.H * p.W;
-  const float* xb = p.x + (int64_t)b * p.x_ch * chw;
-  const int nchunk = (p.Cin + IVC - 1) / IVC;
-  const int nchunk4 = (p.Cin + WCK - 1) / WCK;
-
-  f32x4 acc[4][MBW][NBW];   // consumers: [position 4c + pp][16-channel block][16-tile block]
-#pragma unroll
-  for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-    for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < NBW; ++nb) acc[pp][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (consumer) {
-    // U fragments of 4-channel chunk c4: layout [co tile][chunk4][wave8 = position pair][lane][pp 2][mb 4]; consumer `wave` owns pairs
-    // 2 wave, 2 wave + 1.  u[q][mb]: q = position 4 wave + q.
-    const float* ufr = p.w + (((int64_t)ct * nchunk4 * 8 + 2 * wave) * 64 + lane) * 8;
-    auto load_u = [&](int c4, float (&u)[4][4]) {
-      const float* src = ufr + (int64_t)c4 * (8 * 64 * 8);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {   // the two position pairs: 64 lanes x 8 floats apart
-        const float4 a = reinterpret_cast<const float4*>(src + h * 64 * 8)[0], bq = reinterpret_cast<const float4*>(src + h * 64 * 8)[1];
-        u[2 * h][0] = a.x; u[2 * h][1] = a.y; u[2 * h][2] = a.z; u[2 * h][3] = a.w;
-        u[2 * h + 1][0] = bq.x; u[2 * h + 1][1] = bq.y; u[2 * h + 1][2] = bq.z; u[2 * h + 1][3] = bq.w;
-      }
-    };
-    auto multiply = [&](const float* Vsrc, int ks, const float (&u)[4][4]) {
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp) {
-        const float* vp = Vsrc + (4 * wave + pp) * (IVC * VPITCH) + (4 * ks + kq) * VPITCH + lr;
-        float bv[NBW];
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) bv[nb] = vp[nb * 16];
-#pragma unroll
-        for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NBW; ++nb)
-            acc[pp][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[pp][mb], bv[nb], acc[pp][mb][nb], 0, 0, 0);
-      }
-    };
-    float ua[2][4][4], ub[2][4][4];   // [k-step][position][block] of the current / next interval
-    load_u(0, ua[0]);
-    if (nchunk4 > 1) load_u(1, ua[1]);
-    __syncthreads();   // patch(0) committed
-    __syncthreads();   // V(0) ready
-    for (int i = 0; i < nchunk; i += 2) {
-      // interval i on ua (prefetching ub), interval i + 1 on ub (prefetching ua): no register copies
-      if (2 * i + 2 < nchunk4) load_u(2 * i + 2, ub[0]);
-      if (2 * i + 3 < nchunk4) load_u(2 * i + 3, ub[1]);
-      multiply(Vl + (i & 1) * LDS_V, 0, ua[0]);
-      if (2 * i + 1 < nchunk4) multiply(Vl + (i & 1) * LDS_V, 1, ua[1]);
-      __syncthreads();
-      if (i + 1 >= nchunk) break;
-      if (2 * i + 4 < nchunk4) load_u(2 * i + 4, ua[0]);
-      if (2 * i + 5 < nchunk4) load_u(2 * i + 5, ua[1]);
-      multiply(Vl + ((i + 1) & 1) * LDS_V, 0, ub[0]);
-      if (2 * i + 3 < nchunk4) multiply(Vl + ((i + 1) & 1) * LDS_V, 1, ub[1]);
-      __syncthreads();
-    }
-  } else {
-    const int pw = wave - 4;                       // producer wave: channels pw and pw + 4 of an interval
-    const int ptid = tid - 256;
-    constexpr int PLANE = PR * PC;                 // 10 x 18
-    constexpr int PLD = (PLANE + 63) / 64;         // plane words per lane and channel
-    int p_src[PLD];
-#pragma unroll
-    for (int e = 0; e < PLD; ++e) {
-      const int rem = lane + 64 * e;
-      const int r = rem / PC, c = rem - r * PC;
-      const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
-      p_src[e] = (rem < PLANE && iy >= 0 && ix >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
-    }
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
-    int p_voff[PLD];
-#pragma unroll
-    for (int e = 0; e < PLD; ++e) p_voff[e] = (p_src[e] >= 0 ? p_src[e] : 0) * 4;
-    float preg[2][PLD], pnext[2][PLD];
-    auto issue_p = [&](int c) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ci = c * IVC + pw + 4 * h;
-        const int soff = (ci < p.Cin ? ci : 0) * chw * 4;
-#pragma unroll
-        for (int e = 0; e < PLD; ++e) pnext[h][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, p_voff[e], soff, 0));
-      }
-    };
-    auto rotate_p = [&]() {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < PLD; ++e) preg[h][e] = pnext[h][e];
-    };
-    auto commit_p = [&](float* Pdst, int c) {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int ch = pw + 4 * h, ci = c * IVC + ch;
-        const bool chok = ci < p.Cin;
-        const int cc = chok ? ci : p.Cin - 1;
-        const float sc = uload(p.wcp, b * p.wc_bs + cc * p.wc_cs), sh = uload(p.wshp, cc * p.wsh_cs);
-#pragma unroll
-        for (int e = 0; e < PLD; ++e)
-          if (lane + 64 * e < PLANE) Pdst[ch * PPITCH + lane + 64 * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[h][e], sc, sh) : 0.f;
-      }
-    };
-    auto transform = [&](const float* Psrc, float* Vdst, int c) {   // 2 tasks per thread: (channel, tile, half)
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int task = ptid + it * 256;
-        const int th = task & 1, tq = task >> 1;
-        const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;   // (64 tasks per wave: one channel)
-        const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
-        const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + 2 * t_tx;
-        float dd[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) dd[r][cc] = src[r * PC + cc];
-        const int ci = c * IVC + t_ch;
-        const float sc = uload(p.wtp, b * p.wt_bs + (ci < p.Cin ? ci : p.Cin - 1) * p.wt_cs);
-        float w0[4], w1[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          w0[cc] = (th ? dd[1][cc] - dd[0][cc] : dd[0][cc] - dd[2][cc]) * sc;
-          w1[cc] = (th ? dd[0][cc] - dd[2][cc] : dd[1][cc] + dd[2][cc]) * sc;
-        }
-        const float v0[4] = {w0[0] - w0[2], w0[1] + w0[2], w0[2] - w0[1], w0[1] - w0[3]};
-        const float v1[4] = {w1[0] - w1[2], w1[1] + w1[2], w1[2] - w1[1], w1[1] - w1[3]};
-        float* dst = Vdst + t_ch * VPITCH + t_tile;
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-          dst[((2 * th) * 4 + nu) * (IVC * VPITCH)] = v0[nu];
-          dst[((2 * th + 1) * 4 + nu) * (IVC * VPITCH)] = v1[nu];
-        }
-      }
-    };
-    issue_p(0);
-    rotate_p();
-    commit_p(Pl, 0);
-    if (nchunk > 1) issue_p(1);
-    __syncthreads();
-    transform(Pl, Vl, 0);
-    if (nchunk > 1) {
-      rotate_p();
-      commit_p(Pl + LDS_P, 1);
-      if (nchunk > 2) issue_p(2);
-    }
-    __syncthreads();
-    for (int i = 0; i < nchunk; ++i) {   // interval i: V(i+1) from patch(i+1); patch(i+2) -> the buffer patch(i) has left; prefetch patch(i+3)
-      const int cur = i & 1, nxt = cur ^ 1;
-      if (i + 2 < nchunk) rotate_p();
-      if (i + 3 < nchunk) issue_p(i + 3);
-      if (i + 1 < nchunk) transform(Pl + nxt * LDS_P, Vl + nxt * LDS_V, i + 1);
-      if (i + 2 < nchunk) commit_p(Pl + cur * LDS_P, i + 2);
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue (all eight waves): per pair of 16-channel blocks the sixteen positions meet in LDS (the consumers hold them)
-  constexpr int ETILE = Gm::ETILE, ENB = ETILE / 16, EMB = Gm::EMB, ECO = 16 * EMB;
-  constexpr int EPT = ECO * ETILE / NTHR;
-  float* Ml = smem;  // [16 pos][ECO][ETILE]
-  const int Cout = p.cout_g;
-  const float* osp = p.osp + (int64_t)b * Cout * p.oss;
-  const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW * p.nzs;
-  const float nw = p.nwp[0];
-  float* yb = p.y + ((int64_t)b * p.y_ch + p.y_coff) * p.y_h * p.y_w;
-  const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r1s;
-  const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r2s;
-  const int y_plane = p.y_h * p.y_w;
-  typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-  const bool vec2 = p.r1s <= 1 && p.r2s <= 1;
-#pragma unroll
-  for (int mb0 = 0; mb0 < MBW; mb0 += EMB) {
-    if (mb0 > 0) __syncthreads();
-    if (consumer) {
-#pragma unroll
-      for (int pp = 0; pp < 4; ++pp)
-#pragma unroll
-        for (int m2 = 0; m2 < EMB; ++m2)
-#pragma unroll
-          for (int nb = 0; nb < ENB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              Ml[((4 * wave + pp) * ECO + m2 * 16 + kq * 4 + r) * ETILE + nb * 16 + lr] = acc[pp][mb0 + m2][nb][r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < EPT; ++it) {
-      const int pair = tid + it * NTHR;
-      const int e_co = pair / ETILE, e_t = pair - e_co * ETILE;
-      const int e_tx = e_t % TLX;
-      const int sy = oy0 + 2 * (e_t / TLX), sx = ox0 + 2 * e_tx;
-      float m[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) m[q] = Ml[(q * ECO + e_co) * ETILE + e_t];
-      float t0[4], t1[4];
-#pragma unroll
-      for (int nu = 0; nu < 4; ++nu) {
-        t0[nu] = m[nu] + m[4 + nu] + m[8 + nu];
-        t1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
-      }
-      const float yv[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
-      const int cg = co0 + mb0 * 16 + e_co;
-      if (cg >= p.cout_g) continue;
-      const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
-      const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
-      const int cbase = cg * y_plane;
-      auto fin = [&](float v, float nz, float r1v, float r2v) {
-        v = v * os * cs + cb + b1;
-        v = (v > 0.f ? v : v * p.s1) * p.g1;
-        v += nz * nw + b2;
-        v = (v > 0.f ? v : v * sl2) * p.g2;
-        return v + r1v + r2v;
-      };
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int oy = sy + i, ox = sx;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int ro = cbase + oy * p.y_w + ox;
-        if (vec2 && ox + 1 < p.OW) {
-          f32x2u nz = {0.f, 0.f}, r1v = {0.f, 0.f}, r2v = {0.f, 0.f};
-          if (p.nzs) nz = *reinterpret_cast<const f32x2u*>(nzp + oy * p.OW + ox);
-          if (p.r1s) r1v = *reinterpret_cast<const f32x2u*>(r1b + ro);
-          if (p.r2s) r2v = *reinterpret_cast<const f32x2u*>(r2b + ro);
-          f32x2u o2 = {fin(yv[i][0], nz[0], r1v[0], r2v[0]), fin(yv[i][1], nz[1], r1v[1], r2v[1])};
-          *reinterpret_cast<f32x2u*>(yb + ro) = o2;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int oxj = ox + j;
-            if (oxj >= p.OW) continue;
-            const int rj = ro + j;
-            yb[rj] = fin(yv[i][j], nzp[(oy * p.OW + oxj) * p.nzs], r1b[rj * p.r1s], r2b[rj * p.r2s]);
-          }
-        }
-      }
-    }
-  }
-}
-
-int launch_pc(ConvK q, hipStream_t stream) {
-  using Gm = WG<4, 1>;
-  static bool attr_set = false;
-  const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_winograd: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
-  q.co_tiles = (q.cout_g + Gm::WCO - 1) / Gm::WCO;
-  const int blocks = ((q.W + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((q.H + 2 * Gm::TLY - 1) / (2 * Gm::TLY));
-  q.wg_order = 1;
-  dim3 grid((unsigned)blocks, (unsigned)q.co_tiles, (unsigned)q.B);
-  conv_wino_pc_kernel<<<grid, NTHR, lds, stream>>>(q);
-  return VSP_OK;
-}
-
 template <int MBW, int DMAX>
 int launch_variant(ConvK q, hipStream_t stream) {
   using Gm = WG<MBW, DMAX>;
@@ -827,9 +529,7 @@ int wino_launch(ConvK q, hipStream_t stream) {
   for (int g = 0; g < q.G; ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
   if (dmax == 1) {
     switch (wino_mbw(q.cout_g)) {
-      case 4:
-        if (q.G == 1 && (q.dbg & 0x2000000)) return launch_pc(q, stream);   // producer / consumer form (tuning switch for now)
-        return launch_variant<4, 1>(q, stream);
+      case 4: return launch_variant<4, 1>(q, stream);
       case 2: return launch_variant<2, 1>(q, stream);
       default: return launch_variant<1, 1>(q, stream);
     }
