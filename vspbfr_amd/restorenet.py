@@ -104,7 +104,9 @@ class Restoration_net(nn.Module):
             feats.append(out)
             out = self.encoder_convs[ii + 1](out, sty, enc_noise[ii + 1])  # same latent index as the SMART layer
         out = self.final_layer(out)
-        x_global = self.final_linear[0](out.view(B, -1))  # Dropout2d is the identity in eval mode
+        x_global = self.final_linear[0](out.view(B, -1))
+        if self.training:   # Dropout2d(0.5) of final_linear (models/RestoreNet.py:907-909): the training loop samples fakes in train mode
+            x_global = self.final_linear[1](x_global)
         early = self.final_transfer(x_global).view(B, -1, 4, 4)
         feats.append(H.add3(out, early))
         return x_global, feats[::-1]
@@ -117,8 +119,8 @@ class Restoration_net(nn.Module):
             raise RuntimeError("Restoration_net: the reference's shared `noise=` list / randomize_noise=False cannot be "
                                "served (encoder and decoder need different shapes, models/RestoreNet.py:1018); pass "
                                "enc_noise= and dec_noise= instead")
-        if self.training:
-            raise RuntimeError("Restoration_net (vspbfr_amd) is inference-only: call .eval()")
+        # (always a no-grad forward: in train() mode it is the sampling pass of the training loop -- Dropout2d of final_linear active --
+        #  the differentiable forward over these parameters is vspbfr_amd.training.restoration_net_forward)
         images = images.contiguous()
         if not input_is_latent:
             noise_styles = [self.style(s.contiguous()) for s in noise_styles]

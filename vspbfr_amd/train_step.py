@@ -103,6 +103,8 @@ class RestorationTrainer:
             enc_noise = [torch.randn(s, device=low_img.device) for s in es]
             dec_noise = [torch.randn(s, device=low_img.device) for s in ds]
         inject = None if len(noise) < 2 else random.randint(1, self.G.n_latent - 1)
+        if not torch.is_grad_enabled():   # the discriminator step's fake batch: the fused inference forward (same parameters, same mode)
+            return self.G(low_img, de_feats, latent, noise, inject_index=inject, enc_noise=enc_noise, dec_noise=dec_noise)
         return training.restoration_net_forward(self.G, low_img, de_feats, latent, noise, enc_noise, dec_noise, inject_index=inject)
 
     def _aug(self, img):
