@@ -1,7 +1,7 @@
 """Autotune the conv tile configuration for the layer shapes of ONE TRAINING ITERATION (forward, data-gradient and loss-network
 launches at the training batch size; GPU box).  Micro-benchmark stage of tools/autotune_conv.py over the recorded shapes; winners
 that beat the cost model's pick by > 3 % are MERGED into gpurun_out/conv_tune_train.json (copy its entries into
-vspbfr_amd/conv_tune.json to ship them).  usage: python tools/autotune_train.py [B] [losses]"""
+vspbfr_amd/conv_tune.json to ship them).  usage: python tools/autotune_train.py [B] [losses] [stage_b [size]]"""
 import copy, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -24,12 +24,23 @@ if len(sys.argv) > 2 and sys.argv[2] == "losses":
     from vspbfr_amd.id_loss import IDLoss
     from vspbfr_amd.lpips import PerceptualLoss
     kw = dict(percept_loss=PerceptualLoss().to(dev), percept_weight=0.5, id_loss=IDLoss(None, device=dev), id_weight=0.1)
-tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9, **kw)
-low, real = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1, torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
-G.train()
-tr.step(1, low, real)
-H.RECORDER = []
-tr.step(16, low, real)          # an iteration with the R1 pass
+STAGE_B = len(sys.argv) > 3 and sys.argv[3] == "stage_b"      # code_diffuser_train.py iteration (size argv[4], default 256)
+if STAGE_B:
+    from vspbfr_amd.train_step import CodeDiffuserTrainer
+    size = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+    pipe.psp.E4Enet.out_size = size
+    trb = CodeDiffuserTrainer(pipe.diffusion, pipe.psp, percept_loss=kw.get("percept_loss"), id_loss=kw.get("id_loss"))
+    low, real = torch.rand(B, 3, size, size, device=dev) * 2 - 1, torch.rand(B, 3, size, size, device=dev) * 2 - 1
+    trb.step(low, real)
+    H.RECORDER = []
+    trb.step(low, real)
+else:
+    tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9, **kw)
+    low, real = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1, torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
+    G.train()
+    tr.step(1, low, real)
+    H.RECORDER = []
+    tr.step(16, low, real)          # an iteration with the R1 pass
 torch.cuda.synchronize()
 recs, H.RECORDER = H.RECORDER, None
 uniq = {}

@@ -353,8 +353,11 @@ def tacc_block_forward(blk, x, embd, step):
     h = torch.matmul(F.softmax(torch.matmul(K, Q) / (blk.dk ** 0.5), dim=-1), V)
     a = blk.attention_layer
     q, v = F.linear(x, a.q_matrix.weight), F.linear(x, a.v_matrix.weight)
-    k = F.linear(c, a.k_matrix.weight).permute(0, 2, 1)
-    t = torch.matmul(v, F.softmax(torch.matmul(k, q) / (d ** 0.5), dim=1))
+    # spatial_attention: out = v @ softmax(k^T q / sqrt(d), dim=1).  Evaluated on the TRANSPOSED logits (q^T k, softmax over the LAST
+    # dim, v @ A'^T): the same numbers, but torch's softmax over an inner dim of a (B, 512, 512) tensor is 10x slower than over the last
+    kc = F.linear(c, a.k_matrix.weight)                                                  # (B, 18, 512)
+    att_t = F.softmax(torch.matmul(q.transpose(1, 2), kc) / (d ** 0.5), dim=-1)          # (B, c', c) = softmax_c(score[c, c'])
+    t = torch.matmul(v, att_t.transpose(1, 2))
     t = F.layer_norm(t, (d,), None, None, 1e-5)
     h = F.layer_norm(h + t, (d,), None, None, 1e-5)
     return h * (1.0 + _head(blk.gamma_, c)) + _head(blk.beta_, c)
