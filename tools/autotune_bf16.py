@@ -1,7 +1,7 @@
 """In-situ choice of the vsp_conv2d_bf16 tile variant per layer shape: the pipeline runs once per candidate variant with that
 variant forced on every launch it serves (hip_ops.BF16_FORCE), per-launch HIP events give the time of every shape, the fastest
 variant per shape goes to gpurun_out/conv_tune_bf16.json (copy to vspbfr_amd/conv_tune_bf16.json to ship it).
-usage: python tools/autotune_bf16.py [B] [T]"""
+usage: [ACT_BF16=1] [X3=1] python tools/autotune_bf16.py [B] [T]"""
 import collections, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,6 +16,7 @@ hip_ops.BF16_CONV = "x3" if X3 else True
 hip_ops.BF16_TUNE = {}
 hip_ops.BF16X3_TUNE = {}
 pipe = bench.build_pipeline(dev, T, True)
+pipe.act_bf16 = bool(os.environ.get("ACT_BF16"))   # ACT_BF16=1: tune with bf16 activations in HBM (BASELINE configs[2])
 lq = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
 
 
