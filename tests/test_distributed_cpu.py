@@ -126,7 +126,7 @@ GRAD_WORKER = textwrap.dedent("""
     import os, sys, torch
     import torch.distributed as dist
     sys.path.insert(0, %r)
-    from vspbfr_amd.train_step import allreduce_gradients
+    from vspbfr_amd.train_step import allreduce_gradients, OverlappedGradientReducer
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.manual_seed(0)
@@ -147,6 +147,19 @@ GRAD_WORKER = textwrap.dedent("""
         dist.all_gather(parts, g)
         want = sum(parts) / world
         assert p.grad is not None and torch.allclose(p.grad, want, rtol=0, atol=1e-7), (rank, p.shape)
+    want = [p.grad.clone() for p in net.parameters()]
+    # the hook-driven form (all-reduces started inside backward): the same averaged gradients, bit for bit
+    for p in net.parameters():
+        p.grad = None
+    red = OverlappedGradientReducer(list(net.parameters()), bucket_bytes=1024)
+    with red:
+        out = net[2](net[1](net[0](x)))
+        out.pow(2).mean().backward()
+    assert red.launched >= 2, red.launched
+    for p, w in zip(net.parameters(), want):
+        if p is net[2].bias:                # (the sequential run dropped this gradient on rank 1 by hand)
+            continue
+        assert p.grad is not None and torch.equal(p.grad, w), (rank, p.shape)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok", nb)

@@ -11,8 +11,8 @@ exactly as in restoration_test; the generator runs `training.restoration_net_for
 `discriminator.Discriminator`.  The perceptual (LPIPS-VGG) and identity (ArcFace) terms of the reference need their pretrained
 networks (my_lpips/, Loss/id_loss.py: out of scope): they enter as optional callables with weight 0 by default.
 
-Data parallelism: one process per GPU, every rank owns the same parameters and its shard of the batch; after each backward the
-gradients are averaged with `allreduce_gradients`: parameters are packed into flat buckets in REVERSE registration order (the
+Data parallelism: one process per GPU, every rank owns the same parameters and its shard of the batch; the gradients are averaged
+by `OverlappedGradientReducer` (started from inside backward) / `allreduce_gradients` (after it): parameters are packed into flat buckets in REVERSE registration order (the
 order backward produces them), each bucket is one asynchronous all-reduce (RCCL over xGMI through torch.distributed "nccl"; gloo
 in the CPU tests), unpacked after the last wait.  xGMI is point-to-point -- a ring all-reduce moves 2 (N-1)/N of a bucket over
 the slowest link -- so buckets are large (64 MB default: the generator's 450 MB of fp32 gradients = 7 collectives) rather than the
@@ -61,6 +61,90 @@ def allreduce_gradients(params, bucket_bytes=64 << 20, group=None):
     return len(buckets)
 
 
+class OverlappedGradientReducer:
+    """`allreduce_gradients` started from INSIDE the backward pass: a post-accumulate hook per parameter counts a bucket's gradients
+    in, and the moment the last one lands the bucket is packed and its all-reduce enqueued (asynchronous: on RCCL the collective runs
+    on the communicator's own stream, ordered after the packing, while the compute stream carries on with the rest of backward) --
+    the exchange of the 64 MB buckets of the late layers hides under the backward of the early ones.  Same buckets (reverse
+    registration order), same averaging and the same zero-filling of parameters without a gradient as `allreduce_gradients`, with
+    which it agrees bit for bit (tests/test_distributed_cpu.py).  Buckets become ready in autograd's order, which is the same on every
+    rank for the same graph; whatever is incomplete when backward returns is launched by `finish()` in bucket order.
+
+        red = OverlappedGradientReducer(list(net.parameters()))
+        with red:                    # arms the hooks; a no-op without an initialised process group or with one rank
+            loss.backward()
+        # on exit: remaining buckets launched, all waited for, gradients averaged in place"""
+
+    def __init__(self, params, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self.active = False
+        self.launched = 0
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
+    def _hook(self, p):
+        if not self.active:
+            return
+        i = self.bucket_of[id(p)]
+        self.count[i] += 1
+        if self.count[i] == len(self.buckets[i]):
+            self._launch(i)
+
+    def _launch(self, i):
+        import torch.distributed as dist
+        bucket = self.buckets[i]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+        self.pending[i] = (flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched += 1
+
+    def __enter__(self):
+        self.world = self._world()
+        self.active = self.world > 1
+        self.count = [0] * len(self.buckets)
+        self.pending = {}
+        self.launched = 0
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        active, self.active = self.active, False
+        if not active or exc_type is not None:
+            return False
+        for i in range(len(self.buckets)):          # buckets some parameter of which never received a gradient
+            if i not in self.pending:
+                self._launch(i)
+        for i, bucket in enumerate(self.buckets):
+            flat, work = self.pending[i]
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+        self.pending = {}
+        return False
+
+
 def requires_grad(model, flag=True):
     for p in model.parameters():
         p.requires_grad_(flag)
@@ -86,6 +170,8 @@ class RestorationTrainer:
         self.accum = 0.5 ** (32 / (10 * 1000))
         accumulate(g_ema, generator, 0)
         self.generator_bytes = sum(p.numel() * p.element_size() for p in generator.parameters())
+        self.g_reducer = OverlappedGradientReducer(list(generator.parameters()), bucket_bytes)
+        self.d_reducer = OverlappedGradientReducer(list(discriminator.parameters()), bucket_bytes)
 
     @torch.no_grad()
     def front(self, low_img):
@@ -130,8 +216,8 @@ class RestorationTrainer:
         fake_pred, real_pred = self.D(self._aug(fake.detach())), self.D(self._aug(real_img.detach().clone()))
         d_loss = d_logistic_loss(real_pred, fake_pred)
         self.D.zero_grad(set_to_none=True)
-        d_loss.backward()
-        allreduce_gradients(list(self.D.parameters()), self.bucket_bytes)
+        with self.d_reducer:
+            d_loss.backward()
         self.d_optim.step()
         losses.update(d=d_loss.detach(), real_score=real_pred.mean().detach(), fake_score=fake_pred.mean().detach())
         if self.ada is not None:
@@ -141,8 +227,8 @@ class RestorationTrainer:
             pred = self.D(self._aug(x))
             r1_loss = d_r1_loss(pred, x)
             self.D.zero_grad(set_to_none=True)
-            (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * pred[0]).backward()
-            allreduce_gradients(list(self.D.parameters()), self.bucket_bytes)
+            with self.d_reducer:
+                (self.r1 / 2 * r1_loss * self.d_reg_every + 0 * pred[0]).backward()
             self.d_optim.step()
             losses["r1"] = r1_loss.detach()
         # ---- generator
@@ -158,8 +244,9 @@ class RestorationTrainer:
             t = self.id_loss(fake, real_img.detach()) * self.id_weight
             losses["g_id_loss"], g_loss = t.detach(), g_loss + t
         self.G.zero_grad(set_to_none=True)
-        g_loss.backward()
-        losses["grad_buckets"] = allreduce_gradients(list(self.G.parameters()), self.bucket_bytes)
+        with self.g_reducer:
+            g_loss.backward()
+        losses["grad_buckets"] = self.g_reducer.launched
         self.g_optim.step()
         accumulate(self.G_ema, self.G, self.accum)
         return losses
@@ -188,6 +275,7 @@ class CodeDiffuserTrainer:
         for p in self.params:
             p.requires_grad_(True)
         self.optim = torch.optim.Adam(self.params, lr=lr * ratio, betas=(0 ** ratio, 0.99 ** ratio))
+        self.reducer = OverlappedGradientReducer(self.params, bucket_bytes)
 
     def step(self, low_img, real_img, low_latent=None, target=None, q_noise=None, gen_noise=None):
         """low_img / real_img in [-1, 1] on the device.  low_latent / target: precomputed codes (tests); q_noise / gen_noise: the
@@ -213,8 +301,8 @@ class CodeDiffuserTrainer:
                 losses["latent_id_loss"], loss = t.detach(), loss + t
         for p in self.params:
             p.grad = None
-        loss.backward()
-        allreduce_gradients(self.params, self.bucket_bytes)
+        with self.reducer:
+            loss.backward()
         self.optim.step()
         losses["pred_latent"] = pred.detach()
         return losses
