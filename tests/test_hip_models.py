@@ -677,6 +677,17 @@ def test_training_step_size64():
         l2 = tr2.step(0, low, real, de_feats=de, latent=lat)
     assert all(torch.isfinite(torch.as_tensor(v)).all() for v in l2.values()) and "r1" in l2
     assert not torch.equal(dict(G.named_parameters())[k], gk)
+    # BASELINE configs[4] as written: + 0.5 LPIPS-VGG + 0.1 identity (both frozen, random init): the two terms are reported, finite,
+    # and their gradient reaches the generator (the same batch, the same networks: the G loss differs by exactly the two terms)
+    from vspbfr_amd.id_loss import IDLoss
+    from vspbfr_amd.lpips import PerceptualLoss
+    tr3 = RestorationTrainer(G, G_ema, D, mixing=0.0, percept_loss=PerceptualLoss().to(DEV), percept_weight=0.5,
+                             id_loss=IDLoss(None, device=DEV), id_weight=0.1)
+    with torch.enable_grad():
+        l3 = tr3.step(1, low, real, de_feats=de, latent=lat)
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in l3.values())
+    assert float(l3["g_percept_loss"]) > 0 and float(l3["g_id_loss"]) >= 0
+    assert all(not p_.requires_grad for p_ in tr3.percept_loss.parameters()) and all(not p_.requires_grad for p_ in tr3.id_loss.parameters())
 
 
 def test_ada_augment_golden(golden):

@@ -200,6 +200,7 @@ class PerceptualLoss(nn.Module):
         if vgg_weights is not None:
             load_vgg16_features(self.net.net, vgg_weights)
         self.net.eval()
+        self.net.requires_grad_(False)      # a frozen metric: the `lin` layers included (the reference leaves theirs trainable but never steps them)
 
     def forward(self, pred, target, normalize=False, weight_map=None):
         if weight_map is not None:
