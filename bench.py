@@ -50,7 +50,78 @@ PRESETS = {  # BASELINE.json configs[1..3]
     "c2": dict(batch=8, timesteps=50, sampler="ddpm", conv_dtype="f32"),
     "c3": dict(batch=16, timesteps=50, sampler="ddim", ddim_steps=25, conv_dtype="bf16", act_bf16=True),
     "c4": dict(batch=16, timesteps=50, sampler="ddpm", conv_dtype="f32"),
+    # configs[4]: the restoration_train.py iteration, data parallel, 4 images per GPU (batch 32 on 8 GPUs); a different metric
+    # (training images/s), reported by train_bench() below -- the default line stays the inference metric of BASELINE.json
+    "c5": dict(batch=4, timesteps=4, train=True),
 }
+
+
+def train_bench(args, world, rank, dev):
+    """BASELINE configs[4]: `restoration_train.py` iterations (D step, G step with LPIPS-VGG x 0.5 + ArcFace ID x 0.1, Adam, EMA; the
+    R1 regulariser on its every-16th schedule), frozen front through the inference kernels, one process per GPU, gradients
+    all-reduced over RCCL from inside backward (train_step.OverlappedGradientReducer).  Random-init networks, keyed synthetic batch.
+    Same timing contract as the inference line: W warm-up iterations, K timed ones between barrier + synchronize, max over ranks."""
+    import copy
+    import torch.distributed as dist
+    from vspbfr_amd import hip_ops
+    from vspbfr_amd.discriminator import Discriminator
+    from vspbfr_amd.id_loss import IDLoss
+    from vspbfr_amd.lpips import PerceptualLoss
+    from vspbfr_amd.train_step import RestorationTrainer
+    B = args.batch
+    pipe = build_pipeline(dev, args.timesteps, False)          # T = 4: load_ddpm's default in restoration_train.py
+    G = pipe.generator
+    torch.manual_seed(1)                                        # the same initial weights on every rank
+    D = Discriminator(512).to(dev)
+    tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9,
+                            percept_loss=PerceptualLoss().to(dev), percept_weight=0.5, id_loss=IDLoss(None, device=dev), id_weight=0.1)
+    low, real = hip_ops.keyed_fill([(B, 3, 512, 512), (B, 3, 512, 512)], [hip_ops.SEG_LQ, 60], args.seed, rank * B,
+                                   dist="uniform", device=dev)
+    G.train()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    it = [0]
+
+    def run(n):
+        for _ in range(n):
+            it[0] += 1
+            tr.step(it[0], low, real)                           # iterations 1 .. : the R1 pass falls on every 16th
+    run(args.warmup)
+    prof = hip_ops.ConvProfiler()
+    hip_ops.PROFILER = prof
+    run(1)
+    hip_ops.PROFILER = None
+    sync()
+    fl, conv_ms, n_launch = prof.summary()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        print(json.dumps({
+            "metric": "restoration_train.py images/sec (512x512, RestoreNet + Discriminator fwd/bwd + LPIPS + id_loss + Adam + EMA)",
+            "value": round(world * B / ms * 1e3, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: restoration_train.py iteration, %d images per GPU, 512x512, frozen e4e + "
+                                   "Code_diffuser(T=4) + StyleGAN2 prior front, random-init weights, RCCL gradient all-reduce "
+                                   "from inside backward (64 MB buckets)" % B, "global_batch": world * B},
+            "roofline": {"bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(fl / conv_ms / 1e9 / 157.3, 3), "traffic": None,
+                         "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks)",
+                         "launches": n_launch, "kernel_ms": round(conv_ms, 1),
+                         "measured": "HIP events per launch on the launch stream over one untimed iteration"},
+            "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def launch_check(args, world, rank):
@@ -197,6 +268,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    if getattr(args, "train", False):
+        raise SystemExit(train_bench(args, world, rank, dev))
     from vspbfr_amd import hip_ops
     from vspbfr_amd.pipeline import gather_restored
     hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
