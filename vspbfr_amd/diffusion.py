@@ -260,7 +260,8 @@ class My_DDPM(nn.Module):
         `condi_in`; returns the last denoised latent.  x_T_owned: the caller hands over a scratch tensor (the pipeline's keyed
         draw) that the chain may update in place -- no protective copy."""
         if training:
-            raise RuntimeError("My_DDPM (vspbfr_amd) implements the inference chain only")
+            raise RuntimeError("My_DDPM.forward is the fused inference chain; the training-mode forward of code_diffuser_train.py is "
+                               "vspbfr_amd.training.ddpm_training_forward(ddpm, x, condi_in)")
         cond = condi_in.contiguous()
         B, n_tok = cond.shape[0], cond.shape[1]
         x = x_T.contiguous() if x_T is not None else torch.randn(cond.shape, device=cond.device)
