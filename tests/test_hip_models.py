@@ -436,6 +436,68 @@ def test_config_c2_full_size():
     assert torch.equal(looped["restored"], out["restored"])
 
 
+def test_config_c4_per_gpu_share_full_size():
+    """BASELINE.json configs[3], one rank's share: 16 images, 512^2, 50-step DDPM, fp32 -- the batch the 8-GPU run gives every GPU.
+    Rank r of 8 owns global images [16 r, 16 r + 16): the batch of rank 3 here; two of its images against their batch-1 runs at their
+    GLOBAL indices (what makes the all-gathered result independent of the world size), the whole batch through the two-stream loop,
+    and `shard_range` laying the 128 images out over 8 ranks."""
+    from vspbfr_amd import hip_ops as H
+    from vspbfr_amd.pipeline import shard_range
+    B, T, seed, world, rank = 16, 50, 31, 8, 3
+    lo, hi = shard_range(world * B, rank, world)
+    assert (lo, hi) == (rank * B, (rank + 1) * B)
+    pipe = build_pipeline(T=T, linear_start=1e-4, linear_end=2e-2, with_sample=True)
+    pipe.noise_seed = seed
+    lq = H.keyed_fill([(B, 3, 512, 512)], [H.SEG_LQ], seed, lo, dist="uniform")[0]
+    out = pipe(lq, image_index0=lo)
+    assert out["restored"].shape == (B, 3, 512, 512) and torch.isfinite(out["restored"]).all()
+    e_one = 0.0
+    for b in (0, 11):
+        one = pipe(lq[b:b + 1].contiguous(), image_index0=lo + b)
+        e_one = max(e_one, maxerr(one["restored"], out["restored"][b:b + 1]))
+    looped = list(pipe.run_batches([(lq, lo)]))[0]
+    print(f"C4 share: image vs its batch-1 run {e_one:.2e}")
+    assert e_one < 5e-5      # (batch 16 and batch 1 run different tiles: summation order, see test_pipeline_keyed_noise_is_shard_invariant)
+    assert torch.equal(looped["restored"], out["restored"])
+
+
+def test_config_c5_training_iteration_full_size():
+    """BASELINE.json configs[4], one rank's share: the restoration_train.py iteration at 512^2, 4 images (batch 32 on 8 GPUs), with the
+    frozen front (e4e, Code_diffuser T = 4, StyleGAN2 prior) through the inference kernels, LPIPS-VGG x 0.5 + ArcFace ID x 0.1, Adam
+    and EMA; an R1 iteration and a plain one.  Finite losses, all three loss terms present, every discriminator parameter and
+    (almost) every generator parameter moved, the loss networks and the front did not."""
+    import copy
+    from vspbfr_amd.discriminator import Discriminator
+    from vspbfr_amd.id_loss import IDLoss
+    from vspbfr_amd.lpips import PerceptualLoss
+    from vspbfr_amd.train_step import RestorationTrainer
+    B = 4
+    pipe = build_pipeline(T=4, with_sample=False)
+    G = pipe.generator
+    torch.manual_seed(3)
+    D = Discriminator(512).to(DEV)
+    tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9,
+                            percept_loss=PerceptualLoss().to(DEV), percept_weight=0.5, id_loss=IDLoss(None, device=DEV), id_weight=0.1)
+    low, real = dev(cases.image_batch("c5/low", B, 512)), dev(cases.image_batch("c5/real", B, 512))
+    g0 = {k: v.detach().clone() for k, v in G.named_parameters()}
+    d0 = {k: v.detach().clone() for k, v in D.named_parameters()}
+    front0 = [v.detach().clone() for v in list(pipe.psp.parameters())[:3]] + [v.detach().clone() for v in list(pipe.diffusion.parameters())[:3]]
+    G.train()
+    with torch.enable_grad():
+        l0 = tr.step(16, low, real)          # carries the R1 regulariser
+        l1 = tr.step(17, low, real)
+    G.eval()
+    for l in (l0, l1):
+        assert all(torch.isfinite(torch.as_tensor(v)).all() for v in l.values()), l
+        assert {"d", "g", "g_percept_loss", "g_id_loss"} <= set(l)
+    assert "r1" in l0 and "r1" not in l1
+    assert all(not torch.equal(v, d0[k]) for k, v in D.named_parameters())
+    moved = sum(not torch.equal(v, g0[k]) for k, v in G.named_parameters())
+    assert moved >= len(g0) - 2
+    now = list(pipe.psp.parameters())[:3] + list(pipe.diffusion.parameters())[:3]
+    assert all(torch.equal(a, b) for a, b in zip(front0, now))
+
+
 def test_config_c3_full_size():
     """BASELINE.json configs[2] exactly: batch 16, 512^2, DDIM S = 25 on T = 50, bf16 kernels.  The fp32 HIP run of the same
     step is the yardstick: (a) its DDIM chain against the oracle's sampler on the same codes; (b) the bf16 configuration's
