@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, cons
     oy0 = ty_i * TOH;
     ox0 = tx_i * TOW;
   };
+  // Elements ix .. ix+3 of a row of `w` elements (w >= 4) as ONE 4-element load at a clamped address plus a register shift: no
+  // branch around a load.  A divergent scalar-fallback branch for the quads the image border cuts made the compiler wait for
+  // every load in flight at each join (`s_waitcnt vmcnt(0)` between the three window loads of a thread: three dependent round
+  // trips instead of one -- the same finding as in conv_wgrad.hip).  Positions outside [0, w) come back as zeros.
+  auto quad = [&](const T* row, int ix, int w, bool row_ok) -> f32x4u {
+    const int ixc = min(max(ix, 0), w - 4);
+    f32x4u q = vsp::Elem<T>::load4(row + ixc);
+    const int sh = ix - ixc;                 // > 0: cut by the right border, < 0: by the left one
+    const int a = sh < 0 ? -sh : sh;
+    if (sh > 0) {
+      if (a & 1) q = f32x4u{q[1], q[2], q[3], 0.f};
+      if (a & 2) q = f32x4u{q[2], q[3], 0.f, 0.f};
+    } else if (sh < 0) {
+      if (a & 1) q = f32x4u{0.f, q[0], q[1], q[2]};
+      if (a & 2) q = f32x4u{0.f, 0.f, q[0], q[1]};
+    }
+    return (row_ok && a < 4) ? q : f32x4u{0.f, 0.f, 0.f, 0.f};
+  };
   auto load_window = [&](int t, f32x4u (&v)[NLD]) {
     int plane, oy0, ox0;
     decode(t, plane, oy0, ox0);
@@ -101,20 +119,11 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, cons
     const T* xp = x + (int64_t)plane * in_h * in_w;
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
-      const int idx = threadIdx.x + 256 * it;
+      const int idx = min((int)threadIdx.x + 256 * it, TIH * TIW4 - 1);   // (threads past the window re-load its last quad and drop it)
       const int r = idx / TIW4, c4 = idx - r * TIW4;
       const int iy = iy0 + r, ix = ix0 + 4 * c4;
-      v[it] = f32x4u{0.f, 0.f, 0.f, 0.f};
-      if (idx < TIH * TIW4 && iy >= 0 && iy < in_h) {
-        const T* src = xp + (int64_t)iy * in_w + ix;
-        if (ix >= 0 && ix + 3 < in_w) {
-          v[it] = vsp::Elem<T>::load4(src);
-        } else {  // window crosses the left/right image border
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (ix + j >= 0 && ix + j < in_w) v[it][j] = vsp::Elem<T>::load1(src + j);
-        }
-      }
+      const int iyc = min(max(iy, 0), in_h - 1);
+      v[it] = quad(xp + (int64_t)iyc * in_w, ix, in_w, iy == iyc);
     }
   };
   // flipped taps -> registers (wave-uniform loads)
@@ -137,24 +146,22 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, cons
     for (int rr = 0; rr < RPT; ++rr) {
       nz[rr] = r1[rr] = r2[rr] = f32x4u{0.f, 0.f, 0.f, 0.f};
       const int oy = oyb + rr;
-      if (!epi.enabled || oy >= out_h || ox >= out_w) continue;
-      const int64_t o = ((int64_t)plane * out_h + oy) * out_w + ox;
-      const int64_t on = ((int64_t)b * out_h + oy) * out_w + ox;
+      if (!epi.enabled) continue;
+      // (clamped addresses, uniform branches only: a thread whose quad lies outside the image loads something valid and never stores)
+      const int oyc = min(oy, out_h - 1);
+      const bool rok = oy < out_h;
       const T* res1 = static_cast<const T*>(epi.res1);
       const T* res2 = static_cast<const T*>(epi.res2);
-      if (full) {
-        if (epi.noise) nz[rr] = *reinterpret_cast<const f32x4u*>(epi.noise + on);
-        if (res1) r1[rr] = vsp::Elem<T>::load4(res1 + o);
-        if (res2) r2[rr] = vsp::Elem<T>::load4(res2 + o);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ox + j < out_w) {
-            if (epi.noise) nz[rr][j] = epi.noise[on + j];
-            if (res1) r1[rr][j] = vsp::Elem<T>::load1(res1 + o + j);
-            if (res2) r2[rr][j] = vsp::Elem<T>::load1(res2 + o + j);
-          }
+      if (epi.noise) {
+        const float* nrow = epi.noise + ((int64_t)b * out_h + oyc) * out_w;
+        const int oxc = min(max(ox, 0), out_w - 4), sh = ox - oxc;
+        f32x4u q = *reinterpret_cast<const f32x4u*>(nrow + oxc);
+        if (sh & 1) q = f32x4u{q[1], q[2], q[3], 0.f};
+        if (sh & 2) q = f32x4u{q[2], q[3], 0.f, 0.f};
+        nz[rr] = (rok && sh < 4) ? q : f32x4u{0.f, 0.f, 0.f, 0.f};
       }
+      if (res1) r1[rr] = quad(res1 + ((int64_t)plane * out_h + oyc) * out_w, ox, out_w, rok);
+      if (res2) r2[rr] = quad(res2 + ((int64_t)plane * out_h + oyc) * out_w, ox, out_w, rok);
     }
     float pscale = 1.f, nw = 0.f, ab = 0.f;
     if (epi.enabled) {
