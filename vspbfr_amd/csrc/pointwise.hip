@@ -39,28 +39,51 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
 #pragma unroll
   for (int co = 0; co < CO; ++co) acc[co] = f32x4u{0.f, 0.f, 0.f, 0.f};
   constexpr int UN = 8;
-  for (int c0 = 0; c0 < Cin; c0 += UN) {
-    f32x4u v[UN];
+  if ((HW & 3) == 0 && Cin % UN == 0) {
+    // The shape every layer of the path has: whole quads, whole groups of 8 channels.  No branch around a load (a divergent `full`
+    // test per load made the compiler wait for the loads in flight at every join: the 8 loads of a group left one by one), and the
+    // next group is requested before the FMAs of the current one (clamped channel index: the last group re-reads itself).
+    f32x4u v[UN], n[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      v[u] = f32x4u{0.f, 0.f, 0.f, 0.f};
-      if (c0 + u < Cin) {
-        const TX* src = xb + (int64_t)(c0 + u) * HW;
-        if (full) {
-          v[u] = vsp::Elem<TX>::load4(src);
-        } else {
-          for (int j = 0; j < 4 && p0 + j < HW; ++j) v[u][j] = vsp::Elem<TX>::load1(src + j);
+    for (int u = 0; u < UN; ++u) v[u] = vsp::Elem<TX>::load4(xb + (int64_t)u * HW);
+    for (int c0 = 0; c0 < Cin; c0 += UN) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) n[u] = vsp::Elem<TX>::load4(xb + (int64_t)min(c0 + UN + u, Cin - 1) * HW);
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const float wv = wl[co * Cin + c0 + u];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv, acc[co][j]);
+        }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = n[u];
+    }
+  } else {
+    for (int c0 = 0; c0 < Cin; c0 += UN) {
+      f32x4u v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        v[u] = f32x4u{0.f, 0.f, 0.f, 0.f};
+        if (c0 + u < Cin) {
+          const TX* src = xb + (int64_t)(c0 + u) * HW;
+          if (full) {
+            v[u] = vsp::Elem<TX>::load4(src);
+          } else {
+            for (int j = 0; j < 4 && p0 + j < HW; ++j) v[u][j] = vsp::Elem<TX>::load1(src + j);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (c0 + u >= Cin) break;
+      for (int u = 0; u < UN; ++u) {
+        if (c0 + u >= Cin) break;
 #pragma unroll
-      for (int co = 0; co < CO; ++co) {
-        const float wv = wl[co * Cin + c0 + u];
+        for (int co = 0; co < CO; ++co) {
+          const float wv = wl[co * Cin + c0 + u];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv, acc[co][j]);
+          for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv, acc[co][j]);
+        }
       }
     }
   }
@@ -78,8 +101,10 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
       // models/RestoreNet.py:100-118): zero insertion leaves one tap per parity and axis, 2 x 2 taps of the half-size map
       const int Hh = (int)(HW / W), hh = Hh >> 1, hw = W >> 1;
       const float* sp = up_src + ((int64_t)b * CO + co) * hh * hw;
-      for (int j = 0; j < 4 && p0 + j < HW; ++j) {
-        const int oy = (int)((p0 + j) / W), ox = (int)((p0 + j) - (int64_t)oy * W);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {      // (clamped gathers, validity as a factor: no branch around the 16 loads of a quad)
+        const int64_t pj = p0 + j < HW ? p0 + j : HW - 1;
+        const int oy = (int)(pj / W), ox = (int)(pj - (int64_t)oy * W);
         float a = 0.f;
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty) {
@@ -87,7 +112,9 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
 #pragma unroll
           for (int tx = 0; tx < 2; ++tx) {
             const int kx = (ox & 1) + 2 * tx, sx = (ox + kx - 2) >> 1;
-            if (sy >= 0 && sy < hh && sx >= 0 && sx < hw) a = fmaf(up_k[(3 - ky) * 4 + (3 - kx)], sp[sy * hw + sx], a);
+            const bool ok = sy >= 0 && sy < hh && sx >= 0 && sx < hw;
+            const int syc = min(max(sy, 0), hh - 1), sxc = min(max(sx, 0), hw - 1);
+            a = fmaf(ok ? up_k[(3 - ky) * 4 + (3 - kx)] : 0.f, sp[syc * hw + sxc], a);
           }
         }
         r[j] += a;
