@@ -403,6 +403,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   constexpr int EPT = ECO * ETILE / NTHR;  // (channel, tile) pairs per thread and pass
   typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
   const bool vec2 = d == 1 && p.r1s <= 1 && p.r2s <= 1;  // the two pixels of a tile row are neighbours in memory
+  const bool pairs = vec2 && (p.OW & 1) == 0 && p.OW >= 2;
 #pragma unroll
   for (int mb0 = 0; mb0 < MBW; mb0 += EMB) {
 #pragma unroll
@@ -436,9 +437,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
           t1[nu] = m[4 + nu] - m[8 + nu] - m[12 + nu];
         }
         const float yv[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
+        // No load sits behind a divergent branch (a ragged channel tile, an edge tile): coordinates are clamped, only the STORE is
+        // predicated.  With `continue` / edge tests in front of them the compiler waited for every load in flight at each join --
+        // the six per-channel operands and the noise / residual pairs of a thread left one round trip after the other.
         const int cgi = co0 + mb0 * 16 + e_co;  // channel within the group
-        if (cgi >= p.cout_g) continue;
-        const int cg = g * p.cout_g + cgi;
+        const bool cok = cgi < p.cout_g;
+        const int cg = g * p.cout_g + (cok ? cgi : p.cout_g - 1);
         const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
         const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
         const int cbase = cg * y_plane;
@@ -449,19 +453,31 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
           v = (v > 0.f ? v : v * sl2) * p.g2;
           return v + r1v + r2v;
         };
+        if (pairs) {   // (uniform) even output width: a tile's two pixels are a whole 8-byte pair or lie outside together
+          f32x2u nz[2] = {{0.f, 0.f}, {0.f, 0.f}}, r1v[2] = {{0.f, 0.f}, {0.f, 0.f}}, r2v[2] = {{0.f, 0.f}, {0.f, 0.f}};
+          int ro[2];
+          bool inside[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int oy = (sy + i) * d + ry, ox = sx;
-          if (oy >= p.OH || ox >= p.OW) continue;
-          const int ro = cbase + oy * p.y_w + ox;
-          if (vec2 && ox + 1 < p.OW) {
-            f32x2u nz = {0.f, 0.f}, r1v = {0.f, 0.f}, r2v = {0.f, 0.f};
-            if (p.nzs) nz = *reinterpret_cast<const f32x2u*>(nzp + oy * p.OW + ox);
-            if (p.r1s) r1v = *reinterpret_cast<const f32x2u*>(r1b + ro);
-            if (p.r2s) r2v = *reinterpret_cast<const f32x2u*>(r2b + ro);
-            f32x2u o2 = {fin(yv[i][0], nz[0], r1v[0], r2v[0]), fin(yv[i][1], nz[1], r1v[1], r2v[1])};
-            *reinterpret_cast<f32x2u*>(yb + ro) = o2;
-          } else {
+          for (int i = 0; i < 2; ++i) {
+            const int oy = (sy + i) * d + ry;
+            inside[i] = cok && oy < p.OH && sx < p.OW;
+            const int oyc = min(oy, p.OH - 1), oxc = min(sx, p.OW - 2);
+            ro[i] = cbase + oyc * p.y_w + oxc;
+            if (p.nzs) nz[i] = *reinterpret_cast<const f32x2u*>(nzp + oyc * p.OW + oxc);
+            if (p.r1s) r1v[i] = *reinterpret_cast<const f32x2u*>(r1b + ro[i]);
+            if (p.r2s) r2v[i] = *reinterpret_cast<const f32x2u*>(r2b + ro[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const f32x2u o2 = {fin(yv[i][0], nz[i][0], r1v[i][0], r2v[i][0]), fin(yv[i][1], nz[i][1], r1v[i][1], r2v[i][1])};
+            if (inside[i]) *reinterpret_cast<f32x2u*>(yb + ro[i]) = o2;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int oy = (sy + i) * d + ry, ox = sx;
+            if (!cok || oy >= p.OH || ox >= p.OW) continue;
+            const int ro = cbase + oy * p.y_w + ox;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int oxj = ox + j * d;
