@@ -450,14 +450,17 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     for (int nb = 0; nb < NB; ++nb) {
       const int n = (wn * NB + nb) * 32 + l32;
       const int m = oy0 + (n >> twl), c = ox0 + (n & (TW - 1));
-      if (m > p.H || c > p.W) continue;
+      // (no `continue` in front of the operand loads: a divergent branch there makes the compiler wait for every load in flight at the
+      //  join, and the 6 x 16 x MB per-channel operands of a lane then leave one round trip after the other; only the stores are predicated)
+      const bool pos_ok = m <= p.H && c <= p.W;
       const bool pair = c < p.W;  // column 2c + 1 exists
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int cg = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
-          if (cg >= p.cout_g) continue;
+          const int cg_ = co0 + (wm * MB + mb) * 32 + 8 * (i >> 2) + 4 * kh + (i & 3);
+          const bool ch_ok = cg_ < p.cout_g;
+          const int cg = ch_ok ? cg_ : p.cout_g - 1;
           const int co = g * p.cout_g + cg;
           const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
           const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           };
 #pragma unroll
           for (int py = 0; py < 2; ++py) {
-            if (m + py > p.H) continue;  // row 2m + 1 exists only for m < H
+            if (!pos_ok || !ch_ok || m + py > p.H) continue;  // row 2m + 1 exists only for m < H
             const int yo = (2 * m + py) * p.y_w + 2 * c;
             const float v0 = fin(acc[mb][nb * 4 + py * 2][i]), v1 = fin(acc[mb][nb * 4 + py * 2 + 1][i]);
             if constexpr (IOB) {
@@ -501,14 +504,15 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     __syncthreads();
     auto operands = [&](int row, int& co, float& os, float& cb, float& b2, float& sl2) -> bool {
       const int cg = co0 + ((row >> 5) * MB + mb) * 32 + (row & 31);
-      if (cg >= p.cout_g) return false;
-      co = g * p.cout_g + cg;
+      const bool ok = cg < p.cout_g;
+      co = g * p.cout_g + (ok ? cg : p.cout_g - 1);   // (clamped: the loads below are unconditional, the store is not)
       os = osp[co * p.oss] * p.csp[co * p.css];
       cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
       b2 = p.b2p[co * p.b2s];
       sl2 = p.s2p[co * p.s2s];
-      return true;
+      return ok;
     };
+    const bool quads = (p.OW & 3) == 0 && p.OW >= 4;   // (uniform) a lane's four pixels are inside or outside the row together
     {
 #pragma unroll 2
       for (int it = 0; it < EIT; ++it) {
@@ -523,11 +527,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
         }
         int co;
         float os, cb, b2, sl2;
-        if (!operands(row, co, os, cb, b2, sl2)) continue;
+        const bool ch_ok = operands(row, co, os, cb, b2, sl2);
         const f32x4 av = *reinterpret_cast<const f32x4*>(El + row * NPIX + 4 * q);
         const int n = 4 * q;
         const int oy = (oy0 + (n >> twl)) * d + ry, ox = ox0 + (n & (TW - 1));   // polyphase rows, dense columns
-        if (oy >= p.OH || ox >= p.OW) continue;
         auto fin = [&](float v, float nzv, float r1v, float r2v) {
           v = v * os + cb;
           v = (v > 0.f ? v : v * s1) * g1;
@@ -535,6 +538,21 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           v = (v > 0.f ? v : v * sl2) * g2;
           return v + r1v + r2v;
         };
+        if (quads) {
+          // every load on clamped coordinates, behind uniform tests only; the store alone is predicated (see the transposed branch)
+          const bool inside = ch_ok && oy < p.OH && ox < p.OW;
+          const int oyc = min(oy, p.OH - 1), oxc = min(ox, p.OW - 4);
+          const int ro = co * y_plane + oyc * p.y_w + oxc;
+          f32x4u nzv = {0.f, 0.f, 0.f, 0.f}, r1v = nzv, r2v = nzv;
+          if (has_nz) nzv = *reinterpret_cast<const f32x4u*>(nzp + oyc * p.OW + oxc);
+          if (has_r1) r1v = vsp::Elem<AT>::load4(r1b + ro);
+          if (has_r2) r2v = vsp::Elem<AT>::load4(r2b + ro);
+          const f32x4u o4 = {fin(av[0], nzv[0], r1v[0], r2v[0]), fin(av[1], nzv[1], r1v[1], r2v[1]),
+                             fin(av[2], nzv[2], r1v[2], r2v[2]), fin(av[3], nzv[3], r1v[3], r2v[3])};
+          if (inside) vsp::Elem<AT>::store4(yb + ro, o4);
+          continue;
+        }
+        if (!ch_ok || oy >= p.OH || ox >= p.OW) continue;
         const int ro = co * y_plane + oy * p.y_w + ox;
         if (ox + 3 < p.OW) {
           f32x4u nzv = {0.f, 0.f, 0.f, 0.f}, r1v = nzv, r2v = nzv;
