@@ -308,14 +308,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
         if (i < plane) dst[i] = ((pin >> e) & 1u) ? fmaf(preg[pc][e], psc[pc], psh[pc]) : 0.f;
       }
       if (plane > 64 * PMAX) {  // large halos (dilation 4/8, stride 2): the tail of the plane is loaded directly
+        // Uniform trip count, clamped offsets, the in-image test as a select AFTER the load: with the load inside a divergent test
+        // (and a per-lane loop bound) the compiler waited for each of these loads before issuing the next one.
         const bool chok = ci < p.Cin;
         const float* xc = xb + (int64_t)(chok ? ci : 0) * chw;
 #pragma unroll 4
-        for (int i = lane + 64 * PMAX; i < plane; i += 64) {
+        for (int i0 = 64 * PMAX; i0 < plane; i0 += 64) {
+          const int i = i0 + lane;
           int off;
-          float v = 0.f;
-          if (chok && patch_src(i, off)) v = fmaf(xc[off], psc[pc], psh[pc]);
-          dst[i] = v;
+          const bool in = patch_src(i < plane ? i : plane - 1, off) && chok && i < plane;
+          const float xv = xc[in ? off : 0];
+          if (i < plane) dst[i] = in ? fmaf(xv, psc[pc], psh[pc]) : 0.f;
         }
       }
     }
