@@ -184,6 +184,17 @@ int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_chunk(void);
 int vsp_conv2d_winograd_mbw(int cout_g);
+/* Weight re-layout on the device (a trained weight is re-packed every iteration: restoration_train.py:123-131, 207-212 step the
+ * optimizers between passes).  vsp_pack_weight_f32: OIHW weight (G*cout_g, cin, KH, KW) -> the layout of vsp_conv_params.w,
+ * wp[g][tap][ci][co_g] = scale * w[g*cout_g + co_g][ci][tap'] with tap' = KH*KW-1-tap when `flip`.  `adjoint` (G = 1) packs the
+ * weight of the data gradient instead: the roles of the channels exchanged, wp[tap][i = co][o = ci] = scale * w[co][ci][tap']
+ * (replaces weight.transpose(0,1).flip(2,3) + packing in the reference's conv2d_gradfix.py:152-190 backward).
+ * vsp_winograd_weight_f32: packed weight -> the transformed weight of vsp_conv2d_winograd_f32 in its fragment order
+ * (vsp_winograd_weight_floats() floats); sums in fp64, rounded once. */
+int vsp_pack_weight_f32(float* wp, const float* w, int G, int cout_g, int cin, int KH, int KW, int adjoint, int flip, float scale,
+                        vsp_stream_t stream);
+size_t vsp_winograd_weight_floats(int G, int cin, int cout_g);
+int vsp_winograd_weight_f32(float* U, const float* wp, int G, int cin, int cout_g, vsp_stream_t stream);
 int vsp_conv2d_num_configs(void);
 const char* vsp_conv2d_config_name(int i);
 

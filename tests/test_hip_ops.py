@@ -1090,3 +1090,42 @@ def test_conv_every_config_agrees(H, cfg):
         ran += 1
         close(y, ref, 2e-5, 2e-5, "auto" if i == 0 else lib.vsp_conv2d_config_name(i - 1).decode())
     assert ran > 10
+
+
+@pytest.mark.parametrize("cout,cin,k,groups", [(64, 48, 3, 1), (3, 512, 1, 1), (35, 7, 3, 1), (64, 3, 7, 1), (96, 20, 3, 4), (512, 512, 3, 1)])
+def test_pack_weight_kernel(H, cout, cin, k, groups):
+    """vsp_pack_weight_f32 against the layout statement wp[g][tap][ci][co_g] = scale * w[g cout_g + co_g][ci][tap'] in torch --
+    straight, tap-flipped, and the adjoint form (channels exchanged: the data-gradient weight) -- bit-exact (one fp32 multiply)."""
+    g_ = torch.Generator().manual_seed(12)
+    w = torch.randn(cout, cin, k, k, generator=g_)
+    scale = 0.37
+    for flip in (False, True):
+        got = H.pack_weight(dev(w), groups, flip=flip, scale=scale).cpu()
+        ref = H.pack_weight(w, groups, flip=flip, scale=scale)          # host tensors take the torch expression
+        assert got.shape == ref.shape and torch.equal(got, ref), f"pack flip={flip}"
+        if groups == 1:
+            got = H.pack_weight(dev(w), adjoint=True, flip=flip, scale=scale).cpu()
+            wt = (w * scale).transpose(0, 1)
+            ref = (wt.flip(2, 3) if flip else wt).reshape(1, cin, cout, k * k).permute(0, 3, 2, 1).contiguous()
+            assert got.shape == ref.shape and torch.equal(got, ref), f"adjoint flip={flip}"
+    if groups == 1:
+        st = H.pack_weight_stack([dev(w), dev(w * 2)], adjoint=True, flip=True).cpu()
+        assert torch.equal(st[1], 2 * st[0]) and torch.equal(st[0], H.pack_weight(w, adjoint=True, flip=True)[0])
+
+
+@pytest.mark.parametrize("ng,cin,cout", [(1, 64, 64), (1, 6, 3), (4, 30, 24), (1, 130, 40), (2, 512, 128)])
+def test_winograd_weight_kernel(H, ng, cin, cout):
+    """vsp_winograd_weight_f32 against U = G g G^T in float64 (einsum), laid out in the fragment order include/vspbfr_hip.h states
+    for vsp_conv2d_winograd_f32, zero padding included."""
+    g_ = torch.Generator().manual_seed(13)
+    wp = torch.randn(ng, 9, cin, cout, generator=g_)
+    Gm = torch.tensor(((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0)), dtype=torch.float64)
+    U = torch.einsum("ay,bx,gyxio->gabio", Gm, Gm, wp.double().view(ng, 3, 3, cin, cout)).reshape(ng, 16, cin, cout)
+    ck, mb = H.lib.vsp_conv2d_winograd_chunk(), H.lib.vsp_conv2d_winograd_mbw(cout)
+    nch, nct = (cin + ck - 1) // ck, (cout + 16 * mb - 1) // (16 * mb)
+    Up = U.new_zeros(ng, 16, nch * ck, nct * 16 * mb)
+    Up[:, :, :cin, :cout] = U
+    ref = Up.view(ng, 8, 2, nch, 4, nct, mb, 16).permute(0, 5, 3, 1, 4, 7, 2, 6).float().contiguous().view(-1)
+    got = H.winograd_weight(dev(wp)).cpu()
+    assert got.numel() == ref.numel() == H.lib.vsp_winograd_weight_floats(ng, cin, cout)
+    close(got, ref, 1e-7, 1.2e-7, "winograd weight")

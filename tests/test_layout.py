@@ -65,9 +65,10 @@ def test_shard_range_covers_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_winograd_weight_fragment_layout_cpu():
-    """The host-side Winograd weight transform + fragment ordering (hip_ops.winograd_weight) against a numpy F(2x2,3x3)
-    evaluation that reads U back through the documented index formula of vsp_conv2d_winograd_f32 (no GPU needed)."""
+@pytest.mark.gpu
+def test_winograd_weight_fragment_layout():
+    """The Winograd weight transform + fragment ordering (hip_ops.winograd_weight -> vsp_winograd_weight_f32) against a numpy
+    F(2x2,3x3) evaluation that reads U back through the documented index formula of vsp_conv2d_winograd_f32."""
     import numpy as np
     import torch
     import torch.nn.functional as F
@@ -76,8 +77,8 @@ def test_winograd_weight_fragment_layout_cpu():
     rng = np.random.default_rng(5)
     for G, cin, cout_g, dils in ((1, 6, 20, (1,)), (4, 5, 16, (1, 2, 4, 8)), (1, 9, 70, (1,))):
         w = rng.standard_normal((G, cout_g, cin, 3, 3)).astype(np.float32)
-        wp = torch.stack([H.pack_weight(torch.from_numpy(w[g]))[0] for g in range(G)])
-        frag = H.winograd_weight(wp).numpy()
+        wp = H.pack_weight_stack([torch.from_numpy(w[g]).cuda() for g in range(G)])
+        frag = H.winograd_weight(wp).cpu().numpy()
         ck, mb = lib.vsp_conv2d_winograd_chunk(), lib.vsp_conv2d_winograd_mbw(cout_g)
         nch, ntile = (cin + ck - 1) // ck, (cout_g + 16 * mb - 1) // (16 * mb)
         assert frag.size == G * ntile * nch * 8 * 64 * 2 * mb

@@ -139,11 +139,14 @@ SIGNATURES = {
     "vsp_upfirdn2d_bf16": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
     "vsp_pointwise_bf16": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i64, _p],
     "vsp_keyed_fill_f32": [_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _i, C.c_uint64, _i64, _p, _i, _p],
+    "vsp_pack_weight_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
+    "vsp_winograd_weight_f32": [_p, _p, _i, _i, _i, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
-_SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)]}
+_SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)],
+          "vsp_winograd_weight_floats": [_i, _i, _i]}
 
 
 def _load():

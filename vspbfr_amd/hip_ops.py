@@ -324,11 +324,38 @@ def bf16x3_weight(wp):
     return parts.contiguous().view(-1)
 
 
-def pack_weight(weight, groups=1):
-    """(Cout, Cin, KH, KW) -> [G][KH*KW][Cin][Cout/G] contiguous."""
+def pack_weight(weight, groups=1, adjoint=False, flip=False, scale=1.0, out=None):
+    """(Cout, Cin, KH, KW) -> [G][KH*KW][Cin][Cout/G] contiguous, times `scale`, taps reversed when `flip`.  `adjoint` (one group):
+    the weight of the data gradient, channels exchanged: [KH*KW][i = Cout][o = Cin] (= packing weight.transpose(0, 1)).
+    Device weights are packed by vsp_pack_weight_f32 (one launch); the torch expression serves host tensors (layout tests)."""
     cout, cin, kh, kw = weight.shape
-    assert cout % groups == 0
-    return weight.reshape(groups, cout // groups, cin, kh * kw).permute(0, 3, 2, 1).contiguous()
+    assert cout % groups == 0 and (groups == 1 or not adjoint)
+    if weight.is_cuda:
+        w = _req(weight.detach().contiguous(), "weight")
+        shape = (1, kh * kw, cout, cin) if adjoint else (groups, kh * kw, cin, cout // groups)
+        wp = torch.empty(shape, device=w.device, dtype=torch.float32) if out is None else _req(out, "out")   # out: a slice of a group stack
+        assert tuple(wp.shape) == shape
+        check(lib.vsp_pack_weight_f32(_ptr(wp), _ptr(w), groups, cout // groups, cin, kh, kw, int(adjoint), int(flip), float(scale),
+                                      _stream()), "pack_weight")
+        return wp
+    w = weight * scale if scale != 1.0 else weight
+    if flip:
+        w = w.flip(2, 3)
+    if adjoint:
+        w = w.transpose(0, 1)
+        cout, cin = cin, cout
+    wp = w.reshape(groups, cout // groups, cin, kh * kw).permute(0, 3, 2, 1).contiguous()
+    return wp if out is None else out.copy_(wp)
+
+
+def pack_weight_stack(weights, adjoint=False, flip=False, scale=1.0):
+    """One packed weight with a group per entry of `weights` (equal shapes): the dilated branches of one layer."""
+    cout, cin, kh, kw = weights[0].shape
+    shape = (len(weights), kh * kw, cout, cin) if adjoint else (len(weights), kh * kw, cin, cout)
+    wp = torch.empty(shape, device=weights[0].device, dtype=torch.float32)
+    for i, w in enumerate(weights):
+        pack_weight(w, 1, adjoint, flip, scale, out=wp[i:i + 1])
+    return wp
 
 
 def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
@@ -340,25 +367,16 @@ def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out
     return (OH, OW) == (H, W) and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0)
 
 
-_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
-
-
 def winograd_weight(wp):
     """packed weights (G, 9, Cin, cout_g) -> U = G g G^T in the FRAGMENT order of vsp_conv2d_winograd_f32:
     [group][co tile][chunk][wave 8][lane 64][pp 2][mb MB] with position = 2 wave + pp, ci = CK chunk + (lane >> 4),
-    co = 16 MB tile + 16 mb + (lane & 15); Cin / cout_g zero-padded to multiples of CK / 16 MB.  Computed in float64."""
-    Gm = torch.tensor(_WINO_G, dtype=torch.float64, device=wp.device)
+    co = 16 MB tile + 16 mb + (lane & 15); Cin / cout_g zero-padded to multiples of CK / 16 MB.  Sums in float64, rounded once
+    (vsp_winograd_weight_f32: one launch -- a trained weight is transformed again every iteration)."""
+    wp = _req(wp, "packed weight")
     ng, cin, cout = wp.shape[0], wp.shape[2], wp.shape[3]
-    g = wp.double().view(ng, 3, 3, cin, cout)
-    U = torch.einsum("ay,bx,gyxio->gabio", Gm, Gm, g).reshape(ng, 16, cin, cout)
-    ck, mb = lib.vsp_conv2d_winograd_chunk(), lib.vsp_conv2d_winograd_mbw(cout)
-    assert ck == 4, "fragment layout below assumes one k-step per chunk"
-    nch, nct = (cin + ck - 1) // ck, (cout + 16 * mb - 1) // (16 * mb)
-    Up = U.new_zeros(ng, 16, nch * ck, nct * 16 * mb)
-    Up[:, :, :cin, :cout] = U
-    # [g][wave 8][pp 2][chunk][kq 4][tile][mb][lr 16] -> [g][tile][chunk][wave][kq][lr][pp][mb]
-    Up = Up.view(ng, 8, 2, nch, 4, nct, mb, 16).permute(0, 5, 3, 1, 4, 7, 2, 6)
-    return Up.float().contiguous().view(-1)
+    U = torch.empty(lib.vsp_winograd_weight_floats(ng, cin, cout), device=wp.device, dtype=torch.float32)
+    check(lib.vsp_winograd_weight_f32(_ptr(U), _ptr(wp), ng, cin, cout, _stream()), "winograd_weight")
+    return U
 
 
 def conv2d_out_size(H, W, pc):

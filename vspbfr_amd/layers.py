@@ -149,10 +149,10 @@ class ModulatedConv2d(_Cached):
 
     def packed(self):
         def build():
-            w = self._w_scaled()
+            w = H.pack_weight(self.weight[0], scale=self.scale)
             if self.upsample:  # one-pass stride-2 transposed conv: ordinary 3x3 packing
-                return H.PackedConv(H.pack_weight(w), 1, self.out_channel, self.in_channel, 3, 3, 1, (1,), (1,))
-            return H.PackedConv(H.pack_weight(w), 1, self.out_channel, self.in_channel, self.kernel_size, self.kernel_size,
+                return H.PackedConv(w, 1, self.out_channel, self.in_channel, 3, 3, 1, (1,), (1,))
+            return H.PackedConv(w, 1, self.out_channel, self.in_channel, self.kernel_size, self.kernel_size,
                                 2 if self.downsample else 1, (self.dilation,), (0 if self.downsample else self.padding,))
         return self._derive("packed", [self.weight], build)
 
@@ -248,7 +248,7 @@ class SMARTLayer(_Cached):
 
         def build():
             scale = self.ModulatedConv2ds[0].scale
-            wp = torch.stack([H.pack_weight((w[0] * scale).contiguous())[0] for w in ws]).contiguous()
+            wp = H.pack_weight_stack([w[0] for w in ws], scale=scale)
             pc = H.PackedConv(wp, len(RATES), self.out_channel // len(RATES), self.in_channel, 3, 3, 1, RATES, RATES)
             wsq = torch.cat([(w[0] ** 2).sum((2, 3)) for w in ws], 0).contiguous()
             return pc, wsq
@@ -257,7 +257,7 @@ class SMARTLayer(_Cached):
     def _fusion_pack(self):
         conv = self.fusion[0]
         return self._derive("fusion", [conv.weight], lambda: H.PackedConv(
-            H.pack_weight((conv.weight * conv.scale).contiguous()), 1, self.out_channel, self.out_channel, 3, 3, 1, (1,), (1,)))
+            H.pack_weight(conv.weight, scale=conv.scale), 1, self.out_channel, self.out_channel, 3, 3, 1, (1,), (1,)))
 
     def forward(self, x, style, noise=None):
         x = x.contiguous()
@@ -288,11 +288,11 @@ class LargeConvLayer(_Cached):
 
         def build():
             k = self.kernel_size
-            wp = torch.stack([H.pack_weight((m.weight * m.scale).contiguous())[0] for m in self.dilated_convs]).contiguous()
+            wp = H.pack_weight_stack([m.weight for m in self.dilated_convs], scale=self.dilated_convs[0].scale)
             pads = tuple(m.padding for m in self.dilated_convs)
             pc = H.PackedConv(wp, len(RATES), self.out_channel // len(RATES), self.in_channel, k, k, 1, RATES, pads)
             f = self.fusion[0]
-            pf = H.PackedConv(H.pack_weight((f.weight * f.scale).contiguous()), 1, self.out_channel, self.out_channel, 1, 1, 1,
+            pf = H.PackedConv(H.pack_weight(f.weight, scale=f.scale), 1, self.out_channel, self.out_channel, 1, 1, 1,
                               (1,), (0,))
             return pc, pf
         return self._derive("packs", ws + [self.fusion[0].weight], build)

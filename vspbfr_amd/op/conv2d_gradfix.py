@@ -49,8 +49,7 @@ def _convT_fwd(x, weight, groups):
     """conv_transpose2d(stride 2, padding 0), 3x3; weight (G*Cin_g, Cout_g, 3, 3)."""
     cg = x.shape[1] // groups
     if groups == 1:   # the one-pass transposed kernel (all four sub-pixel phases from one staged patch), whole batch in one launch
-        w_oihw = weight.transpose(0, 1).contiguous()
-        pc = hip_ops.PackedConv(hip_ops.pack_weight(w_oihw), 1, w_oihw.shape[0], cg, 3, 3, 1, (1,), (1,))
+        pc = hip_ops.PackedConv(hip_ops.pack_weight(weight, adjoint=True), 1, weight.shape[1], cg, 3, 3, 1, (1,), (1,))
         return hip_ops.conv_transpose2d_s2_fused(x.contiguous(), pc)
     outs = []
     for g in range(groups):
@@ -66,8 +65,21 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
     cout, cg, kh, kw = weight.shape
     if stride == 1:
         # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
+        if groups == 1 and not torch.is_grad_enabled():
+            # first-order pass: the adjoint weight is packed by one launch, once per weight version (a frozen loss network keeps
+            # it for the whole run; the product `weight * scale` of an equalised layer is a temporary and takes its packing with it)
+            key = (weight._version, weight.data_ptr(), padding, dilation)
+            cached = getattr(weight, "_vsp_adjoint", None)
+            if cached is None or cached[0] != key:
+                cached = (key, hip_ops.PackedConv(hip_ops.pack_weight(weight, adjoint=True, flip=True), 1, cg, cout, kh, kw, 1,
+                                                  (dilation,), (dilation * (kh - 1) - padding,)))
+                try:
+                    weight._vsp_adjoint = cached
+                except (AttributeError, RuntimeError):
+                    pass
+            return hip_ops.conv2d_packed(g.contiguous(), cached[1])
         if not weight.requires_grad and not torch.is_grad_enabled():
-            # frozen weight, first-order pass (the loss networks): the adjoint weight is built -- and packed -- once per version
+            # frozen grouped weight, first-order pass: the adjoint weight is built -- and packed -- once per version
             key = (weight._version, weight.data_ptr(), groups)
             cached = getattr(weight, "_vsp_adjoint", None)
             if cached is None or cached[0] != key:
@@ -85,8 +97,8 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
         # when H + 2 padding is even; padding 1 (the ResNet bottleneck of the identity loss) crops the border back off
         if groups == 1 and padding == 0 and not torch.is_grad_enabled():
             # first-order pass: the one-pass transposed kernel writes straight into the (H, W) gradient (no padded copy)
-            w_oihw = weight.transpose(0, 1).contiguous()       # conv_transpose2d reads (Cout, Cin, 3, 3) as (in, out): oihw = (Cin, Cout)
-            pc = hip_ops.PackedConv(hip_ops.pack_weight(w_oihw), 1, cg, cout, 3, 3, 1, (1,), (1,))
+            # conv_transpose2d reads (Cout, Cin, 3, 3) as (in, out): the adjoint packing of the weight as it lies
+            pc = hip_ops.PackedConv(hip_ops.pack_weight(weight, adjoint=True), 1, cg, cout, 3, 3, 1, (1,), (1,))
             return hip_ops.conv_transpose2d_s2_into(g.contiguous(), pc, x_shape[2:])
         dx = conv_transpose2d(g, weight, stride=2, padding=0, groups=groups)
         ph, pw = x_shape[2] + 2 * padding - dx.shape[2], x_shape[3] + 2 * padding - dx.shape[3]

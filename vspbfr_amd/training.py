@@ -74,14 +74,16 @@ def modulated_conv_grouped(x, conv, style, modulation=None):
 def _adjoint_pack(layer):
     """Packed weight of the data gradient of `layer` (cached per weight version on the layer)."""
     def build():
-        w = layer._w_scaled()                                         # (Cout, Cin, k, k), scale folded in
         k, d = layer.kernel_size, layer.dilation
         if layer.upsample:       # forward = transposed conv; adjoint = stride-2 conv of g, weight read as (out = ci, in = co)
-            return H.PackedConv(H.pack_weight(w.transpose(0, 1).contiguous()), 1, layer.in_channel, layer.out_channel, 3, 3, 2, (1,), (0,))
+            return H.PackedConv(H.pack_weight(layer.weight[0], adjoint=True, scale=layer.scale), 1, layer.in_channel, layer.out_channel,
+                                3, 3, 2, (1,), (0,))
         if layer.downsample:     # forward = stride-2 conv; adjoint = one-pass transposed conv (ordinary 3x3 packing of (out = ci, in = co))
-            return H.PackedConv(H.pack_weight(w.transpose(0, 1).contiguous()), 1, layer.in_channel, layer.out_channel, 3, 3, 1, (1,), (1,))
-        wt = w.transpose(0, 1).flip(2, 3).contiguous()                # stride 1: correlation with the flipped kernel, channels exchanged
-        return H.PackedConv(H.pack_weight(wt), 1, layer.in_channel, layer.out_channel, k, k, 1, (d,), (d * (k - 1) - layer.padding,))
+            return H.PackedConv(H.pack_weight(layer.weight[0], adjoint=True, scale=layer.scale), 1, layer.in_channel, layer.out_channel,
+                                3, 3, 1, (1,), (1,))
+        # stride 1: correlation with the flipped kernel, channels exchanged
+        return H.PackedConv(H.pack_weight(layer.weight[0], adjoint=True, flip=True, scale=layer.scale), 1, layer.in_channel,
+                            layer.out_channel, k, k, 1, (d,), (d * (k - 1) - layer.padding,))
     return layer._derive("adjoint", [layer.weight], build)
 
 
@@ -159,7 +161,7 @@ def _smart_adjoint_pack(layer):
         m0 = layer.ModulatedConv2ds[0]
         cg = layer.out_channel // len(ws)
         # true grouped conv over g: group i reads its branch's cg channels, writes Cin channels, dilation / padding of branch i
-        wp = torch.stack([H.pack_weight((w[0] * m0.scale).transpose(0, 1).flip(2, 3).contiguous())[0] for w in ws]).contiguous()
+        wp = H.pack_weight_stack([w[0] for w in ws], adjoint=True, flip=True, scale=m0.scale)
         dil = tuple(m.dilation for m in layer.ModulatedConv2ds)
         pad = tuple(m.dilation * (m.kernel_size - 1) - m.padding for m in layer.ModulatedConv2ds)
         return H.PackedConv(wp, len(ws), layer.in_channel, cg, 3, 3, 1, dil, pad, x_group_stride=cg)
