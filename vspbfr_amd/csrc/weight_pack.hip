@@ -12,27 +12,34 @@
 namespace {
 
 // Straight packing: o = output channel inside its group (fastest in Wp), i = input channel (fastest of the two in the source).
-// A 32 x 32 (i, o) tile per tap goes through LDS so that both the reads (along i, stride T) and the writes (along o) stay in
-// a few contiguous runs.
+// A 32 (o) x 32 (i) tile with up to 9 taps goes through LDS: the source is read as the contiguous (ci, tap) run of each output
+// channel, the destination written as runs along o.
+constexpr int kTapChunk = 9;
 __global__ __launch_bounds__(256) void pack_weight_kernel(float* __restrict__ wp, const float* __restrict__ w, int cout_g, int cin, int T,
                                                           int flip, float scale) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[kTapChunk][32][33];
   const int g = blockIdx.z, i0 = blockIdx.y * 32, o0 = blockIdx.x * 32;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* src = w + (int64_t)g * cout_g * cin * T;
   float* dst = wp + (int64_t)g * T * cin * cout_g;
-  for (int tap = 0; tap < T; ++tap) {
-    const int ts = flip ? T - 1 - tap : tap;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int o = o0 + ty + 8 * k, i = i0 + tx;
-      tile[tx][ty + 8 * k] = (o < cout_g && i < cin) ? src[((int64_t)o * cin + i) * T + ts] * scale : 0.f;
+  const int ni = min(32, cin - i0);
+  for (int t0 = 0; t0 < T; t0 += kTapChunk) {
+    const int nt = min(kTapChunk, T - t0);
+    for (int ol = wv; ol < 32; ol += 4) {                       // a wavefront per output channel: (ci, tap) run of ni * nt floats
+      const int o = o0 + ol;
+      if (o >= cout_g) break;
+      const float* row = src + ((int64_t)o * cin + i0) * T + t0;
+      for (int e = lane; e < ni * nt; e += 64) {
+        const int il = e / nt, tl = e - il * nt;
+        tile[tl][il][ol] = row[(int64_t)il * T + tl] * scale;
+      }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = i0 + ty + 8 * k, o = o0 + tx;
-      if (i < cin && o < cout_g) dst[((int64_t)tap * cin + i) * cout_g + o] = tile[ty + 8 * k][tx];
+    for (int r = ty; r < nt * 32; r += 8) {                     // rows (tap, i) of 32 output channels
+      const int tl = r >> 5, il = r & 31;
+      const int tap = flip ? T - 1 - (t0 + tl) : t0 + tl;
+      if (il < ni && o0 + tx < cout_g) dst[((int64_t)tap * cin + i0 + il) * cout_g + o0 + tx] = tile[tl][il][tx];
     }
     __syncthreads();
   }
