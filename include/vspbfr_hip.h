@@ -184,6 +184,11 @@ int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_chunk(void);
 int vsp_conv2d_winograd_mbw(int cout_g);
+/* 1x1 convolution, stride 1, on small maps as one GEMM (the bottleneck 1x1 layers of the identity loss network at 7x7 / 4x4,
+ * Loss/id_loss.py:13,27-41): y[b][co][p] = act(sum_ci w[co][ci] x[b][ci][p] + bias[co]); w row-major (Cout, Cin) = the OIHW
+ * weight as it lies; Cin a multiple of 16; bias may be NULL; act: 0 none, 1 leaky relu (slope) times gain. */
+int vsp_conv1x1_small_f32(float* y, const float* w, const float* x, const float* bias, int B, int Cout, int Cin, int P, int act,
+                          float slope, float gain, vsp_stream_t stream);
 /* Weight re-layout on the device (a trained weight is re-packed every iteration: restoration_train.py:123-131, 207-212 step the
  * optimizers between passes).  vsp_pack_weight_f32: OIHW weight (G*cout_g, cin, KH, KW) -> the layout of vsp_conv_params.w,
  * wp[g][tap][ci][co_g] = scale * w[g*cout_g + co_g][ci][tap'] with tap' = KH*KW-1-tap when `flip`.  `adjoint` (G = 1) packs the

@@ -1129,3 +1129,24 @@ def test_winograd_weight_kernel(H, ng, cin, cout):
     got = H.winograd_weight(dev(wp)).cpu()
     assert got.numel() == ref.numel() == H.lib.vsp_winograd_weight_floats(ng, cin, cout)
     close(got, ref, 1e-7, 1.2e-7, "winograd weight")
+
+
+@pytest.mark.parametrize("cin,cout,hw,B", [(1024, 256, 7, 8), (256, 1024, 7, 8), (2048, 512, 4, 8), (64, 40, 5, 3), (512, 128, 14, 2),
+                                           (16, 3, 1, 1), (128, 512, 14, 8)])
+def test_conv1x1_small_gemm(H, cin, cout, hw, B):
+    """vsp_conv1x1_small_f32 (1x1 conv on a small map as a K-split GEMM) against F.conv2d in float64: plain, with bias, with
+    bias + ReLU; through hip_ops.conv2d (which routes these shapes to it) and through the data-gradient path of conv2d_gradfix."""
+    from vspbfr_amd.op import conv2d_gradfix
+    g_ = torch.Generator().manual_seed(21)
+    x, w = torch.randn(B, cin, hw, hw, generator=g_), torch.randn(cout, cin, 1, 1, generator=g_) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g_)
+    ref = F.conv2d(x.double(), w.double())
+    close(H.conv1x1_small(dev(x), dev(w).view(cout, cin)), ref.float(), 2e-5, 1e-4, "plain")
+    close(H.conv2d(dev(x), dev(w), dev(b)), (ref + b.double().view(1, -1, 1, 1)).float(), 2e-5, 1e-4, "bias")
+    close(H.conv2d(dev(x), dev(w), None, act2=1, bias2=dev(b), slope2=0.0, gain2=1.0),
+          F.relu(ref + b.double().view(1, -1, 1, 1)).float(), 2e-5, 1e-4, "bias+relu")
+    if cout % 16 == 0:
+        gy = torch.randn(B, cout, hw, hw, generator=g_)
+        with torch.no_grad():
+            dx = conv2d_gradfix._dgrad(dev(gy), dev(w), x.shape, 1, 0, 1, 1)
+        close(dx, F.conv_transpose2d(gy.double(), w.double()).float(), 2e-5, 1e-4, "dgrad")

@@ -139,6 +139,7 @@ SIGNATURES = {
     "vsp_upfirdn2d_bf16": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
     "vsp_pointwise_bf16": [_p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i64, _p],
     "vsp_keyed_fill_f32": [_p, _i, C.POINTER(C.c_int64), C.POINTER(C.c_int32), _i, C.c_uint64, _i64, _p, _i, _p],
+    "vsp_conv1x1_small_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "vsp_pack_weight_f32": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p],
     "vsp_winograd_weight_f32": [_p, _p, _i, _i, _i, _p],
     "vsp_conv2d_winograd_chunk": [],

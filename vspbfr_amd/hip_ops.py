@@ -522,10 +522,33 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     return out
 
 
+CONV1X1_SMALL_MAX_P = 1024   # maps up to 32 x 32 (measured to 28 x 28, batch 8: tools/bench_1x1_gemm.py); larger maps amortise the tiled kernel's weight slabs
+
+
+def conv1x1_small(x, w2d, bias=None, act=False, slope=0.2, gain=SQRT2):
+    """y[b, co, p] = act(w2d @ x[b] + bias) for a 1x1 stride-1 conv on a small map (vsp_conv1x1_small_f32); w2d = (Cout, Cin)."""
+    x, w2d = _req(x, "x"), _req(w2d, "weight")
+    B, cin, Hh, Ww = x.shape
+    cout = w2d.shape[0]
+    if w2d.shape[1] != cin:
+        raise RuntimeError(f"conv1x1_small: input has {cin} channels, weight expects {w2d.shape[1]}")
+    y = torch.empty((B, cout, Hh, Ww), device=x.device, dtype=torch.float32)
+    check(lib.vsp_conv1x1_small_f32(_ptr(y), _ptr(w2d), _ptr(x), _ptr(_opt(bias, "bias")), B, cout, cin, Hh * Ww, int(bool(act)),
+                                    float(slope), float(gain), _stream()), "conv1x1_small")
+    return y
+
+
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, **epi):
     """F.conv2d-shaped convenience entry (groups=1): packs the weight on the fly (tests, generic callers)."""
     weight = _req(weight, "weight")
     cout, cin, kh, kw = weight.shape
+    if (kh == 1 and kw == 1 and stride == 1 and padding == 0 and cin % 16 == 0 and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[2] * x.shape[3] <= CONV1X1_SMALL_MAX_P and not (set(epi) - {"act2", "bias2", "slope2", "gain2"})
+            and not (bias is not None and epi.get("bias2") is not None)):
+        act = epi.get("act2", 0)
+        if act in (0, 1):   # GEMM-shaped: K = Cin against a few hundred columns
+            return conv1x1_small(x, weight.view(cout, cin), bias if bias is not None else epi.get("bias2"), act == 1,
+                                 epi.get("slope2", 0.2), epi.get("gain2", SQRT2))
     # The packed (and, on a Winograd layer, transformed) weight rides on the tensor object it was built from: a long-lived weight
     # (frozen loss networks, folded BatchNorm weights) is packed once per version, a temporary dies with its packing.
     key = (weight._version, weight.data_ptr(), stride, dilation, padding)

@@ -65,6 +65,18 @@ def _dgrad(g, weight, x_shape, stride, padding, dilation, groups):
     cout, cg, kh, kw = weight.shape
     if stride == 1:
         # adjoint of a stride-1 correlation: correlation of g with the flipped kernel, channels exchanged inside each group
+        if (groups == 1 and not torch.is_grad_enabled() and kh == 1 and kw == 1 and padding == 0 and cout % 16 == 0
+                and x_shape[2] * x_shape[3] <= hip_ops.CONV1X1_SMALL_MAX_P):
+            # 1x1 on a small map (the bottlenecks of the identity network): the data gradient is the GEMM W^T g
+            key = (weight._version, weight.data_ptr(), "1x1")
+            cached = getattr(weight, "_vsp_adjoint", None)
+            if cached is None or cached[0] != key:
+                cached = (key, weight.detach().view(cout, cg).t().contiguous())
+                try:
+                    weight._vsp_adjoint = cached
+                except (AttributeError, RuntimeError):
+                    pass
+            return hip_ops.conv1x1_small(g.contiguous(), cached[1])
         if groups == 1 and not torch.is_grad_enabled():
             # first-order pass: the adjoint weight is packed by one launch, once per weight version (a frozen loss network keeps
             # it for the whole run; the product `weight * scale` of an equalised layer is a temporary and takes its packing with it)
