@@ -1150,3 +1150,64 @@ def test_conv1x1_small_gemm(H, cin, cout, hw, B):
         with torch.no_grad():
             dx = conv2d_gradfix._dgrad(dev(gy), dev(w), x.shape, 1, 0, 1, 1)
         close(dx, F.conv_transpose2d(gy.double(), w.double()).float(), 2e-5, 1e-4, "dgrad")
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=8, cin=512, cout=512, hw=(4, 4), k=3, stride=1, G=1),
+    dict(B=3, cin=64, cout=40, hw=(9, 7), k=3, stride=1, G=1),
+    dict(B=4, cin=128, cout=96, hw=(8, 8), k=3, stride=2, G=1),
+    dict(B=2, cin=32, cout=64, hw=(16, 16), k=3, stride=1, G=4, dil=(1, 2, 4, 8)),      # dilation groups over one input
+    dict(B=2, cin=16, cout=48, hw=(6, 6), k=3, stride=2, G=3, true_groups=True),         # true groups (style heads)
+    dict(B=1, cin=2048, cout=512, hw=(1, 1), k=1, stride=1, G=1),
+    dict(B=5, cin=48, cout=20, hw=(5, 5), k=1, stride=1, G=1),
+], ids=lambda c: f"{c['cin']}-{c['cout']}-{c['hw'][0]}-k{c['k']}s{c['stride']}G{c['G']}")
+def test_conv_smallmap_kernel(H, case):
+    """The K-split small-map kernel (conv_smallmap.hip, configuration "smallmap") against the tiled kernel on the same launch
+    parameters -- every prologue / epilogue operand of the contract switched on -- and against F.conv2d in float64 for the plain
+    convolution."""
+    c = case
+    g_ = torch.Generator().manual_seed(41)
+    B, cin, cout, (Hh, Ww), k, st, G = c["B"], c["cin"], c["cout"], c["hw"], c["k"], c["stride"], c["G"]
+    sm = H.CONFIG_IDS["smallmap"]
+    cg = cout // G
+    true_groups = c.get("true_groups", False)
+    dil = c.get("dil", (1,) * G)
+    xc = cin * G if true_groups else cin
+    x = dev(torch.randn(B, xc, Hh, Ww, generator=g_))
+    ws = [torch.randn(cg, cin, k, k, generator=g_) / math.sqrt(cin * k * k) for _ in range(G)]
+    pad = tuple(d * (k // 2) for d in dil) if st == 1 else (0,) * G
+    wp = H.pack_weight_stack([dev(w_) for w_ in ws])
+    if G == 1:
+        pc = H.PackedConv(wp, 1, cg, cin, k, k, st, (dil[0],), (pad[0],))
+    elif true_groups:
+        pc = H.PackedConv(wp, G, cg, cin, k, k, st, (1,), (pad[0],), x_group_stride=cin)
+    else:
+        pc = H.PackedConv(wp, G, cg, cin, k, k, st, dil, pad)
+    # plain convolution against float64
+    refs = []
+    for gi in range(G):
+        xi = x.cpu().double()[:, gi * cin:(gi + 1) * cin] if true_groups else x.cpu().double()
+        refs.append(F.conv2d(xi, ws[gi].double(), None, st, pad[gi], dil[gi]))
+    ref = torch.cat(refs, 1).float()
+    y = H.conv2d_packed(x, pc, tile_hint=sm, winograd=False)
+    close(y, ref, 2e-5, 2e-5, "plain")
+    OH, OW = ref.shape[2:]
+    # every operand of the contract, against the tiled kernel
+    s_in = dev(torch.rand(B, xc, generator=g_) + 0.5)
+    kw = dict(in_scale=s_in, out_scale=dev(torch.rand(B, cout, generator=g_) + 0.5), act1=True, bias1=dev(torch.randn(cout, generator=g_)),
+              noise=dev(torch.randn(B, 1, OH, OW, generator=g_)), noise_w=dev(torch.tensor([0.3])), act2=1,
+              bias2=dev(torch.randn(cout, generator=g_)), res1=dev(torch.randn(B, cout, OH, OW, generator=g_)),
+              res2=dev(torch.randn(B, cout, OH, OW, generator=g_)))
+    close(H.conv2d_packed(x, pc, tile_hint=sm, winograd=False, **kw), H.conv2d_packed(x, pc, winograd=False, bf16=False, **kw), 3e-5, 3e-5, "epilogue")
+    if not true_groups:
+        kw2 = dict(in_scale=dev(torch.rand(xc, generator=g_) + 0.5), in_scale_per_sample=False, in_shift=dev(torch.randn(xc, generator=g_)),
+                   ch_scale=dev(torch.rand(cout, generator=g_) + 0.5), ch_bias=dev(torch.randn(cout, generator=g_)), act2=2,
+                   prelu=dev(torch.rand(cout, generator=g_)))
+        close(H.conv2d_packed(x, pc, tile_hint=sm, winograd=False, **kw2), H.conv2d_packed(x, pc, winograd=False, bf16=False, **kw2), 3e-5, 3e-5,
+              "folded-BN operands")
+    # strided placement into a larger output (sub-pixel phase form)
+    out_a = torch.zeros(B, cout + 3, 2 * OH + 1, 2 * OW + 2, device=x.device)
+    out_b = torch.zeros_like(out_a)
+    H.conv2d_packed(x, pc, out=out_a, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), tile_hint=sm, winograd=False)
+    H.conv2d_packed(x, pc, out=out_b, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), winograd=False, bf16=False)
+    close(out_a, out_b, 3e-5, 3e-5, "placement")

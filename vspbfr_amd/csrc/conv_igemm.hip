@@ -280,13 +280,14 @@ static int fill_convk(const vsp_conv_params& p, int x_ch, ConvK& q) {
   return VSP_OK;
 }
 
+// configuration index kNumCfgs (tile_hint kNumCfgs + 1) names the small-map kernel of conv_smallmap.hip
 extern "C" int vsp_conv2d_num_configs(void) {
   build_table();
-  return kNumCfgs;
+  return kNumCfgs + 1;
 }
 extern "C" const char* vsp_conv2d_config_name(int i) {
   build_table();
-  return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "";
+  return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : (i == kNumCfgs ? "smallmap" : "");
 }
 
 extern "C" int vsp_conv2d_winograd_chunk(void) { return vspconv::wino_chunk(); }
@@ -432,13 +433,26 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
               "conv2d: one input image and one group's weights must each be smaller than 2 GiB (32-bit buffer offsets)");
   const int Cout = p.G * p.cout_g;
   (void)Cout;
+  {
+    // the small-map kernel: named (tile_hint kNumCfgs + 1), preferred by the tuned table (negative), or -- for a shape the table
+    // does not know -- when the whole batch has at most 256 output positions against K >= 1024
+    const int sm = kNumCfgs + 1;
+    const bool named = p.tile_hint == sm, preferred = p.tile_hint == -sm;
+    const bool guess = p.tile_hint == 0 && (int64_t)p.B * p.OH * p.OW <= 256 && (int64_t)p.Cin * p.KH * p.KW >= 1024;
+    if (named || preferred || guess) {
+      ConvK q{};
+      if (int rc = fill_convk(p, x_ch, q)) return rc;
+      if (vspconv::smallmap_eligible(q, p.transposed != 0)) return vspconv::smallmap_launch(q, vsp::as_stream(stream));
+      VSP_REQUIRE(!named, "conv2d: configuration smallmap does not fit this problem (Cin %% 16 == 0, at most 8192 output positions, not transposed)");
+    }
+  }
   Plan best{};
   bool found = false;
   if (p.tile_hint > 0) {
     VSP_REQUIRE(p.tile_hint <= kNumCfgs, "conv2d: tile_hint %d out of range", p.tile_hint);
     found = make_plan(p, p.tile_hint - 1, &best);
     VSP_REQUIRE(found, "conv2d: configuration %s does not fit this problem", kCfgs[p.tile_hint - 1].name);
-  } else if (p.tile_hint < 0 && -p.tile_hint <= kNumCfgs) {
+  } else if (p.tile_hint < 0 && -p.tile_hint <= kNumCfgs) {  // (-(kNumCfgs + 1), not eligible: the cost model decides)
     // a PREFERENCE (tuned table): the table is keyed by geometry only, the same shape may come with an operand this
     // configuration cannot serve (e.g. an input shift with the LDS-DMA staging) -- then the cost model decides
     found = make_plan(p, -p.tile_hint - 1, &best);

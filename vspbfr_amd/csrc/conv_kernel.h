@@ -615,6 +615,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
 // conv_wino.hip: Winograd F(2x2,3x3) launch (q.w = transformed weights [16][Cin][Cout]); tiles are set inside
 int wino_launch(ConvK q, hipStream_t stream);
+// conv_smallmap.hip: K-split GEMM form for layers with few output positions (q filled by fill_convk: no tile plan needed)
+bool smallmap_eligible(const ConvK& q, bool transposed);
+int smallmap_launch(const ConvK& q, hipStream_t stream);
 int wino_chunk();           // input channels per chunk the transformed-weight layout is built for
 int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout) for a layer with cout_g channels per group
 

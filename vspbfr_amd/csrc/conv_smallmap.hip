@@ -1,0 +1,178 @@
+// Convolution on SMALL maps (a few hundred output positions in the whole batch) as a K-split GEMM, same contract and epilogue as
+// vsp_conv2d_f32.  The 4x4 ... 16x16 levels of Restoration_net / the StyleGAN2 prior / the style heads have K = Cin KH KW of
+// 4608 against 8 ... 2048 columns: the tiled kernel (conv_kernel.h) walks K in LDS-staged chunks inside ONE workgroup per output
+// tile -- two barriers and a global round trip per chunk, 50 - 130 us for layers whose data is one pass over 9 MB of weights.
+// Here: rows of the GEMM = output positions (b, oy, ox), columns = output channels; both MFMA operands are loaded from global
+// memory straight into fragments (A: x at the tap's shifted position, zero outside, input scale / shift applied in registers;
+// B: packed weights Wp[g][tap][ci][co], 16 consecutive channels per row), K = (tap, ci) is split over the 8 wavefronts of a
+// workgroup in 16-channel sub-steps with the next sub-steps prefetched in registers, and the partial tiles meet once in LDS.
+#include "conv_kernel.h"
+#include "vsp_common.h"
+
+namespace vspconv {
+namespace {
+
+constexpr int kSW = 8;   // wavefronts per workgroup = K split
+
+template <int MI, int NI, int KU>   // wave tile 16 MI positions x 16 NI channels; KU sub-steps (16 input channels of one tap) in flight
+__global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, const int N, const int co_tiles) {
+  __shared__ float red[kSW][MI * NI * 4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 16 * MI;
+  const int g = blockIdx.y / co_tiles, co0 = (blockIdx.y - g * co_tiles) * 16 * NI;
+  const int gg = p.G > 4 ? 0 : g;   // more than four groups share one geometry
+  const int dil = p.dil[gg], pady = p.pady[gg], padx = p.padx[gg];
+  const int P = p.OH * p.OW, HW = p.H * p.W, T = p.KH * p.KW;
+  const bool scaled = p.in_scale != nullptr, shifted = p.in_shift != nullptr;
+
+  int iy0[MI], ix0[MI];
+  const float* xb[MI];
+  const float* sb[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int n = min(n0 + 16 * mi + r, N - 1);
+    const int b = n / P, q = n - b * P;
+    const int oy = q / p.OW, ox = q - oy * p.OW;
+    iy0[mi] = oy * p.sy - pady;
+    ix0[mi] = ox * p.sx - padx;
+    xb[mi] = p.x + ((int64_t)b * p.x_ch + g * p.x_gs + 4 * kq) * HW;
+    sb[mi] = scaled ? p.in_scale + (int64_t)b * p.in_scale_bstride + g * p.x_gs + 4 * kq : p.x;
+  }
+  const float* shb = shifted ? p.in_shift + 4 * kq : p.x;
+  const float* wb[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    wb[ni] = p.w + ((int64_t)g * T * p.Cin + 4 * kq) * p.cout_g + min(co0 + 16 * ni + r, p.cout_g - 1);
+
+  const int c16 = p.Cin >> 4;
+  const int S = T * c16;
+  auto fetch = [&](int s, float (*A)[4], float (*Bf)[4]) {   // s: uniform per wavefront
+    const int tap = s / c16, cc = s - tap * c16;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int iy = iy0[mi] + ky * dil, ix = ix0[mi] + kx * dil;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float* xp = xb[mi] + (int64_t)(16 * cc) * HW + (ok ? iy * p.W + ix : 0);
+      float v[4], sc[4], sh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = xp[e * HW];
+      if (scaled) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[e] = sb[mi][16 * cc + e];
+      }
+      if (shifted) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sh[e] = shb[16 * cc + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = v[e];
+        if (scaled) t *= sc[e];
+        if (shifted) t += sh[e];
+        A[mi][e] = ok ? t : 0.f;
+      }
+    }
+    const int64_t wo = ((int64_t)tap * p.Cin + 16 * cc) * p.cout_g;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Bf[ni][e] = wb[ni][wo + (int64_t)e * p.cout_g];
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float a[KU][MI][4], bq[KU][NI][4], an[KU][MI][4], bn[KU][NI][4];
+  const int iters = (S + kSW * KU - 1) / (kSW * KU);
+#pragma unroll
+  for (int u = 0; u < KU; ++u) fetch(min(wv * KU + u, S - 1), a[u], bq[u]);
+  for (int it = 0; it < iters; ++it) {
+    const int sbase = (it * kSW + wv) * KU;
+    const int snext = it + 1 < iters ? sbase + kSW * KU : sbase;
+#pragma unroll
+    for (int u = 0; u < KU; ++u) fetch(min(snext + u, S - 1), an[u], bn[u]);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (sbase + u < S) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mi][e], bq[u][ni][e], acc[mi][ni], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[u][mi][e] = an[u][mi][e];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[u][ni][e] = bn[u][ni][e];
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wv][(mi * NI + ni) * 4 + i][lane] = acc[mi][ni][i];
+  __syncthreads();
+
+  // ---- epilogue (the operand conventions of conv_kernel.h: absent operands read a constant through a zero stride)
+  const int Cout = p.G * p.cout_g;
+  const float nw = p.nwp[0];
+  const int y_plane = p.y_h * p.y_w;
+  for (int q = wv; q < MI * NI * 4; q += kSW) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kSW; ++k) s += red[k][q][lane];
+    const int i = q & 3, ni = (q >> 2) % NI, mi = (q >> 2) / NI;
+    const int n = n0 + 16 * mi + 4 * kq + i, cg = co0 + 16 * ni + r;
+    if (n >= N || cg >= p.cout_g) continue;
+    const int b = n / P, pq = n - b * P;
+    const int oy = pq / p.OW, ox = pq - oy * p.OW;
+    const int co = g * p.cout_g + cg;
+    const int64_t ro = ((int64_t)b * p.y_ch + p.y_coff + co) * y_plane + (oy * p.osy + p.ooy) * p.y_w + ox * p.osx + p.oox;
+    const int64_t rr = ((int64_t)b * p.res_ch + p.res_coff + co) * y_plane + (oy * p.osy + p.ooy) * p.y_w + ox * p.osx + p.oox;
+    float v = s * p.osp[((int64_t)b * Cout + co) * p.oss];
+    v = v * p.csp[co * p.css] + p.cbp[co * p.cbs];
+    v += p.b1p[co * p.b1s];
+    v = (v > 0.f ? v : v * p.s1) * p.g1;
+    v += p.nzp[((int64_t)b * P + pq) * p.nzs] * nw;
+    v += p.b2p[co * p.b2s];
+    v = (v > 0.f ? v : v * p.s2p[co * p.s2s]) * p.g2;
+    v += p.r1p[rr * p.r1s];
+    v += p.r2p[rr * p.r2s];
+    p.y[ro] = v;
+  }
+}
+
+}  // namespace
+
+bool smallmap_eligible(const ConvK& q, bool transposed) {
+  return !transposed && q.io_bf16 == 0 && q.Cin % 16 == 0 && (int64_t)q.B * q.OH * q.OW <= 8192;
+}
+
+int smallmap_launch(const ConvK& q, hipStream_t stream) {
+  const int N = q.B * q.OH * q.OW;
+  // 32-position tiles when that still gives every CU a workgroup, else 16
+  const int t2 = ((N + 31) / 32) * ((q.cout_g + 31) / 32) * q.G;
+  if (t2 >= 256) {
+    const int ct = (q.cout_g + 31) / 32;
+    conv_smallmap_kernel<2, 2, 2><<<dim3((N + 31) / 32, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
+  } else {
+    const int ct = (q.cout_g + 31) / 32;
+    conv_smallmap_kernel<1, 2, 2><<<dim3((N + 15) / 16, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
+  }
+  return vsp::check_launch("conv2d (small-map kernel)");
+}
+
+}  // namespace vspconv
