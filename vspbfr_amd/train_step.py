@@ -165,8 +165,10 @@ class RestorationTrainer:
             from .non_leaking import AdaptiveAugment
             self.ada = AdaptiveAugment(ada_target, ada_length, ada_every, next(discriminator.parameters()).device)
         g_ratio, d_ratio = g_reg_every / (g_reg_every + 1), d_reg_every / (d_reg_every + 1)   # restoration_train.py:397-408
-        self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio))
-        self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio))
+        # device parameters: the single-kernel (fused) multi-tensor Adam; same update rule as restoration_train.py:123-131
+        fused = all(p.is_cuda for p in generator.parameters()) and all(p.is_cuda for p in discriminator.parameters())
+        self.g_optim = torch.optim.Adam(generator.parameters(), lr=lr * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio), fused=fused)
+        self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio), fused=fused)
         self.accum = 0.5 ** (32 / (10 * 1000))
         accumulate(g_ema, generator, 0)
         self.generator_bytes = sum(p.numel() * p.element_size() for p in generator.parameters())
@@ -274,7 +276,7 @@ class CodeDiffuserTrainer:
         self.params = list(diffusion.model.parameters())
         for p in self.params:
             p.requires_grad_(True)
-        self.optim = torch.optim.Adam(self.params, lr=lr * ratio, betas=(0 ** ratio, 0.99 ** ratio))
+        self.optim = torch.optim.Adam(self.params, lr=lr * ratio, betas=(0 ** ratio, 0.99 ** ratio), fused=all(p.is_cuda for p in self.params))
         self.reducer = OverlappedGradientReducer(self.params, bucket_bytes)
 
     def step(self, low_img, real_img, low_latent=None, target=None, q_noise=None, gen_noise=None):
