@@ -115,8 +115,13 @@ class VGG16Slices(nn.Module):
                     h = max_pool2d(h, 2, 2)
                 else:
                     c = getattr(sl, name)
-                    if torch.is_grad_enabled() and (h.requires_grad or c.weight.requires_grad):
+                    if torch.is_grad_enabled() and c.weight.requires_grad:
                         h = fused_leaky_relu(conv2d_gradfix.conv2d(h, c.weight, padding=1), c.bias, 0.0, 1.0)
+                    elif torch.is_grad_enabled() and h.requires_grad:
+                        # frozen weights, gradient w.r.t. the image only (the loss network of restoration_train.py:237-241):
+                        # bias + ReLU in the conv epilogue, backward = ReLU mask from y + data-gradient conv
+                        from .id_loss import _ConvBiasAct
+                        h = _ConvBiasAct.apply(h, c.weight, c.bias, 1, 1, True)
                     else:   # frozen branch: bias + ReLU in the conv epilogue
                         h = hip_ops.conv2d(h.contiguous(), c.weight, None, 1, 1, 1, act2=1, bias2=c.bias, slope2=0.0, gain2=1.0)
             outs.append(h)
