@@ -18,6 +18,9 @@ torch.manual_seed(1)
 D = Discriminator(512).to(dev)
 G_ema = copy.deepcopy(G)
 LOSSES = len(sys.argv) > 3 and sys.argv[3] == "losses"
+if "x3" in sys.argv[3:]:   # experiment: forward / data-gradient convolutions on the split-precision bf16 pipe (fp32-grade), weight gradients fp32
+    from vspbfr_amd import hip_ops
+    hip_ops.BF16_CONV = "x3"
 kw = {}
 if LOSSES:
     from vspbfr_amd.id_loss import IDLoss

@@ -7,6 +7,8 @@ there is no CPU path (the reference's own CPU branch lives in oracle/, test-only
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -267,6 +269,11 @@ class PackedConv:
 # "bf16 kernels" configuration (BASELINE configs[2]): eligible convolutions run on vsp_conv2d_bf16 (bf16 MFMA, fp32
 # accumulate, fp32 activations in HBM).  Off by default: the parity path is fp32 end to end.
 BF16_CONV = False   # True: bf16 operands; "x3": split precision (hi + lo bf16 pairs, three MFMAs per product: fp32-grade results)
+_env_dtype = os.environ.get("VSPBFR_CONV_DTYPE", "")   # process-wide default of the switch: "bf16" / "bf16x3" (entry points set it explicitly)
+if _env_dtype:
+    if _env_dtype not in ("f32", "bf16", "bf16x3"):
+        raise RuntimeError(f"VSPBFR_CONV_DTYPE must be f32, bf16 or bf16x3 (got {_env_dtype!r})")
+    BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[_env_dtype]
 
 
 def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
