@@ -1,5 +1,6 @@
-"""The ATen ops of one training iteration ranked by the bytes they move (elements of their largest operand x 4), with call sites: where
-the torch glue between the kernels is worth replacing.  usage: python tools/trace_train_ops.py [B]"""
+"""The ATen ops of one training iteration ranked by the bytes they move (elements of their largest operand x 4): where the torch glue
+between the kernels is worth replacing.  The call-site column is filled only where the profiler recorded a Python stack (it does not
+on the autograd thread: "?").  usage: python tools/trace_train_ops.py [B]"""
 import collections, copy, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
