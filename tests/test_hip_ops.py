@@ -1211,3 +1211,26 @@ def test_conv_smallmap_kernel(H, case):
     H.conv2d_packed(x, pc, out=out_a, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), tile_hint=sm, winograd=False)
     H.conv2d_packed(x, pc, out=out_b, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), winograd=False, bf16=False)
     close(out_a, out_b, 3e-5, 3e-5, "placement")
+
+
+def test_conv_smallmap_random_shapes(H):
+    """Thirty seeded random small-map problems (ragged channel counts, odd maps, both strides, dilation, 1x1 / 3x3 / 5x5 kernels,
+    batch 1..9): the small-map kernel against F.conv2d in float64, with the per-sample input scale folded in."""
+    rng = np.random.default_rng(77)
+    sm = H.CONFIG_IDS["smallmap"]
+    for it in range(30):
+        B, cin, cout = int(rng.integers(1, 10)), 16 * int(rng.integers(1, 9)), int(rng.integers(1, 70))
+        Hh, Ww = int(rng.integers(1, 13)), int(rng.integers(1, 13))
+        k = int(rng.choice([1, 3, 3, 5]))
+        st = int(rng.choice([1, 1, 2]))
+        dil = 1 if st == 2 or k == 1 else int(rng.choice([1, 2, 3]))
+        pad = int(rng.integers(0, dil * (k // 2) + 1))
+        if (Hh + 2 * pad - dil * (k - 1) - 1) < 0 or (Ww + 2 * pad - dil * (k - 1) - 1) < 0:
+            continue
+        g_ = torch.Generator().manual_seed(1000 + it)
+        x, w = torch.randn(B, cin, Hh, Ww, generator=g_), torch.randn(cout, cin, k, k, generator=g_) / math.sqrt(cin * k * k)
+        s_in = torch.rand(B, cin, generator=g_) + 0.5
+        pc = H.PackedConv(H.pack_weight(dev(w)), 1, cout, cin, k, k, st, (dil,), (pad,))
+        ref = F.conv2d(x.double() * s_in.double().view(B, cin, 1, 1), w.double(), None, st, pad, dil).float()
+        y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), tile_hint=sm, winograd=False, bf16=False)
+        close(y, ref, 3e-5, 3e-5, f"case {it}: B{B} {cin}->{cout} {Hh}x{Ww} k{k} s{st} d{dil} p{pad}")
