@@ -422,7 +422,10 @@ def test_config_c2_full_size():
     # (a)
     sd = weights.synth_state_dict("diffuser", weights.load_specs()["diffuser"], cases.SEED)
     x_T = torch.from_numpy(R.keyed_fill((B, 18, 512), H.SEG_XT, seed, i0))
-    e_chain = maxerr(out["pre_latent"], _oracle_chain(sd, out["latent"].cpu(), x_T, T))
+    ref_chain = _oracle_chain(sd, out["latent"].cpu(), x_T, T)
+    e_chain = maxerr(out["pre_latent"], ref_chain)
+    ref_t = ref_chain if torch.is_tensor(ref_chain) else torch.from_numpy(np.asarray(ref_chain))
+    e_img = (out["pre_latent"].cpu() - ref_t).abs().reshape(B, -1).max(1).values
     # (b)
     e_one = 0.0
     for b in range(B):
@@ -431,7 +434,11 @@ def test_config_c2_full_size():
     # (c)
     looped = list(pipe.run_batches([(lq, i0)]))[0]
     print(f"C2: chain vs oracle {e_chain:.2e}   image vs its batch-1 run {e_one:.2e}   |restored|max {float(out['restored'].abs().max()):.2f}")
-    assert e_chain < 5e-4     # measured 2.3e-4 over 8 images x 50 steps on latents of |max| ~25 (BASELINE: 1e-3)
+    # BASELINE's bound on latents of |max| ~25.  Per image the free-running error is 3e-5 ... 2e-4 with a heavy tail (tools/
+    # chain_error_probe.py over 48 images: batch maxima 1.2e-4 ... 6.3e-4; which image carries the maximum moves with 1e-6 changes of
+    # the encoder's codes), so the batch maximum is held to the stated tolerance and the typical image to a fifth of it
+    assert e_chain < 1e-3
+    assert float(e_img.median()) < 2e-4, e_img
     assert e_one < 1e-5
     assert torch.equal(looped["restored"], out["restored"])
 

@@ -14,7 +14,11 @@ namespace {
 
 constexpr int kSW = 8;   // wavefronts per workgroup = K split
 
-template <int MI, int NI, int KU>   // wave tile 16 MI positions x 16 NI channels; KU sub-steps (16 input channels of one tap) in flight
+// wave tile 16 MI positions x 16 NI channels; KU sub-steps (16 input channels of one tap) in flight.
+// VEC: the NI column tiles interleave -- tile ni holds channels co0 + NI r + ni -- so that ONE NI-float load per lane and weight row
+// feeds all NI tiles (cout_g a multiple of NI, 16-byte aligned weights); otherwise tile ni = channels co0 + 16 ni + r, scalar loads.
+// (The kernel is bound by instruction issue, not by memory: ~22 instructions per MFMA with scalar weight loads on 16-position tiles.)
+template <int MI, int NI, int KU, bool VEC>
 __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, const int N, const int co_tiles) {
   __shared__ float red[kSW][MI * NI * 4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
@@ -39,10 +43,12 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
     sb[mi] = scaled ? p.in_scale + (int64_t)b * p.in_scale_bstride + g * p.x_gs + 4 * kq : p.x;
   }
   const float* shb = shifted ? p.in_shift + 4 * kq : p.x;
+  typedef float wvec __attribute__((ext_vector_type(NI)));
   const float* wb[NI];
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
-    wb[ni] = p.w + ((int64_t)g * T * p.Cin + 4 * kq) * p.cout_g + min(co0 + 16 * ni + r, p.cout_g - 1);
+    wb[ni] = p.w + ((int64_t)g * T * p.Cin + 4 * kq) * p.cout_g +
+             (VEC ? min(co0 + NI * r, p.cout_g - NI) : min(co0 + 16 * ni + r, p.cout_g - 1));   // VEC: only wb[0] is used
 
   const int c16 = p.Cin >> 4;
   const int S = T * c16;
@@ -74,10 +80,19 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
       }
     }
     const int64_t wo = ((int64_t)tap * p.Cin + 16 * cc) * p.cout_g;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int e = 0; e < 4; ++e) {
+        const wvec v = *reinterpret_cast<const wvec*>(wb[0] + wo + (int64_t)e * p.cout_g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Bf[ni][e] = wb[ni][wo + (int64_t)e * p.cout_g];
+        for (int ni = 0; ni < NI; ++ni) Bf[ni][e] = v[ni];
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bf[ni][e] = wb[ni][wo + (int64_t)e * p.cout_g];
+    }
   };
 
   f32x4 acc[MI][NI];
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
 #pragma unroll
     for (int k = 0; k < kSW; ++k) s += red[k][q][lane];
     const int i = q & 3, ni = (q >> 2) % NI, mi = (q >> 2) / NI;
-    const int n = n0 + 16 * mi + 4 * kq + i, cg = co0 + 16 * ni + r;
+    const int n = n0 + 16 * mi + 4 * kq + i, cg = VEC ? co0 + NI * r + ni : co0 + 16 * ni + r;
     if (n >= N || cg >= p.cout_g) continue;
     const int b = n / P, pq = n - b * P;
     const int oy = pq / p.OW, ox = pq - oy * p.OW;
@@ -163,15 +178,24 @@ bool smallmap_eligible(const ConvK& q, bool transposed) {
 
 int smallmap_launch(const ConvK& q, hipStream_t stream) {
   const int N = q.B * q.OH * q.OW;
-  // 32-position tiles when that still gives every CU a workgroup, else 16
-  const int t2 = ((N + 31) / 32) * ((q.cout_g + 31) / 32) * q.G;
-  if (t2 >= 256) {
-    const int ct = (q.cout_g + 31) / 32;
-    conv_smallmap_kernel<2, 2, 2><<<dim3((N + 31) / 32, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
-  } else {
-    const int ct = (q.cout_g + 31) / 32;
-    conv_smallmap_kernel<1, 2, 2><<<dim3((N + 15) / 16, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
+  const int n16 = (N + 15) / 16, n32 = (N + 31) / 32;
+  const bool al = vsp::aligned16(q.w);
+  if (al && q.cout_g % 4 == 0) {
+    // 16 positions x 64 channels per workgroup when that fills the chip; else 32-channel tiles (twice the workgroups)
+    const int ct4 = (q.cout_g + 63) / 64, ct2 = (q.cout_g + 31) / 32;
+    if (n16 * ct4 * q.G >= 192)
+      conv_smallmap_kernel<1, 4, 2, true><<<dim3(n16, ct4 * q.G), 64 * kSW, 0, stream>>>(q, N, ct4);
+    else if (n32 * ct2 * q.G >= 256)
+      conv_smallmap_kernel<2, 2, 2, true><<<dim3(n32, ct2 * q.G), 64 * kSW, 0, stream>>>(q, N, ct2);
+    else
+      conv_smallmap_kernel<1, 2, 2, true><<<dim3(n16, ct2 * q.G), 64 * kSW, 0, stream>>>(q, N, ct2);
+    return vsp::check_launch("conv2d (small-map kernel)");
   }
+  const int ct = (q.cout_g + 31) / 32;
+  if (n32 * ct * q.G >= 256)
+    conv_smallmap_kernel<2, 2, 2, false><<<dim3(n32, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
+  else
+    conv_smallmap_kernel<1, 2, 2, false><<<dim3(n16, ct * q.G), 64 * kSW, 0, stream>>>(q, N, ct);
   return vsp::check_launch("conv2d (small-map kernel)");
 }
 
