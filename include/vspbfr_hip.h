@@ -453,6 +453,12 @@ int vsp_plane_dot_scale_f32(float* out, float* a, const float* b, const float* s
 int vsp_noise_bias_act_f32(float* y, const float* x, const float* noise, const float* noise_w, const float* bias, int B, int C,
                            int64_t hw, float slope, float gain, vsp_stream_t stream);
 int vsp_noise_dot_f32(float* out, const float* gx, const float* noise, int B, int C, int64_t hw, vsp_stream_t stream);
+/* Backward of the tail of a SMART layer (reference models/RestoreNet.py:220-244: FusedLeakyReLU(bias1) -> NoiseInjection ->
+ * FusedLeakyReLU(bias2); the forward is the fusion conv's epilogue: act1 / bias1 / noise / act2 / bias2 of vsp_conv_params) from the
+ * final output y alone: g1 = gradient entering the conv, db1[c], db2[c], dnw[0] (the three are zeroed here, then accumulated). */
+int vsp_smart_tail_bwd_f32(float* g1, float* db1, float* db2, float* dnw, const float* g, const float* y, const float* noise,
+                           const float* noise_w, const float* bias2, int B, int C, int64_t hw, float slope, float gain,
+                           vsp_stream_t stream);
 /* out[c] = sum over b and the plane of x[b, c, :] (x (B, C, hw) dense): bias gradients of the training step */
 int vsp_channel_sum_f32(float* out, const float* x, int B, int C, int64_t hw, vsp_stream_t stream);
 

@@ -1234,3 +1234,31 @@ def test_conv_smallmap_random_shapes(H):
         ref = F.conv2d(x.double() * s_in.double().view(B, cin, 1, 1), w.double(), None, st, pad, dil).float()
         y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), tile_hint=sm, winograd=False, bf16=False)
         close(y, ref, 3e-5, 3e-5, f"case {it}: B{B} {cin}->{cout} {Hh}x{Ww} k{k} s{st} d{dil} p{pad}")
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 9, 7), (3, 16, 64, 64), (1, 3, 5, 5)])
+def test_smart_tail_backward(H, shape):
+    """vsp_smart_tail_bwd_f32 (FusedLeakyReLU(b1) -> NoiseInjection -> FusedLeakyReLU(b2), backward from the final output alone)
+    against torch autograd over the three-step statement in float64: gradient entering the conv, d b1, d b2, d noise weight."""
+    g_ = torch.Generator().manual_seed(17)
+    B, C_, Hh, Ww = shape
+    x, noise = torch.randn(*shape, generator=g_), torch.randn(B, 1, Hh, Ww, generator=g_)
+    b1, b2, nw = torch.randn(C_, generator=g_) * 0.3, torch.randn(C_, generator=g_) * 0.3, torch.tensor([0.4])
+    gy = torch.randn(*shape, generator=g_)
+    s2 = math.sqrt(2)
+
+    def tail(x_, b1_, nw_, b2_):
+        y1 = F.leaky_relu(x_ + b1_.view(1, -1, 1, 1), 0.2) * s2
+        return F.leaky_relu(y1 + nw_ * noise.double() + b2_.view(1, -1, 1, 1), 0.2) * s2
+    with torch.enable_grad():
+        args = [t.double().requires_grad_(True) for t in (x, b1, nw, b2)]
+        y = tail(*args)
+        dx, db1, dnw, db2 = torch.autograd.grad(y, args, gy.double())
+    g1, gb1, gb2, gnw = H.smart_tail_bwd(dev(gy), dev(y.detach().float()), dev(noise), dev(nw), dev(b2))
+    # elements whose first activation sits within rounding of zero may take the other slope: exclude |y1| < 1e-5 from the pointwise check
+    y1 = (F.leaky_relu(x.double() + b1.double().view(1, -1, 1, 1), 0.2) * s2)
+    safe = (y1.abs() > 1e-5)
+    assert float(((g1.cpu().double() - dx).abs() * safe).max()) < 1e-5
+    close(gb1, db1.float(), 1e-4, 1e-4, "d bias1")
+    close(gb2, db2.float(), 1e-4, 1e-4, "d bias2")
+    close(gnw, dnw.float(), 1e-4, 1e-4, "d noise weight")

@@ -133,6 +133,7 @@ SIGNATURES = {
     "vsp_channel_sum_f32": [_p, _p, _i, _i, _i64, _p],
     "vsp_noise_bias_act_f32": [_p, _p, _p, _p, _p, _i, _i, _i64, C.c_float, C.c_float, _p],
     "vsp_noise_dot_f32": [_p, _p, _p, _i, _i, _i64, _p],
+    "vsp_smart_tail_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i64, C.c_float, C.c_float, _p],
     "vsp_plane_dot_scale_f32": [_p, _p, _p, _p, _i64, _i64, _p],
     "vsp_convert_f32_to_bf16": [_p, _p, _i64, _p],
     "vsp_convert_bf16_to_f32": [_p, _p, _i64, _p],

@@ -146,6 +146,63 @@ __global__ __launch_bounds__(256) void noise_dot_kernel(float* __restrict__ out,
   if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// ---- backward of the tail of a SMART layer -- FusedLeakyReLU(bias1) -> NoiseInjection -> FusedLeakyReLU(bias2), which the forward
+// runs as the fusion conv's epilogue (reference models/RestoreNet.py:220-244) -- as ONE stream over (g, y): both slope masks, the
+// gradient that enters the conv, and the three parameter gradients.  Only the final y is kept: the first activation's output is
+// recovered from it,  pre2 = y / m2,  y1 = pre2 - nw * noise - bias2  (m = gain or slope * gain by sign).
+__global__ __launch_bounds__(256) void smart_tail_bwd_kernel(float* __restrict__ g1, float* __restrict__ db1, float* __restrict__ db2,
+                                                             float* __restrict__ dnw, const float* __restrict__ g,
+                                                             const float* __restrict__ y, const float* __restrict__ noise,
+                                                             const float* __restrict__ nw, const float* __restrict__ bias2, int C,
+                                                             int64_t hw, float slope, float gain) {
+  const int64_t plane = blockIdx.y;
+  const int b = (int)(plane / C), c = (int)(plane - (int64_t)b * C);
+  const float w = nw[0], b2 = bias2[c];
+  const float mp = gain, mn = slope * gain, ip = 1.f / gain, in = 1.f / (slope * gain);
+  const float* gp = g + plane * hw;
+  const float* yp = y + plane * hw;
+  const float* np = noise + (int64_t)b * hw;
+  float* op = g1 + plane * hw;
+  float s1 = 0.f, s2 = 0.f, sw = 0.f;
+  auto f = [&](float gv, float yv, float nz) {
+    const bool pos = yv > 0.f;
+    const float g2 = gv * (pos ? mp : mn);
+    const float y1 = yv * (pos ? ip : in) - w * nz - b2;
+    const float o = g2 * (y1 > 0.f ? mp : mn);
+    s2 += g2;
+    sw = fmaf(g2, nz, sw);
+    s1 += o;
+    return o;
+  };
+  if ((hw & 3) == 0) {
+    for (int64_t i = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < hw; i += 4 * 256 * (int64_t)gridDim.x) {
+      const float4 gv = *reinterpret_cast<const float4*>(gp + i), yv = *reinterpret_cast<const float4*>(yp + i),
+                   nz = *reinterpret_cast<const float4*>(np + i);
+      *reinterpret_cast<float4*>(op + i) = make_float4(f(gv.x, yv.x, nz.x), f(gv.y, yv.y, nz.y), f(gv.z, yv.z, nz.z), f(gv.w, yv.w, nz.w));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += 256 * (int64_t)gridDim.x) op[i] = f(gp[i], yp[i], np[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+    sw += __shfl_xor(sw, o, 64);
+  }
+  __shared__ float red[3][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s1;
+    red[1][threadIdx.x >> 6] = s2;
+    red[2][threadIdx.x >> 6] = sw;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(db1 + c, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+    unsafeAtomicAdd(db2 + c, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    unsafeAtomicAdd(dnw, (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]));
+  }
+}
+
 inline int plane_blocks(int64_t planes, int64_t hw) {   // blocks per plane: ~8 workgroups per CU in all, >= 4096 elements each
   int64_t nb = (8 * vsp::kNumCU + planes - 1) / planes;
   if (nb > hw / 4096) nb = hw / 4096;
@@ -175,4 +232,22 @@ extern "C" int vsp_noise_dot_f32(float* out, const float* gx, const float* noise
   VSP_REQUIRE((int64_t)B * C <= 65535, "noise_dot: too many planes for one grid");
   noise_dot_kernel<<<dim3((unsigned)plane_blocks((int64_t)B * C, hw), (unsigned)(B * C)), 256, 0, st>>>(out, gx, noise, C, hw);
   return vsp::check_launch("noise_dot");
+}
+
+extern "C" int vsp_smart_tail_bwd_f32(float* g1, float* db1, float* db2, float* dnw, const float* g, const float* y, const float* noise,
+                                      const float* noise_w, const float* bias2, int B, int C, int64_t hw, float slope, float gain,
+                                      vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && C >= 1 && hw >= 0, "smart_tail_bwd: bad dims");
+  VSP_REQUIRE(db1 && db2 && dnw, "smart_tail_bwd: null output");
+  VSP_REQUIRE(slope > 0.f && gain > 0.f, "smart_tail_bwd: slope and gain must be positive (the masks are recovered from signs)");
+  hipStream_t st = vsp::as_stream(stream);
+  if (hipMemsetAsync(db1, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(db2, 0, sizeof(float) * C, st) != hipSuccess ||
+      hipMemsetAsync(dnw, 0, sizeof(float), st) != hipSuccess)
+    return vsp::fail(VSP_ELAUNCH, "smart_tail_bwd: memset failed");
+  if ((int64_t)B * C * hw == 0) return VSP_OK;
+  VSP_REQUIRE(g1 && g && y && noise && noise_w && bias2, "smart_tail_bwd: null pointer");
+  VSP_REQUIRE((int64_t)B * C <= 65535, "smart_tail_bwd: too many planes for one grid");
+  smart_tail_bwd_kernel<<<dim3((unsigned)plane_blocks((int64_t)B * C, hw), (unsigned)(B * C)), 256, 0, st>>>(
+      g1, db1, db2, dnw, g, y, noise, noise_w, bias2, C, hw, slope, gain);
+  return vsp::check_launch("smart_tail_bwd");
 }

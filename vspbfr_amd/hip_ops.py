@@ -1096,6 +1096,19 @@ def noise_dot(gx, noise):
     return out
 
 
+def smart_tail_bwd(g, y, noise, noise_w, bias2, slope=0.2, gain=SQRT2):
+    """Backward of FusedLeakyReLU(bias1) -> NoiseInjection -> FusedLeakyReLU(bias2) from the final output y (vsp_smart_tail_bwd_f32):
+    returns (g1 = gradient entering the conv, d bias1 (C,), d bias2 (C,), d noise_weight (1,))."""
+    g, y, noise = _req(g, "g"), _req(y, "y"), _req(noise, "noise")
+    B, Cc, Hh, Ww = g.shape
+    g1 = torch.empty_like(g)
+    sums = torch.empty(2 * Cc + 1, device=g.device, dtype=torch.float32)
+    check(lib.vsp_smart_tail_bwd_f32(_ptr(g1), _ptr(sums), C.c_void_p(sums.data_ptr() + 4 * Cc), C.c_void_p(sums.data_ptr() + 8 * Cc),
+                                     _ptr(g), _ptr(y), _ptr(noise), _ptr(_req(noise_w, "noise_w")), _ptr(_req(bias2, "bias2")), B, Cc,
+                                     Hh * Ww, float(slope), float(gain), _stream()), "smart_tail_bwd")
+    return g1, sums[:Cc], sums[Cc:2 * Cc], sums[2 * Cc:]
+
+
 def channel_sum(x):
     """(B, C, ...) -> (C,): sum over the batch and everything behind the channel dimension (bias gradients)."""
     x = _req(x, "x")

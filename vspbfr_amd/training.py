@@ -247,11 +247,44 @@ def styled_conv(x, layer, style, noise):
     return noise_bias_act(out, noise, layer.noise.weight, layer.activate.bias)
 
 
+class _FusionTail(Function):
+    """The fusion conv of a SMART layer with its tail -- FusedLeakyReLU, NoiseInjection, FusedLeakyReLU -- in the conv's epilogue (the
+    launch the inference module makes), and ONE backward stream for the tail (vsp_smart_tail_bwd_f32: both masks from the final y, the
+    two bias gradients and the noise-weight gradient) in front of the data- and weight-gradient convs.  First order (generator only)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias1, noise, noise_w, bias2, layer):
+        x, noise = x.contiguous(), noise.contiguous()
+        y = H.conv2d_packed(x, layer._fusion_pack(), act1=True, bias1=bias1, noise=noise, noise_w=noise_w, act2=1, bias2=bias2)
+        ctx.layer = layer
+        ctx.save_for_backward(x, y, noise, noise_w, bias2)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y, noise, noise_w, bias2 = ctx.saved_tensors
+        layer = ctx.layer
+        conv = layer.fusion[0]
+        g1, db1, db2, dnw = H.smart_tail_bwd(g.contiguous(), y, noise, noise_w, bias2)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            c = layer.out_channel
+            adj = layer._derive("fusion_adjoint", [conv.weight], lambda: H.PackedConv(
+                H.pack_weight(conv.weight, adjoint=True, flip=True, scale=conv.scale), 1, c, c, 3, 3, 1, (1,), (1,)))
+            dx = H.conv2d_packed(g1, adj)
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            dw = H.conv2d_wgrad(x, g1, tuple(conv.weight.shape), 1, 1, 1, 1) * conv.scale
+        return dx, dw, db1, None, dnw, db2, None
+
+
 def smart_layer(x, layer, style, noise):
     """SMART_layer.forward (reference models/RestoreNet.py:220-244): the four dilated branches share ONE modulation; fusion conv,
     FusedLeakyReLU, noise, FusedLeakyReLU."""
     out = smart_branches(x, layer, style)
     f = layer.fusion[0]
+    if torch.is_grad_enabled():
+        return _FusionTail.apply(out, f.weight, layer.fusion[1].bias, noise, layer.noise.weight, layer.activate.bias, layer)
     out = conv2d_gradfix.conv2d(out, f.weight * f.scale, padding=1)
     out = fused_leaky_relu(out, layer.fusion[1].bias)
     return noise_bias_act(out, noise, layer.noise.weight, layer.activate.bias)
