@@ -691,6 +691,26 @@ def test_discriminator64_losses_and_double_backward(golden):
         assert abs(g_loss.item() - float(g["g_loss"][0])) < 1e-5
         worst["d_fake_image"] = rel(xf.grad, g["d_fake_image"])
         assert abs(float(xf.grad.norm()) - float(g["d_fake_image_norm"][0])) < 5e-3 * float(g["d_fake_image_norm"][0])
+        # the same two first-order passes through the fused ConvLayer form the training step uses (discriminator.first_order():
+        # bias + leaky ReLU in the conv epilogue, hand-written backward) against the same reference gradients
+        from vspbfr_amd.discriminator import first_order
+        D.zero_grad()
+        with first_order():
+            rp, fp = D(real), D(fake)
+            d_loss = d_logistic_loss(rp, fp)
+        d_loss.backward()
+        assert maxerr(rp, g["real_pred"]) < 2e-5 and maxerr(fp, g["fake_pred"]) < 2e-5
+        assert abs(d_loss.item() - float(g["d_loss"][0])) < 1e-5
+        for n in names:
+            worst["d-fused/" + n] = rel(params[n].grad, g["gd/" + n])
+            assert abs(float(params[n].grad.norm()) - float(g["nd/" + n][0])) < 5e-3 * float(g["nd/" + n][0]) + 1e-9, n
+        D.zero_grad()
+        xf = fake.detach().clone().requires_grad_(True)
+        with first_order():
+            g_loss = g_nonsaturating_loss(D(xf))
+        g_loss.backward()
+        assert abs(g_loss.item() - float(g["g_loss"][0])) < 1e-5
+        worst["d_fake_image-fused"] = rel(xf.grad, g["d_fake_image"])
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:5]
     print("discriminator: worst relative gradient errors", top)
     assert top[0][1] < 4e-2, top

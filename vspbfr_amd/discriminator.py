@@ -7,15 +7,81 @@ forward is differentiable to second order -- the R1 penalty differentiates the i
 the way is: op.conv2d_gradfix (forward / data-gradient kernels + vsp_conv2d_wgrad_f32), op.fused_leaky_relu, op.upfirdn2d, and
 torch tensor algebra for the minibatch-stddev statistic and the two linear layers (plain library GEMMs).
 ADA augmentation lives in vspbfr_amd/non_leaking.py."""
+import contextlib
 import math
 
 import torch
 import torch.nn.functional as F
 from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
+from . import hip_ops
 from .layers import Blur, EqualConv2d, EqualLinear, LeakyBias
 from .op import conv2d_gradfix, fused_leaky_relu, upfirdn2d
 from .training import equal_linear
+
+
+# The R1 penalty differentiates the discriminator's input gradient again, so by default every operator of the forward is twice
+# differentiable.  The logistic-loss passes of the training step (restoration_train.py:196-212, 225-234) only need first order: inside
+# `first_order()` an activated ConvLayer runs as ONE launch (bias + leaky ReLU in the conv epilogue, equalised-lr scale folded into
+# the packing) with a hand-written backward -- slope mask from y, bias sum, data- and weight-gradient kernels.
+_FIRST_ORDER = False
+
+
+@contextlib.contextmanager
+def first_order():
+    global _FIRST_ORDER
+    old, _FIRST_ORDER = _FIRST_ORDER, True
+    try:
+        yield
+    finally:
+        _FIRST_ORDER = old
+
+
+def _cached_pack(conv, name, build):
+    key = (conv.weight._version, conv.weight.data_ptr())
+    cache = conv.__dict__.setdefault("_vsp_packs", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = cache[name] = (key, build())
+    return hit[1]
+
+
+class _ConvLrelu(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv):
+        x = x.contiguous()
+        cout, cin, k, _ = weight.shape
+        pc = _cached_pack(conv, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(weight, scale=conv.scale), 1, cout, cin, k, k,
+                                                                  conv.stride, (1,), (conv.padding,)))
+        y = hip_ops.conv2d_packed(x, pc, act2=1, bias2=bias)
+        ctx.conv = conv
+        ctx.save_for_backward(x, y, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y, weight = ctx.saved_tensors
+        conv = ctx.conv
+        cout, cin, k, _ = weight.shape
+        g1 = hip_ops.fused_bias_act(g.contiguous(), g.new_empty(0), y, 3, 1, 0.2, 2 ** 0.5)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if conv.stride == 1:
+                adj = _cached_pack(conv, "adj", lambda: hip_ops.PackedConv(
+                    hip_ops.pack_weight(weight, adjoint=True, flip=True, scale=conv.scale), 1, cin, cout, k, k, 1, (1,), (k - 1 - conv.padding,)))
+                dx = hip_ops.conv2d_packed(g1, adj)
+            else:   # 3x3, stride 2, padding 0 (behind the blur): the one-pass transposed kernel writes straight into the input-sized gradient
+                adj = _cached_pack(conv, "adj", lambda: hip_ops.PackedConv(
+                    hip_ops.pack_weight(weight, adjoint=True, scale=conv.scale), 1, cin, cout, 3, 3, 1, (1,), (1,)))
+                dx = hip_ops.conv_transpose2d_s2_into(g1, adj, x.shape[2:])
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            dw = hip_ops.conv2d_wgrad(x, g1, tuple(weight.shape), conv.stride, conv.padding, 1, 1) * conv.scale
+        if ctx.needs_input_grad[2]:
+            db = hip_ops.channel_sum(g1)
+        return dx, dw, db, None
 
 
 class ConvLayer(nn.Sequential):
@@ -33,10 +99,15 @@ class ConvLayer(nn.Sequential):
         super().__init__(*layers)
 
     def forward(self, x):
-        for m in self:
+        mods = list(self)
+        fused = (_FIRST_ORDER and torch.is_grad_enabled() and isinstance(mods[-1], LeakyBias) and mods[-2].bias is None
+                 and (mods[-2].stride == 1 or (mods[-2].weight.shape[2] == 3 and mods[-2].padding == 0)))
+        for m in mods:
             if isinstance(m, Blur):
                 x = upfirdn2d(x, m.kernel, pad=m.pad)
             elif isinstance(m, EqualConv2d):
+                if fused:
+                    return _ConvLrelu.apply(x, m.weight, mods[-1].bias, m)
                 x = conv2d_gradfix.conv2d(x, m.weight * m.scale, bias=m.bias, stride=m.stride, padding=m.padding)
             else:
                 x = fused_leaky_relu(x, m.bias)

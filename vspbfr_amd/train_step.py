@@ -23,7 +23,7 @@ import random
 import torch
 
 from . import training
-from .discriminator import accumulate, d_logistic_loss, d_r1_loss, g_nonsaturating_loss
+from .discriminator import accumulate, d_logistic_loss, d_r1_loss, first_order, g_nonsaturating_loss
 from .restorenet import mixing_noise
 
 
@@ -215,7 +215,8 @@ class RestorationTrainer:
         requires_grad(self.D, True)
         with torch.no_grad():
             fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
-        fake_pred, real_pred = self.D(self._aug(fake.detach())), self.D(self._aug(real_img.detach().clone()))
+        with first_order():   # logistic loss: first-order passes (the R1 pass below keeps the twice-differentiable operators)
+            fake_pred, real_pred = self.D(self._aug(fake.detach())), self.D(self._aug(real_img.detach().clone()))
         d_loss = d_logistic_loss(real_pred, fake_pred)
         self.D.zero_grad(set_to_none=True)
         with self.d_reducer:
@@ -237,7 +238,8 @@ class RestorationTrainer:
         requires_grad(self.G, True)
         requires_grad(self.D, False)
         fake = self.generate(low_img, de_feats, latent, mixing_noise(B, self.G.style_dim, self.mixing, dev))
-        g_loss = g_nonsaturating_loss(self.D(self._aug(fake)))
+        with first_order():
+            g_loss = g_nonsaturating_loss(self.D(self._aug(fake)))
         losses["g"] = g_loss.detach()
         if self.percept_loss is not None and self.percept_weight > 0:
             t = self.percept_loss(fake, real_img.detach()).sum() * self.percept_weight
