@@ -49,14 +49,16 @@ def _cached_pack(conv, name, build):
 
 
 class _ConvLrelu(Function):
+    """`gain`: the activation's gain (sqrt 2 of FusedLeakyReLU; 1 when the ResBlock's 1 / sqrt 2 is folded in)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, conv):
+    def forward(ctx, x, weight, bias, conv, gain=2 ** 0.5):
         x = x.contiguous()
         cout, cin, k, _ = weight.shape
         pc = _cached_pack(conv, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(weight, scale=conv.scale), 1, cout, cin, k, k,
                                                                   conv.stride, (1,), (conv.padding,)))
-        y = hip_ops.conv2d_packed(x, pc, act2=1, bias2=bias)
-        ctx.conv = conv
+        y = hip_ops.conv2d_packed(x, pc, act2=1, bias2=bias, gain2=gain)
+        ctx.conv, ctx.gain = conv, gain
         ctx.save_for_backward(x, y, weight)
         return y
 
@@ -66,7 +68,7 @@ class _ConvLrelu(Function):
         x, y, weight = ctx.saved_tensors
         conv = ctx.conv
         cout, cin, k, _ = weight.shape
-        g1 = hip_ops.fused_bias_act(g.contiguous(), g.new_empty(0), y, 3, 1, 0.2, 2 ** 0.5)
+        g1 = hip_ops.fused_bias_act(g.contiguous(), g.new_empty(0), y, 3, 1, 0.2, ctx.gain)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if conv.stride == 1:
@@ -81,7 +83,41 @@ class _ConvLrelu(Function):
             dw = hip_ops.conv2d_wgrad(x, g1, tuple(weight.shape), conv.stride, conv.padding, 1, 1) * conv.scale
         if ctx.needs_input_grad[2]:
             db = hip_ops.channel_sum(g1)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
+
+
+class _SkipConvAdd(Function):
+    """Tail of a ResBlock, (main + skip(x)) / sqrt 2 (models/RestoreNet.py:1196-1202), as the epilogue of the skip's 1x1 stride-2 conv:
+    y = main + conv(xb, W scale / sqrt 2) with `main` already carrying its 1 / sqrt 2 (activation gain 1 instead of sqrt 2)."""
+
+    @staticmethod
+    def forward(ctx, xb, weight, main, conv):
+        xb, main = xb.contiguous(), main.contiguous()
+        cout, cin = weight.shape[:2]
+        sc = conv.scale / math.sqrt(2)
+        pc = _cached_pack(conv, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(weight, scale=sc), 1, cout, cin, 1, 1, 2, (1,), (0,)))
+        y = hip_ops.conv2d_packed(xb, pc, res1=main)
+        ctx.conv = conv
+        ctx.save_for_backward(xb, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xb, weight = ctx.saved_tensors
+        conv = ctx.conv
+        cout, cin = weight.shape[:2]
+        sc = conv.scale / math.sqrt(2)
+        g = g.contiguous()
+        dxb = dw = None
+        if ctx.needs_input_grad[0]:   # the 1x1 adjoint lands on the even pixels of the blurred input
+            adj = _cached_pack(conv, "adj", lambda: hip_ops.PackedConv(hip_ops.pack_weight(weight, adjoint=True, scale=sc), 1, cin, cout,
+                                                                       1, 1, 1, (1,), (0,)))
+            dxb = torch.zeros_like(xb)
+            hip_ops.conv2d_packed(g, adj, out=dxb, out_stride=(2, 2))
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            dw = hip_ops.conv2d_wgrad(xb, g, tuple(weight.shape), 2, 0, 1, 1) * sc
+        return dxb, dw, g if ctx.needs_input_grad[2] else None, None
 
 
 class ConvLayer(nn.Sequential):
@@ -98,7 +134,7 @@ class ConvLayer(nn.Sequential):
             layers.append(LeakyBias(out_channel))
         super().__init__(*layers)
 
-    def forward(self, x):
+    def forward(self, x, gain=2 ** 0.5):
         mods = list(self)
         fused = (_FIRST_ORDER and torch.is_grad_enabled() and isinstance(mods[-1], LeakyBias) and mods[-2].bias is None
                  and (mods[-2].stride == 1 or (mods[-2].weight.shape[2] == 3 and mods[-2].padding == 0)))
@@ -107,7 +143,7 @@ class ConvLayer(nn.Sequential):
                 x = upfirdn2d(x, m.kernel, pad=m.pad)
             elif isinstance(m, EqualConv2d):
                 if fused:
-                    return _ConvLrelu.apply(x, m.weight, mods[-1].bias, m)
+                    return _ConvLrelu.apply(x, m.weight, mods[-1].bias, m, gain)
                 x = conv2d_gradfix.conv2d(x, m.weight * m.scale, bias=m.bias, stride=m.stride, padding=m.padding)
             else:
                 x = fused_leaky_relu(x, m.bias)
@@ -122,6 +158,11 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, blur_kernel=blur_kernel, activate=False, bias=False)
 
     def forward(self, x):
+        if _FIRST_ORDER and torch.is_grad_enabled():
+            # first-order passes: the 1 / sqrt 2 rides in conv2's activation gain and the skip's weight scale, the sum in the skip's epilogue
+            main = self.conv2(self.conv1(x), gain=1.0)
+            blur, conv = self.skip[0], self.skip[1]
+            return _SkipConvAdd.apply(upfirdn2d(x, blur.kernel, pad=blur.pad), conv.weight, main, conv)
         return (self.conv2(self.conv1(x)) + self.skip(x)) / math.sqrt(2)
 
 
