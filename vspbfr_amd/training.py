@@ -308,6 +308,19 @@ def to_rgb(x, layer, style, skip=None):
     return out
 
 
+class _Add3(Function):
+    """a + b + c in one stream (the decoder's `out + features[k] + de_feats[k]`, models/RestoreNet.py:1035); the gradient is the
+    incoming one for every operand that asks."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        return H.add3(a.contiguous(), b.contiguous(), c.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g if need else None for need in ctx.needs_input_grad)
+
+
 def restoration_net_forward(net, images, de_feats, pre_styles, noise_styles, enc_noise, dec_noise, inject_index=None):
     """Restoration_net.forward + encoder_forward (reference models/RestoreNet.py:915-942, 968-1046) with explicit noise maps
     (enc_noise: 2 per encoder level, dec_noise: 1 + 2 per decoder level, as the inference module takes them).  Dropout2d of
@@ -350,7 +363,7 @@ def restoration_net_forward(net, images, de_feats, pre_styles, noise_styles, enc
     for j in range(net.log_size - 2):
         out = styled_conv(out, net.convs[2 * j], sty(i), dec_noise[1 + 2 * j])
         k = (i + 1) // 2
-        out = out + feats[k] + de_feats[k]
+        out = _Add3.apply(out, feats[k], de_feats[k])
         out = smart_layer(out, net.convs[2 * j + 1], sty(i + 1), dec_noise[2 + 2 * j])
         skip = to_rgb(out, net.to_rgbs[j], sty(i + 2), skip)
         i += 2
