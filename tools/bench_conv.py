@@ -27,6 +27,7 @@ SHAPES = [
     ("irse32", 8, 256, 256, 32, 32, 3, 1, 1, 1, 1),
     ("c16", 8, 512, 512, 16, 16, 3, 1, 1, 1, 1),
     ("c8", 8, 512, 512, 8, 8, 3, 1, 1, 1, 1),
+    ("c4", 8, 512, 512, 4, 4, 3, 1, 1, 1, 1),
 ]
 
 
