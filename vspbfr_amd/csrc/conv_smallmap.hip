@@ -21,7 +21,7 @@ constexpr int kSW = 8;   // wavefronts per workgroup = K split
 template <int MI, int NI, int KU, bool VEC>
 __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, const int N, const int co_tiles) {
   __shared__ float red[kSW][MI * NI * 4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, kq = lane >> 4;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16 * MI;
   const int g = blockIdx.y / co_tiles, co0 = (blockIdx.y - g * co_tiles) * 16 * NI;
   const int gg = p.G > 4 ? 0 : g;   // more than four groups share one geometry
@@ -52,9 +52,22 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
 
   const int c16 = p.Cin >> 4;
   const int S = T * c16;
-  auto fetch = [&](int s, float (*A)[4], float (*Bf)[4]) {   // s: uniform per wavefront
-    const int tap = s / c16, cc = s - tap * c16;
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  // The K walk keeps (tap row, tap column, 16-channel step) as wavefront-uniform counters advanced by 8 KU sub-steps per iteration
+  // (no integer division per sub-step).
+  struct KPos { int ky, kx, cc; };
+  auto advance = [&](KPos& k, int steps) {
+    k.cc += steps;
+    while (k.cc >= c16) {
+      k.cc -= c16;
+      if (++k.kx == p.KW) {
+        k.kx = 0;
+        ++k.ky;
+      }
+    }
+  };
+  auto fetch = [&](KPos k, float (*A)[4], float (*Bf)[4]) {   // k: uniform per wavefront; past the end -> the last sub-step (unused)
+    if (k.ky >= p.KH) k = KPos{p.KH - 1, p.KW - 1, c16 - 1};
+    const int ky = k.ky, kx = k.kx, cc = k.cc, tap = ky * p.KW + kx;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int iy = iy0[mi] + ky * dil, ix = ix0[mi] + kx * dil;
@@ -102,16 +115,21 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   float a[KU][MI][4], bq[KU][NI][4], an[KU][MI][4], bn[KU][NI][4];
   const int iters = (S + kSW * KU - 1) / (kSW * KU);
+  KPos kc[KU], kn[KU];   // position of the operands in hand / of the next fetch
 #pragma unroll
-  for (int u = 0; u < KU; ++u) fetch(min(wv * KU + u, S - 1), a[u], bq[u]);
+  for (int u = 0; u < KU; ++u) {
+    const int s0 = wv * KU + u, tap0 = s0 / c16;
+    kc[u] = KPos{tap0 / p.KW, tap0 % p.KW, s0 - tap0 * c16};
+    fetch(kc[u], a[u], bq[u]);
+    kn[u] = kc[u];
+    advance(kn[u], kSW * KU);
+  }
   for (int it = 0; it < iters; ++it) {
-    const int sbase = (it * kSW + wv) * KU;
-    const int snext = it + 1 < iters ? sbase + kSW * KU : sbase;
 #pragma unroll
-    for (int u = 0; u < KU; ++u) fetch(min(snext + u, S - 1), an[u], bn[u]);
+    for (int u = 0; u < KU; ++u) fetch(kn[u], an[u], bn[u]);
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      if (sbase + u < S) {
+      if (kc[u].ky < p.KH) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -120,6 +138,8 @@ __global__ __launch_bounds__(64 * kSW) void conv_smallmap_kernel(const ConvK p, 
             for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mi][e], bq[u][ni][e], acc[mi][ni], 0, 0, 0);
       }
+      kc[u] = kn[u];
+      advance(kn[u], kSW * KU);
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
