@@ -59,13 +59,20 @@ struct WG {  // workgroup geometry: MBW 16-channel blocks x NBW 16-tile blocks (
   static constexpr int TLX = NBW == 8 ? 16 : 8;
   static constexpr int TLY = NTILE / TLX;
   static constexpr int PR = 2 * TLY + 2, PC = 2 * TLX + 2 * DMAX;  // PC: the widest patch row (dilation DMAX)
-  static constexpr int PPITCH = (PR * PC + 15) / 16 * 16;
+  // Patch ROW pitch (round 3, bank conflicts).  The transform reads a task's window as 16-byte rows (ds_read2_b64: 16-lane groups,
+  // bank = dword mod 32); a group holds the 8 tile columns of TWO tile rows (window rows 2 apart), so with 8-tile-wide geometries
+  // the row pitch must put two rows 16 banks apart: pitch == 8 (mod 16) -> 24 for the 18-word rows (the pitch-18 image made every
+  // transform read a 2-way conflict: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.39).  16-tile-wide geometries fill all 32 banks
+  // from one row and keep the dense image; so do the dilated variants (their row width depends on the group's dilation).
+  static constexpr int PCP = (DMAX == 1 && TLX == 8) ? 24 : PC;
+  static constexpr int PPITCH = (PR * PCP + 15) / 16 * 16;
   static constexpr int VPITCH = NTILE + 16;           // k-slot rows 16 banks apart
   static constexpr int LDS_V = 16 * IVC * VPITCH;     // floats, two buffers
   static constexpr int LDS_P = IVC * PPITCH;          // floats, two buffers
   static constexpr int ETILE = NTILE > 64 ? 64 : NTILE;  // tiles per epilogue pass
   static constexpr int EMB = (MBW >= 2 && ETILE <= 32) ? 2 : 1;  // 16-channel blocks per epilogue pass
-  static constexpr int LDS_M = 16 * 16 * EMB * ETILE;
+  static constexpr int EP = ETILE + 4;                // epilogue row pitch: 4 rows (one k-slot group) = 16 banks
+  static constexpr int LDS_M = 16 * 16 * EMB * EP;
   static constexpr int LDS_STAGE = 2 * LDS_V + 2 * LDS_P;
   static constexpr int LDS_FLOATS = LDS_STAGE > LDS_M ? LDS_STAGE : LDS_M;
   static constexpr int UF = 2 * MBW;                  // U floats per lane and chunk: [pp 2][mb MBW]
@@ -77,6 +84,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR;
   constexpr int PPITCH = Gm::PPITCH, VPITCH = Gm::VPITCH, LDS_V = Gm::LDS_V, LDS_P = Gm::LDS_P, UF = Gm::UF;
   constexpr int IVC = Gm::IVC, KS = Gm::KS;
+  constexpr bool PADROW = Gm::PCP != Gm::PC;        // padded patch rows (undilated 8-tile-wide geometries)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vl = smem;               // 2 x [16][IVC][VPITCH]
   float* Pl = smem + 2 * LDS_V;   // 2 x [IVC][PPITCH]
@@ -156,6 +164,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   }
   const int oy0 = ty_i * (2 * TLY), ox0 = tx_i * (2 * TLX);   // sub-image rows, image columns
   const int PC = 2 * TLX + 2 * d;                             // patch row of this group
+  const int PCP = PADROW ? Gm::PCP : PC;                      // its pitch in LDS
   const int co0 = ct * WCO;                                   // within the group
   const int chw = p.H * p.W;
   const float* xb = p.x + (int64_t)b * p.x_ch * chw;
@@ -168,21 +177,26 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
   constexpr int PTH = NTHR / IVC;                  // threads per channel plane
   constexpr int PLD = (PR * Gm::PC + PTH - 1) / PTH;
   const int p_ch = __builtin_amdgcn_readfirstlane(tid / PTH), p_t = tid % PTH;  // (PTH is a multiple of 64: wave-uniform)
-  int p_src[PLD];  // image offset of plane word p_t + PTH e (-1: outside the image / beyond the plane)
+  // per word e of this thread: byte offset inside the channel image (0 when outside), a validity bit, and -- with padded rows --
+  // its LDS word (row r of the plane lives at r * PCP)
+  int p_voff[PLD];
+  int p_dst[PADROW ? PLD : 1];
+  unsigned p_in = 0;
 #pragma unroll
   for (int e = 0; e < PLD; ++e) {
     const int rem = p_t + PTH * e;
     const int r = rem / PC, c = rem - r * PC;
     const int sy = oy0 - 1 + r, ix = ox0 - d + c;
     const int iy = sy * d + ry;
-    p_src[e] = (rem < PLANE && sy >= 0 && ix >= 0 && iy < p.H && ix < p.W) ? iy * p.W + ix : -1;
+    const bool in = rem < PLANE && sy >= 0 && ix >= 0 && iy < p.H && ix < p.W;
+    p_voff[e] = in ? (iy * p.W + ix) * 4 : 0;
+    p_in |= in ? (1u << e) : 0u;
+    if constexpr (PADROW) p_dst[e] = p_ch * PPITCH + r * Gm::PCP + c;
   }
+  if constexpr (!PADROW) p_dst[0] = p_ch * PPITCH + p_t;
   // buffer loads: resource = this image, scalar offset = the channel plane, vector offset = the lane's byte offset in a plane
   // (flat pointers cost a 64-bit VALU add per load and the registers of the 64-bit lane addresses)
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
-  int p_voff[PLD];
-#pragma unroll
-  for (int e = 0; e < PLD; ++e) p_voff[e] = (p_src[e] >= 0 ? p_src[e] : 0) * 4;
   float preg[PLD], pnext[PLD];
   auto issue_p = [&](int c) {  // chunk c -> pnext (raw values: nothing may consume them before the commit two steps later)
     const int ci = c * IVC + p_ch;
@@ -197,7 +211,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     const float sc = uload(p.wcp, b * p.wc_bs + cc * p.wc_cs), sh = uload(p.wshp, cc * p.wsh_cs);
 #pragma unroll
     for (int e = 0; e < PLD; ++e)
-      if (PLD * PTH == PLANE || p_t + PTH * e < PLANE) Pdst[p_ch * PPITCH + p_t + PTH * e] = (p_src[e] >= 0 && chok) ? fmaf(preg[e], sc, sh) : 0.f;
+      if (PLD * PTH == PLANE || p_t + PTH * e < PLANE)
+        Pdst[PADROW ? p_dst[e] : p_dst[0] + PTH * e] = (((p_in >> e) & 1u) && chok) ? fmaf(preg[e], sc, sh) : 0.f;
   };
 
   // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
@@ -216,7 +231,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     }
   };
 
-  // ---- transform: task = (channel, tile, half); half h produces V rows 2h, 2h+1 of the tile's 4x4 window
+  // ---- transform: task = (channel, tile, half); half h produces V rows 2h, 2h+1 of the tile's 4x4 window.
+  // Task -> lane (round 3): 32 consecutive tiles of ONE half per half-wave (tile = task bits 0-4 and 6.., half = bit 5).  The V
+  // stores of a 32-lane group then hit 32 consecutive words (with the half in bit 0, lanes 2k and 2k+1 wrote the same bank), and
+  // a 16-lane group of the window reads covers 8 tile columns x 2 tile rows -- conflict-free on the padded patch rows (Gm::PCP).
+  auto task_half = [](int task) { return (task >> 5) & 1; };
+  auto task_tile = [](int task) { return (task & 31) | (((task >> 6) & (NTILE / 32 - 1)) << 5); };
   constexpr int TASKS = 2 * IVC * NTILE;
   constexpr int TPT = (TASKS + NTHR - 1) / NTHR;
   static_assert(TASKS % NTHR == 0, "every thread runs TPT transform tasks");
@@ -225,27 +245,27 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 #pragma unroll
     for (int it = 0; it < TPT; ++it) {
       const int task = tid + it * NTHR;
-      const int th = task & 1, tq = task >> 1;
-      const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
+      const int th = task_half(task), t_tile = task_tile(task);
+      const int t_ch = __builtin_amdgcn_readfirstlane(task / (2 * NTILE));
       const int t_ty = t_tile / TLX, t_tx = t_tile - t_ty * TLX;
       // tile column t_tx: column residue t_tx % d, position t_tx / d -> first window column (patch coordinates) rx + 2 d pos
       const int c0 = DMAX == 1 ? 2 * t_tx : (t_tx % d) + 2 * d * (t_tx / d);
-      const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PC + c0;
+      const float* src = Psrc + t_ch * PPITCH + (2 * t_ty + th) * PCP + c0;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) tdd[it][r][cc] = src[r * PC + cc * d];
+        for (int cc = 0; cc < 4; ++cc) tdd[it][r][cc] = src[r * PCP + cc * d];
     }
   };
   auto transform_write = [&](float* Vdst, int c) {  // chunk c: V = B^T d B, the style scale rides on V
 #pragma unroll
     for (int it = 0; it < TPT; ++it) {
       const int task = tid + it * NTHR;
-      const int th = task & 1, tq = task >> 1;
+      const int th = task_half(task), t_tile = task_tile(task);
       // (2 NTILE tasks per channel, a multiple of 64: the channel is wave-uniform -> the style scale comes through the scalar
       //  cache on lgkmcnt; as a per-lane global load it put a vmcnt(0) -- i.e. the latency of the patch and U prefetches just
       //  issued -- into every interval)
-      const int t_ch = __builtin_amdgcn_readfirstlane(tq / NTILE), t_tile = tq - t_ch * NTILE;
+      const int t_ch = __builtin_amdgcn_readfirstlane(task / (2 * NTILE));
       const int ci = c * IVC + t_ch;
       const float sc = uload(p.wtp, b * p.wt_bs + (ci < p.Cin ? ci : p.Cin - 1) * p.wt_cs);
       const auto& dd = tdd[it];
@@ -389,8 +409,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 
   // ---- epilogue: per 16-channel block and (at most) 64 tiles, all sixteen positions through LDS, one thread per
   //      (channel, tile): Y = A^T M A, then the fused operand chain of the direct kernel
-  constexpr int ETILE = Gm::ETILE, ENB = ETILE / 16;
-  float* Ml = smem;  // [16 pos][16 co][ETILE]
+  constexpr int ETILE = Gm::ETILE, ENB = ETILE / 16, EP = Gm::EP;
+  float* Ml = smem;  // [16 pos][16 co][EP]: rows padded so that the four k-slot groups of a store land 16 banks apart
   const int Cout = p.G * p.cout_g;
   const float* osp = p.osp + (int64_t)b * Cout * p.oss;
   const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW * p.nzs;
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
           for (int nb = 0; nb < ENB; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              Ml[((2 * wave + pp) * ECO + m2 * 16 + kq * 4 + r) * ETILE + nb * 16 + lr] = acc[pp][mb0 + m2][th * ENB + nb][r];
+              Ml[((2 * wave + pp) * ECO + m2 * 16 + kq * 4 + r) * EP + nb * 16 + lr] = acc[pp][mb0 + m2][th * ENB + nb][r];
       __syncthreads();
 #pragma unroll
       for (int it = 0; it < EPT; ++it) {
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         const int sx = ox0 + (DMAX == 1 ? 2 * e_tx : (e_tx % d) + 2 * d * (e_tx / d));   // first output column of the tile
         float m[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) m[q] = Ml[(q * ECO + e_co) * ETILE + e_t];
+        for (int q = 0; q < 16; ++q) m[q] = Ml[(q * ECO + e_co) * EP + e_t];
         float t0[4], t1[4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
