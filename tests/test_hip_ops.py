@@ -1213,6 +1213,102 @@ def test_conv_smallmap_kernel(H, case):
     close(out_a, out_b, 3e-5, 3e-5, "placement")
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, cin=32, cout=160, hw=(37, 41), stride=2, pad=1),                         # ragged tiles and channel tiles, stride 2
+    dict(B=3, cin=16, cout=24, hw=(33, 33), stride=2, pad=0),                          # StyledConv_down geometry (odd map, no padding)
+    dict(B=2, cin=24, cout=72, hw=(21, 50), stride=1, pad=1),
+    dict(B=1, cin=8, cout=40, hw=(40, 24), stride=1, pad=3, dil=3),
+    dict(B=2, cin=16, cout=64, hw=(48, 40), stride=1, G=4, dil=(1, 2, 4, 8)),          # the four dilated SMART branches
+    dict(B=2, cin=8, cout=32, hw=(19, 23), stride=1, G=4, dil=(1, 2, 4, 8)),
+    dict(B=2, cin=16, cout=48, hw=(22, 22), stride=2, pad=1, G=3, true_groups=True),   # true groups (style heads)
+    dict(B=2, cin=16, cout=40, hw=(32, 32), transposed=True),                          # up-conv: tiles + edge strips
+    dict(B=3, cin=8, cout=20, hw=(13, 21), transposed=True),                           # up-conv: ragged tiles
+], ids=lambda c: f"{c['cin']}-{c['cout']}-{c['hw'][0]}x{c['hw'][1]}-s{c.get('stride', 1)}G{c.get('G', 1)}{'t' if c.get('transposed') else ''}")
+def test_conv_pipelined_kernels(H, case):
+    """Every configuration of the double-buffered pipeline kernels (conv_pipe.hip, names "...p3...") that accepts the launch: the
+    plain convolution against F.conv2d / F.conv_transpose2d in float64, then every prologue / epilogue operand of the contract
+    against the tiled kernel (conv_igemm_kernel) on the same launch parameters."""
+    from vspbfr_amd._lib import lib
+    c = case
+    g_ = torch.Generator().manual_seed(53)
+    B, cin, cout, (Hh, Ww) = c["B"], c["cin"], c["cout"], c["hw"]
+    st, G, tr = c.get("stride", 1), c.get("G", 1), c.get("transposed", False)
+    true_groups = c.get("true_groups", False)
+    cg = cout // G
+    dil = c.get("dil", 1)
+    dil = dil if isinstance(dil, tuple) else (dil,) * G
+    pad = tuple(dil) if G == 4 and not true_groups else (c.get("pad", 0),) * G
+    xc = cin * G if true_groups else cin
+    x = dev(torch.randn(B, xc, Hh, Ww, generator=g_))
+    ws = [torch.randn(cg, cin, 3, 3, generator=g_) / math.sqrt(cin * 9) for _ in range(G)]
+    wp = H.pack_weight_stack([dev(w_) for w_ in ws])
+    if tr:
+        pc = H.PackedConv(wp, 1, cout, cin, 3, 3, 1, (1,), (0,))
+        ref = F.conv_transpose2d(x.cpu().double(), ws[0].double().transpose(0, 1), stride=2).float()
+    else:
+        if G == 1:
+            pc = H.PackedConv(wp, 1, cg, cin, 3, 3, st, (dil[0],), (pad[0],))
+        elif true_groups:
+            pc = H.PackedConv(wp, G, cg, cin, 3, 3, st, (1,), (pad[0],), x_group_stride=cin)
+        else:
+            pc = H.PackedConv(wp, G, cg, cin, 3, 3, st, dil, pad)
+        refs = []
+        for gi in range(G):
+            xi = x.cpu().double()[:, gi * cin:(gi + 1) * cin] if true_groups else x.cpu().double()
+            refs.append(F.conv2d(xi, ws[gi].double(), None, st, pad[gi], dil[gi]))
+        ref = torch.cat(refs, 1).float()
+    OH, OW = ref.shape[2:]
+    s_in = dev(torch.rand(B, xc, generator=g_) + 0.5)
+    kw = dict(in_scale=s_in, out_scale=dev(torch.rand(B, cout, generator=g_) + 0.5), act1=True, bias1=dev(torch.randn(cout, generator=g_)),
+              act2=1, bias2=dev(torch.randn(cout, generator=g_)))
+    if not tr:   # (the transposed mode has no noise / residual epilogue: they follow the blur)
+        kw.update(noise=dev(torch.randn(B, 1, OH, OW, generator=g_)), noise_w=dev(torch.tensor([0.3])),
+                  res1=dev(torch.randn(B, cout, OH, OW, generator=g_)), res2=dev(torch.randn(B, cout, OH, OW, generator=g_)))
+    kw2 = dict(in_scale=dev(torch.rand(xc, generator=g_) + 0.5), in_scale_per_sample=False, ch_scale=dev(torch.rand(cout, generator=g_) + 0.5),
+               ch_bias=dev(torch.randn(cout, generator=g_)), act2=2, prelu=dev(torch.rand(cout, generator=g_)))
+    base = dict(transposed=tr, winograd=False, bf16=False)
+    want, want2 = H.conv2d_packed(x, pc, **base, **kw), H.conv2d_packed(x, pc, **base, **kw2)
+    ran = 0
+    for i in range(lib.vsp_conv2d_num_configs()):
+        name = lib.vsp_conv2d_config_name(i).decode()
+        if "p3" not in name:
+            continue
+        try:
+            y = H.conv2d_packed(x, pc, tile_hint=i + 1, **base)
+        except RuntimeError:
+            continue   # this configuration does not serve the launch (mode, patch rows, chunk size)
+        ran += 1
+        close(y, ref, 2e-5, 2e-5, name + " plain")
+        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw), want, 3e-5, 3e-5, name + " epilogue")
+        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw2), want2, 3e-5, 3e-5, name + " per-channel operands")
+        if not tr and st == 1 and G == 1:   # strided placement into a larger tensor, channel window
+            out_a = torch.zeros(B, cout + 3, 2 * OH + 1, 2 * OW + 2, device=x.device)
+            out_b = torch.zeros_like(out_a)
+            H.conv2d_packed(x, pc, out=out_a, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), tile_hint=i + 1, **base)
+            H.conv2d_packed(x, pc, out=out_b, y_coff=2, out_stride=(2, 2), out_offset=(1, 1), **base)
+            close(out_a, out_b, 3e-5, 3e-5, name + " placement")
+    assert ran >= 2, "no pipelined configuration accepted this launch"
+
+
+def test_conv_pipelined_refuses_what_it_does_not_serve(H):
+    """A named pipelined configuration must refuse (not mis-compute) launches outside its contract: an input shift, Cin that is not a
+    multiple of the chunk, a 1x1 kernel."""
+    pid = next(v for k, v in H.CONFIG_IDS.items() if "p3" in k and not k.endswith(("t", "d")))
+    g_ = torch.Generator().manual_seed(3)
+    x = dev(torch.randn(1, 16, 20, 20, generator=g_))
+    w = dev(torch.randn(32, 16, 3, 3, generator=g_))
+    pc = H.PackedConv(H.pack_weight(w), 1, 32, 16, 3, 3, 1, (1,), (1,))
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(x, pc, tile_hint=pid, in_shift=dev(torch.randn(16, generator=g_)), winograd=False, bf16=False)
+    x5 = dev(torch.randn(1, 5, 20, 20, generator=g_))
+    pc5 = H.PackedConv(H.pack_weight(dev(torch.randn(32, 5, 3, 3, generator=g_))), 1, 32, 5, 3, 3, 1, (1,), (1,))
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(x5, pc5, tile_hint=pid, winograd=False, bf16=False)
+    pc1 = H.PackedConv(H.pack_weight(dev(torch.randn(32, 16, 1, 1, generator=g_))), 1, 32, 16, 1, 1, 1, (1,), (0,))
+    with pytest.raises(RuntimeError):
+        H.conv2d_packed(x, pc1, tile_hint=pid, winograd=False, bf16=False)
+
+
 def test_conv_smallmap_random_shapes(H):
     """Thirty seeded random small-map problems (ragged channel counts, odd maps, both strides, dilation, 1x1 / 3x3 / 5x5 kernels,
     batch 1..9): the small-map kernel against F.conv2d in float64, with the per-sample input scale folded in."""

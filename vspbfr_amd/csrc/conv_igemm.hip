@@ -19,6 +19,8 @@ extern const Cfg kCfgsF[];
 extern const int kNumF;
 extern const Cfg kCfgsG[];
 extern const int kNumG;
+extern const Cfg kCfgsP[];  // conv_pipe.hip: the double-buffered single-pipeline kernels (PF field 3)
+extern const int kNumP;
 }  // namespace vspconv
 
 namespace {
@@ -43,10 +45,12 @@ static void build_table() {
   for (int i = 0; i < vspconv::kNumE && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsE[i];
   for (int i = 0; i < vspconv::kNumF && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsF[i];
   for (int i = 0; i < vspconv::kNumG && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsG[i];
+  for (int i = 0; i < vspconv::kNumP && n < kMaxCfgs; ++i) kCfgs[n++] = vspconv::kCfgsP[i];
   kNumCfgs = n;
 }
 
 constexpr size_t kMaxLds = 100 * 1024;  // > 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize (set once per kernel)
+constexpr size_t kMaxLdsPipe = 160 * 1024;  // conv_pipe.hip: one workgroup may own the whole LDS of a CU
 
 struct Plan {
   int cfg;
@@ -54,6 +58,7 @@ struct Plan {
   bool dg;
   int strip_col, strip_row;  // transposed mode edge strips (strip_col < 0: ragged tiles instead)
   size_t lds;
+  int ps;                    // conv_pipe.hip: plane pitch of the staged patch (floats)
 };
 
 static int ilog2_ceil(int v) {
@@ -87,6 +92,7 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   int twl = ilog2_ceil(p.OW);
   // cap the tile width: 16-pixel MFMA column blocks want >= 16 contiguous pixels; wider tiles cut halo re-reads
   int cap = NPIX >= 256 ? 5 : 4;  // 32 or 16
+  if (k.PF == 3 && dg) cap = NPIX >= 512 ? 5 : 4;  // shared patch with a halo of 8: square tiles stage the fewest words
   if (twl > cap) twl = cap;
   if ((1 << twl) > NPIX) twl = ilog2_ceil(NPIX);
   const int TW = 1 << twl, TH = NPIX / TW;
@@ -100,12 +106,25 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   out->strip_row = 0;
   out->tiles_x = (p.OW + TW - 1) / TW;
   out->tiles_y = (p.OH + TH - 1) / TH;
-  if (tc && NPIX <= 128 && p.H % TH == 0 && p.W % TW == 0) {
+  if (tc && (NPIX <= 128 || k.PF == 3) && p.H % TH == 0 && p.W % TW == 0) {
     out->tiles_x = p.W / TW;
     out->tiles_y = p.H / TH;
     out->strip_col = (p.H + NPIX - 1) / NPIX;
     out->strip_row = (p.W + 1 + NPIX - 1) / NPIX;
     if ((NPIX + 1) * 2 > plane) plane = (NPIX + 1) * 2;
+  }
+  if (k.PF == 3) {  // conv_pipe.hip: 3x3 only, vector weight rows, whole 64-word patch rows per wave, two LDS buffers
+    if (p.KH != 3 || p.KW != 3 || p.cout_g % 4 != 0 || !vsp::aligned16(p.w) || p.in_shift || p.Cin % k.CK != 0) return false;
+    const int NW = k.WM * k.WN, wpc = k.CK >= NW ? 1 : NW / k.CK;
+    const int nrow = (plane + 63) / 64;
+    if (nrow > k.PMAX * wpc) return false;  // (PMAX field = PROWS: 64-word rows of a channel plane per wave)
+    const int ps = host_round_pitch(k.PMAX * wpc * 64, !tc && p.stride_x != 1);   // every staged row lands inside its own plane
+    const size_t lds = 2 * ((size_t)9 * k.CK * WS + (size_t)k.CK * ps) * sizeof(float);
+    if (lds > kMaxLdsPipe) return false;
+    out->cfg = c; out->tw_log2 = twl; out->th = TH;
+    out->co_tiles = dg ? (p.cout_g + 15) / 16 : (p.cout_g + CO_T - 1) / CO_T;
+    out->dg = dg; out->lds = lds; out->ps = ps;
+    return true;
   }
   const int PS = host_round_pitch(plane, !tc && p.stride_x != 1);
   // LDS-DMA staging: no input shift; 1x1 / 3x3 kernels only (the tap walk of the DMA variants was found wrong on a 4x4 kernel by the
@@ -461,7 +480,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     double best_cost = 0.0;
     for (int c = 0; c < kNumCfgs; ++c) {
       Plan pl{};
-      if (is_dg(kCfgs[c])) continue;  // the fused dilation-group kernels are only used when named (tile_hint / tuned table)
+      if (is_dg(kCfgs[c]) || kCfgs[c].PF == 3) continue;  // the fused dilation-group and the pipelined kernels are only used when named (tile_hint / tuned table)
       if (!make_plan(p, c, &pl)) continue;
       const double cost = plan_cost(p, pl);
       if (!found || cost < best_cost) {
@@ -493,11 +512,16 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     q.dbg = dbg;
   }
 
+  if (k.PF == 3) {  // conv_pipe.hip: plane pitch from the plan, per-channel input scale / shift as pointer + stride
+    const float* kc = device_consts();
+    q.bf_plane = best.ps;
+    q.wcp = p.in_scale ? p.in_scale : kc;      q.wc_cs = p.in_scale ? 1 : 0;  q.wc_bs = p.in_scale ? p.in_scale_bstride : 0;
+  }
   if (best.lds > 64 * 1024) {
     static bool raised[kMaxCfgs] = {};
     if (!raised[best.cfg]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)kMaxLds);
+                                         (int)(k.PF == 3 ? kMaxLdsPipe : kMaxLds));
       if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
       raised[best.cfg] = true;
     }
