@@ -52,7 +52,7 @@ PRESETS = {  # BASELINE.json configs[1..3]
     "c4": dict(batch=16, timesteps=50, sampler="ddpm", conv_dtype="f32"),
     # configs[4]: the restoration_train.py iteration, data parallel, 4 images per GPU (batch 32 on 8 GPUs); a different metric
     # (training images/s), reported by train_bench() below -- the default line stays the inference metric of BASELINE.json
-    "c5": dict(batch=4, timesteps=4, train=True),
+    "c5": dict(batch=4, timesteps=4, train=True, steps=16),   # K = 16 = d_reg_every: exactly one R1 pass in the timed region
 }
 
 
@@ -96,6 +96,14 @@ def train_bench(args, world, rank, dev):
     hip_ops.PROFILER = None
     sync()
     fl, conv_ms, n_launch = prof.summary()
+    # The R1 pass (a double backward through D) runs on every d_reg_every-th iteration: the timed region starts right after a
+    # multiple of it, so that K timed iterations contain exactly floor(K / d_reg_every) of them -- one in sixteen with the default
+    # K = 16 of this preset, as in the schedule being priced; the count is stated in the line.
+    while it[0] % tr.d_reg_every:
+        run(1)
+    sync()
+    first = it[0] + 1
+    n_r1 = sum(1 for i in range(first, first + args.steps) if i % tr.d_reg_every == 0)
     t0 = time.perf_counter()
     run(args.steps)
     sync()
@@ -113,9 +121,12 @@ def train_bench(args, world, rank, dev):
             "config": {"workload": "BASELINE configs[4]: restoration_train.py iteration, %d images per GPU, 512x512, frozen e4e + "
                                    "Code_diffuser(T=4) + StyleGAN2 prior front, random-init weights, RCCL gradient all-reduce "
                                    "from inside backward (64 MB buckets)" % B, "global_batch": world * B},
+            "r1": {"d_reg_every": tr.d_reg_every, "r1_iterations_in_timed_region": n_r1,
+                   "note": "the timed region starts right after a multiple of d_reg_every; K a multiple of it prices the schedule exactly"},
             "roofline": {"bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(fl / conv_ms / 1e9 / 157.3, 3), "traffic": None,
-                         "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks)",
+                         "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks); "
+                                   "EFFECTIVE rate: algorithmic direct-conv FLOPs of every launch (Winograd launches execute 16/36 of theirs) / kernel time",
                          "launches": n_launch, "kernel_ms": round(conv_ms, 1),
                          "measured": "HIP events per launch on the launch stream over one untimed iteration"},
             "cpu_baseline": None}))
@@ -250,7 +261,10 @@ def main():
                                                                  "of a stand-in batch, JSON line with value null")
     args = ap.parse_args()
     if args.preset:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
         for k, v in PRESETS[args.preset].items():
+            if k == "steps" and "--steps" in given:   # (a preset's default K does not override an explicit one)
+                continue
             setattr(args, k, v)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -358,8 +372,10 @@ def main():
         # bf16 configuration: the dense bf16 MFMA peak (MI355X_MICROARCH.md); the conv family then mixes bf16 (stride-1 3x3)
         # and fp32 (stride-2, transposed, small-map) launches, all priced against the bf16 peak
         PEAK = {"f32": PEAK_FP32_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.conv_dtype]  # bf16x3: three MFMAs per product
-        KERNEL_NOTE = ("conv family: conv_igemm_kernel (direct, all tile configs) + conv_wino_kernel (Winograd F(2x2,3x3)); achieved = "
-                       "algorithmic FLOPs / time, i.e. an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
+        KERNEL_NOTE = ("conv family: conv_pipe_kernel (direct, double-buffered pipeline: stride-2 / transposed / dilation groups) + "
+                       "conv_igemm_kernel / conv_smallmap_kernel (direct, small maps and 1x1) + conv_wino_kernel (Winograd F(2x2,3x3)); "
+                       "achieved / frac = ALGORITHMIC FLOPs / time, i.e. an effective rate on the Winograd layers; executed_tflops / "
+                       "executed_frac = what the matrix pipe ran (Winograd launches at 16/36 of their algorithmic count)") if args.conv_dtype == "f32" else (
             "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + the fp32 "
             "conv_igemm_kernel on small maps and 1x1 layers; achieved = algorithmic FLOPs / time against the dense bf16 MFMA peak; with "
             "fp32 activations in HBM the 512^2 / 256^2 layers are fabric-bound (DESIGN 9)")
@@ -378,7 +394,7 @@ def main():
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
                        "launch": "two captured HIP graphs (A+B, C+D) replayed per batch" if args.graphs else "eager (one host launch per kernel)",
                        "rng": "torch device RNG, one randn per consumer" if args.torch_rng else
-                              "keyed Philox draws by (seed, global image index): 2 launches per batch, world-size invariant",
+                              "keyed Philox draws by (seed, global image index): 2 launches per batch, world-size invariant (mixing = 0: no per-batch style-mixing coin)",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),
@@ -418,6 +434,12 @@ def main():
                                   "launches_per_step": rl["launches_per_step"]}
             rl["achieved"], rl["frac"] = round(fl / (ms * 1e-3) / 1e12, 2), round(fl / (ms * 1e-3) / 1e12 / PEAK, 4)
             rl["launches_per_step"], rl["algorithmic_gflop_per_step"], rl["kernel_ms_per_step"] = n, round(fl / 1e9, 1), round(ms, 2)
+            # `achieved` / `frac` count ALGORITHMIC work (2 Cin 9 FLOP per output): the Winograd layers execute 16/36 of
+            # theirs, so the figure is an effective rate there.  What the matrix pipe EXECUTED per second stands next to it.
+            ex = iso.executed_flops()
+            rl["executed_tflops"], rl["executed_frac"] = round(ex / (ms * 1e-3) / 1e12, 2), round(ex / (ms * 1e-3) / 1e12 / PEAK, 4)
+            rl["by_kernel_family"] = {k: {"algorithmic_tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms": round(v[1], 2), "launches": v[2]}
+                                      for k, v in sorted(iso.by_kind().items()) if v[1] > 0}
             rl["measured"] = ("HIP events per launch on the launch stream over one serial step inside bench.py, right before the "
                               "timed region (no second stream in flight)")
         if world == 1 and not args.no_cpu_baseline:

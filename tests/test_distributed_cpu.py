@@ -181,3 +181,63 @@ def test_bucketed_gradient_allreduce_world2(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+FROZEN_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from vspbfr_amd.train_step import OverlappedGradientReducer, RestorationTrainer, requires_grad
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(19, 23), torch.nn.ReLU(), torch.nn.Linear(23, 7))
+    requires_grad(net, False)                      # a module left frozen by whoever used it last (an inference pipeline, another trainer)
+    red = OverlappedGradientReducer(list(net.parameters()), bucket_bytes=512)
+    assert len(red.buckets) >= 2 and sum(len(b) for b in red.buckets) == 4, "every parameter must be bucketed"
+    requires_grad(net, True)
+    x = torch.randn(5, 19, generator=torch.Generator().manual_seed(7 + rank))
+    net(x).pow(2).mean().backward()
+    mine = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        p.grad = None
+    with red:
+        net(x).pow(2).mean().backward()
+    assert red.launched == len(red.buckets)
+    for p, g in zip(net.parameters(), mine):
+        parts = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(parts, g)
+        assert torch.allclose(p.grad, sum(parts) / world, rtol=0, atol=1e-7), "gradients were not averaged over the ranks"
+    # a PARTLY frozen parameter list is refused (ranks that froze different subsets would issue different collectives)
+    net[0].weight.requires_grad_(False)
+    try:
+        OverlappedGradientReducer(list(net.parameters()))
+        raise SystemExit("partly frozen parameter list was accepted")
+    except ValueError:
+        pass
+    # the trainer thaws what it is given before it plans its buckets
+    G, Ge, D = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 1)
+    requires_grad(G, False); requires_grad(D, False)
+    tr = RestorationTrainer(G, Ge, D)
+    assert all(p.requires_grad for p in G.parameters()) and all(p.requires_grad for p in D.parameters())
+    assert sum(len(b) for b in tr.g_reducer.buckets) == 2 and sum(len(b) for b in tr.d_reducer.buckets) == 2
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""" % ROOT)
+
+
+def test_gradient_reducer_on_frozen_modules_world2(tmp_path):
+    """a reducer (and a RestorationTrainer) built on modules that are frozen at construction must still exchange every
+    gradient once they are thawed; a partly frozen parameter list is refused."""
+    script = tmp_path / "frozen_worker.py"
+    script.write_text(FROZEN_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o

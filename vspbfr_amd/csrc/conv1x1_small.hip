@@ -97,6 +97,7 @@ extern "C" int vsp_conv1x1_small_f32(float* y, const float* w, const float* x, c
   VSP_REQUIRE(Cin % 16 == 0, "conv1x1_small: the input channel count must be a multiple of 16 (got %d)", Cin);
   if (B == 0) return VSP_OK;
   VSP_REQUIRE(y && w && x, "conv1x1_small: null pointer");
+  VSP_REQUIRE(vsp::aligned16(w), "conv1x1_small: the weight must be 16-byte aligned (its rows are read as 16-byte fragments)");
   const int64_t N64 = (int64_t)B * P;
   VSP_REQUIRE(N64 < (1 << 30), "conv1x1_small: too many columns");
   const int N = (int)N64;

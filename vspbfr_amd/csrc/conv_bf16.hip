@@ -624,13 +624,8 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
     if (q.io_bf16) return launch_bf<MB, NB, WM, WN, PT, MODE, false, true>(q, gm, stream);
   }
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_bf16: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static vsp::LdsAttrOnce attr;   // per device
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB>), 150 * 1024, "conv2d_bf16")) return rc;
   q.tw_log2 = gm.twl;
   q.bf_pitch = gm.pitch;
   q.bf_plane = gm.plane;

@@ -518,13 +518,8 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     q.wcp = p.in_scale ? p.in_scale : kc;      q.wc_cs = p.in_scale ? 1 : 0;  q.wc_bs = p.in_scale ? p.in_scale_bstride : 0;
   }
   if (best.lds > 64 * 1024) {
-    static bool raised[kMaxCfgs] = {};
-    if (!raised[best.cfg]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k.kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(k.PF == 3 ? kMaxLdsPipe : kMaxLds));
-      if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
-      raised[best.cfg] = true;
-    }
+    static vsp::LdsAttrOnce raised[kMaxCfgs];   // per configuration and device
+    if (int rc = raised[best.cfg].ensure(reinterpret_cast<const void*>(k.kern), (int)(k.PF == 3 ? kMaxLdsPipe : kMaxLds), "conv2d")) return rc;
   }
   q.wg_order = (q.dbg & 0x1000000) ? 0 : 1;   // XCD-aware order (conv_kernel.h); VSP_CONV_DBG = 16777216 keeps the dispatch order
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y + (best.strip_col > 0 ? best.strip_col + best.strip_row : 0)), (unsigned)gy,

@@ -254,16 +254,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 
 template <int NTAP, int WCO, int NB>
 int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static vsp::LdsAttrOnce attr1, attr2;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
+  if (int rc = attr1.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+  if (int rc = attr2.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
   if (xj == 1)
     conv_wgrad_kernel<NTAP, WCO, NB, 1><<<grid, WG_NT, lds, st>>>(k);
   else

@@ -358,6 +358,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     // fences (718 us on 512 -> 512 at 64^2 against 688: a fenced block of VALU work leaves the pipe to the other waves only) and
     // sched_group_barrier patterns (one MFMA : two VALU), which the scheduler does not honour across the LDS waits; an
     // anti-phase start of the two workgroups of a CU (s_sleep of half an interval for every other group of 32): no effect.
+    // Round 3: OPPOSITE interval orders for the two waves a workgroup places on one SIMD (waves 0-3 multiply first, waves 4-7
+    // transform and commit first; every order is legal inside an interval).  As one loop with both orders hipcc spills the
+    // accumulators; as two loops the younger half still needs 21 spill slots at 128 VGPRs (512 -> 512 at 64^2: 652 -> 827 us), and
+    // with a 256-register budget (one workgroup per CU) the opposite orders are SLOWER than the common one (826 vs 765 us): the
+    // transform placed in front of the MFMAs exposes its LDS round trip in every interval, which costs more than the partner's
+    // MFMAs cover.
     constexpr bool SPLIT = TPT == 1;
 #if VSP_WINO_PIN
     if constexpr (FULL && KS == 2 && SPLIT && DMAX == 1) {
@@ -515,14 +521,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
 template <int MBW, int DMAX>
 int launch_variant(ConvK q, hipStream_t stream) {
   using Gm = WG<MBW, DMAX>;
-  static bool attr_set = false;
+  static vsp::LdsAttrOnce attr;   // per device
   const size_t lds = (size_t)Gm::LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<MBW, DMAX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_winograd: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino_kernel<MBW, DMAX>), (int)lds, "conv2d_winograd")) return rc;
   q.co_tiles = (q.cout_g + Gm::WCO - 1) / Gm::WCO;
   int blocks = 0;  // the largest per-group tile count (groups with a smaller dilation exit early)
   for (int g = 0; g < q.G; ++g) {

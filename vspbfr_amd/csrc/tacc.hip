@@ -329,16 +329,9 @@ int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2
   static const bool use_valu = getenv("VSP_TACC_VALU") != nullptr;  // the first (VALU/LDS) version, kept for A/B runs
   const size_t lds = use_valu ? (size_t)(2 * NTOK * D + D * CA_PITCH + 8 * 32) * sizeof(float)
                               : vsptacc::CA_LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_chan_attn_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_chan_attn_mfma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_chan_attn: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static vsp::LdsAttrOnce attr_a, attr_b;   // per device
+  if (int rc = attr_a.ensure(reinterpret_cast<const void*>(tacc_chan_attn_kernel), 150 * 1024, "tacc_chan_attn")) return rc;
+  if (int rc = attr_b.ensure(reinterpret_cast<const void*>(tacc_chan_attn_mfma_kernel), 150 * 1024, "tacc_chan_attn")) return rc;
   dim3 grid(D / CA_COLS, B);
   if (use_valu)
     tacc_chan_attn_kernel<<<grid, 256, lds, vsp::as_stream(stream)>>>(t, P, ldp, q2_off, v2_off, ek, wk, wk_stride, tfrac,
@@ -359,13 +352,8 @@ int vsp_tacc_tail_f32(float* y, float* pn, const float* P, int ldp, int k_off, i
   VSP_REQUIRE(ldp % 4 == 0 && k_off % 4 == 0 && v_off % 4 == 0 && vsp::aligned16(P) && vsp::aligned16(eQ) && vsp::aligned16(wq),
               "tacc_tail: operands must be 16-byte aligned (contiguous wq column expected)");
   const size_t lds = (size_t)3 * NTOK * D * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_tail_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_tail: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static vsp::LdsAttrOnce attr;   // per device
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(tacc_tail_kernel), (int)lds, "tacc_tail")) return rc;
   tacc_tail_kernel<<<B, 576, lds, vsp::as_stream(stream)>>>(y, pn, P, ldp, k_off, v_off, eQ, wq, tfrac,
                                                             1.0f / sqrtf((float)NTOK), t, gamma, beta, xold, c1, c2, idx, 1e-5f);
   return vsp::check_launch("tacc_tail");

@@ -295,18 +295,11 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
                     vsp::aligned16(k.wk) && vsp::aligned16(k.gamma) && vsp::aligned16(k.beta),
                 "tacc_chain: block %d operands must be 16-byte aligned", i);
   }
-  static bool attr_set = false;
+  static vsp::LdsAttrOnce attr_a, attr_p;   // per device
   const size_t lds = vsptacc::CA_LDS_FLOATS * sizeof(float);
   constexpr size_t pj_lds = (size_t)(PJ_KW * PJ_NJ * 4 * 64 + PJ_KW * 4 * 2 * PJ_NJ * 16) * sizeof(float);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_attn_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(tacc_proj_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)pj_lds);
-    if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_chain: cannot reserve LDS: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (int rc = attr_a.ensure(reinterpret_cast<const void*>(tacc_attn_kernel), 150 * 1024, "tacc_chain")) return rc;
+  if (int rc = attr_p.ensure(reinterpret_cast<const void*>(tacc_proj_kernel), (int)pj_lds, "tacc_chain")) return rc;
   hipStream_t st = vsp::as_stream(stream);
   const int M = p.B * NTOK;
   float* P = p.work;

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <atomic>
 #include "../../include/vspbfr_hip.h"
 
 namespace vsp {
@@ -29,6 +30,22 @@ inline int check_launch(const char* what) {
 inline hipStream_t as_stream(vsp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one flag bit per device ordinal (a process that drives a
+// second GPU, or two threads racing through a first call, must not launch a > 64 KB kernel without it; setting it twice is harmless).
+struct LdsAttrOnce {
+  std::atomic<uint64_t> done{0};
+  int ensure(const void* fn, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return fail(VSP_ELAUNCH, "%s: hipGetDevice failed", what);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return VSP_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(VSP_ELAUNCH, "%s: cannot reserve %d bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+    if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return VSP_OK;
+  }
+};
 
 // MI355X: 256 CUs; memory-bound grids are capped at 8 resident 256-thread blocks per CU and grid-strided.
 constexpr int kNumCU = 256;

@@ -40,6 +40,22 @@ class ConvProfiler:
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return fl, ms, len(self.records)
 
+    def executed_flops(self):
+        """FLOPs the matrix pipe actually EXECUTED: a Winograd F(2x2,3x3) launch runs 16 multiplies per 2x2 output tile where the
+        direct form (the algorithmic count of `summary`) has 36; every other kernel executes its algorithmic count."""
+        return sum(r[0] * (16.0 / 36.0 if (len(r[3]) > 7 and r[3][7] == "wino") else 1.0) for r in self.records)
+
+    def by_kind(self):
+        """{kernel family: (algorithmic FLOPs, ms, launches)} -- direct / pipelined / tconv / wino / bf16."""
+        out = {}
+        for r in self.records:
+            k = r[3][7] if len(r[3]) > 7 else "?"
+            a = out.setdefault(k, [0.0, 0.0, 0])
+            a[0] += r[0]
+            a[1] += r[1].elapsed_time(r[2])
+            a[2] += 1
+        return {k: (v[0], v[1], v[2]) for k, v in out.items()}
+
     def algorithmic_bytes(self):
         """Sum over the launches of the bytes a convolution must move when every operand crosses HBM exactly once: input image,
         output, weights, noise map and residuals at their element sizes (the unit of the HBM roofline)."""

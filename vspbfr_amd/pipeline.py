@@ -53,8 +53,12 @@ class RestorationPipeline:
                  with_sample=True, noise_seed=None):
         """noise_seed=None: every random draw comes from torch's device RNG stream, one `randn` per consumer, as in the
         reference.  noise_seed=int: KEYED draws (hip_ops.keyed_fill): x_T, z and all 46 noise maps of a batch are functions of
-        (noise_seed, global image index, tensor id) drawn by two launches (one per stage pair) -- the result for an image does
-        not depend on the batch it travels in or on the rank that computes it."""
+        (noise_seed, global image index, tensor id) drawn by two launches (one per stage pair) -- with mixing = 0 (bench, CLI
+        default of this repository's tests) the result for an image does not depend on the batch it travels in or on the rank that
+        computes it.  With mixing > 0 that invariance does NOT hold: the reference flips ONE style-mixing coin and draws
+        ONE inject index per BATCH (restoration_test.py:77-82), which is kept here and keyed by the batch's first global image index,
+        so an image's result then depends on which batch it is in; graph capture refuses mixing > 0 for the same reason (the coin
+        would be frozen into the graph)."""
         self.generator, self.psp, self.diffusion = generator.eval(), psp_embedding.eval(), diffusion.eval()
         self.mixing, self.with_sample, self.noise_seed = mixing, with_sample, noise_seed
         self._index_tensor = None  # device int64 base index (graph replays)

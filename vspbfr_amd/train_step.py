@@ -77,7 +77,19 @@ class OverlappedGradientReducer:
 
     def __init__(self, params, bucket_bytes=64 << 20, group=None):
         self.group = group
-        self.params = [p for p in params if p.requires_grad]
+        params = list(params)
+        # The bucket plan is fixed here, and every rank must issue the SAME collectives: a parameter that is frozen at this moment
+        # (a generator handed over from an inference pipeline after requires_grad_(False), a discriminator another trainer left
+        # frozen) would silently drop out of the exchange while backward still computes its gradient once it is thawed -- ranks
+        # would diverge.  So: every parameter is bucketed and hooked; which of them receive a gradient in a given backward is
+        # decided per pass (`finish` zero-fills the rest), and a caller that really wants a subset passes exactly that subset.
+        frozen = [p for p in params if not p.requires_grad]
+        if frozen and len(frozen) < len(params):
+            raise ValueError(f"OverlappedGradientReducer: {len(frozen)} of {len(params)} parameters are frozen at construction; pass the "
+                             "trainable subset explicitly or thaw the module first (requires_grad_(True))")
+        for p in frozen:          # an entirely frozen module (its owner toggles requires_grad per step): hooks need a grad-requiring leaf
+            p.requires_grad_(True)
+        self.params = params
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -153,7 +165,7 @@ def requires_grad(model, flag=True):
 class RestorationTrainer:
     def __init__(self, generator, g_ema, discriminator, psp_embedding=None, diffusion=None, lr=0.002, g_reg_every=4, d_reg_every=16,
                  r1=10.0, mixing=0.9, percept_loss=None, percept_weight=0.0, id_loss=None, id_weight=0.0, bucket_bytes=64 << 20,
-                 augment=False, augment_p=0.0, ada_target=0.6, ada_length=500 * 1000, ada_every=256):
+                 augment=False, augment_p=0.0, ada_target=0.6, ada_length=500 * 1000, ada_every=8):
         self.G, self.G_ema, self.D = generator, g_ema, discriminator
         self.psp, self.diffusion = psp_embedding, diffusion
         self.d_reg_every, self.r1, self.mixing = d_reg_every, r1, mixing
@@ -171,6 +183,10 @@ class RestorationTrainer:
         self.d_optim = torch.optim.Adam(discriminator.parameters(), lr=lr * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio), fused=fused)
         self.accum = 0.5 ** (32 / (10 * 1000))
         accumulate(g_ema, generator, 0)
+        # the step toggles requires_grad on G and D every iteration and leaves D frozen at its end; a trainer built on modules in that
+        # state (or on a generator taken from an inference pipeline) must still exchange every gradient
+        requires_grad(generator, True)
+        requires_grad(discriminator, True)
         self.generator_bytes = sum(p.numel() * p.element_size() for p in generator.parameters())
         self.g_reducer = OverlappedGradientReducer(list(generator.parameters()), bucket_bytes)
         self.d_reducer = OverlappedGradientReducer(list(discriminator.parameters()), bucket_bytes)
