@@ -149,6 +149,24 @@ def launch_check(args, world, rank):
     local = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1).expand(-1, 3, 8, 8).contiguous()
     full = gather_restored(local) if world > 1 else local
     ok = torch.equal(full[:, 0, 0, 0], torch.arange(world * B, dtype=torch.float32))
+    # the loop bench.py runs: `steps` full batches and a RAGGED last one (world * B - 3 images: the last rank(s) get fewer), each
+    # exchanged by the preallocated asynchronous gather one batch behind the computation
+    from vspbfr_amd.pipeline import RestoredGather
+    gat, pending, got = RestoredGather(), None, []
+    sizes = [world * B] * args.steps + [max(world * B - 3, 1)]
+    base = 0
+    for n_img in sizes:
+        lo, hi = shard_range(n_img, rank, world)
+        counts = [shard_range(n_img, r, world)[1] - shard_range(n_img, r, world)[0] for r in range(world)]
+        mine = (base + torch.arange(lo, hi, dtype=torch.float32)).view(-1, 1, 1, 1).expand(-1, 3, 8, 8).contiguous()
+        h = gat.start(mine, counts if len(set(counts)) > 1 else None)
+        if pending is not None:
+            got.append(pending[0].result().clone())
+        pending = (h, n_img)
+        base += n_img
+    got.append(pending[0].result().clone())
+    seen = torch.cat([g[:, 0, 0, 0] for g in got])
+    ok = ok and torch.equal(seen, torch.arange(sum(sizes), dtype=torch.float32)) and len(gat._out) <= 4
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -305,6 +323,8 @@ def main():
     # this rank's shard of the global LQ batch: images [rank*B, (rank+1)*B), uniform(-1, 1) keyed by the global image index
     lq = hip_ops.keyed_fill([(B, 3, 512, 512)], [hip_ops.SEG_LQ], args.seed, rank * B, dist="uniform", device=dev)[0]
     step_no = [0]
+    from vspbfr_amd.pipeline import RestoredGather
+    gatherer = RestoredGather()   # preallocated, asynchronous: the exchange of batch i runs under C + D of batch i+1
 
     def batches(n):
         """n steps: the same LQ shard with fresh noise -- step k restores global images [k*W*B, (k+1)*W*B)."""
@@ -317,17 +337,29 @@ def main():
         """n steps = n batches through A+B+C+D.  --overlap (default): RestorationPipeline.run_batches, i.e. stages A+B of
         batch i+1 are enqueued on a second HIP stream before stages C+D of batch i (the first batch's A+B is not hidden);
         every batch is complete when the closing synchronize returns."""
-        res = None
+        res, pending = None, None
+
+        def exchange(restored):
+            """start this batch's all-gather behind its kernels, then collect the PREVIOUS batch's (which ran under this batch's C + D)"""
+            nonlocal res, pending
+            if world == 1:
+                res = restored
+                return
+            h = gatherer.start(restored)
+            if pending is not None:
+                res = pending.result()
+            pending = h
         if args.no_overlap:
             for x, i0 in batches(n):
-                res = pipe(x, image_index0=i0)["restored"]
-                res = gather_restored(res) if world > 1 else res
+                exchange(pipe(x, image_index0=i0)["restored"])
         elif args.graphs:
             for o in pipe.run_batches_graphed(batches(n)):
-                res = gather_restored(o["restored"]) if world > 1 else o["restored"]
+                exchange(o["restored"])
         else:
             for o in pipe.run_batches(batches(n)):
-                res = gather_restored(o["restored"]) if world > 1 else o["restored"]
+                exchange(o["restored"])
+        if pending is not None:
+            res = pending.result()
         return res
 
     def sync():

@@ -108,6 +108,20 @@ def test_sharded_restoration_equals_single_rank(tmp_path):
         assert f"rank {r} ok" in o
 
 
+def test_bench_self_launch_world4_ragged():
+    """World size 4 through the same self-launch: the launch check also runs bench.py's exchange loop -- full batches and a RAGGED
+    last one (the last ranks get fewer images) through the preallocated asynchronous RestoredGather, one batch behind."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["launch_check"] == "ok"
+
+
 def test_bench_self_launch_world2():
     """`python bench.py --gpus 2` with no torchrun environment must start the 2-rank job by itself (as a child process) and
     hand rank 0's JSON line through; --launch-check runs that control path without GPU work."""

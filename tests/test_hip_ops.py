@@ -901,6 +901,22 @@ def test_torch_extension_modules(golden):
         close(y.view(B, C_, y.shape[1], y.shape[2]), golden("ops")[name], 1e-6, 1e-6, name)
     with pytest.raises(RuntimeError):
         fused.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.zeros(0), 3, 0, 0.2, 1.0)      # CPU tensor: TORCH_CHECK
+    # half and double tensors (the reference dispatches over float, double, half: op/fused_bias_act_kernel.cu:96,
+    # op/upfirdn2d_kernel.cu:311): converted at the boundary, result in the input's type
+    x, b = cases.lrelu_inputs(next(n for n in cases.LRELU_CASES if cases.lrelu_inputs(n)[1] is not None))
+    want = golden("ops")[next(n for n in cases.LRELU_CASES if cases.lrelu_inputs(n)[1] is not None)]
+    for dt, tol in ((torch.float64, 1e-6), (torch.float16, 2e-3)):
+        y = fused.fused_bias_act(dev(x).to(dt), dev(b).to(dt), e.to(dt), 3, 0, 0.2, math.sqrt(2))
+        assert y.dtype == dt
+        close(y.float(), want, tol, tol * 4, f"fused {dt}")
+    x, k, up, down, pad = cases.fir_inputs("fir_blur_after_up")
+    B, C_, Hh, Ww = x.shape
+    for dt, tol in ((torch.float64, 1e-6), (torch.float16, 2e-3)):
+        y = upfirdn2d_op.upfirdn2d(dev(x).to(dt).reshape(-1, Hh, Ww, 1), dev(k).to(dt), up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3])
+        assert y.dtype == dt
+        close(y.float().view(B, C_, y.shape[1], y.shape[2]), golden("ops")["fir_blur_after_up"], tol, tol * 4, f"upfirdn2d {dt}")
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(dev(x).to(torch.int32), e, e, 3, 0, 0.2, 1.0)                           # unsupported dtype
 
 
 # ------------------------------------------------------------------------------------------------ loss-network operators

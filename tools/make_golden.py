@@ -590,14 +590,111 @@ def gen_diffuser_train():
     print("diffuser_train.npz: l_kd %.4f l_abs %.4f loss %.4f, %d parameters, %.1fs" % (l_kd.item(), l_abs.item(), loss.item(), len(names), time.time() - t0))
 
 
+# ---- f3: the published checkpoints (README.md:49-54) --------------------------------------------------------------------------------
+REAL_FILES = {"restorenet": "restoration_net.pt", "diffuser": "code_diffuser.pt", "psp": "style_encoder_decoder.pt"}
+
+
+def _sha256(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def real_lq_batch(lq_dir, n):
+    """The LQ inputs of the real-checkpoint fixture as the reference's test loader hands them over (dataset.py:436-495:
+    ImageFolder_restore_test_no_gt -> RGB, centre crop to a square, LANCZOS resize to 512, [-1, 1]); without a folder: n keyed
+    synthetic images (the mechanics can be exercised without faces; parity on faces needs real ones)."""
+    if not lq_dir:
+        return cases.image_batch("real512", n, 512), ["keyed:real512/%d" % i for i in range(n)]
+    from PIL import Image
+    names = sorted(f for f in os.listdir(lq_dir) if f.lower().endswith((".png", ".jpg", ".jpeg")))[:n]
+    assert len(names) == n, f"need {n} images under {lq_dir}"
+    ims = []
+    for f in names:
+        im = Image.open(os.path.join(lq_dir, f)).convert("RGB")
+        w, h = im.size
+        m = min(w, h)
+        im = im.crop(((w - m) // 2, (h - m) // 2, (w - m) // 2 + m, (h - m) // 2 + m)).resize((512, 512), Image.LANCZOS)
+        ims.append(torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float() / 127.5 - 1.0)
+    return torch.stack(ims), names
+
+
+def gen_real512(ckpt_dir=None, lq_dir=None, n=2, out_name="real512.npz", stride=1):
+    """SURVEY 8f row 3 (the real-checkpoint path): the REFERENCE's modules with the published weights (restoration_test.py:31-40,
+    239-254: restoration_net.pt["g_ema"], code_diffuser.pt["att_mapper"], the pSp dict of style_encoder_decoder.pt) on CPU, n faces,
+    every draw pinned by name (oracle.cases) -> the 8-bit images `save_image` would write, stored with the checkpoint hashes.
+    tests/test_hip_models.py::test_real_checkpoint_parity loads the same files on the GPU box and asserts <= 1 LSB."""
+    from argparse import Namespace
+    ckpt_dir = ckpt_dir or os.environ.get("VSPBFR_CKPT_DIR")
+    if not ckpt_dir:
+        raise SystemExit("real512: pass --ckpt-dir (or VSPBFR_CKPT_DIR) with " + ", ".join(REAL_FILES.values()))
+    t0 = time.time()
+    case, T = "real512", 4
+    paths = {k: os.path.join(ckpt_dir, v) for k, v in REAL_FILES.items()}
+    g_ck = torch.load(paths["restorenet"], map_location="cpu")
+    d_ck = torch.load(paths["diffuser"], map_location="cpu")
+    p_ck = torch.load(paths["psp"], map_location="cpu")
+    g = RN.Restoration_net(512, 512, 8, channel_multiplier=2)
+    g.load_state_dict(g_ck["g_ema"])
+    g.eval()
+    net = Code_diffuser(timesteps=T)
+    net.load_state_dict(d_ck["att_mapper"])
+    net.eval()
+    ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T)        # restoration_test.py:31-40
+    enc = Encoder4Editing(50, "ir_se", Namespace(input_channel=3, stylegan_size=1024))
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in p_ck["state_dict"].items() if k.startswith("encoder.")})
+    enc.eval()
+    dec = SG.Generator(1024, 512, 8, channel_multiplier=2)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in p_ck["state_dict"].items() if k.startswith("decoder.")})
+    dec.eval()
+    latent_avg = p_ck["latent_avg"].float()
+    lq, names = real_lq_batch(lq_dir, n)
+    B = lq.shape[0]
+    x256 = torch.nn.functional.interpolate(lq, (256, 256), mode="bilinear")
+    codes = (enc(x256) + latent_avg.repeat(B, 1, 1))[:, :18]
+    x = cases.tensor(case, "x_T", (B, 18, 512))
+    for i in reversed(range(T)):
+        x, _ = ddpm.p_sample(x, torch.full((B,), i, dtype=torch.long), codes, clip_denoised=ddpm.clip_denoised)
+    pre = x
+    gnoise = cases.noise_list(case, "g", omodels.generator_noise_shapes(1024, B))
+    img1024, feats = dec([pre], input_is_latent=True, noise=gnoise, return_features=True)
+    sample = torch.nn.AdaptiveAvgPool2d((512, 512))(img1024)
+    enc_s, dec_s = omodels.restoration_noise_shapes(512, B)
+    NOISE_QUEUE.clear()
+    NOISE_QUEUE.extend(cases.noise_list(case, "enc", enc_s) + cases.noise_list(case, "dec", dec_s))
+    restored = g(lq, feats[:16], pre, [cases.tensor(case, "z", (B, 512))])
+    assert not NOISE_QUEUE
+    q = lambda t: omodels.save_image_quantize(t)[:, :, ::stride, ::stride].permute(0, 2, 3, 1).contiguous().numpy().astype(np.uint8)  # noqa: E731
+    out = {"restored_u8": q(restored), "sample_u8": q(sample), "stride": np.array([stride]), "codes": np_(codes), "pre_latent": np_(pre),
+           "names": np.array(names), "sha256": np.array([_sha256(paths[k]) for k in ("restorenet", "diffuser", "psp")]),
+           "restored_stats": np.array([restored.mean(), restored.std(), restored.abs().max()], dtype=np.float32)}
+    if lq_dir:   # (keyed synthetic inputs regenerate from their names)
+        out["lq"] = np_(lq)
+    dst = os.path.join(GOLD, out_name)
+    np.savez_compressed(dst, **out)
+    print(os.path.basename(dst) + ":", B, "images, restored stats", out["restored_stats"], "%.1fs" % (time.time() - t0))
+
+
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
        "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "lpips": gen_lpips, "idloss": gen_idloss, "diffuser_train": gen_diffuser_train}
+OPTIONAL = {"real512": gen_real512}   # needs the published checkpoints: not part of the default set
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=",".join(ALL))
+    ap.add_argument("--ckpt-dir", default=None, help="real512: folder with restoration_net.pt, code_diffuser.pt, style_encoder_decoder.pt")
+    ap.add_argument("--lq-dir", default=None, help="real512: folder with the LQ faces (default: keyed synthetic images)")
+    ap.add_argument("--out-name", default="real512.npz", help="real512: fixture file name under tests/golden")
+    ap.add_argument("--n-images", type=int, default=2, help="real512: number of faces")
+    ap.add_argument("--stride", type=int, default=1, help="real512: keep every stride-th pixel of the 8-bit images (harness dry runs)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     for k in args.only.split(","):
-        ALL[k]()
+        if k in OPTIONAL:
+            OPTIONAL[k](args.ckpt_dir, args.lq_dir, n=args.n_images, out_name=args.out_name, stride=args.stride)
+        else:
+            ALL[k]()

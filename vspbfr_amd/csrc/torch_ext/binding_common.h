@@ -8,10 +8,18 @@
 #include <c10/hip/HIPStream.h>
 #include "../../../include/vspbfr_hip.h"
 
-#define VSP_CHECK_INPUT(x)                                                         \
-  TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");                         \
-  TORCH_CHECK((x).is_contiguous(), #x " must be contiguous");                      \
-  TORCH_CHECK((x).scalar_type() == at::kFloat, #x " must be float32")
+// Element types: the reference's modules dispatch over float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// op/fused_bias_act_kernel.cu:96, op/upfirdn2d_kernel.cu:311).  The gfx950 kernels compute in fp32; half and double tensors are
+// converted at this boundary (one cast launch each way) and the result is returned in the input's type -- for half that is what the
+// reference's kernel does internally (it accumulates in the tensor's scalar type, i.e. LESS precisely), for double the arithmetic is
+// fp32 (documented deviation: the restoration path is fp32 end to end).
+#define VSP_CHECK_INPUT(x)                                                                                           \
+  TORCH_CHECK((x).is_cuda(), #x " must be a CUDA tensor");                                                           \
+  TORCH_CHECK((x).is_contiguous(), #x " must be contiguous");                                                        \
+  TORCH_CHECK((x).scalar_type() == at::kFloat || (x).scalar_type() == at::kHalf || (x).scalar_type() == at::kDouble, \
+              #x " must be float32, float16 or float64")
+
+inline torch::Tensor vsp_f32(const torch::Tensor& x) { return x.scalar_type() == at::kFloat ? x : x.to(at::kFloat); }
 
 inline void* vsp_current_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
 inline void vsp_raise(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", vsp_last_error()); }

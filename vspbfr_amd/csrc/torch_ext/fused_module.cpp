@@ -6,16 +6,20 @@ torch::Tensor fused_bias_act(const torch::Tensor& input, const torch::Tensor& bi
   VSP_CHECK_INPUT(input);
   if (bias.numel()) { VSP_CHECK_INPUT(bias); }
   if (refer.numel()) { VSP_CHECK_INPUT(refer); }
-  auto x = input.contiguous();
+  TORCH_CHECK(!bias.numel() || bias.scalar_type() == input.scalar_type(), "bias must have the input's dtype");
+  TORCH_CHECK(!refer.numel() || refer.scalar_type() == input.scalar_type(), "refer must have the input's dtype");
+  const auto x = vsp_f32(input.contiguous());
+  const auto bias32 = bias.numel() ? vsp_f32(bias) : bias;
+  const auto refer32 = refer.numel() ? vsp_f32(refer) : refer;
   auto y = torch::empty_like(x);
   int64_t step_b = 1;
   for (int i = 2; i < x.dim(); ++i) step_b *= x.size(i);
   TORCH_CHECK(!refer.numel() || refer.numel() == x.numel(), "refer must have the same number of elements as input");
-  vsp_raise(vsp_fused_bias_act_f32(y.data_ptr<float>(), x.data_ptr<float>(), bias.numel() ? bias.data_ptr<float>() : nullptr,
-                                   refer.numel() ? refer.data_ptr<float>() : nullptr, x.numel(), (int)step_b, (int)bias.numel(), act, grad,
+  vsp_raise(vsp_fused_bias_act_f32(y.data_ptr<float>(), x.data_ptr<float>(), bias.numel() ? bias32.data_ptr<float>() : nullptr,
+                                   refer.numel() ? refer32.data_ptr<float>() : nullptr, x.numel(), (int)step_b, (int)bias.numel(), act, grad,
                                    alpha, scale, vsp_current_stream()),
             "fused_bias_act");
-  return y;
+  return input.scalar_type() == at::kFloat ? y : y.to(input.scalar_type());
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) { m.def("fused_bias_act", &fused_bias_act, "fused bias act (gfx950)"); }

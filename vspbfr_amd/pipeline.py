@@ -298,3 +298,63 @@ def gather_restored(local, counts=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
+
+
+class RestoredGather:
+    """The all-gather of the restored images as an ASYNCHRONOUS, preallocated exchange (round 3): `start(local)` enqueues the
+    collective behind everything already on the current stream and returns at once (RCCL runs it on the communicator's own
+    stream); `result()` makes the current stream wait for it and hands out the full batch.  Called as
+
+        for out in pipe.run_batches(batches):          # C + D of batch i enqueued ...
+            h = gather.start(out["restored"])          # ... its all-gather behind them ...
+            if pending is not None: full = pending.result()   # ... and the PREVIOUS batch's result is waited for only now, i.e.
+            pending = h                                 #     its exchange ran under this batch's C + D
+
+    the exchange of batch i overlaps the convolutions of batch i+1 instead of sitting on the critical path after each batch, and no
+    (W B, 3, 512, 512) tensor is allocated per step: two output buffers alternate (a handle's buffer is reused two starts later --
+    consume or copy the result before that).  Ragged splits (`counts` = per-rank batch sizes, equal on every rank) pad every
+    rank's share to the largest one in a preallocated staging tensor and return a view of the gathered rows in rank order.
+    Single-rank / uninitialised process group: `result()` returns `local` unchanged."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._out = {}      # (slot, shape key) -> gathered buffer
+        self._pad = {}      # (slot, shape key) -> padded staging buffer of this rank
+        self._n = 0
+
+    class Handle:
+        def __init__(self, work, out, counts, local, mx):
+            self.work, self.out, self.counts, self.local, self.mx = work, out, counts, local, mx
+
+        def result(self):
+            if self.work is None:
+                return self.local
+            self.work.wait()          # orders the CURRENT stream behind the collective (no host block on RCCL)
+            if self.counts is None:
+                return self.out
+            if all(c == self.mx for c in self.counts):
+                return self.out
+            rows = self.out.view((len(self.counts), self.mx) + tuple(self.out.shape[1:]))
+            return torch.cat([rows[r, :c] for r, c in enumerate(self.counts)], 0)
+
+    def start(self, local, counts=None):
+        import torch.distributed as dist
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return RestoredGather.Handle(None, None, None, local, 0)
+        world = dist.get_world_size(self.group)
+        slot = self._n & 1
+        self._n += 1
+        mx = local.shape[0] if counts is None else max(counts)
+        key = (slot, mx, tuple(local.shape[1:]), local.dtype, local.device)
+        out = self._out.get(key)
+        if out is None:
+            out = self._out[key] = torch.empty((world * mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        src = local.contiguous()
+        if src.shape[0] != mx:          # this rank's share is shorter than the longest one: stage it in the padded buffer
+            pad = self._pad.get(key)
+            if pad is None:
+                pad = self._pad[key] = torch.zeros((mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+            pad[:src.shape[0]].copy_(src)
+            src = pad
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        return RestoredGather.Handle(work, out, counts, local, mx)
