@@ -363,7 +363,9 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     // accumulators; as two loops the younger half still needs 21 spill slots at 128 VGPRs (512 -> 512 at 64^2: 652 -> 827 us), and
     // with a 256-register budget (one workgroup per CU) the opposite orders are SLOWER than the common one (826 vs 765 us): the
     // transform placed in front of the MFMAs exposes its LDS round trip in every interval, which costs more than the partner's
-    // MFMAs cover.
+    // MFMAs cover.  Also measured and dropped: the interval's scalar operands (style scale, affine pair) fetched at its top behind a
+    // full scheduling fence instead of right in front of their `s_waitcnt` -- 2 % slower on every layer (655 -> 666 us): the fence
+    // costs the scheduler more freedom than the exposed scalar-cache round trips cost time.
     constexpr bool SPLIT = TPT == 1;
 #if VSP_WINO_PIN
     if constexpr (FULL && KS == 2 && SPLIT && DMAX == 1) {
