@@ -76,6 +76,7 @@ static int host_round_pitch(int n, int odd) {
 // Fill the geometry of configuration c for problem p; returns false if it does not fit (LDS / index limits).
 static bool is_tc(const Cfg& k) { return k.name[strlen(k.name) - 1] == 't'; }
 static bool is_dg(const Cfg& k) { return k.name[strlen(k.name) - 1] == 'd'; }
+static bool is_fg(const Cfg& k) { const size_t n = strlen(k.name); return n >= 2 && k.name[n - 2] == 'f'; }   // conv_pipe.hip fixed geometry
 
 static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const Cfg& k = kCfgs[c];
@@ -95,6 +96,11 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   if (k.PF == 3 && dg) cap = NPIX >= 512 ? 5 : 4;  // shared patch with a halo of 8: square tiles stage the fewest words
   if (twl > cap) twl = cap;
   if ((1 << twl) > NPIX) twl = ilog2_ceil(NPIX);
+  const bool fg = k.PF == 3 && is_fg(k);
+  if (fg) {  // conv_pipe.hip fixed geometry (dilation-group mode): 16 x 16 pixels, dilations exactly 1, 2, 4, 8
+    twl = 4;
+    if (!dg || p.dil[0] != 1 || p.dil[1] != 2 || p.dil[2] != 4 || p.dil[3] != 8) return false;
+  }
   const int TW = 1 << twl, TH = NPIX / TW;
   int dmax = 1;
   for (int g = 0; g < (p.G > 4 ? 1 : p.G); ++g) dmax = p.dil[g] > dmax ? p.dil[g] : dmax;
@@ -117,8 +123,9 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
     if (p.KH != 3 || p.KW != 3 || p.cout_g % 4 != 0 || !vsp::aligned16(p.w) || p.in_shift || p.Cin % k.CK != 0) return false;
     const int NW = k.WM * k.WN, wpc = k.CK >= NW ? 1 : NW / k.CK;
     const int nrow = (plane + 63) / 64;
-    if (nrow > k.PMAX * wpc) return false;  // (PMAX field = PROWS: 64-word rows of a channel plane per wave)
+    // (PMAX field = PROWS: 64-word rows of a channel plane per wave; checked below once the pitch is known)
     const int ps = host_round_pitch(k.PMAX * wpc * 64, !tc && p.stride_x != 1);   // every staged row lands inside its own plane
+    if (nrow > k.PMAX * wpc) return false;
     const size_t lds = 2 * ((size_t)9 * k.CK * WS + (size_t)k.CK * ps) * sizeof(float);
     if (lds > kMaxLdsPipe) return false;
     out->cfg = c; out->tw_log2 = twl; out->th = TH;

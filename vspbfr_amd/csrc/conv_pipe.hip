@@ -39,9 +39,17 @@ __device__ __forceinline__ float uload(const float* base, int idx) {  // wave-un
 
 // MODE 0: plain / grouped conv (stride 1 or 2, per-group dilation); 1: stride-2 transposed 3x3 (four sub-pixel phases);
 // 2: the four dilation groups of a SMART layer from one shared patch (M-block = group)
-template <int MB, int NB, int WM, int WN, int CK, int PROWS, int OCC, int MODE>
+//
+// FG = true (round 3, "fixed geometry", dilation-group mode): the tile is 16 x 16 pixels and the dilations are 1, 2, 4, 8, so the patch
+// row pitch, the plane pitch and the size of an LDS buffer are constants and the interval is instantiated per buffer PARITY: every
+// fragment read is ONE base register + an immediate.  The generic kernel pays a v_add per B read (12 VALU + 12 LDS instructions per 8
+// MFMAs on the dilation groups: PMC 65 % MFMA busy): 64 -> 4 x 16 at 512^2 1550 -> 1406 us (110 TFLOP/s).  The same treatment of the
+// transposed mode (main tiles only, strips as a second launch; unit = k-step with all nine taps sharing 2 x (NP + 1) shifted B
+// fragments: 15 reads per 18 MFMAs instead of 27) was built and measured: 678 vs 669 us at 512 -> 256 / 64^2 -- no gain, removed.
+template <int MB, int NB, int WM, int WN, int CK, int PROWS, int OCC, int MODE, bool FG = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const ConvK p) {
   constexpr bool TC = MODE == 1, DG = MODE == 2;
+  static_assert(!FG || DG, "fixed geometry serves the dilation-group mode");
   static_assert(!TC || NB % 4 == 0, "transposed mode: N-blocks come in groups of four sub-pixel phases");
   static_assert(!DG || (MB == 4 && WM == 1), "dilation-group mode: M-block = group");
   constexpr int NP = TC ? NB / 4 : NB;  // 16-wide groups of patch positions per wave
@@ -49,6 +57,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
   constexpr int CO_T = 16 * MB * WM;
   constexpr int WS = (CO_T % 32 == 0) ? CO_T + 16 : CO_T;
   constexpr int T = 9, KS = CK / 4, NU = T * KS;
+  // fixed geometry (FG): 16-wide tiles
+  constexpr int F_NPOS = 16 * WN * NP;                     // positions / pixels per workgroup
+  constexpr int F_TH = F_NPOS / 16;
+  constexpr int F_PW = TC ? 17 : 32;                       // patch row: 16 + 1 (transposed) / 16 + 2 * 8 (dilation groups)
+  constexpr int F_WPC = CK >= WM * WN ? 1 : WM * WN / CK;
+  constexpr int F_PS = ((PROWS * F_WPC * 64) & ~31) + 16 >= PROWS * F_WPC * 64 ? ((PROWS * F_WPC * 64) & ~31) + 16
+                                                                               : ((PROWS * F_WPC * 64) & ~31) + 48;   // = round_pitch(.., 0)
+  constexpr int F_BUF = T * CK * WS + CK * F_PS;
+  static_assert(!FG || !DG || F_TH == 16, "dilation-group fixed geometry: 16 x 16 pixels");
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -73,9 +90,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
   const int g = DG ? 0 : by / p.co_tiles;
   const int co0 = DG ? by * 16 : (by % p.co_tiles) * CO_T;  // within the group
   const int b = bz;
-  int twl = p.tw_log2, TH = p.th, oy0 = ty_i * p.th, ox0 = tx_i << p.tw_log2;
+  int twl = FG ? 4 : p.tw_log2, TH = FG ? F_TH : p.th, oy0 = ty_i * (FG ? F_TH : p.th), ox0 = tx_i << (FG ? 4 : p.tw_log2);
   int mlim = p.H + 1;  // transposed: first invalid position row of this block
-  if (TC && p.strip_col >= 0) {  // edge strips of the (H+1) x (W+1) position grid (see conv_igemm_kernel)
+  if (TC && !FG && p.strip_col >= 0) {  // edge strips of the (H+1) x (W+1) position grid (see conv_igemm_kernel)
     constexpr int NPIXB = 16 * WN * NP;
     mlim = p.H;
     int j = tile - p.tiles_x * p.tiles_y;
@@ -90,10 +107,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
   const int gi = p.G > 4 ? 0 : g;
   const int D = DG ? max(max(p.dil[0], p.dil[1]), max(p.dil[2], p.dil[3])) : p.dil[gi];
   const int PH = TC ? TH + 1 : (TH - 1) * p.sy + 2 * D + 1;
-  const int PW = TC ? TW + 1 : (TW - 1) * p.sx + 2 * D + 1;
+  const int PW = FG ? F_PW : TC ? TW + 1 : (TW - 1) * p.sx + 2 * D + 1;
   const int plane = PH * PW;
-  const int PS = p.bf_plane;                        // plane pitch (host: >= the 64-word rows the waves stage, == 16 mod 32 or odd)
-  const int BUF = T * CK * WS + CK * PS;            // floats per LDS buffer
+  const int PS = FG ? F_PS : p.bf_plane;            // plane pitch (host: >= the 64-word rows the waves stage, == 16 mod 32 or odd)
+  const int BUF = FG ? F_BUF : T * CK * WS + CK * PS;   // floats per LDS buffer
   const int iy0 = TC ? oy0 - 1 : DG ? oy0 - D : oy0 * p.sy - p.pady[gi];
   const int ix0 = TC ? ox0 - 1 : DG ? ox0 - D : ox0 * p.sx - p.padx[gi];
 
@@ -318,10 +335,84 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     }
     __syncthreads();
   }
-  int iv = 0;
-  for (; iv < nchunk - 2; ++iv) interval(iv, std::true_type{}, std::true_type{});
-  if (nchunk >= 2) { interval(iv, std::true_type{}, std::false_type{}); ++iv; }
-  interval(iv, std::false_type{}, std::false_type{});
+  if constexpr (!FG) {
+    int iv = 0;
+    for (; iv < nchunk - 2; ++iv) interval(iv, std::true_type{}, std::true_type{});
+    if (nchunk >= 2) { interval(iv, std::true_type{}, std::false_type{}); ++iv; }
+    interval(iv, std::false_type{}, std::false_type{});
+  } else {
+    // ---- fixed geometry: every LDS address of the MFMA phase is `base register + immediate`; the interval exists once per buffer
+    //      parity (cur / nxt are constants), sub-step = one tap of one k-step
+    const int fa = a_lane;                                   // A fragments: smem[fa + imm]
+    const int fb = T * CK * WS + (wn * NP) * F_PW + lr + kq * F_PS;   // B fragments: smem[fb + imm] (position group np: + np * F_PW)
+    constexpr int NS = T * KS;                               // sub-steps per interval
+    constexpr int NSI = NS >= 6 ? NS / 3 : 1, NSC = NS - NSI;
+    auto staging = [&](int sidx, int i, auto commit_tag, auto issue_tag, float* nxt) {
+      constexpr bool COMMIT = decltype(commit_tag)::value, ISSUE = decltype(issue_tag)::value;
+      if (COMMIT && sidx < NSC) {
+#pragma unroll
+        for (int k = sidx * NITEM / NSC; k < (sidx + 1) * NITEM / NSC; ++k) commit_item(k, nxt);
+      }
+      if (ISSUE && sidx >= NSC) {
+#pragma unroll
+        for (int k = (sidx - NSC) * NITEM / NSI; k < (sidx - NSC + 1) * NITEM / NSI; ++k) issue_item(k, (i + 2) * CK);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      // dilation groups 1, 2, 4, 8 (the host checks them): group gg's tap (ky, kx) sits at (8 - d) (PW + 1) + (ky PW + kx) d
+      float ga[2][4], gb[2][4][NB];
+      auto load_dg = [&](int u, int cur, float (&a)[4], float (&b)[4][NB]) {
+        const int tap = u / KS, c4 = u % KS;
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) a[gg] = smem[fa + cur + (tap * CK + c4 * 4) * WS + gg * 16];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int d_ = 1 << gg;
+          const int off = (8 - d_) * (F_PW + 1) + (ky * F_PW + kx) * d_;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b[gg][nb] = smem[fb + cur + c4 * 4 * F_PS + nb * F_PW + off];
+        }
+      };
+      auto interval_fg = [&](int i, auto par_tag, auto commit_tag, auto issue_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool COMMIT = decltype(commit_tag)::value;
+        constexpr int cur = PAR * F_BUF, nxo = (1 - PAR) * F_BUF;
+        if constexpr (COMMIT) load_scales((i + 1) * CK);
+        load_dg(0, cur, ga[0], gb[0]);
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+          const int s_ = u & 1;
+          if (u + 1 < NS) load_dg(u + 1, cur, ga[s_ ^ 1], gb[s_ ^ 1]);
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[gg][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s_][gg], gb[s_][gg][nb], acc[gg][nb], 0, 0, 0);
+          staging(u, i, commit_tag, issue_tag, smem + nxo);
+        }
+        __syncthreads();
+      };
+      int iv = 0;
+      for (; iv + 3 < nchunk; iv += 2) {
+        interval_fg(iv, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+        interval_fg(iv + 1, std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{});
+      }
+      for (; iv < nchunk; ++iv) {
+        const bool c_ = iv + 1 < nchunk, s2 = iv + 2 < nchunk;
+        if (iv & 1) {
+          if (s2) interval_fg(iv, std::integral_constant<int, 1>{}, std::true_type{}, std::true_type{});
+          else if (c_) interval_fg(iv, std::integral_constant<int, 1>{}, std::true_type{}, std::false_type{});
+          else interval_fg(iv, std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+        } else {
+          if (s2) interval_fg(iv, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{});
+          else if (c_) interval_fg(iv, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
+          else interval_fg(iv, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+        }
+      }
+    }
+  }
 
   // ---- epilogue (the operand chain of conv_igemm_kernel; absent operands are constants behind a zero stride)
   const int Cout = p.G * p.cout_g;
@@ -441,6 +532,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
         conv_pipe_kernel<4, NB, 1, WN, CK, PROWS, OCC, 2>                                            \
   }
 
+// fixed-geometry variant of the dilation-group mode: name suffix "fd"
+#define VSP_CFGPDF(NB, WN, CK, PROWS, OCC)                                                           \
+  {                                                                                                  \
+    4, NB, 1, WN, CK, 1, PROWS, 3, OCC, "4x" #NB "x1x" #WN "x" #CK "k1p3o" #OCC "r" #PROWS "fd",       \
+        conv_pipe_kernel<4, NB, 1, WN, CK, PROWS, OCC, 2, true>                                      \
+  }
+
 extern const Cfg kCfgsP[] = {
     VSP_CFGP(4, 4, 2, 4, 8, 18, 1),    // 128 co x 256 pix, stride-2 patches up to 33 x 33
     VSP_CFGP(4, 2, 2, 4, 8, 9, 1),     // 128 co x 128 pix
@@ -471,6 +569,11 @@ extern const Cfg kCfgsP[] = {
     VSP_CFGPD(4, 4, 4, 16, 1),         // 4 waves x 64 pix
     VSP_CFGPD(4, 4, 8, 16, 1),
     VSP_CFGPD(4, 8, 4, 12, 1),         // 4 x 16 co x 512 pix (16 x 32 tile, 32 x 48 patch)
+    // fixed geometry (constant-offset fragment reads, intervals per buffer parity)
+    // (OCC = waves per SIMD the register budget must admit: 4 = two 8-wave workgroups per CU, i.e. at most 128 VGPRs)
+    VSP_CFGPDF(2, 8, 4, 8, 4),         // 4 x 16 co x 256 pix
+    VSP_CFGPDF(2, 8, 4, 8, 2),
+    VSP_CFGPDF(2, 8, 8, 16, 1),
 };
 extern const int kNumP = sizeof(kCfgsP) / sizeof(kCfgsP[0]);
 
