@@ -333,6 +333,19 @@ def test_linear(H, M, N, K):
     close(H.linear(dev(x), dev(w), dev(b), act=2), torch.sigmoid(F.linear(x, w, b)), 3e-5, 3e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 512, 2048), (16, 130, 1024), (5, 511, 768), (1, 64, 512), (13, 32, 4096)])
+def test_linear_few_rows(H, M, N, K):
+    """The few-row form of the small GEMM (one wave per output column, M <= 16, K a multiple of 256: the style modulations of
+    every modulated conv at batch 8 / 16) against float64, contiguous rows and rows that are a strided slice latent[:, i]."""
+    g_ = torch.Generator().manual_seed(M * 1000 + N)
+    x, w, b = torch.randn(M, K, generator=g_), torch.randn(N, K, generator=g_) / math.sqrt(K), torch.randn(N, generator=g_)
+    ref = F.linear(x.double(), w.double() * 0.7, b.double() * 0.3)
+    close(H.linear(dev(x), dev(w), dev(b), alpha=0.7, bias_scale=0.3), ref.float(), 2e-5, 2e-5, "plain")
+    close(H.linear(dev(x), dev(w), dev(b), alpha=0.7, bias_scale=0.3, act=1), (F.leaky_relu(ref, 0.2) * math.sqrt(2)).float(), 2e-5, 2e-5, "lrelu")
+    lat = torch.randn(M, 18, K, generator=g_)
+    close(H.linear(dev(lat)[:, 7], dev(w), None, alpha=0.7), F.linear(lat[:, 7].double(), w.double() * 0.7).float(), 2e-5, 2e-5, "strided rows")
+
+
 def test_gemm_strided_batched(H):
     B, T, D = 3, 18, 64
     Kt, Q, V = torch.randn(B, T, D), torch.randn(B, T, D), torch.randn(B, T, D)

@@ -14,6 +14,7 @@
 // for A and B alike: the products pair up correctly and a 16-wide k-step costs one 16-byte load per operand
 // block (64-byte segments per row instead of the 16-byte segments a scalar fragment load would touch).
 #include "vsp_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -139,6 +140,75 @@ __global__ __launch_bounds__(64 * KW) void gemm_nt_kernel(const GemmK p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Few-row form (round 3): C[m, n] for M <= 16 rows -- every EqualLinear of the path at batch 8 / 16: the style modulations of all
+// modulated convolutions (8 x 2048 against 512 x 2048: a 4 MB weight per launch), the style MLP, final_linear.  The tiled kernel
+// above puts (N / 64) x 1 workgroups on the chip and walks K in one wave-quartet each: 25 us for 4 MB (160 GB/s) -- 45 such launches
+// per inference step.  Here ONE WAVE owns one output column: it streams its weight row as 16-byte loads (K / 256 per lane, all
+// issued before the first use), multiplies it against the M rows of x (the same addresses in every wave: L1 / L2 hits), reduces
+// with DPP adds; N / 4 workgroups of four waves.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+  v += dpp_mov_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f<0x141>(v);  // row_half_mirror
+  v += dpp_mov_f<0x140>(v);  // row_mirror
+  const int iv = __float_as_int(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(iv, 0)) + __int_as_float(__builtin_amdgcn_readlane(iv, 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(iv, 32)) + __int_as_float(__builtin_amdgcn_readlane(iv, 48)));
+}
+
+template <int MR, int KI>   // MR rows at most, KI = K / 256 16-byte pieces per lane (0: run-time trip count)
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemmK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= p.N) return;
+  const float* wrow = p.Bm + (int64_t)n * p.b_ns + lane * 4;
+  const float* arow = p.A + lane * 4;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const int ki = KI ? KI : p.K / 256;
+#pragma unroll KI ? KI : 4
+  for (int i = 0; i < ki; ++i) {
+    const float4 w = *reinterpret_cast<const float4*>(wrow + i * 256);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const float4 a = *reinterpret_cast<const float4*>(arow + (int64_t)(m < p.M ? m : 0) * p.a_ms + i * 256);
+      acc[m] = fmaf(a.x, w.x, fmaf(a.y, w.y, fmaf(a.z, w.z, fmaf(a.w, w.w, acc[m]))));
+    }
+  }
+  const float bv = p.bias ? p.bias[n] * p.bias_scale : 0.f;
+  float out = 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    const float v = wave_sum_f(acc[m]);
+    if (lane == m) out = v;
+  }
+  if (lane < p.M) {
+    float v = out * p.alpha + bv;
+    if (p.act == 1) v = (v > 0.f ? v : v * p.slope) * p.gain;
+    else if (p.act == 2) v = 1.f / (1.f + expf(-v));
+    p.C[(int64_t)lane * p.c_ms + n] = v;
+  }
+}
+
+template <int MR>
+static void launch_gemv(const GemmK& q, hipStream_t st) {
+  const dim3 grid((unsigned)((q.N + 3) / 4));
+  switch (q.K / 256) {
+    case 2: gemv_rows_kernel<MR, 2><<<grid, 256, 0, st>>>(q); break;
+    case 4: gemv_rows_kernel<MR, 4><<<grid, 256, 0, st>>>(q); break;
+    case 8: gemv_rows_kernel<MR, 8><<<grid, 256, 0, st>>>(q); break;
+    default: gemv_rows_kernel<MR, 0><<<grid, 256, 0, st>>>(q); break;
+  }
+}
+
 }  // namespace
 
 extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
@@ -153,6 +223,13 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
           p.alpha, p.bias, p.bias_scale, p.act, p.slope, p.gain, p.bias_zs};
   const bool vec = p.a_ks == 1 && p.b_ks == 1 && p.a_ms % 4 == 0 && p.b_ns % 4 == 0 && p.a_zs % 4 == 0 &&
                    p.b_zs % 4 == 0 && vsp::aligned16(p.A) && vsp::aligned16(p.Bm);
+  if (vec && p.Z == 1 && p.M <= 16 && p.K >= 512 && p.K % 256 == 0 && p.b_ns >= p.K && p.a_ms >= p.K) {   // few rows against a deep K
+    static const bool off = getenv("VSP_GEMV_OFF") != nullptr;   // (A/B runs)
+    if (!off) {
+      if (p.M <= 8) launch_gemv<8>(q, vsp::as_stream(stream)); else launch_gemv<16>(q, vsp::as_stream(stream));
+      return vsp::check_launch("gemm");
+    }
+  }
   dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);
   VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");
   if (vec)
