@@ -389,6 +389,13 @@ typedef struct vsp_tacc_chain_params {
 
 size_t vsp_tacc_chain_work_floats(int B);
 int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
+/* The same chain as ONE persistent launch per 64 steps (tacc_persist.hip): a cluster of 16 workgroups owns an image for the whole
+ * loop (reference ldm/ddpm.py:421-429 x models/CodeDiffuser.py:86-116,133-140), two cluster barriers per block instead of three
+ * launch boundaries.  Same parameter block and results as vsp_tacc_chain_f32 (summation orders are identical); `work` must hold
+ * vsp_tacc_chain_persistent_work_floats(B) floats.  B <= 16 and n_blocks <= 4 (one 512-thread workgroup per CU must be resident
+ * for every (image, slice) pair): VSP_ENOTSUP otherwise -- callers fall back to vsp_tacc_chain_f32. */
+size_t vsp_tacc_chain_persistent_work_floats(int B);
+int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 activations in HBM (BASELINE configs[2] "bf16 kernels"; the fp32 path above is the parity path).  A bf16 tensor is

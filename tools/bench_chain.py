@@ -10,14 +10,17 @@ torch.manual_seed(0)
 net = Code_diffuser(timesteps=T).to(dev).eval()
 ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T).to(dev)
 cond = torch.randn(B, 18, 512, device=dev)
-for _ in range(2):
-    ddpm(x=cond, condi_in=cond, training=False)
-torch.cuda.synchronize()
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-s.record()
-N = 5
-for _ in range(N):
-    ddpm(x=cond, condi_in=cond, training=False)
-e.record(); torch.cuda.synchronize()
-ms = s.elapsed_time(e) / N
-print(f"chain B={B} T={T}: {ms:.3f} ms  ({ms * 1000 / (4 * T):.1f} us per TACC block incl. prepare)")
+from vspbfr_amd import hip_ops as H
+for pers in (False, True):   # three launches per block / one persistent launch (vsp_tacc_chain_persistent_f32)
+    H.TACC_PERSISTENT = pers
+    for _ in range(2):
+        ddpm(x=cond, condi_in=cond, training=False)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    N = 5
+    for _ in range(N):
+        ddpm(x=cond, condi_in=cond, training=False)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / N
+    print(f"chain B={B} T={T} {'persistent' if pers else 'launched  '}: {ms:.3f} ms  ({ms * 1000 / (4 * T):.1f} us per TACC block incl. prepare)")
