@@ -365,7 +365,12 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
     // transform placed in front of the MFMAs exposes its LDS round trip in every interval, which costs more than the partner's
     // MFMAs cover.  Also measured and dropped: the interval's scalar operands (style scale, affine pair) fetched at its top behind a
     // full scheduling fence instead of right in front of their `s_waitcnt` -- 2 % slower on every layer (655 -> 666 us): the fence
-    // costs the scheduler more freedom than the exposed scalar-cache round trips cost time.
+    // costs the scheduler more freedom than the exposed scalar-cache round trips cost time.  And the 64-tile geometry (MBW x NBW = 16:
+    // 128 accumulator registers, one workgroup per CU, 256-register budget, same U layout): with this interval program 771 us against
+    // 649 on 512 -> 512 at 64^2 (the one-workgroup penalty of the 32-tile kernel, 765, is all it gets back), and as a PINNED sequence
+    // of 16 steps -- four MFMAs + one slice of transform / fragment reads / commit, a full fence per step, the way conv_pipe.hip runs
+    // the direct convolution -- 1021 us: the slices carry LDS and scalar-cache waits that a fence turns into pipe idle time (the
+    // direct kernel's slices are stores and address-free loads).
     constexpr bool SPLIT = TPT == 1;
 #if VSP_WINO_PIN
     if constexpr (FULL && KS == 2 && SPLIT && DMAX == 1) {
