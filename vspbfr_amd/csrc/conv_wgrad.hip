@@ -20,6 +20,7 @@
 // Groups: true groups (x channels g Cin_g ...), or a SHARED input with per-group dilation / padding (the four SMART branches in
 // one launch).  LDS pitches: channel rows 2 (mod 32) words apart: the 16 x 2 lanes of an access group hit 32 distinct banks.
 #include "vsp_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,6 +30,9 @@ typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
 
 #ifndef VSP_WG_UNROLL
 #define VSP_WG_UNROLL 2
+#endif
+#ifndef VSP_WG_SGB   // 1: interleave one LDS read per MFMA in the unrolled loop (sched_group_barrier)
+#define VSP_WG_SGB 1
 #endif
 #ifndef VSP_WG_ABL   // tuning builds only: 1 no atomics, 2 no MFMAs, 4 no staging after the first chunk
 #define VSP_WG_ABL 0
@@ -52,7 +56,9 @@ struct WgradK {
   int64_t dw_elems;
 };
 
-template <int NTAP, int WCO, int NB, int XJ>
+// S: 0 = any chunk shape and stride (run-time LDS addresses), 1 / 2 = ROW-SEGMENT chunks (tcl = 6) of a stride-S layer: the MFMA loop
+// is fully unrolled with one LDS base per (ci block, tap) and the pixel offset as an immediate, B fragments fetched one unit ahead.
+template <int NTAP, int WCO, int NB, int XJ, int S = 0>
 __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   constexpr int WCI = 4 / WCO;
   constexpr int CO_T = 16 * WCO, CI_T = 16 * NB * WCI;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   const int cot = blockIdx.y / ci_tiles, cit = blockIdx.y - cot * ci_tiles;
   const int co0 = cot * CO_T, ci0 = cit * CI_T;
   const int KW = NTAP == 1 ? 1 : p.KW;
-  const int d = p.dil[p.per_group ? g : 0], pad = p.pad[p.per_group ? g : 0], s = p.stride;
+  const int d = p.dil[p.per_group ? g : 0], pad = p.pad[p.per_group ? g : 0], s = S ? S : p.stride;
   const int XWP = p.xwp, plane = p.plane;
   const int TC = 1 << p.tcl, TR = WG_PX >> p.tcl;                 // chunk: TR output rows x TC columns (TR > 1: small maps)
   const int xw = (TC - 1) * s + (KW - 1) * d + 1 + ((4 - (pad & 3)) & 3);   // slab row of this group (aligned origin)
@@ -179,6 +185,13 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
   const int wco = wave % WCO, wci = wave / WCO;
   const float* ap = Dl + (wco * 16 + r) * DPITCH + kq;
   const float* bp = Xl + (wci * NB * 16 + r) * plane + kq * s + xs_al;
+  const float* bt[NB][NTAP];   // (S != 0) LDS base of (ci block, tap): the pixel offset of a k-step is an immediate
+  if constexpr (S != 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) bt[nb][t] = bp + nb * 16 * plane + (t / 3) * rmul * XWP + (t % 3) * d;
+  }
 
   int ch = blockIdx.x;
   if (ch < p.chunks) fetch(ch);
@@ -194,6 +207,37 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
 #if VSP_WG_ABL & 2
     continue;
 #endif
+    if constexpr (S != 0 && NTAP == 9) {
+      // unit u = (k-step u / NB, ci block u % NB): 9 MFMAs.  The nine B fragments of unit u + 1 (and the A fragment of the next
+      // k-step) are read while the MFMAs of unit u issue: a wave alone keeps the matrix pipe fed (with the reads issued right before
+      // their MFMAs the LDS latency showed once per 8 MFMAs: 82 % of the MFMA rate with the staging removed, VSP_WG_ABL = 4).
+      constexpr int NU = (WG_PX / 4) * NB;
+      float bq[2][NTAP], aq[2];
+      aq[0] = ap[0];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) bq[0][t] = bt[0][t][0];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int step = u / NB, nb = u % NB;
+        if (u + 1 < NU) {
+          const int step1 = (u + 1) / NB, nb1 = (u + 1) % NB;
+          if (nb1 == 0) aq[step1 & 1] = ap[4 * step1];
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) bq[(u + 1) & 1][t] = bt[nb1][t][4 * step1 * S];
+        }
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) acc[nb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[step & 1], bq[u & 1][t], acc[nb][t], 0, 0, 0);
+#if VSP_WG_SGB
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll VSP_WG_UNROLL
     for (int k0 = 0; k0 < WG_PX; k0 += 4) {
       const float a = ap[k0];
@@ -206,6 +250,7 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
           const float bv = bp[nb * 16 * plane + ky * rmul * XWP + kb + kx * d];
           acc[nb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[nb][t], 0, 0, 0);
         }
+    }
     }
   }
   // D layout: lane (r, kq) holds rows 4 kq + j (output channel), column r (input channel)
@@ -254,13 +299,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 
 template <int NTAP, int WCO, int NB>
 int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st) {
-  static vsp::LdsAttrOnce attr1, attr2;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
-  if (int rc = attr1.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-  if (int rc = attr2.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-  if (xj == 1)
+  static vsp::LdsAttrOnce attr1, attr2, attr3, attr4;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
+  // row-segment chunks of a 3x3 layer: the unrolled loop (stride 1 stages one item per thread, stride 2 two)
+  const int fast = (NTAP == 9 && k.tcl == 6 && xj == k.stride && !std::getenv("VSP_WGRAD_GENERIC")) ? k.stride : 0;
+  if (fast == 1) {
+    if (int rc = attr3.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+    conv_wgrad_kernel<NTAP, WCO, NB, 1, 1><<<grid, WG_NT, lds, st>>>(k);
+  } else if (fast == 2) {
+    if (int rc = attr4.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+    conv_wgrad_kernel<NTAP, WCO, NB, 2, 2><<<grid, WG_NT, lds, st>>>(k);
+  } else if (xj == 1) {
+    if (int rc = attr1.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
     conv_wgrad_kernel<NTAP, WCO, NB, 1><<<grid, WG_NT, lds, st>>>(k);
-  else
+  } else {
+    if (int rc = attr2.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
     conv_wgrad_kernel<NTAP, WCO, NB, 2><<<grid, WG_NT, lds, st>>>(k);
+  }
   return VSP_OK;
 }
 
