@@ -1042,6 +1042,24 @@ def test_conv2d_wgrad_tile_shapes(H, cfg):
     close(dw, w.grad.float(), 2e-5, 2e-5 * float(w.grad.abs().max()), "dw")
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(3, 16, (32, 32)), (3, 40, (23, 27)), (1, 5, (7, 9)), (4, 64, (64, 48))])
+def test_conv2d_wgrad_few_input_channels(H, cin, cout, hw):
+    """The stream form of the 1x1 weight gradient (FromRGB: at most 4 input channels): per-sample scales, a channel window into a wider
+    dy, ragged planes (no 16-byte rows), accumulation."""
+    g_ = torch.Generator().manual_seed(23)
+    B = 3
+    x, s = torch.randn(B, cin, *hw, generator=g_), torch.rand(B, cin, generator=g_) + 0.5
+    gy, dm = torch.randn(B, cout + 5, *hw, generator=g_), torch.rand(B, cout + 5, generator=g_) + 0.5
+    ref = torch.einsum("bohw,bihw->oi", (gy[:, 5:] * dm[:, 5:, None, None]).double(), (x * s[:, :, None, None]).double()).float()[:, :, None, None]
+    dw = H.conv2d_wgrad(dev(x), dev(gy), (cout, cin, 1, 1), 1, 0, 1, 1, x_scale=dev(s), dy_scale=dev(dm), dy_coff=5)
+    close(dw, ref, 2e-5, 2e-5 * float(ref.abs().max()), "dw")
+    dw2 = H.conv2d_wgrad(dev(x), dev(gy), (cout, cin, 1, 1), 1, 0, 1, 1, x_scale=dev(s), dy_scale=dev(dm), dy_coff=5, out=dw.clone(), accumulate=True)
+    close(dw2, 2 * ref, 2e-5, 4e-5 * float(ref.abs().max()), "accumulated dw")
+    plain = H.conv2d_wgrad(dev(x), dev(gy[:, :cout].contiguous()), (cout, cin, 1, 1), 1, 0)
+    ref0 = torch.einsum("bohw,bihw->oi", gy[:, :cout].double(), x.double()).float()[:, :, None, None]
+    close(plain, ref0, 2e-5, 2e-5 * float(ref0.abs().max()), "dw without scales")
+
+
 def test_conv2d_wgrad_shared_input_groups(H):
     """The four dilated SMART branches as one weight-gradient launch: shared input, per-group dilation / padding, per-sample scales;
     channel window into a wider dy; accumulation."""

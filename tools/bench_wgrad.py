@@ -34,3 +34,15 @@ for cin, cout, size, stride, G in SHAPES:
     if G > 1:
         fl = 2.0 * B * cout * oh * oh * cin * 9
     print(f"{cin}->{cout} @{size} s{stride} G{G}: {ms*1e3:.0f} us  {fl/ms/1e9:.1f} TF")
+for cin, cout, size in [(3, 16, 512), (3, 64, 512)]:   # FromRGB: the stream form
+    x, dy = torch.randn(B, cin, size, size, device=dev), torch.randn(B, cout, size, size, device=dev)
+    for _ in range(2):
+        H.conv2d_wgrad(x, dy, (cout, cin, 1, 1), 1, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        H.conv2d_wgrad(x, dy, (cout, cin, 1, 1), 1, 0)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"{cin}->{cout} 1x1 @{size}: {ms*1e3:.0f} us  {(x.numel() + dy.numel()) * 4 / ms / 1e6:.0f} GB/s")

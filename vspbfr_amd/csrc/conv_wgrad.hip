@@ -34,6 +34,9 @@ typedef float f32x2a __attribute__((ext_vector_type(2), aligned(8)));
 #ifndef VSP_WG_SGB   // 1: interleave one LDS read per MFMA in the unrolled loop (sched_group_barrier)
 #define VSP_WG_SGB 1
 #endif
+#ifndef VSP_WG_WALK  // 1: a workgroup walks a consecutive run of chunks down a column segment; 0: chunks strided by the grid
+#define VSP_WG_WALK 1
+#endif
 #ifndef VSP_WG_ABL   // tuning builds only: 1 no atomics, 2 no MFMAs, 4 no staging after the first chunk
 #define VSP_WG_ABL 0
 #endif
@@ -59,7 +62,7 @@ struct WgradK {
 // S: 0 = any chunk shape and stride (run-time LDS addresses), 1 / 2 = ROW-SEGMENT chunks (tcl = 6) of a stride-S layer: the MFMA loop
 // is fully unrolled with one LDS base per (ci block, tap) and the pixel offset as an immediate, B fragments fetched one unit ahead.
 template <int NTAP, int WCO, int NB, int XJ, int S = 0>
-__global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
+__global__ __launch_bounds__(WG_NT, S != 0 ? 2 : 1) void conv_wgrad_kernel(const WgradK p) {
   constexpr int WCI = 4 / WCO;
   constexpr int CO_T = 16 * WCO, CI_T = 16 * NB * WCI;
   constexpr int NITX = CI_T / 4;   // X items (one float4 each) per thread: channel = wave + 4 it
@@ -113,8 +116,15 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
     return v;
   };
   auto fetch = [&](int ch) {
+#if VSP_WG_WALK
+    // chunk order: rows of one column segment are consecutive, and a workgroup owns a consecutive run: two of the three slab rows of a
+    // chunk are the previous chunk's (L2), and the run stays inside a few pages of every channel plane
+    const int rb = ch % p.rbs, cs = ch / p.rbs;
+    const int seg = cs % p.segs, b = cs / p.segs;
+#else
     const int seg = ch % p.segs, row = ch / p.segs;
     const int rb = row % p.rbs, b = row / p.rbs;
+#endif
     const int oy0 = rb * TR, ox0 = seg * TC;
     {  // dY: quad d_q = pixels 4 d_q .. + 3 of the chunk = row ty, columns tx .. tx + 3
       const int ty = (4 * d_q) >> p.tcl, tx = (4 * d_q) & (TC - 1);
@@ -193,16 +203,22 @@ __global__ __launch_bounds__(WG_NT) void conv_wgrad_kernel(const WgradK p) {
       for (int t = 0; t < NTAP; ++t) bt[nb][t] = bp + nb * 16 * plane + (t / 3) * rmul * XWP + (t % 3) * d;
   }
 
-  int ch = blockIdx.x;
-  if (ch < p.chunks) fetch(ch);
-  for (; ch < p.chunks; ch += gridDim.x) {
+#if VSP_WG_WALK
+  const int ch_lo = (int)((int64_t)p.chunks * blockIdx.x / gridDim.x), ch_hi = (int)((int64_t)p.chunks * (blockIdx.x + 1) / gridDim.x);
+  const int ch_step = 1;
+#else
+  const int ch_lo = blockIdx.x, ch_hi = p.chunks, ch_step = gridDim.x;
+#endif
+  int ch = ch_lo;
+  if (ch < ch_hi) fetch(ch);
+  for (; ch < ch_hi; ch += ch_step) {
 #if VSP_WG_ABL & 4
-    if (ch == (int)blockIdx.x) { commit(); __syncthreads(); }
+    if (ch == ch_lo) { commit(); __syncthreads(); }
 #else
     __syncthreads();   // the MFMAs of the previous chunk have read the slabs
     commit();
     __syncthreads();
-    if (ch + (int)gridDim.x < p.chunks) fetch(ch + gridDim.x);
+    if (ch + ch_step < ch_hi) fetch(ch + ch_step);
 #endif
 #if VSP_WG_ABL & 2
     continue;
@@ -297,18 +313,143 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   }
 }
 
+// 1x1, stride 1, at most 4 input channels (FromRGB of the discriminator, the RGB side of a skip: 3 -> 16 / 64 at 512^2): a stream, not
+// a GEMM -- the MFMA kernel above spends a 16 x 64 tile on 3 columns (0.27 ms for 80 MB).  One workgroup = a pixel range of one image and
+// 16 output channels; every thread keeps 16 x CIN sums over its pixels (16-byte loads), wave reduction, one fp32 atomic per wave and sum.
+template <int CIN>
+__global__ __launch_bounds__(256) void wgrad_fewin_kernel(const WgradK p, int px_per_block) {
+  const int b = blockIdx.y, co0 = blockIdx.z * 16;
+  const int64_t hw = (int64_t)p.H * p.W;
+  const int64_t p0 = (int64_t)blockIdx.x * px_per_block, p1 = p0 + px_per_block < hw ? p0 + px_per_block : hw;
+  const float* xb = p.x + ((int64_t)b * p.x_ch + p.x_coff) * hw;
+  const float* yb = p.dy + ((int64_t)b * p.dy_ch + p.dy_coff + co0) * hw;
+  const int nco = p.Cout_g - co0 < 16 ? p.Cout_g - co0 : 16;
+  float acc[16][CIN];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) acc[c][i] = 0.f;
+  const bool vec = (hw & 3) == 0 && (px_per_block & 3) == 0 && ((reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.dy)) & 15) == 0;
+  if (vec) {
+    for (int64_t q = p0 + 4 * threadIdx.x; q < p1; q += 4 * 256) {
+      float4 xv[CIN];
+#pragma unroll
+      for (int i = 0; i < CIN; ++i) xv[i] = i < p.Cin_g ? *reinterpret_cast<const float4*>(xb + i * hw + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c >= nco) break;
+        const float4 g = *reinterpret_cast<const float4*>(yb + c * hw + q);
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) acc[c][i] += g.x * xv[i].x + g.y * xv[i].y + g.z * xv[i].z + g.w * xv[i].w;
+      }
+    }
+  } else {
+    for (int64_t q = p0 + threadIdx.x; q < p1; q += 256) {
+      float xv[CIN];
+#pragma unroll
+      for (int i = 0; i < CIN; ++i) xv[i] = i < p.Cin_g ? xb[i * hw + q] : 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        if (c >= nco) break;
+        const float g = yb[c * hw + q];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) acc[c][i] += g * xv[i];
+      }
+    }
+  }
+  __shared__ float red[4][16 * CIN];
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) {
+      float v = acc[c][i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c * CIN + i] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 16 * CIN) {
+    const int c = threadIdx.x / CIN, i = threadIdx.x - c * CIN;
+    if (c < nco && i < p.Cin_g) {
+      const float sc = (p.xs ? p.xs[(int64_t)b * p.x_ch + p.x_coff + i] : 1.f) * (p.dys ? p.dys[(int64_t)b * p.dy_ch + p.dy_coff + co0 + c] : 1.f);
+      const float v = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * sc;
+      const int64_t off = (int64_t)(co0 + c) * p.Cin_g + i;
+      if (p.work) p.work[((int64_t)b * gridDim.x + blockIdx.x) * p.dw_elems + off] = v;   // one copy per (image, pixel range)
+      else unsafeAtomicAdd(p.dw + off, v);
+    }
+  }
+}
+
+// dw[e] (+)= sum over the copies: one wave per element (a few hundred elements, up to ~1000 copies)
+__global__ __launch_bounds__(64) void fewin_reduce_kernel(float* __restrict__ dw, const float* __restrict__ work, int64_t n, int copies,
+                                                           int accumulate) {
+  const int64_t e = blockIdx.x;
+  float a = 0.f;
+  for (int c = threadIdx.x; c < copies; c += 64) a += work[(int64_t)c * n + e];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (threadIdx.x == 0) dw[e] = (accumulate ? dw[e] : 0.f) + a;
+}
+
+// pixel range per workgroup of the stream form: ~1 workgroup per CU (the partial sums meet in `copies` = ranges * B copies of dw)
+inline bool fewin_form(const vsp_conv_wgrad_params& q) {
+  return q.KH == 1 && q.KW == 1 && q.G == 1 && q.stride == 1 && q.Cin_g <= 4 && q.pad == 0 && !q.per_group_geometry && q.OH == q.H && q.OW == q.W;
+}
+inline int64_t fewin_range(const vsp_conv_wgrad_params& q) {
+  const int64_t hw = (int64_t)q.H * q.W;
+  const int co_blocks = (q.Cout_g + 15) / 16;
+  int64_t per = hw * q.B * co_blocks / vsp::kNumCU / co_blocks / q.B;
+  per = per < 4096 ? 4096 : per;
+  return (per + 1023) / 1024 * 1024;
+}
+
+// The same sum when dw is small and the copies are many (64-channel layers at 512^2: 9216 quads, 384 copies -- one thread per quad
+// walking every copy is a 36-workgroup launch bound by its own load latency, 90 us): SL threads share the copies of a quad.
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void wgrad_reduce_sliced_kernel(float* __restrict__ dw, const float* __restrict__ work, int64_t n4,
+                                                                       int copies, int accumulate) {
+  __shared__ float4 red[SL][64];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int sl = threadIdx.y;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+#pragma unroll 4
+    for (int c = sl; c < copies; c += SL) {
+      const float4 v = reinterpret_cast<const float4*>(work)[(int64_t)c * n4 + i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  red[sl][threadIdx.x] = a;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    a = accumulate ? reinterpret_cast<const float4*>(dw)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const float4 v = red[k][threadIdx.x];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = a;
+  }
+}
+
 template <int NTAP, int WCO, int NB>
 int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st) {
   static vsp::LdsAttrOnce attr1, attr2, attr3, attr4;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
   // row-segment chunks of a 3x3 layer: the unrolled loop (stride 1 stages one item per thread, stride 2 two)
   const int fast = (NTAP == 9 && k.tcl == 6 && xj == k.stride && !std::getenv("VSP_WGRAD_GENERIC")) ? k.stride : 0;
-  if (fast == 1) {
-    if (int rc = attr3.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-    conv_wgrad_kernel<NTAP, WCO, NB, 1, 1><<<grid, WG_NT, lds, st>>>(k);
-  } else if (fast == 2) {
-    if (int rc = attr4.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-    conv_wgrad_kernel<NTAP, WCO, NB, 2, 2><<<grid, WG_NT, lds, st>>>(k);
-  } else if (xj == 1) {
+  if constexpr (NTAP == 9) {
+    if (fast == 1) {
+      if (int rc = attr3.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+      conv_wgrad_kernel<NTAP, WCO, NB, 1, 1><<<grid, WG_NT, lds, st>>>(k);
+      return VSP_OK;
+    }
+    if constexpr (WCO == 4) if (fast == 2) {   // (two staging items per lane always take the 64-co tile)
+      if (int rc = attr4.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+      conv_wgrad_kernel<NTAP, WCO, NB, 2, 2><<<grid, WG_NT, lds, st>>>(k);
+      return VSP_OK;
+    }
+  }
+  if (xj == 1) {
     if (int rc = attr1.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
     conv_wgrad_kernel<NTAP, WCO, NB, 1><<<grid, WG_NT, lds, st>>>(k);
   } else {
@@ -353,8 +494,12 @@ Plan make_plan(const vsp_conv_wgrad_params& q) {
   pl.segs = (q.OW + (1 << pl.tcl) - 1) >> pl.tcl;
   pl.rbs = (q.OH + (WG_PX >> pl.tcl) - 1) / (WG_PX >> pl.tcl);
   pl.chunks = (int64_t)q.B * pl.rbs * pl.segs;
-  // split the pixel dimension so that ~3 workgroups per CU are in flight, every workgroup keeping >= 8 chunks when it can
-  pl.split = (3 * vsp::kNumCU + (int64_t)pl.tiles * q.G - 1) / ((int64_t)pl.tiles * q.G);
+  // split the pixel dimension so that every CU slot holds a workgroup, every workgroup keeping >= 8 chunks when it can
+  // (resident workgroups per CU: two at the 200+ registers of the 3x3 kernels with 32 accumulator columns or a 64-channel X tile, else 3.
+  //  A grid of 3 per CU on 2 slots ran as one full round and one half-empty one: 64 -> 64 at 512^2 833 -> 775 us, 64 -> 4 x 16: 1138 -> 931 us.
+  //  Stride 2 measured the other way round -- 3 per CU: 408 / 376 us, 2 per CU: 433 / 399 us on 64 -> 128 at 256^2 / 256 -> 512 at 64^2.)
+  const int per_cu = (q.KH == 3 && q.stride == 1 && (pl.nb == 2 || pl.wco != 4)) ? 2 : 3;
+  pl.split = (per_cu * vsp::kNumCU + (int64_t)pl.tiles * q.G - 1) / ((int64_t)pl.tiles * q.G);
   if (pl.split > pl.chunks / 8) pl.split = pl.chunks / 8;
   if (pl.split < 1) pl.split = 1;
   return pl;
@@ -366,6 +511,7 @@ extern "C" size_t vsp_conv2d_wgrad_work_floats(const vsp_conv_wgrad_params* pp) 
   if (!pp) return 0;
   const vsp_conv_wgrad_params& q = *pp;
   if (q.B <= 0 || q.G < 1 || q.Cin_g < 1 || q.Cout_g < 1 || q.OH <= 0 || q.OW <= 0 || q.KH < 1 || q.KW < 1 || q.stride < 1) return 0;
+  if (fewin_form(q)) return (size_t)((((int64_t)q.H * q.W + fewin_range(q) - 1) / fewin_range(q)) * q.B) * q.Cout_g * q.Cin_g;   // stream form
   const Plan pl = make_plan(q);
   return (size_t)pl.split * (size_t)q.G * q.Cout_g * q.Cin_g * q.KH * q.KW;
 }
@@ -414,6 +560,25 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   VSP_REQUIRE(k.x_coff + (q.G - 1) * k.x_gs + q.Cin_g <= k.x_ch && k.dy_coff + q.G * q.Cout_g <= k.dy_ch,
               "conv2d_wgrad: channel window exceeds the tensor (x %d+%d of %d, dy %d+%d of %d)", k.x_coff, (q.G - 1) * k.x_gs + q.Cin_g,
               k.x_ch, k.dy_coff, q.G * q.Cout_g, k.dy_ch);
+  if (fewin_form(q)) {   // the stream form (wgrad_fewin_kernel)
+    const int64_t hw = (int64_t)q.H * q.W, per = fewin_range(q);
+    const int co_blocks = (q.Cout_g + 15) / 16;
+    const int64_t ranges = (hw + per - 1) / per, copies = ranges * q.B;
+    VSP_REQUIRE(ranges <= 0x7fffffff && q.B <= 65535 && co_blocks <= 65535, "conv2d_wgrad: grid too large");
+    const bool copies_fit = use_work && (int64_t)q.work_floats >= copies * dw_elems && vsp::aligned16(q.work);
+    if (copies_fit) {   // every (copy, element) is written exactly once: no memset
+      k.work = q.work;
+      k.dw_elems = dw_elems;
+    } else if (!q.accumulate && use_work && hipMemsetAsync(q.dw, 0, dw_bytes, st) != hipSuccess) {
+      return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
+    }
+    dim3 grid((unsigned)ranges, (unsigned)q.B, (unsigned)co_blocks);
+    wgrad_fewin_kernel<4><<<grid, 256, 0, st>>>(k, (int)per);
+    if (copies_fit) {
+      fewin_reduce_kernel<<<(unsigned)dw_elems, 64, 0, st>>>(q.dw, q.work, dw_elems, (int)copies, q.accumulate ? 1 : 0);
+    }
+    return vsp::check_launch("conv2d_wgrad");
+  }
   const Plan pl = make_plan(q);
   const int xw4 = pl.xw4, xj = pl.xj, wco = pl.wco, nb = pl.nb, tiles = pl.tiles;
   const int64_t chunks = pl.chunks;
@@ -456,7 +621,11 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   if (use_work) {
     int blocks = (int)((dw_elems / 4 + 255) / 256);
     blocks = blocks < 1 ? 1 : (blocks > vsp::kMaxStreamBlocks ? vsp::kMaxStreamBlocks : blocks);
-    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(q.dw, q.work, dw_elems, (int)split, q.accumulate ? 1 : 0);
+    if (dw_elems % 4 == 0 && blocks < 2 * vsp::kNumCU && split >= 32)
+      wgrad_reduce_sliced_kernel<16><<<(unsigned)((dw_elems / 4 + 63) / 64), dim3(64, 16), 0, st>>>(q.dw, q.work, dw_elems / 4, (int)split,
+                                                                                               q.accumulate ? 1 : 0);
+    else
+      wgrad_reduce_kernel<<<blocks, 256, 0, st>>>(q.dw, q.work, dw_elems, (int)split, q.accumulate ? 1 : 0);
   }
   return vsp::check_launch("conv2d_wgrad");
 }
