@@ -1,6 +1,6 @@
 """The ATen ops of one training iteration ranked by the bytes they move (elements of their largest operand x 4): where the torch glue
 between the kernels is worth replacing.  The call-site column is filled only where the profiler recorded a Python stack (it does not
-on the autograd thread: "?").  usage: python tools/trace_train_ops.py [B]"""
+on the autograd thread: "?").  usage: python tools/trace_train_ops.py [B] [losses]"""
 import collections, copy, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,7 +13,12 @@ pipe = bench.build_pipeline(dev, 4, False)
 G = pipe.generator
 torch.manual_seed(1)
 D = Discriminator(512).to(dev)
-tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9)
+kw = {}
+if len(sys.argv) > 2 and sys.argv[2] == "losses":
+    from vspbfr_amd.id_loss import IDLoss
+    from vspbfr_amd.lpips import PerceptualLoss
+    kw = dict(percept_loss=PerceptualLoss().to(dev), percept_weight=0.5, id_loss=IDLoss(None, device=dev), id_weight=0.1)
+tr = RestorationTrainer(G, copy.deepcopy(G), D, psp_embedding=pipe.psp, diffusion=pipe.diffusion, mixing=0.9, **kw)
 low, real = torch.rand(B, 3, 512, 512, device=dev) * 2 - 1, torch.rand(B, 3, 512, 512, device=dev) * 2 - 1
 G.train()
 tr.step(1, low, real)
@@ -46,3 +51,6 @@ tot = sum(a[1] for a in agg.values())
 print(f"ATen ops: {sum(a[0] for a in agg.values())}, {tot * 4 / 1e9:.2f} GB of largest operands")
 for (name, site), (cnt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{n * 4 / 1e6:9.1f} MB  x{cnt:4d}  {name:26s} {site}")
+print("-- by launch count")
+for (name, site), (cnt, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"x{cnt:4d}  {n * 4 / 1e6:9.1f} MB  {name:26s} {site}")

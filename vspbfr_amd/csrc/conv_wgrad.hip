@@ -61,7 +61,9 @@ struct WgradK {
 
 // S: 0 = any chunk shape and stride (run-time LDS addresses), 1 / 2 = ROW-SEGMENT chunks (tcl = 6) of a stride-S layer: the MFMA loop
 // is fully unrolled with one LDS base per (ci block, tap) and the pixel offset as an immediate, B fragments fetched one unit ahead.
-template <int NTAP, int WCO, int NB, int XJ, int S = 0>
+// TCL (S != 0): log2 of the chunk width -- 6: one row segment of 64 pixels; 5 / 4: 2 x 32 / 4 x 16 pixels of a 32- / 16-wide map (dense
+// slab rows): the row part of the offset is added to the bases once per chunk row.
+template <int NTAP, int WCO, int NB, int XJ, int S = 0, int TCL = 6>
 __global__ __launch_bounds__(WG_NT, S != 0 ? 2 : 1) void conv_wgrad_kernel(const WgradK p) {
   constexpr int WCI = 4 / WCO;
   constexpr int CO_T = 16 * WCO, CI_T = 16 * NB * WCI;
@@ -227,20 +229,33 @@ __global__ __launch_bounds__(WG_NT, S != 0 ? 2 : 1) void conv_wgrad_kernel(const
       // unit u = (k-step u / NB, ci block u % NB): 9 MFMAs.  The nine B fragments of unit u + 1 (and the A fragment of the next
       // k-step) are read while the MFMAs of unit u issue: a wave alone keeps the matrix pipe fed (with the reads issued right before
       // their MFMAs the LDS latency showed once per 8 MFMAs: 82 % of the MFMA rate with the staging removed, VSP_WG_ABL = 4).
-      constexpr int NU = (WG_PX / 4) * NB;
+      constexpr int NU = (WG_PX / 4) * NB, SPR = (1 << TCL) / 4;   // units; k-steps per chunk row
       float bq[2][NTAP], aq[2];
+      const float* br[NB][NTAP];   // bases of the chunk row the NEXT unit reads
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) br[nb][t] = bt[nb][t];
       aq[0] = ap[0];
 #pragma unroll
-      for (int t = 0; t < NTAP; ++t) bq[0][t] = bt[0][t][0];
+      for (int t = 0; t < NTAP; ++t) bq[0][t] = br[0][t][0];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const int step = u / NB, nb = u % NB;
         if (u + 1 < NU) {
           const int step1 = (u + 1) / NB, nb1 = (u + 1) % NB;
-          if (nb1 == 0) aq[step1 & 1] = ap[4 * step1];
+          if (nb1 == 0) {
+            aq[step1 & 1] = ap[4 * step1];
+            if (TCL < 6 && step1 % SPR == 0) {   // next chunk row: S slab rows down
 #pragma unroll
-          for (int t = 0; t < NTAP; ++t) bq[(u + 1) & 1][t] = bt[nb1][t][4 * step1 * S];
+              for (int n2 = 0; n2 < NB; ++n2)
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) br[n2][t] += S * XWP;
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) bq[(u + 1) & 1][t] = br[nb1][t][4 * (step1 % SPR) * S];
         }
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) acc[nb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[step & 1], bq[u & 1][t], acc[nb][t], 0, 0, 0);
@@ -432,21 +447,30 @@ __global__ __launch_bounds__(64 * SL) void wgrad_reduce_sliced_kernel(float* __r
   }
 }
 
+template <int NTAP, int WCO, int NB, int XJ, int S, int TCL>
+int launch_wgrad_fast(const WgradK& k, dim3 grid, size_t lds, hipStream_t st) {
+  static vsp::LdsAttrOnce attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, XJ, S, TCL>), (int)kMaxLds, "conv2d_wgrad")) return rc;
+  conv_wgrad_kernel<NTAP, WCO, NB, XJ, S, TCL><<<grid, WG_NT, lds, st>>>(k);
+  return VSP_OK;
+}
+
 template <int NTAP, int WCO, int NB>
 int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st) {
-  static vsp::LdsAttrOnce attr1, attr2, attr3, attr4;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
-  // row-segment chunks of a 3x3 layer: the unrolled loop (stride 1 stages one item per thread, stride 2 two)
-  const int fast = (NTAP == 9 && k.tcl == 6 && xj == k.stride && !std::getenv("VSP_WGRAD_GENERIC")) ? k.stride : 0;
+  static vsp::LdsAttrOnce attr1, attr2;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
+  // 3x3 layers on chunks of 64 / 2 x 32 / 4 x 16 pixels: the unrolled loop (stride 1 stages one item per thread, stride 2 two)
   if constexpr (NTAP == 9) {
-    if (fast == 1) {
-      if (int rc = attr3.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 1, 1>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-      conv_wgrad_kernel<NTAP, WCO, NB, 1, 1><<<grid, WG_NT, lds, st>>>(k);
-      return VSP_OK;
-    }
-    if constexpr (WCO == 4) if (fast == 2) {   // (two staging items per lane always take the 64-co tile)
-      if (int rc = attr4.ensure(reinterpret_cast<const void*>(conv_wgrad_kernel<NTAP, WCO, NB, 2, 2>), (int)kMaxLds, "conv2d_wgrad")) return rc;
-      conv_wgrad_kernel<NTAP, WCO, NB, 2, 2><<<grid, WG_NT, lds, st>>>(k);
-      return VSP_OK;
+    if (k.tcl >= 4 && xj == k.stride && !std::getenv("VSP_WGRAD_GENERIC")) {
+      if (k.stride == 1) {
+        if (k.tcl == 6) return launch_wgrad_fast<NTAP, WCO, NB, 1, 1, 6>(k, grid, lds, st);
+        if (k.tcl == 5) return launch_wgrad_fast<NTAP, WCO, NB, 1, 1, 5>(k, grid, lds, st);
+        return launch_wgrad_fast<NTAP, WCO, NB, 1, 1, 4>(k, grid, lds, st);
+      }
+      if constexpr (WCO == 4) {   // (two staging items per lane always take the 64-co tile)
+        if (k.tcl == 6) return launch_wgrad_fast<NTAP, WCO, NB, 2, 2, 6>(k, grid, lds, st);
+        if (k.tcl == 5) return launch_wgrad_fast<NTAP, WCO, NB, 2, 2, 5>(k, grid, lds, st);
+        return launch_wgrad_fast<NTAP, WCO, NB, 2, 2, 4>(k, grid, lds, st);
+      }
     }
   }
   if (xj == 1) {
