@@ -167,6 +167,13 @@ typedef struct vsp_conv_params {
    * the bf16-ACTIVATION configuration of BASELINE configs[2]: 2 B per element through HBM instead of 4.  Every other operand
    * (noise, scales, biases) and the accumulation stay fp32; y is rounded to nearest even once, after the epilogue chain. */
   int io_bf16;
+  /* dil_by_input_quarter = 1 (vsp_conv2d_f32 only): the DATA GRADIENT of four dilated branches over one input (the SMART / LargeConv
+   * layers, reference models/RestoreNet.py:205-215, 742-750) in one pass:  y = sum_q conv(x[:, q Cin/4 : (q+1) Cin/4], W_q, dil[q]),
+   * pad = dil.  G = 4 and x_group_stride = 0 as in the forward dilation-group call, but the four "groups" are the four blocks of
+   * cout_g output channels of ONE convolution over all Cin input channels (w = [4][9][Cin][cout_g], cout_g <= 16 per launch row),
+   * and dil[q] / pad[q] belong to input-channel quarter q.  3x3, stride 1, Cin a multiple of 16; served by the pipelined kernels
+   * only (VSP_ENOTSUP when no configuration fits). */
+  int dil_by_input_quarter;
 } vsp_conv_params;
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);

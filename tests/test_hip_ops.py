@@ -1337,6 +1337,27 @@ def test_conv_pipelined_kernels(H, case):
     assert ran >= 2, "no pipelined configuration accepted this launch"
 
 
+@pytest.mark.parametrize("cin,cout,hw", [(64, 64, (40, 56)), (128, 32, (33, 20)), (64, 128, (16, 16))])
+def test_conv_dilation_by_input_quarter(H, cin, cout, hw):
+    """vsp_conv_params.dil_by_input_quarter (conv_pipe.hip MODE 3): y = sum_q conv(x[q-th quarter], W_q, dilation = padding = d_q) as
+    ONE convolution -- the data gradient of the four dilated SMART branches -- with the per-sample input / output scales and a bias."""
+    g_ = torch.Generator().manual_seed(31)
+    B, rates, c = 2, (1, 2, 4, 8), cin // 4
+    x = torch.randn(B, cin, *hw, generator=g_)
+    ws = [torch.randn(cout, c, 3, 3, generator=g_) * 0.1 for _ in rates]
+    s, dm, bias = torch.rand(B, cin, generator=g_) + 0.5, torch.rand(B, cout, generator=g_) + 0.5, torch.randn(cout, generator=g_)
+    xs = (x * s[:, :, None, None]).double()
+    ref = sum(F.conv2d(xs[:, q * c:(q + 1) * c], ws[q].double(), None, 1, r, r) for q, r in enumerate(rates))
+    ref = (ref * dm[:, :, None, None].double() + bias[None, :, None, None].double()).float()
+    wp = H.pack_weight(dev(torch.cat(ws, 1)))                                   # (1, 9, Cin, Cout)
+    w4 = wp.view(9, cin, 4, cout // 4).permute(2, 0, 1, 3).contiguous()         # four blocks of Cout / 4 output channels
+    pc = H.PackedConv(w4, 4, cout // 4, cin, 3, 3, 1, rates, rates, dil_by_input_quarter=True)
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s), out_scale=dev(dm), ch_bias=dev(bias))
+    close(y, ref, 2e-5, 2e-5 * float(ref.abs().max()), "y")
+    with pytest.raises(RuntimeError):   # the Winograd / bf16 entries do not serve it
+        H.conv2d_packed(dev(x), pc, winograd=True)
+
+
 def test_conv_pipelined_refuses_what_it_does_not_serve(H):
     """A named pipelined configuration must refuse (not mis-compute) launches outside its contract: an input shift, Cin that is not a
     multiple of the chunk, a 1x1 kernel."""

@@ -33,6 +33,7 @@ SKIP = ("aten::empty", "aten::empty_like", "aten::empty_strided", "aten::view", 
         "aten::lift_fresh", "aten::result_type", "aten::stride", "aten::is_nonzero", "aten::detach_", "aten::_to_copy", "aten::flatten",
         "aten::view_as", "aten::expand_as", "aten::contiguous", "aten::unflatten")
 agg = collections.defaultdict(lambda: [0, 0])
+byshape = collections.defaultdict(lambda: [0, 0])
 for ev in prof.events():
     if not ev.name.startswith("aten::") or ev.name in SKIP:
         continue
@@ -47,6 +48,8 @@ for ev in prof.events():
             site = "torch.optim"; break
     a = agg[(ev.name, site)]
     a[0] += 1; a[1] += n
+    b = byshape[(ev.name, tuple(shapes))]
+    b[0] += 1; b[1] += n
 tot = sum(a[1] for a in agg.values())
 print(f"ATen ops: {sum(a[0] for a in agg.values())}, {tot * 4 / 1e9:.2f} GB of largest operands")
 for (name, site), (cnt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
@@ -54,3 +57,6 @@ for (name, site), (cnt, n) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]
 print("-- by launch count")
 for (name, site), (cnt, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"x{cnt:4d}  {n * 4 / 1e6:9.1f} MB  {name:26s} {site}")
+print("-- by (op, operand shapes)")
+for (name, shapes), (cnt, n) in sorted(byshape.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f"{n * 4 / 1e6:9.1f} MB  x{cnt:4d}  {name:22s} {shapes}")

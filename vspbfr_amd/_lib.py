@@ -46,6 +46,7 @@ class ConvParams(C.Structure):
         ("res1", C.c_void_p), ("res2", C.c_void_p), ("res_ch", C.c_int), ("res_coff", C.c_int),
         ("tile_hint", C.c_int), ("x_ch", C.c_int), ("x_group_stride", C.c_int), ("transposed", C.c_int),
         ("io_bf16", C.c_int),
+        ("dil_by_input_quarter", C.c_int),
     ]
 
 

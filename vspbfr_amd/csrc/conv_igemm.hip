@@ -76,13 +76,16 @@ static int host_round_pitch(int n, int odd) {
 // Fill the geometry of configuration c for problem p; returns false if it does not fit (LDS / index limits).
 static bool is_tc(const Cfg& k) { return k.name[strlen(k.name) - 1] == 't'; }
 static bool is_dg(const Cfg& k) { return k.name[strlen(k.name) - 1] == 'd'; }
+static bool is_kg(const Cfg& k) { return k.name[strlen(k.name) - 1] == 'a'; }   // conv_pipe.hip: data gradient of the dilation groups
 static bool is_fg(const Cfg& k) { const size_t n = strlen(k.name); return n >= 2 && k.name[n - 2] == 'f'; }   // conv_pipe.hip fixed geometry
 
 static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   const Cfg& k = kCfgs[c];
   const bool tc = is_tc(k);
   if (tc != (p.transposed != 0)) return false;
-  const bool dg = is_dg(k);
+  const bool kg = is_kg(k);
+  if (kg != (p.dil_by_input_quarter != 0)) return false;
+  const bool dg = is_dg(k) || kg;   // (the data-gradient form shares the staging geometry and the weight image)
   if (dg) {  // four dilated branches over one input, padding = dilation (SMART / LargeConv layers)
     if (p.G != 4 || p.x_group_stride != 0 || p.stride_y != 1 || p.stride_x != 1 || p.KH != 3 || p.KW != 3) return false;
     for (int g = 0; g < 4; ++g)
@@ -121,6 +124,7 @@ static bool make_plan(const vsp_conv_params& p, int c, Plan* out) {
   }
   if (k.PF == 3) {  // conv_pipe.hip: 3x3 only, vector weight rows, whole 64-word patch rows per wave, two LDS buffers
     if (p.KH != 3 || p.KW != 3 || p.cout_g % 4 != 0 || !vsp::aligned16(p.w) || p.in_shift || p.Cin % k.CK != 0) return false;
+    if (kg && (p.Cin % 16 != 0 || (p.Cin / 4) % k.CK != 0)) return false;   // a chunk lies inside one input-channel quarter
     const int NW = k.WM * k.WN, wpc = k.CK >= NW ? 1 : NW / k.CK;
     const int nrow = (plane + 63) / 64;
     // (PMAX field = PROWS: 64-word rows of a channel plane per wave; checked below once the pitch is known)
@@ -238,6 +242,8 @@ static int validate_conv(const vsp_conv_params& p, int* x_ch_out, bool* empty) {
   VSP_REQUIRE(p.x_group_stride == 0 || !p.in_shift, "conv2d: an input shift is not supported with grouped input");
   VSP_REQUIRE(p.KH >= 1 && p.KW >= 1 && p.KH * p.KW <= 49, "conv2d: unsupported kernel %dx%d", p.KH, p.KW);
   VSP_REQUIRE(p.stride_y >= 1 && p.stride_x >= 1 && p.stride_x <= 2 && p.stride_y <= 2, "conv2d: stride must be 1 or 2");
+  VSP_REQUIRE(p.dil_by_input_quarter == 0 || (p.dil_by_input_quarter == 1 && p.G == 4 && p.x_group_stride == 0 && p.Cin % 16 == 0 && !p.transposed),
+              "conv2d: dil_by_input_quarter needs G = 4 blocks of output channels over one shared input with Cin %% 16 == 0");
   VSP_REQUIRE(p.OH >= 0 && p.OW >= 0, "conv2d: negative output size");
   VSP_REQUIRE(p.osy >= 1 && p.osx >= 1 && p.ooy >= 0 && p.oox >= 0, "conv2d: bad output stride/offset");
   VSP_REQUIRE(!p.noise || p.noise_w, "conv2d: noise given without noise_w");
@@ -330,6 +336,7 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
                 "conv2d_winograd: group %d needs dilation 1, 2, 4 or 8 and padding = dilation (got dilation %d, padding %d/%d)", g,
                 p.dil[g], p.pad_y[g], p.pad_x[g]);
   VSP_REQUIRE(p.io_bf16 == 0, "conv2d_winograd: fp32 activations only (io_bf16 is served by vsp_conv2d_bf16)");
+  VSP_REQUIRE(p.dil_by_input_quarter == 0, "conv2d_winograd: dil_by_input_quarter is served by vsp_conv2d_f32");
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0, "conv2d_winograd: dense output only");
   VSP_REQUIRE(p.OH == p.H && p.OW == p.W, "conv2d_winograd: output size must equal the input size");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd: transformed weights must be 16-byte aligned");
@@ -418,6 +425,7 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   }
   VSP_REQUIRE(!(split && p.io_bf16), "conv2d_bf16x3: the split-precision form keeps fp32 activations (io_bf16 = 0)");
   VSP_REQUIRE(p.io_bf16 == 0 || p.io_bf16 == 1, "conv2d_bf16: io_bf16 must be 0 or 1");
+  VSP_REQUIRE(p.dil_by_input_quarter == 0, "conv2d_bf16: dil_by_input_quarter is served by vsp_conv2d_f32");
   q.io_bf16 = p.io_bf16;
   {
     static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
@@ -465,7 +473,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     const int sm = kNumCfgs + 1;
     const bool named = p.tile_hint == sm, preferred = p.tile_hint == -sm;
     const bool guess = p.tile_hint == 0 && (int64_t)p.B * p.OH * p.OW <= 256 && (int64_t)p.Cin * p.KH * p.KW >= 1024;
-    if (named || preferred || guess) {
+    if ((named || preferred || guess) && !p.dil_by_input_quarter) {
       ConvK q{};
       if (int rc = fill_convk(p, x_ch, q)) return rc;
       if (vspconv::smallmap_eligible(q, p.transposed != 0)) return vspconv::smallmap_launch(q, vsp::as_stream(stream));
@@ -487,9 +495,11 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     double best_cost = 0.0;
     for (int c = 0; c < kNumCfgs; ++c) {
       Plan pl{};
-      if (is_dg(kCfgs[c]) || kCfgs[c].PF == 3) continue;  // the fused dilation-group and the pipelined kernels are only used when named (tile_hint / tuned table)
+      // the fused dilation-group and the pipelined kernels are only used when named (tile_hint / tuned table); the data gradient of
+      // the dilation groups exists only there: its configurations are tried in table order
+      if (p.dil_by_input_quarter ? !is_kg(kCfgs[c]) : (is_dg(kCfgs[c]) || kCfgs[c].PF == 3)) continue;
       if (!make_plan(p, c, &pl)) continue;
-      const double cost = plan_cost(p, pl);
+      const double cost = p.dil_by_input_quarter ? (double)c : plan_cost(p, pl);
       if (!found || cost < best_cost) {
         best = pl;
         best_cost = cost;

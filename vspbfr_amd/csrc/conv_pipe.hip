@@ -48,10 +48,13 @@ __device__ __forceinline__ float uload(const float* base, int idx) {  // wave-un
 // fragments: 15 reads per 18 MFMAs instead of 27) was built and measured: 678 vs 669 us at 512 -> 256 / 64^2 -- no gain, removed.
 template <int MB, int NB, int WM, int WN, int CK, int PROWS, int OCC, int MODE, bool FG = false>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const ConvK p) {
-  constexpr bool TC = MODE == 1, DG = MODE == 2;
+  // KG (MODE 3): the DATA GRADIENT of the four dilation groups in one pass -- the staging, weight image and channel mapping of the
+  // dilation-group mode (four blocks of 16 output channels over one shared 32-halo patch), but the dilation belongs to the INPUT
+  // channel quarter a chunk lies in and all four M-blocks multiply the same B fragments: out = sum_q conv(x[q], W[q], dil[q]).
+  constexpr bool TC = MODE == 1, DG = MODE == 2, KG = MODE == 3, DGS = DG || KG;
   static_assert(!FG || DG, "fixed geometry serves the dilation-group mode");
   static_assert(!TC || NB % 4 == 0, "transposed mode: N-blocks come in groups of four sub-pixel phases");
-  static_assert(!DG || (MB == 4 && WM == 1), "dilation-group mode: M-block = group");
+  static_assert(!DGS || (MB == 4 && WM == 1), "dilation-group modes: M-block = group / block of 16 output channels");
   constexpr int NP = TC ? NB / 4 : NB;  // 16-wide groups of patch positions per wave
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int CO_T = 16 * MB * WM;
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     by = lrem - tile * GY;
   }
   const int tx_i = tile % p.tiles_x, ty_i = tile / p.tiles_x;
-  const int g = DG ? 0 : by / p.co_tiles;
-  const int co0 = DG ? by * 16 : (by % p.co_tiles) * CO_T;  // within the group
+  const int g = DGS ? 0 : by / p.co_tiles;
+  const int co0 = DGS ? by * 16 : (by % p.co_tiles) * CO_T;  // within the group
   const int b = bz;
   int twl = FG ? 4 : p.tw_log2, TH = FG ? F_TH : p.th, oy0 = ty_i * (FG ? F_TH : p.th), ox0 = tx_i << (FG ? 4 : p.tw_log2);
   int mlim = p.H + 1;  // transposed: first invalid position row of this block
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
   }
   const int TW = 1 << twl;
   const int gi = p.G > 4 ? 0 : g;
-  const int D = DG ? max(max(p.dil[0], p.dil[1]), max(p.dil[2], p.dil[3])) : p.dil[gi];
+  const int D = DGS ? max(max(p.dil[0], p.dil[1]), max(p.dil[2], p.dil[3])) : p.dil[gi];
   const int PH = TC ? TH + 1 : (TH - 1) * p.sy + 2 * D + 1;
   const int PW = FG ? F_PW : TC ? TW + 1 : (TW - 1) * p.sx + 2 * D + 1;
   const int plane = PH * PW;
   const int PS = FG ? F_PS : p.bf_plane;            // plane pitch (host: >= the 64-word rows the waves stage, == 16 mod 32 or odd)
   const int BUF = FG ? F_BUF : T * CK * WS + CK * PS;   // floats per LDS buffer
-  const int iy0 = TC ? oy0 - 1 : DG ? oy0 - D : oy0 * p.sy - p.pady[gi];
-  const int ix0 = TC ? ox0 - 1 : DG ? ox0 - D : ox0 * p.sx - p.padx[gi];
+  const int iy0 = TC ? oy0 - 1 : DGS ? oy0 - D : oy0 * p.sy - p.pady[gi];
+  const int ix0 = TC ? ox0 - 1 : DGS ? ox0 - D : ox0 * p.sx - p.padx[gi];
 
   // per-lane fragment offsets
   int pixoff[NP];
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
   constexpr int kOOB = 0x7ffffff0;
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, (p.x_ch - g * p.x_gs) * chw * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, (DG ? 4 : 1) * T * p.Cin * p.cout_g * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, (DGS ? 4 : 1) * T * p.Cin * p.cout_g * 4, 0x00020000);
   const unsigned pw_magic = (unsigned)(((1ull << 32) + PW - 1) / PW);  // exact floor(i / PW) for i < 2^16, PW <= 2^8
 
   // ---- staging plan (chunk-invariant).  Patch: a wave owns whole 64-word rows of a channel plane -- PCH channels per wave
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     const bool piece = i < WITEMS;                   // (only the tail pass can run out of pieces)
     wdst[w] = piece ? row * WS + c4 * 4 + sub
                     : (RV == 2 ? ((tid >> 3) % (T * CK)) * WS + CO_T + (tid & 7) * 2 : (tid >> 4) * WS + CO_T + (tid & 15));
-    if constexpr (DG) {
+    if constexpr (DGS) {
       const int cc = co0 + (c4 & 3) * 4 + sub;
       woff[w] = (piece && cc < p.cout_g) ? (((c4 >> 2) * T * p.Cin + tap * p.Cin + cl) * p.cout_g + cc) * 4 : kOOB;
     } else {
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
 
   // ---- one unit of MFMAs: tap = u / KS, k-step = u % KS.  Fragments are read one unit ahead into the other register set.
   float af[2][MB], bfr[2][NP];
+  int kg_d = D, kg_b = 0;   // KG: dilation of the input-channel quarter of the current chunk, offset of its taps inside the halo-D patch
   auto load_frag = [&](int u, const float* buf, float (&a)[MB], float (&bq)[NP]) {
     const int tap = u / KS, c4 = u % KS;
     const int ky = tap / 3, kx = tap % 3;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) a[mb] = wt[mb * 16];
     if constexpr (!DG) {
-      const int boff = TC ? (1 - (ky >> 1)) * PW + (1 - (kx >> 1)) : (ky * PW + kx) * D;
+      const int boff = TC ? (1 - (ky >> 1)) * PW + (1 - (kx >> 1)) : KG ? kg_b + (ky * PW + kx) * kg_d : (ky * PW + kx) * D;
 #pragma unroll
       for (int np = 0; np < NP; ++np) bq[np] = buf[c4 * 4 * PS + pixoff[np] + boff];
     }
@@ -301,6 +305,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     const float* cur = smem + (i & 1) * BUF;
     float* nxt = smem + ((i + 1) & 1) * BUF;
     if constexpr (COMMIT) load_scales((i + 1) * CK);
+    if constexpr (KG) {
+      const int q4 = p.Cin >> 2, ci = i * CK;
+      kg_d = ci < q4 ? p.dil[0] : ci < 2 * q4 ? p.dil[1] : ci < 3 * q4 ? p.dil[2] : p.dil[3];
+      kg_b = (D - kg_d) * (PW + 1);
+    }
     if constexpr (DG) load_frag_dg(0, cur, af[0], bdg[0]); else load_frag(0, cur, af[0], bfr[0]);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -486,9 +495,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int cg = DG ? co0 + kq * 4 + r : co0 + (wm * MB + mb) * 16 + kq * 4 + r;  // channel within the group
+        const int cg = DGS ? co0 + kq * 4 + r : co0 + (wm * MB + mb) * 16 + kq * 4 + r;  // channel within the group
         const bool cok = cg < p.cout_g;
-        const int co = (DG ? mb : g) * p.cout_g + (cok ? cg : 0);
+        const int co = (DGS ? mb : g) * p.cout_g + (cok ? cg : 0);
         const float os = osp[co * oss], cs = p.csp[co * css], cb = p.cbp[co * cbs];
         const float b1 = p.b1p[co * b1s], b2 = p.b2p[co * b2s], sl2 = p.s2p[co * s2s];
         const int cbase = co * y_plane;
@@ -539,6 +548,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
         conv_pipe_kernel<4, NB, 1, WN, CK, PROWS, OCC, 2, true>                                      \
   }
 
+// data gradient of the dilation groups (MODE 3): name suffix "a"
+#define VSP_CFGPK(NB, WN, CK, PROWS, OCC)                                                            \
+  {                                                                                                  \
+    4, NB, 1, WN, CK, 1, PROWS, 3, OCC, "4x" #NB "x1x" #WN "x" #CK "k1p3o" #OCC "r" #PROWS "a",        \
+        conv_pipe_kernel<4, NB, 1, WN, CK, PROWS, OCC, 3>                                            \
+  }
+
 extern const Cfg kCfgsP[] = {
     VSP_CFGP(4, 4, 2, 4, 8, 18, 1),    // 128 co x 256 pix, stride-2 patches up to 33 x 33
     VSP_CFGP(4, 2, 2, 4, 8, 9, 1),     // 128 co x 128 pix
@@ -574,6 +590,11 @@ extern const Cfg kCfgsP[] = {
     VSP_CFGPDF(2, 8, 4, 8, 4),         // 4 x 16 co x 256 pix
     VSP_CFGPDF(2, 8, 4, 8, 2),
     VSP_CFGPDF(2, 8, 8, 16, 1),
+    // the data gradient of the four dilation groups (appended: earlier indices keep their meaning)
+    VSP_CFGPK(2, 8, 4, 8, 2),          // 64 co x 256 pix, two workgroups per CU
+    VSP_CFGPK(2, 8, 8, 16, 1),
+    VSP_CFGPK(4, 8, 4, 12, 1),         // 64 co x 512 pix (16 x 32 tile, 32 x 48 patch)
+    VSP_CFGPK(4, 4, 4, 16, 1),         // 4 waves x 64 pix
 };
 extern const int kNumP = sizeof(kCfgsP) / sizeof(kCfgsP[0]);
 

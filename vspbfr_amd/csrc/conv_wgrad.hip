@@ -628,8 +628,10 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
     if (split > (int64_t)q.work_floats / dw_elems) split = (int64_t)q.work_floats / dw_elems;
     k.work = q.work;
     k.dw_elems = dw_elems;
-    // a tile the channel counts do not fill leaves holes in a copy, as do blocks without a chunk: the copies start from zero
-    if (hipMemsetAsync(q.work, 0, (size_t)split * dw_bytes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
+    // a tile the channel counts do not fill leaves holes in a copy, as do blocks without a chunk: those copies start from zero
+    // (full tiles and split <= chunks: every element of every copy is stored -- the memset was 56 MB per launch on the big layers)
+    const bool holes = q.Cout_g % co_t != 0 || q.Cin_g % ci_t != 0 || split > chunks;
+    if (holes && hipMemsetAsync(q.work, 0, (size_t)split * dw_bytes, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "conv2d_wgrad: memset failed");
   }
   const size_t lds = ((size_t)co_t * DPITCH + (size_t)ci_t * k.plane) * sizeof(float);
   VSP_REQUIRE(lds <= kMaxLds, "conv2d_wgrad: row segment with halo does not fit LDS (dilation %d)", dmax);

@@ -105,9 +105,14 @@ BF16X3_TUNE = _load_bf16_tune("conv_tune_bf16x3.json")
 BF16_FORCE = 0
 
 
+# the data gradient of the four dilated SMART branches as one convolution (conv_pipe.hip MODE 3) instead of a grouped conv + a sum over
+# the branches (tools / A-B runs can switch it off)
+SMART_ADJOINT_ONE_PASS = os.environ.get("VSP_SMART_ADJOINT_ONE_PASS", "1") != "0"
+
+
 def conv_key(B, Cin, H, W, pc, OH, OW):
     return f"{B},{Cin},{H},{W},{pc.G},{pc.cout_g},{pc.kh},{pc.kw},{pc.stride},{pc.dil[0]},{OH},{OW}" + (
-        f",g{pc.x_group_stride}" if pc.x_group_stride else "")
+        f",g{pc.x_group_stride}" if pc.x_group_stride else "") + (",q" if pc.dil_by_input_quarter else "")
 
 
 def _stream():
@@ -240,11 +245,15 @@ class PackedConv:
     """A convolution weight in the kernel's layout Wp[g][tap][ci][co_g] (include/vspbfr_hip.h) plus its geometry.
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
-    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "_wino", "_bf16", "_bf16x3")
+    __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
+                 "_wino", "_bf16", "_bf16x3")
 
-    def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0):
+    def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
         self.stride = stride
+        # True: the data gradient of four dilated branches in one pass (include/vspbfr_hip.h: dil_by_input_quarter) -- G = 4 blocks of
+        # cout_g output channels over ALL cin input channels, dil / pad belong to the input-channel quarter
+        self.dil_by_input_quarter = bool(dil_by_input_quarter)
         self.x_group_stride = x_group_stride  # > 0: true grouped conv, group g reads input channels [g*stride, +cin)
         rep = lambda t, fill: tuple(t) * 4 if len(t) == 1 else tuple(t) + (fill,) * (4 - len(t))  # noqa: E731
         self.dil = rep(dil, 1)          # one value = the same geometry for every group
@@ -296,7 +305,7 @@ def bf16_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_off
     """What vsp_conv2d_bf16 serves: 3x3 kernels with >= 16 input channels as (a) stride 1, padding = dilation, G <= 4 dilation
     groups over one input or true groups; (b) stride 2, dilation 1, padding 0 or 1, G = 1 or true groups; (c) the stride-2
     transposed conv (G = 1); dense output for (a) and (b)."""
-    if pc.kh != 3 or pc.kw != 3 or pc.cin < 16 or pc.cin % 8:
+    if pc.kh != 3 or pc.kw != 3 or pc.cin < 16 or pc.cin % 8 or pc.dil_by_input_quarter:
         return False
     if transposed:
         return pc.G == 1
@@ -383,7 +392,7 @@ def pack_weight_stack(weights, adjoint=False, flip=False, scale=1.0):
 
 def winograd_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
     """3x3, stride 1, padding = dilation, G = 1 or up to four dilation groups over one shared input, dense output."""
-    if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.x_group_stride != 0 or not 1 <= pc.G <= 4:
+    if transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.x_group_stride != 0 or not 1 <= pc.G <= 4 or pc.dil_by_input_quarter:
         return False
     if any(pc.pad_y[g] != pc.dil[g] or pc.pad_x[g] != pc.dil[g] or pc.dil[g] not in (1, 2, 4, 8) for g in range(pc.G)):
         return False
@@ -492,6 +501,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     p.tile_hint = tile_hint
     p.x_ch, p.x_group_stride = x_ch, pc.x_group_stride
     p.transposed = 1 if transposed else 0
+    p.dil_by_input_quarter = 1 if pc.dil_by_input_quarter else 0
     if rt is not None and (rt.shape[0] != B or rt.shape[2] != out.shape[2] or rt.shape[3] != out.shape[3]):
         raise RuntimeError("conv2d: residual must match the output tensor's batch and spatial size")
     prof = PROFILER

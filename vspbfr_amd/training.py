@@ -154,18 +154,32 @@ class _NoCtx:
 
 
 # ---- the four dilated branches of a SMART layer as ONE launch (shared input and modulation, per-branch weight / demodulation)
-def _smart_adjoint_pack(layer):
+def _smart_adjoint_pack(layer, hw=None):
+    """Packed weight of the data gradient of the four branches.  Maps of 64 x 64 and larger (`hw`): ONE convolution over all nb * cg
+    gradient channels whose dilation follows the input-channel quarter (vsp_conv_params.dil_by_input_quarter) -- no (B, nb * Cin, H, W)
+    intermediate, no sum over the branches; smaller maps (the 256-pixel tiles of the pipelined kernel leave the chip under-filled: 512 channels at 32^2 326 vs 175 us): a true grouped
+    conv, group i = branch i, summed by the caller."""
     ws = [m.weight for m in layer.ModulatedConv2ds]
+    m0 = layer.ModulatedConv2ds[0]
+    cg, cin = layer.out_channel // len(ws), layer.in_channel
+    dil = tuple(m.dilation for m in layer.ModulatedConv2ds)
+    pad = tuple(m.dilation * (m.kernel_size - 1) - m.padding for m in layer.ModulatedConv2ds)
 
     def build():
-        m0 = layer.ModulatedConv2ds[0]
-        cg = layer.out_channel // len(ws)
         # true grouped conv over g: group i reads its branch's cg channels, writes Cin channels, dilation / padding of branch i
         wp = H.pack_weight_stack([w[0] for w in ws], adjoint=True, flip=True, scale=m0.scale)
-        dil = tuple(m.dilation for m in layer.ModulatedConv2ds)
-        pad = tuple(m.dilation * (m.kernel_size - 1) - m.padding for m in layer.ModulatedConv2ds)
         return H.PackedConv(wp, len(ws), layer.in_channel, cg, 3, 3, 1, dil, pad, x_group_stride=cg)
-    return layer._derive("branches_adjoint", ws, build)
+
+    def build_q():
+        wp = H.pack_weight_stack([w[0] for w in ws], adjoint=True, flip=True, scale=m0.scale)   # [branch][tap][cg][Cin]
+        # weight image: four blocks of Cin / 4 output channels, [block][tap][q * cg + c][Cin / 4]
+        a = wp.permute(1, 0, 2, 3).reshape(9, len(ws) * cg, cin)
+        w2 = a.view(9, len(ws) * cg, 4, cin // 4).permute(2, 0, 1, 3).contiguous()
+        return H.PackedConv(w2, 4, cin // 4, len(ws) * cg, 3, 3, 1, dil, pad, dil_by_input_quarter=True)
+
+    one_pass = (H.SMART_ADJOINT_ONE_PASS and hw is not None and min(hw) >= 64 and len(ws) == 4 and cg % 4 == 0 and cin % 16 == 0
+                and pad == dil)
+    return layer._derive("branches_adjoint_q", ws, build_q) if one_pass else layer._derive("branches_adjoint", ws, build)
 
 
 class _SmartBranches(Function):
@@ -190,8 +204,12 @@ class _SmartBranches(Function):
         d_demod = H.plane_dot(g, y) / demod
         dx = ds = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            parts = H.conv2d_packed(g, _smart_adjoint_pack(layer), in_scale=demod)          # (B, nb * Cin, H, W)
-            dxs = parts.view(B, nb, cin, Hh, Ww).sum(1)
+            adj = _smart_adjoint_pack(layer, (Hh, Ww))
+            if adj.dil_by_input_quarter:
+                dxs = H.conv2d_packed(g, adj, in_scale=demod)                                # (B, Cin, H, W): the branches summed in the K loop
+            else:
+                parts = H.conv2d_packed(g, adj, in_scale=demod)                              # (B, nb * Cin, H, W)
+                dxs = parts.view(B, nb, cin, Hh, Ww).sum(1)
             ds = H.plane_dot_scale_(dxs, x, s)
             dx = dxs
         dws = [None] * nb
