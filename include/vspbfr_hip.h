@@ -289,6 +289,14 @@ int vsp_axpby_idx_f32(float* out, const float* x, const float* y, const float* a
  * (models/RestoreNet.py:376-379 with the tap sum hoisted: wsq[co,ci] = sum_taps W[co,ci,:,:]^2). */
 int vsp_demod_f32(float* out, const float* style, const float* wsq, int B, int Cin, int Cout, float wscale,
                   float eps, vsp_stream_t stream);
+/* The same coefficients under autograd (training rows; reference models/RestoreNet.py:376-379 differentiated by torch): forward from
+ * the weight w[Cout, Cin, K] (K taps) -- wsq[co, ci] = sum_k w^2 is written for the backward -- and the gradient of a loss through
+ * `out` with respect to the style and the weight:  t = -0.5 wscale^2 out^3 g;  dstyle[b, ci] = 2 style[b, ci] sum_co t[b, co] wsq[co, ci];
+ * dw[co, ci, k] = 2 w[co, ci, k] sum_b t[b, co] style[b, ci]^2 (overwritten, not accumulated; either output may be NULL).  B <= 16. */
+int vsp_demod_weight_f32(float* out, float* wsq, const float* style, const float* w, int B, int Cin, int Cout, int K, float wscale,
+                         float eps, vsp_stream_t stream);
+int vsp_demod_weight_bwd_f32(float* dstyle, float* dw, const float* g, const float* out, const float* style, const float* wsq,
+                             const float* w, int B, int Cin, int Cout, int K, float wscale, vsp_stream_t stream);
 /* 2x2 mean pooling of [planes, 2*OH, 2*OW] (F.interpolate bilinear 512->256 with align_corners=False is
  * exactly this, Loss/e4e_embedding.py:97; AdaptiveAvgPool2d 1024->512, e4e/models/psp.py:246). */
 int vsp_avgpool2x2_f32(float* out, const float* x, int64_t planes, int OH, int OW, vsp_stream_t stream);

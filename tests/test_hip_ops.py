@@ -1042,6 +1042,29 @@ def test_conv2d_wgrad_tile_shapes(H, cfg):
     close(dw, w.grad.float(), 2e-5, 2e-5 * float(w.grad.abs().max()), "dw")
 
 
+@pytest.mark.parametrize("B,cin,cout,k", [(3, 40, 24, 3), (4, 512, 128, 3), (16, 64, 3, 1), (1, 7, 5, 3)])
+def test_demod_weight_and_gradient(H, B, cin, cout, k):
+    """vsp_demod_weight_f32 / _bwd_f32 (training: demodulation coefficients from the weight, gradient in style and weight) against
+    torch autograd of the reference expression in float64."""
+    g_ = torch.Generator().manual_seed(41)
+    w = torch.randn(1, cout, cin, k, k, generator=g_)
+    s, gy = torch.randn(B, cin, generator=g_), torch.randn(B, cout, generator=g_)
+    scale = 1 / math.sqrt(cin * k * k)
+    wd, sd = w.double().requires_grad_(True), s.double().requires_grad_(True)
+    with torch.enable_grad():
+        ref = torch.rsqrt(F.linear(sd * sd, wd[0].pow(2).sum((2, 3))) * scale ** 2 + 1e-8)
+        ref.backward(gy.double())
+    out, wsq = H.demod_weight(dev(s), dev(w), scale)
+    close(out, ref.detach().float(), 1e-5, 1e-6, "demod")
+    close(wsq, w[0].pow(2).sum((2, 3)), 1e-5, 1e-6, "wsq")
+    ds, dw = H.demod_weight_bwd(dev(gy), out, dev(s), wsq, dev(w), scale)
+    close(ds, sd.grad.float(), 2e-5, 2e-5 * float(sd.grad.abs().max()), "dstyle")
+    close(dw, wd.grad.float(), 2e-5, 2e-5 * float(wd.grad.abs().max()), "dweight")
+    assert dw.shape == w.shape
+    ds2, dw2 = H.demod_weight_bwd(dev(gy), out, dev(s), wsq, dev(w), scale, need_style=False)
+    assert ds2 is None and torch.equal(dw2, dw)
+
+
 @pytest.mark.parametrize("cin,cout,hw", [(3, 16, (32, 32)), (3, 40, (23, 27)), (1, 5, (7, 9)), (4, 64, (64, 48))])
 def test_conv2d_wgrad_few_input_channels(H, cin, cout, hw):
     """The stream form of the 1x1 weight gradient (FromRGB: at most 4 input channels): per-sample scales, a channel window into a wider

@@ -128,6 +128,80 @@ __global__ __launch_bounds__(256) void demod_kernel(float* out, const float* sty
   if (lane == 0) out[row] = rsqrtf(s * wscale2 + eps);
 }
 
+// ---- demodulation under autograd (training): the coefficients straight from the weight, and their gradient.  The torch expression
+//      rsqrt(linear(s^2, w^2.sum(taps)) * c + eps) is 7 launches forward and ~14 backward per modulated layer (61 layers per iteration,
+//      every one a few microseconds of a 2 MB tensor); here: one launch forward, two backward.
+constexpr int kDemodMaxB = 16;
+// one workgroup per output channel: wsq[co, :] = sum_taps w^2 (kept for the backward), out[b, co] for every sample
+__global__ __launch_bounds__(256) void demod_weight_kernel(float* __restrict__ out, float* __restrict__ wsq, const float* __restrict__ style,
+                                                            const float* __restrict__ w, int B, int Cin, int Cout, int K, float wscale2,
+                                                            float eps) {
+  const int co = blockIdx.x;
+  float acc[kDemodMaxB];
+#pragma unroll
+  for (int b = 0; b < kDemodMaxB; ++b) acc[b] = 0.f;
+  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
+    const float* wp = w + ((int64_t)co * Cin + ci) * K;
+    float q = 0.f;
+    for (int k = 0; k < K; ++k) q = fmaf(wp[k], wp[k], q);
+    wsq[(int64_t)co * Cin + ci] = q;
+#pragma unroll
+    for (int b = 0; b < kDemodMaxB; ++b)
+      if (b < B) {
+        const float st = style[(int64_t)b * Cin + ci];
+        acc[b] = fmaf(st * st, q, acc[b]);
+      }
+  }
+  __shared__ float red[4][kDemodMaxB];
+#pragma unroll
+  for (int b = 0; b < kDemodMaxB; ++b) {
+    const float v = wave_sum(acc[b]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < B) {
+    const int b = threadIdx.x;
+    out[(int64_t)b * Cout + co] = rsqrtf((red[0][b] + red[1][b] + red[2][b] + red[3][b]) * wscale2 + eps);
+  }
+}
+// t[b, co] = -0.5 wscale^2 out^3 g  (d out / d (sum s^2 wsq));  dw[co, ci, k] = 2 w[co, ci, k] sum_b t[b, co] s[b, ci]^2: one thread per (co, ci)
+__global__ __launch_bounds__(256) void demod_weight_bwd_w_kernel(float* __restrict__ dw, const float* __restrict__ g, const float* __restrict__ out,
+                                                                  const float* __restrict__ style, const float* __restrict__ w, int B, int Cin,
+                                                                  int Cout, int K, float c) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)Cout * Cin) return;
+  const int co = (int)(i / Cin), ci = (int)(i - (int64_t)co * Cin);
+  float d = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float o = out[(int64_t)b * Cout + co], st = style[(int64_t)b * Cin + ci];
+    d = fmaf(c * g[(int64_t)b * Cout + co] * o * o * o, st * st, d);
+  }
+  d *= 2.f;
+  const float* wp = w + i * K;
+  float* dp = dw + i * K;
+  for (int k = 0; k < K; ++k) dp[k] = wp[k] * d;
+}
+// dstyle[b, ci] = 2 s[b, ci] sum_co t[b, co] wsq[co, ci]: a workgroup = one sample x 64 input channels, the output channels in 4 quarters
+__global__ __launch_bounds__(256) void demod_weight_bwd_s_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ out,
+                                                                  const float* __restrict__ style, const float* __restrict__ wsq, int Cin,
+                                                                  int Cout, float c) {
+  const int b = blockIdx.y, ci = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (ci < Cin) {
+    for (int co = q; co < Cout; co += 4) {
+      const float o = out[(int64_t)b * Cout + co];
+      acc = fmaf(c * g[(int64_t)b * Cout + co] * o * o * o, wsq[(int64_t)co * Cin + ci], acc);
+    }
+  }
+  __shared__ float red[4][64];
+  red[q][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q == 0 && ci < Cin) {
+    const int l = threadIdx.x;
+    ds[(int64_t)b * Cin + ci] = 2.f * style[(int64_t)b * Cin + ci] * (red[0][l] + red[1][l] + red[2][l] + red[3][l]);
+  }
+}
+
 __global__ __launch_bounds__(256) void avgpool2x2_kernel(float* out, const float* x, int64_t planes, int OH, int OW) {
   const int64_t total = planes * OH * OW;
   const int IW = 2 * OW;
@@ -358,6 +432,30 @@ int vsp_demod_f32(float* out, const float* style, const float* wsq, int B, int C
   demod_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, vsp::as_stream(stream)>>>(out, style, wsq, B, Cin, Cout,
                                                                                 wscale * wscale, eps);
   return vsp::check_launch("demod");
+}
+
+int vsp_demod_weight_f32(float* out, float* wsq, const float* style, const float* w, int B, int Cin, int Cout, int K, float wscale, float eps,
+                         vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && K >= 1, "demod_weight: bad dims");
+  if (B > kDemodMaxB) return vsp::fail(VSP_ENOTSUP, "demod_weight: at most %d samples per call (got %d)", kDemodMaxB, B);
+  VSP_REQUIRE(out && wsq && style && w, "demod_weight: null pointer");
+  demod_weight_kernel<<<(unsigned)Cout, 256, 0, vsp::as_stream(stream)>>>(out, wsq, style, w, B, Cin, Cout, K, wscale * wscale, eps);
+  return vsp::check_launch("demod_weight");
+}
+
+int vsp_demod_weight_bwd_f32(float* dstyle, float* dw, const float* g, const float* out, const float* style, const float* wsq, const float* w,
+                             int B, int Cin, int Cout, int K, float wscale, vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && K >= 1, "demod_weight_bwd: bad dims");
+  VSP_REQUIRE(g && out && style && (!dstyle || wsq) && (!dw || w), "demod_weight_bwd: null pointer");
+  VSP_REQUIRE(B <= 65535, "demod_weight_bwd: batch too large");
+  const float c = -0.5f * wscale * wscale;
+  hipStream_t st = vsp::as_stream(stream);
+  if (dw) {
+    const int64_t n = (int64_t)Cout * Cin;
+    demod_weight_bwd_w_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dw, g, out, style, w, B, Cin, Cout, K, c);
+  }
+  if (dstyle && B > 0) demod_weight_bwd_s_kernel<<<dim3((unsigned)((Cin + 63) / 64), (unsigned)B), 256, 0, st>>>(dstyle, g, out, style, wsq, Cin, Cout, c);
+  return vsp::check_launch("demod_weight_bwd");
 }
 
 int vsp_avgpool2x2_f32(float* out, const float* x, int64_t planes, int OH, int OW, vsp_stream_t stream) {

@@ -108,6 +108,8 @@ BF16_FORCE = 0
 # the data gradient of the four dilated SMART branches as one convolution (conv_pipe.hip MODE 3) instead of a grouped conv + a sum over
 # the branches (tools / A-B runs can switch it off)
 SMART_ADJOINT_ONE_PASS = os.environ.get("VSP_SMART_ADJOINT_ONE_PASS", "1") != "0"
+# training: demodulation coefficients and their gradient on the fused kernels (vsp_demod_weight_f32) instead of torch autograd
+FUSED_DEMOD_GRAD = os.environ.get("VSP_FUSED_DEMOD_GRAD", "1") != "0"
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
@@ -766,6 +768,32 @@ def demod_coefs(style, wsq, wscale, eps=1e-8):
     out = torch.empty((B, Cout), device=style.device, dtype=style.dtype)
     check(lib.vsp_demod_f32(_ptr(out), _ptr(style), _ptr(wsq), B, Cin, Cout, wscale, eps, _stream()), "demod")
     return out
+
+
+def demod_weight(style, weight, wscale, eps=1e-8):
+    """(demod (B, Cout), wsq (Cout, Cin)) straight from the weight (..., Cout, Cin, kh, kw): the training form of demod_coefs."""
+    style, weight = _req(style, "style"), _req(weight, "weight")
+    B, Cin = style.shape
+    Cout, K = weight.shape[-4], weight.shape[-1] * weight.shape[-2]
+    if weight.shape[-3] != Cin or weight.numel() != Cout * Cin * K:
+        raise RuntimeError(f"demod_weight: style {tuple(style.shape)} does not match weight {tuple(weight.shape)}")
+    out = torch.empty((B, Cout), device=style.device, dtype=torch.float32)
+    wsq = torch.empty((Cout, Cin), device=style.device, dtype=torch.float32)
+    check(lib.vsp_demod_weight_f32(_ptr(out), _ptr(wsq), _ptr(style), _ptr(weight), B, Cin, Cout, K, float(wscale), float(eps), _stream()),
+          "demod_weight")
+    return out, wsq
+
+
+def demod_weight_bwd(g, out, style, wsq, weight, wscale, need_style=True, need_weight=True):
+    """Gradient of a loss through demod_weight's `out`: (dstyle (B, Cin) or None, dweight shaped like weight or None)."""
+    g, out, style, wsq, weight = _req(g, "g"), _req(out, "out"), _req(style, "style"), _req(wsq, "wsq"), _req(weight, "weight")
+    B, Cin = style.shape
+    Cout, K = wsq.shape[0], weight.numel() // wsq.numel()
+    ds = torch.empty_like(style) if need_style else None
+    dw = torch.empty_like(weight) if need_weight else None
+    check(lib.vsp_demod_weight_bwd_f32(_ptr(ds), _ptr(dw), _ptr(g), _ptr(out), _ptr(style), _ptr(wsq), _ptr(weight), B, Cin, Cout, K,
+                                       float(wscale), _stream()), "demod_weight_bwd")
+    return ds, dw
 
 
 def avgpool2x2(x):
