@@ -462,6 +462,8 @@ typedef struct vsp_conv_wgrad_params {
   float* work;             /* optional workspace: the split-K partial sums go to private copies of dw (plain stores) and a second
                             * kernel adds them up, instead of fp32 atomics into dw (25 % of the kernel's time at 512 channels);  */
   size_t work_floats;      /* floats in `work`: at least one copy of dw, vsp_conv2d_wgrad_work_floats() for the full split */
+  float dw_scale;          /* 0 = 1: the sum is multiplied by it before it is stored / added (the layer's equalized-lr factor, so that dw is
+                            * the gradient of the PARAMETER: reference models/RestoreNet.py:131, 150 `weight * self.scale`) */
 } vsp_conv_wgrad_params;
 /* workspace size (floats) with which vsp_conv2d_wgrad_f32 runs its preferred split for these parameters */
 size_t vsp_conv2d_wgrad_work_floats(const vsp_conv_wgrad_params* p);

@@ -55,7 +55,7 @@ class ConvWgradParams(C.Structure):
         (n, C.c_int) for n in ("B", "Cin_g", "H", "W", "G", "Cout_g", "OH", "OW", "KH", "KW", "stride", "dil", "pad", "x_ch", "x_coff", "dy_ch",
                                "dy_coff", "x_shared", "per_group_geometry")] + [("dil_g", C.c_int * 4), ("pad_g", C.c_int * 4),
                                                                                 ("accumulate", C.c_int), ("work", C.c_void_p),
-                                                                                ("work_floats", C.c_size_t)]
+                                                                                ("work_floats", C.c_size_t), ("dw_scale", C.c_float)]
 
 
 class TaccBlock(C.Structure):

@@ -57,6 +57,7 @@ struct WgradK {
   int tcl, rbs, nrows, rstep, rmul;   // chunk = 2^tcl columns x (64 >> tcl) rows; slab rows, input-row step of a slab row, slab rows per tap row
   float* work;       // null: fp32 atomics into dw; else [gridDim.x][dw elements] partial copies, plain stores
   int64_t dw_elems;
+  float scale;       // every partial sum is multiplied by it (the equalized-lr factor of the layer: dL/dW_param = scale dL/dW_conv)
 };
 
 // S: 0 = any chunk shape and stride (run-time LDS addresses), 1 / 2 = ROW-SEGMENT chunks (tcl = 6) of a stride-S layer: the MFMA loop
@@ -300,10 +301,10 @@ __global__ __launch_bounds__(WG_NT, S != 0 ? 2 : 1) void conv_wgrad_kernel(const
       if (p.work) {   // this workgroup's private copy: every (split index, tile) pair is written exactly once
         float* dst = p.work + (int64_t)blockIdx.x * p.dw_elems + off;
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) dst[t] = acc[nb][t][j];
+        for (int t = 0; t < NTAP; ++t) dst[t] = acc[nb][t][j] * p.scale;
       } else {
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) unsafeAtomicAdd(p.dw + off + t, acc[nb][t][j]);
+        for (int t = 0; t < NTAP; ++t) unsafeAtomicAdd(p.dw + off + t, acc[nb][t][j] * p.scale);
       }
     }
   }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void wgrad_fewin_kernel(const WgradK p, int px
   if (threadIdx.x < 16 * CIN) {
     const int c = threadIdx.x / CIN, i = threadIdx.x - c * CIN;
     if (c < nco && i < p.Cin_g) {
-      const float sc = (p.xs ? p.xs[(int64_t)b * p.x_ch + p.x_coff + i] : 1.f) * (p.dys ? p.dys[(int64_t)b * p.dy_ch + p.dy_coff + co0 + c] : 1.f);
+      const float sc = (p.xs ? p.xs[(int64_t)b * p.x_ch + p.x_coff + i] : 1.f) * (p.dys ? p.dys[(int64_t)b * p.dy_ch + p.dy_coff + co0 + c] : 1.f) * p.scale;
       const float v = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * sc;
       const int64_t off = (int64_t)(co0 + c) * p.Cin_g + i;
       if (p.work) p.work[((int64_t)b * gridDim.x + blockIdx.x) * p.dw_elems + off] = v;   // one copy per (image, pixel range)
@@ -575,6 +576,7 @@ extern "C" int vsp_conv2d_wgrad_f32(const vsp_conv_wgrad_params* pp, vsp_stream_
   if (q.B == 0 || q.OH == 0 || q.OW == 0) return VSP_OK;
   VSP_REQUIRE(q.x && q.dy, "conv2d_wgrad: null input");
   k.x = q.x; k.dy = q.dy; k.dw = q.dw; k.xs = q.x_scale; k.dys = q.dy_scale;
+  k.scale = q.dw_scale != 0.f ? q.dw_scale : 1.f;
   k.B = q.B; k.Cin_g = q.Cin_g; k.H = q.H; k.W = q.W; k.G = q.G; k.Cout_g = q.Cout_g; k.OH = q.OH; k.OW = q.OW;
   k.KH = q.KH; k.KW = q.KW; k.stride = q.stride;
   k.x_gs = q.x_shared ? 0 : q.Cin_g;

@@ -80,7 +80,7 @@ class _ConvLrelu(Function):
                     hip_ops.pack_weight(weight, adjoint=True, scale=conv.scale), 1, cin, cout, 3, 3, 1, (1,), (1,)))
                 dx = hip_ops.conv_transpose2d_s2_into(g1, adj, x.shape[2:])
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
-            dw = hip_ops.conv2d_wgrad(x, g1, tuple(weight.shape), conv.stride, conv.padding, 1, 1) * conv.scale
+            dw = hip_ops.conv2d_wgrad(x, g1, tuple(weight.shape), conv.stride, conv.padding, 1, 1, scale=conv.scale)
         if ctx.needs_input_grad[2]:
             db = hip_ops.channel_sum(g1)
         return dx, dw, db, None, None
@@ -116,7 +116,7 @@ class _SkipConvAdd(Function):
             dxb = torch.zeros_like(xb)
             hip_ops.conv2d_packed(g, adj, out=dxb, out_stride=(2, 2))
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
-            dw = hip_ops.conv2d_wgrad(xb, g, tuple(weight.shape), 2, 0, 1, 1) * sc
+            dw = hip_ops.conv2d_wgrad(xb, g, tuple(weight.shape), 2, 0, 1, 1, scale=sc)
         return dxb, dw, g if ctx.needs_input_grad[2] else None, None
 
 
@@ -194,8 +194,8 @@ class Discriminator(nn.Module):
         sd = torch.sqrt(sd.var(0, unbiased=False) + 1e-8).mean([2, 3, 4], keepdims=True).squeeze(2)
         out = torch.cat([out, sd.repeat(group, 1, height, width)], 1)
         out = self.final_conv(out)
-        out = equal_linear(out.view(batch, -1), self.final_linear[0])
-        return equal_linear(out, self.final_linear[1])
+        out = equal_linear(out.view(batch, -1), self.final_linear[0], twice_differentiable=True)
+        return equal_linear(out, self.final_linear[1], twice_differentiable=True)
 
 
 # ---------------------------------------------------------------------------------------------------- adversarial losses

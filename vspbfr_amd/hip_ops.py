@@ -1086,11 +1086,12 @@ def keyed_fill(shapes, ids, seed, image_index0, dist="normal", device=None, inde
 
 # ----------------------------------------------------------------------------------------------- convolution backward
 def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1, x_scale=None, dy_scale=None, x_shared=False,
-                 dy_coff=0, out=None, accumulate=False):
+                 dy_coff=0, out=None, accumulate=False, scale=1.0):
     """dL/dW of y = conv2d(x * x_scale, W, stride, padding, dilation, groups) * dy_scale given dL/dy (vsp_conv2d_wgrad_f32):
     x (B, G*Cin_g, H, W), dy (B, G*Cout_g, OH, OW) -> (G*Cout_g, Cin_g, KH, KW); the scales are optional (B, channels).
     `x_shared`: every group reads the same Cin_g channels of x; `dilation` / `padding` may then be per-group tuples (<= 4 groups: the
-    dilated SMART branches in one launch).  `dy_coff`: first channel of dy used (dy may hold more channels than G*Cout_g)."""
+    dilated SMART branches in one launch).  `dy_coff`: first channel of dy used (dy may hold more channels than G*Cout_g).
+    `scale` multiplies the result (the layer's equalized-lr factor: the gradient of the parameter, not of the scaled weight)."""
     from ._lib import ConvWgradParams
     x, dy = _req(x, "x"), _req(dy, "dy")
     cout, cin_g, kh, kw = (int(v) for v in weight_shape)
@@ -1119,6 +1120,7 @@ def conv2d_wgrad(x, dy, weight_shape, stride=1, padding=0, dilation=1, groups=1,
     else:
         p.dil, p.pad = int(dilation), int(padding)
     p.x_shared, p.dy_ch, p.dy_coff, p.accumulate = int(bool(x_shared)), dy.shape[1], int(dy_coff), int(bool(accumulate))
+    p.dw_scale = float(scale)
     # split-K partial sums in private copies of dw (torch's caching allocator: stream-ordered) instead of fp32 atomics
     wf = int(lib.vsp_conv2d_wgrad_work_floats(C.byref(p))) if WGRAD_WORKSPACE else 0
     if wf > 0:

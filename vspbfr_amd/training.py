@@ -25,8 +25,49 @@ from . import hip_ops as H
 from .op import conv2d_gradfix, fused_leaky_relu, upfirdn2d
 
 
-def equal_linear(x, lin):
-    """EqualLinear.forward (reference models/RestoreNet.py:161-171)."""
+_ONES = {}
+
+
+class _EqualLinearGemm(Function):
+    """scale * x @ W^T (+ lr_mul * bias) with the equalized-lr factors as the alpha / beta of the GEMM calls: one launch forward, three
+    backward (the torch expression `F.linear(x, W * scale, bias * lr_mul)` is 3 + 5: ~50 such layers per iteration)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, lr_mul):
+        x2 = x.reshape(-1, x.shape[-1])
+        if bias is not None:
+            y = torch.addmm(bias, x2, weight.t(), beta=lr_mul, alpha=scale)
+        else:
+            y = torch.addmm(x2.new_empty((1, weight.shape[0])), x2, weight.t(), beta=0, alpha=scale)   # (beta = 0: the input is not read)
+        ctx.save_for_backward(x2, weight)
+        ctx.scale, ctx.lr_mul, ctx.xshape = scale, lr_mul, x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x2, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(g2.new_empty((1, weight.shape[1])), g2, weight, beta=0, alpha=ctx.scale).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.addmm(g2.new_empty((1, weight.shape[1])), g2.t(), x2, beta=0, alpha=ctx.scale)
+        if ctx.needs_input_grad[2]:
+            key = (g2.device, g2.shape[0])
+            if key not in _ONES:
+                _ONES[key] = torch.ones(g2.shape[0], device=g2.device)
+            db = torch.addmv(g2.new_empty(g2.shape[1]), g2.t(), _ONES[key], beta=0, alpha=ctx.lr_mul)
+        return dx, dw, db, None, None
+
+
+def equal_linear(x, lin, twice_differentiable=False):
+    """EqualLinear.forward (reference models/RestoreNet.py:161-171).  `twice_differentiable`: the discriminator's layers (the R1 penalty
+    differentiates through their gradient) keep the torch expression."""
+    if H.FUSED_DEMOD_GRAD and x.is_cuda and not twice_differentiable:
+        if lin.activation:
+            return fused_leaky_relu(_EqualLinearGemm.apply(x, lin.weight, None, lin.scale, lin.lr_mul), lin.bias * lin.lr_mul)
+        return _EqualLinearGemm.apply(x, lin.weight, lin.bias, lin.scale, lin.lr_mul)
     if lin.activation:
         return fused_leaky_relu(F.linear(x, lin.weight * lin.scale), lin.bias * lin.lr_mul)
     return F.linear(x, lin.weight * lin.scale, bias=None if lin.bias is None else lin.bias * lin.lr_mul)
@@ -121,11 +162,11 @@ class _ModConv(Function):
             dx = dxs
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
             if layer.upsample:   # the stride-2 weight gradient with the roles of x and g exchanged; result in (Cin, Cout, 3, 3)
-                dw = H.conv2d_wgrad(g, x, (cin, cout, 3, 3), 2, 0, 1, 1, x_scale=demod, dy_scale=s).transpose(0, 1)
+                dw = H.conv2d_wgrad(g, x, (cin, cout, 3, 3), 2, 0, 1, 1, x_scale=demod, dy_scale=s, scale=layer.scale).transpose(0, 1)
             else:
                 dw = H.conv2d_wgrad(x, g, (cout, cin, k, k), 2 if layer.downsample else 1, 0 if layer.downsample else layer.padding,
-                                    layer.dilation, 1, x_scale=s, dy_scale=demod)
-            dw = (dw * layer.scale).unsqueeze(0)
+                                    layer.dilation, 1, x_scale=s, dy_scale=demod, scale=layer.scale)
+            dw = dw.unsqueeze(0)   # (the equalized-lr factor is folded into the kernel's store)
         return dx, dw, ds, d_demod, None
 
 
@@ -238,9 +279,9 @@ class _SmartBranches(Function):
         if any(ctx.needs_input_grad[4:]) and not conv2d_gradfix.weight_gradients_disabled:
             ms = layer.ModulatedConv2ds   # one launch: 4 groups over the shared input, each with its branch's dilation
             dw = H.conv2d_wgrad(x, g, (nb * cg, cin, 3, 3), 1, tuple(m.padding for m in ms), tuple(m.dilation for m in ms), nb,
-                                x_scale=s, dy_scale=demod, x_shared=True)
+                                x_scale=s, dy_scale=demod, x_shared=True, scale=ms[0].scale)   # (equal shapes: one factor)
             for i, m in enumerate(ms):
-                dws[i] = (dw[i * cg:(i + 1) * cg] * m.scale).unsqueeze(0)
+                dws[i] = dw[i * cg:(i + 1) * cg].unsqueeze(0)
         return (dx, ds, d_demod, None, *dws)
 
 
@@ -314,7 +355,7 @@ class _FusionTail(Function):
                 H.pack_weight(conv.weight, adjoint=True, flip=True, scale=conv.scale), 1, c, c, 3, 3, 1, (1,), (1,)))
             dx = H.conv2d_packed(g1, adj)
         if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
-            dw = H.conv2d_wgrad(x, g1, tuple(conv.weight.shape), 1, 1, 1, 1) * conv.scale
+            dw = H.conv2d_wgrad(x, g1, tuple(conv.weight.shape), 1, 1, 1, 1, scale=conv.scale)
         return dx, dw, db1, None, dnw, db2, None
 
 
