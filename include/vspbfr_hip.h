@@ -385,6 +385,10 @@ typedef struct vsp_tacc_block {
   const float* wk;
   const float* gamma;
   const float* beta;
+  /* optional (NULL: read wcat): the same [4D, D] matrix in MFMA FRAGMENT order -- [n / 16][k / 16][lane = 16 (k % 16 / 4) + n % 16][k % 4]
+   * -- so that a wavefront's 16-byte-per-lane load is 1 KiB of consecutive memory (read row-major, the 16 lanes of a quarter wave hit
+   * 16 different cache lines for 16 bytes each: the projection was bound by the texture-address path, not by its MFMAs) */
+  const float* wcat_frag;
 } vsp_tacc_block;
 
 typedef struct vsp_tacc_chain_params {
@@ -411,6 +415,12 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
  * for every (image, slice) pair): VSP_ENOTSUP otherwise -- callers fall back to vsp_tacc_chain_f32. */
 size_t vsp_tacc_chain_persistent_work_floats(int B);
 int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
+/* ... with `cluster` = 1, 2, 4, 8 or 16 workgroups per image (vsp_tacc_chain_persistent_f32 = 16, the latency form).  Small clusters are
+ * the THROUGHPUT forms: in a batch loop that hides the chain under the previous batch's convolutions (restoration_test.py's
+ * `for batch in loader`, vspbfr_amd/pipeline.py run_batches) the chain costs the CU-time it holds, not its latency -- cluster 4 runs the
+ * same arithmetic in the same order (bit-identical results) on 4 B CUs for ~2x the wall time of the launched chain.  B * cluster <= 256
+ * and B <= 32: VSP_ENOTSUP otherwise. */
+int vsp_tacc_chain_cluster_f32(const vsp_tacc_chain_params* p, int cluster, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 activations in HBM (BASELINE configs[2] "bf16 kernels"; the fp32 path above is the parity path).  A bf16 tensor is

@@ -103,6 +103,12 @@ def test_diffuser_ddpm_golden(golden, name):
         pers = H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, **kw)
         assert torch.isfinite(pers).all()
         assert maxerr(pers, launched.cpu().numpy()) < 1e-5, rep
+    for cluster in (8, 4, 2, 1):   # the throughput forms: fewer, fatter workgroups, the same arithmetic in the same order
+        pers = H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=cluster, **kw)
+        assert torch.equal(pers, H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=16, **kw)), cluster
+        assert maxerr(pers, launched.cpu().numpy()) < 1e-5, cluster
+    with pytest.raises(RuntimeError):
+        H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=3, **kw)
     # free-running chain (the sampler's own call)
     final = ddpm(x=dev(cond), condi_in=dev(cond), training=False, x_T=dev(x_T))
     sd64 = {k: v.double() for k, v in sd.items()}

@@ -59,7 +59,7 @@ class ConvWgradParams(C.Structure):
 
 
 class TaccBlock(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wcat", "eQ", "ek", "wq", "wk", "gamma", "beta")]
+    _fields_ = [(n, C.c_void_p) for n in ("wcat", "eQ", "ek", "wq", "wk", "gamma", "beta", "wcat_frag")]
 
 
 class TaccChainParams(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
     "vsp_tacc_chain_f32": [_p, _p],
     "vsp_tacc_chain_persistent_f32": [_p, _p],
+    "vsp_tacc_chain_cluster_f32": [_p, _i, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],

@@ -53,7 +53,7 @@ constexpr int PJ_NJ = 4;                  // 16-column blocks per workgroup: the
                                           // of a sample, so wider tiles (fewer workgroups per sample) cut it
 
 __global__ __launch_bounds__(64 * PJ_KW) void tacc_proj_kernel(float* __restrict__ P, const float* __restrict__ y,
-                                                               const float* __restrict__ W, int ldp) {
+                                                               const float* __restrict__ W, int ldp, const float* __restrict__ Wf) {
   constexpr int NJ = PJ_NJ;
   extern __shared__ __attribute__((aligned(16))) float pj_smem[];
   float* red = pj_smem;                            // MFMA partials of every wave: [wave][j][r][lane]
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(64 * PJ_KW) void tacc_proj_kernel(float* __restrict
     r16[s] = *reinterpret_cast<const float4*>(y16 + k0);
     r17[s] = *reinterpret_cast<const float4*>(y16 + D + k0);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bw[s][j] = *reinterpret_cast<const float4*>(w0 + (int64_t)j * 16 * D + k0);
+    for (int j = 0; j < NJ; ++j)   // Wf: the matrix in fragment order [n / 16][k / 16][lane][4] (one wave instruction = 1 KiB of consecutive memory)
+      bw[s][j] = Wf ? reinterpret_cast<const float4*>(Wf)[((int64_t)((n0 >> 4) + j) * (D / 16) + (k0 >> 4)) * 64 + lane]
+                    : *reinterpret_cast<const float4*>(w0 + (int64_t)j * 16 * D + k0);
   }
   __builtin_amdgcn_sched_barrier(0);  // keep every load in flight together (the scheduler would sink half of them)
   // Rows 0..15 of the sample run on MFMA; rows 16 and 17 would cost a second, 7/8 empty MFMA row block (half of all matrix
@@ -316,7 +318,7 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
     for (int bi = 0; bi < p.n_blocks; ++bi) {
       const vsp_tacc_block& k = p.blocks[bi];
       const bool last = bi == p.n_blocks - 1;
-      tacc_proj_kernel<<<(4 * D / (16 * PJ_NJ)) * p.B, 64 * PJ_KW, pj_lds, st>>>(P, cur, k.wcat, 4 * D);
+      tacc_proj_kernel<<<(4 * D / (16 * PJ_NJ)) * p.B, 64 * PJ_KW, pj_lds, st>>>(P, cur, k.wcat, 4 * D, k.wcat_frag);
       tacc_attn_kernel<<<16 * p.B + (M + vsptacc::CA_NW - 1) / vsptacc::CA_NW, 64 * vsptacc::CA_NW, lds, st>>>(tb, hb, P, 4 * D, k.ek, k.wk, k.eQ, k.wq, tf, p.B);
       float* out = last ? p.x : yb[bi & 1];
       const size_t hoff = (size_t)step * M * D;

@@ -32,7 +32,11 @@ using vsptacc::NTOK;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-constexpr int G = 16;        // workgroups per image
+// workgroups per image: template argument G of the kernel.  16 = latency form (one 128-column slice of the projection, one 32-column
+// block of the channel attention and one or two token rows per workgroup); 4 / 2 / 1 = THROUGHPUT forms for the two-stream batch loop,
+// where the chain hides under the previous batch's convolutions and what it costs is the CU-time it holds (round 3: the launched
+// chain takes 4.2 ms of a 46.6 ms step although its latency is hidden -- 600 launches x 256 workgroups x ~9 us of mostly waiting):
+// fewer, fatter workgroups do the same arithmetic in the same order (bit-identical results) on B * G CUs.
 constexpr int NTH = 512;     // threads per workgroup (8 waves)
 constexpr int COH = 17;      // cache policy of the exchanged tensors: sc0 | sc1 (write-through stores, L1 / L2-bypassing loads)
 constexpr int MAXS = 64;     // steps per launch
@@ -88,6 +92,7 @@ __device__ __forceinline__ void cst1(__amdgpu_buffer_rsrc_t r, int off, float v)
 }
 
 // cluster barrier: arrival k of this image (k = 1, 2, ...).  Every wave drains its write-through stores, one lane arrives and polls.
+template <int G>
 __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned* tmo, unsigned k) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -112,18 +117,25 @@ __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned* tmo, un
 constexpr int PJ_NS = D / 16 / 8;   // 16-wide k-steps per wave
 constexpr int PJ_NJ = 4;            // 16-column blocks per pass
 constexpr int PJ_RED = 8 * PJ_NJ * 4 * 64;
-constexpr int SCR_FLOATS = (int)vsptacc::CA_LDS_FLOATS > PJ_RED + 8 * 4 * 2 * PJ_NJ * 16 ? (int)vsptacc::CA_LDS_FLOATS : PJ_RED + 8 * 4 * 2 * PJ_NJ * 16;
-constexpr size_t LDS_BYTES = (size_t)(NTOK * D + SCR_FLOATS) * sizeof(float);
+constexpr int PJ_SCR = 2 * (PJ_RED + 8 * 4 * 2 * PJ_NJ * 16);   // two buffer pairs
+#ifndef VSP_TP_YPAD
+#define VSP_TP_YPAD 4
+#endif
+constexpr int YP = D + VSP_TP_YPAD;   // row pitch of the workgroup's copy of y: the 16 rows of a fragment read land in 16 different 16-byte slots
+constexpr int SCR_FLOATS = (int)vsptacc::CA_LDS_FLOATS > PJ_SCR ? (int)vsptacc::CA_LDS_FLOATS : PJ_SCR;
+constexpr size_t LDS_BYTES = (size_t)(NTOK * YP + SCR_FLOATS) * sizeof(float);
 
+template <int G>
 __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
+  static_assert(G == 16 || G == 8 || G == 4 || G == 2 || G == 1, "cluster size");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ylds = smem;             // [18][512]: this workgroup's copy of the block input
-  float* scr = smem + NTOK * D;   // phase scratch
-  const int tid = threadIdx.x, lane = tid & 63;
+  float* ylds = smem;             // [18][YP]: this workgroup's copy of the block input (normalised IN PLACE by the projection)
+  float* scr = smem + NTOK * YP;  // phase scratch
+  const int tid0 = threadIdx.x, tid = tid0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, kq = lane >> 4;
   const int wid = blockIdx.x;
-  const int b = wid >> 4, g = 2 * (wid & 7) + ((wid >> 3) & 1);   // XCD x (= wid % 8, observed) owns slices 2x, 2x + 1 of every image
+  // G = 16: XCD x (= wid % 8, observed) owns slices 2x, 2x + 1 of every image; smaller clusters: slice g of an image on XCD wid % 8
+  const int b = wid / G, g = G == 16 ? 2 * (wid & 7) + ((wid >> 3) & 1) : wid % G;
   const int M = p.B * NTOK;
   const __amdgpu_buffer_rsrc_t Prs = __builtin_amdgcn_make_buffer_rsrc(p.P, 0, M * 4 * D * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(p.tb, 0, M * D * 4, 0x00020000);
@@ -131,11 +143,20 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(p.xb, 0, 2 * M * D * 4, 0x00020000);
   unsigned* cnt = p.sync + b;
   unsigned* tmo = p.sync + 32;
+#ifndef VSP_TP_ABL   // tuning builds: 1 no projection MFMAs / FMAs, 2 no projection weight loads, 4 no projection reduction + stores
+#define VSP_TP_ABL 0
+#endif
+#ifdef VSP_TP_TIMING   // tuning builds: cycles of workgroup 0 per phase (proj, barrier 1, attention, barrier 2, post) in sync[40..44]
+  unsigned long long tph[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define TP_MARK(i) { const unsigned long long tn = __builtin_readcyclecounter(); tph[i] += tn - tlast; tlast = tn; }
+#else
+#define TP_MARK(i)
+#endif
   unsigned bar = 0;
   const int rowb = b * NTOK;   // first token row of this image
 
   for (int i = tid; i < NTOK * D / 4; i += NTH)
-    reinterpret_cast<float4*>(ylds)[i] = reinterpret_cast<const float4*>(p.xio + (int64_t)rowb * D)[i];
+    *reinterpret_cast<float4*>(ylds + (i >> 7) * YP + (i & 127) * 4) = reinterpret_cast<const float4*>(p.xio + (int64_t)rowb * D)[i];
   __syncthreads();
 
   for (int s = 0; s < p.n_steps; ++s) {
@@ -144,19 +165,31 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
     for (int bi = 0; bi < p.n_blocks; ++bi) {
       const vsp_tacc_block& k = p.blk[bi];
       const bool last = bi == p.n_blocks - 1;
+      // The thread index is re-made OPAQUE per block evaluation: otherwise the compiler hoists every lane-dependent byte offset of the
+      // three phases (about 60 of them) out of the step / block loops, spills them, and reloads them at their uses with a scratch load
+      // + vmcnt(0) -- which also waits for the weight prefetch in flight.  Recomputing an offset is one VALU instruction.
+      int tidz;
+#ifndef VSP_TP_NO_OPAQUE
+      asm volatile("v_mov_b32 %0, %1" : "=v"(tidz) : "v"(tid0));
+#else
+      tidz = tid0;
+#endif
+      const int tid = tidz, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
       // ------------------------------------------------------------------------------------------------ proj
       {
-        float* red = scr;
-        float* red2 = scr + PJ_RED;
-        const float* y0 = ylds + lr * D + 4 * kq;
-        const float* y16 = ylds + 16 * D + 4 * kq;
-        float4 a0[PJ_NS], r16[PJ_NS], r17[PJ_NS];
+        float* red = scr;   // two [partial sums | rows 16 / 17] buffer pairs
+        float4 rn[PJ_NS];   // PixelNorm factors of this lane's k columns (the passes re-read y from LDS and scale it: 16 registers, not 48)
+        float* y0 = ylds + lr * YP + 4 * kq;
+        float* y16 = ylds + 16 * YP + 4 * kq;
+        // PixelNorm once per block, IN PLACE: a wave normalises exactly the k columns it multiplies (all 18 rows), so no other wave reads
+        // what it rewrites, and the passes re-read their A fragments from LDS instead of keeping 48 registers per lane alive next to two
+        // weight register sets.  (The un-normalised y is not needed again: the post phase writes the next block's input.)
 #pragma unroll
         for (int q = 0; q < PJ_NS; ++q) {
           const int k0 = (wave + 8 * q) * 16;
           float4 a = *reinterpret_cast<const float4*>(y0 + k0);
           float4 pp = *reinterpret_cast<const float4*>(y16 + k0);
-          float4 qq = *reinterpret_cast<const float4*>(y16 + D + k0);
+          float4 qq = *reinterpret_cast<const float4*>(y16 + YP + k0);
           const float rx = rsqrtf((row16_sum(a.x * a.x) + fmaf(pp.x, pp.x, qq.x * qq.x)) * (1.f / NTOK) + 1e-8f);
           const float ry = rsqrtf((row16_sum(a.y * a.y) + fmaf(pp.y, pp.y, qq.y * qq.y)) * (1.f / NTOK) + 1e-8f);
           const float rz = rsqrtf((row16_sum(a.z * a.z) + fmaf(pp.z, pp.z, qq.z * qq.z)) * (1.f / NTOK) + 1e-8f);
@@ -164,18 +197,41 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
           a.x *= rx; a.y *= ry; a.z *= rz; a.w *= rw;
           pp.x *= rx; pp.y *= ry; pp.z *= rz; pp.w *= rw;
           qq.x *= rx; qq.y *= ry; qq.z *= rz; qq.w *= rw;
-          a0[q] = a; r16[q] = pp; r17[q] = qq;
+#ifdef VSP_TP_INPLACE
+          *reinterpret_cast<float4*>(y0 + k0) = a;
+          if (lr == 0) {
+            *reinterpret_cast<float4*>(y16 + k0) = pp;
+            *reinterpret_cast<float4*>(y16 + YP + k0) = qq;
+          }
+#else
+          rn[q] = make_float4(rx, ry, rz, rw);
+#endif
         }
-        for (int pass = 0; pass < 2; ++pass) {
-          const int n0 = g * 128 + pass * 64;
+        // (every wave reads back only what it wrote itself: no workgroup barrier)
+        constexpr int NPASS = 4 * D / 64 / G;   // 64-column passes over this workgroup's slice of the 2048 projection columns
+        static_assert(NPASS % 2 == 0, "passes come in pairs (two weight register sets)");
+        // The weights of pass i + 1 are loaded before the MFMAs of pass i (two register sets): with one set every pass began with an
+        // exposed L2 round trip (cluster 4: 8 passes, 45 us per block against 15 us of MFMA issue).  The partial-sum buffers alternate
+        // too, so a pass has ONE workgroup barrier and its reduction + stores run under the next pass's loads.
+        auto load_w = [&](float4 (&bw)[PJ_NS][PJ_NJ], int pass) {
+          const int n0 = g * (4 * D / G) + pass * 64;
           const float* w0 = k.wcat + (int64_t)(n0 + lr) * D + 4 * kq;
-          float4 bw[PJ_NS][PJ_NJ];
+          // fragment-order copy: [n / 16][k / 16][lane][4] -- one wave instruction = 1 KiB of consecutive memory
+          const float4* wf = reinterpret_cast<const float4*>(k.wcat_frag) + ((int64_t)(n0 >> 4) * (D / 16)) * 64 + lane;
 #pragma unroll
           for (int q = 0; q < PJ_NS; ++q) {
             const int k0 = (wave + 8 * q) * 16;
 #pragma unroll
-            for (int j = 0; j < PJ_NJ; ++j) bw[q][j] = *reinterpret_cast<const float4*>(w0 + (int64_t)j * 16 * D + k0);
+            for (int j = 0; j < PJ_NJ; ++j)
+              bw[q][j] = (VSP_TP_ABL & 2) ? make_float4(1.f, 1.f, 1.f, (float)k0)
+                         : k.wcat_frag  ? wf[(j * (D / 16) + (k0 >> 4)) * 64]
+                                        : *reinterpret_cast<const float4*>(w0 + (int64_t)j * 16 * D + k0);
           }
+        };
+        auto run_pass = [&](const float4 (&bw)[PJ_NS][PJ_NJ], float4 (&bwn)[PJ_NS][PJ_NJ], int pass) {
+          const int n0 = g * (4 * D / G) + pass * 64;
+          float* redp = red + (pass & 1) * (PJ_RED + 8 * 4 * 2 * PJ_NJ * 16);
+          float* red2p = redp + PJ_RED;
           f32x4 acc[PJ_NJ];
           float e[2][PJ_NJ];
 #pragma unroll
@@ -185,10 +241,25 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
           }
 #pragma unroll
           for (int q = 0; q < PJ_NS; ++q) {
-            const float4 a = a0[q], pp = r16[q], qq = r17[q];
+            // the next pass's weights leave AFTER this pass's first k-slice has been consumed: every older load has landed by then,
+            // so the in-order vmcnt wait in front of the first MFMA never covers a load that was just issued
+            if (q == 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (pass + 1 < NPASS) load_w(bwn, pass + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            const int k0 = (wave + 8 * q) * 16;
+            float4 a = *reinterpret_cast<const float4*>(y0 + k0), pp = *reinterpret_cast<const float4*>(y16 + k0),
+                   qq = *reinterpret_cast<const float4*>(y16 + YP + k0);
+#ifndef VSP_TP_INPLACE
+            a.x *= rn[q].x; a.y *= rn[q].y; a.z *= rn[q].z; a.w *= rn[q].w;
+            pp.x *= rn[q].x; pp.y *= rn[q].y; pp.z *= rn[q].z; pp.w *= rn[q].w;
+            qq.x *= rn[q].x; qq.y *= rn[q].y; qq.z *= rn[q].z; qq.w *= rn[q].w;
+#endif
 #pragma unroll
             for (int j = 0; j < PJ_NJ; ++j) {
               const float4 w = bw[q][j];
+              if (VSP_TP_ABL & 1) { acc[j][0] += w.x + w.y + w.z + w.w + a.x; continue; }
               acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[j], 0, 0, 0);
               acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[j], 0, 0, 0);
               acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[j], 0, 0, 0);
@@ -197,32 +268,41 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
               e[1][j] = fmaf(qq.x, w.x, fmaf(qq.y, w.y, fmaf(qq.z, w.z, fmaf(qq.w, w.w, e[1][j]))));
             }
           }
-          if (pass) __syncthreads();   // the first pass's partial sums have been read
 #pragma unroll
           for (int j = 0; j < PJ_NJ; ++j) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[((wave * PJ_NJ + j) * 4 + r) * 64 + lane] = acc[j][r];
-            red2[(((wave * 4 + kq) * 2 + 0) * PJ_NJ + j) * 16 + lr] = e[0][j];
-            red2[(((wave * 4 + kq) * 2 + 1) * PJ_NJ + j) * 16 + lr] = e[1][j];
+            for (int r = 0; r < 4; ++r) redp[((wave * PJ_NJ + j) * 4 + r) * 64 + lane] = acc[j][r];
+            red2p[(((wave * 4 + kq) * 2 + 0) * PJ_NJ + j) * 16 + lr] = e[0][j];
+            red2p[(((wave * 4 + kq) * 2 + 1) * PJ_NJ + j) * 16 + lr] = e[1][j];
           }
-          __syncthreads();
+          __syncthreads();   // (the other buffer pair was last read before the previous pass's barrier)
+          if (VSP_TP_ABL & 4) return;
           for (int jr = wave; jr < PJ_NJ * 4; jr += 8) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += red[(w * PJ_NJ * 4 + jr) * 64 + lane];
+            for (int w = 0; w < 8; ++w) v += redp[(w * PJ_NJ * 4 + jr) * 64 + lane];
             cst1(Prs, ((rowb + kq * 4 + (jr & 3)) * 4 * D + n0 + (jr >> 2) * 16 + lr) * 4, v);
           }
           if (wave < 2) {
             for (int j = kq; j < PJ_NJ; j += 4) {
               float v = 0.f;
 #pragma unroll
-              for (int i = 0; i < 8 * 4; ++i) v += red2[((i * 2 + wave) * PJ_NJ + j) * 16 + lr];
+              for (int i = 0; i < 8 * 4; ++i) v += red2p[((i * 2 + wave) * PJ_NJ + j) * 16 + lr];
               cst1(Prs, ((rowb + 16 + wave) * 4 * D + n0 + j * 16 + lr) * 4, v);
             }
           }
+        };
+        float4 bwA[PJ_NS][PJ_NJ], bwB[PJ_NS][PJ_NJ];
+        load_w(bwA, 0);
+        for (int pass = 0; pass < NPASS; pass += 2) {
+          run_pass(bwA, bwB, pass);
+          run_pass(bwB, bwA, pass + 1);
         }
+        __syncthreads();   // the scratch area changes hands
       }
-      cluster_barrier(cnt, tmo, ++bar);
+      TP_MARK(0)
+      cluster_barrier<G>(cnt, tmo, ++bar);
+      TP_MARK(1)
       // ------------------------------------------------------------------------------------------------ attn: channel attention
       {
         constexpr int NW = 8, MT = D / 16 / NW;
@@ -232,17 +312,7 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
         float* redm = v2s + NTOK * VP;       // [NW][32]
         float* reds = redm + NW * 32;        // [NW][32]
         float* tpart = reds + NW * 32;       // [NW-1][4][4][64]
-        const int cb = g;
         const float scale = 0.044194173824159216f;   // 1 / sqrt(512)
-        float qb[5][2];
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const int tok = 4 * q + kq;
-            const float v = cld1(Prs, ((rowb + (tok < NTOK ? tok : 0)) * 4 * D + 2 * D + cb * 32 + nt * 16 + lr) * 4);
-            qb[q][nt] = tok < NTOK ? v * scale : 0.f;
-          }
         {
           constexpr int TR = NTH / 128, NIT = (20 + TR - 1) / TR;
           const int c4 = tid & 127, tr = tid >> 7;
@@ -270,6 +340,18 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
           }
         }
         __syncthreads();
+        constexpr int NCB = 16 / G;   // 32-column blocks of the channel attention per workgroup (k2 / v2 are staged once)
+        for (int cbi = 0; cbi < NCB; ++cbi) {
+        const int cb = g * NCB + cbi;
+        float qb[5][2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int tok = 4 * q + kq;
+            const float v = cld1(Prs, ((rowb + (tok < NTOK ? tok : 0)) * 4 * D + 2 * D + cb * 32 + nt * 16 + lr) * 4);
+            qb[q][nt] = tok < NTOK ? v * scale : 0.f;
+          }
         f32x4 L[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -360,10 +442,11 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
               }
           }
         }
+        if (cbi + 1 < NCB) __syncthreads();   // redm / reds / tpart are rewritten by the next column block
+        }
         // ---------------------------------------------------------------------------------------------- attn: token attention
-        // rows g and (g < 2) 16 + g of this image, one wave each (waves 1 and 2: wave 0 is finishing the channel attention)
-        const int trow = wave == 1 ? g : (wave == 2 && g < 2 ? 16 + g : -1);
-        if (trow >= 0) {
+        // rows g, g + G, ... of this image, one wave each, starting at wave 1 (wave 0 is finishing the channel attention)
+        for (int trow = g + G * ((wave + 7) & 7); trow < NTOK; trow += 8 * G) {
           const float sscale = 0.23570226039551584f;  // 1 / sqrt(18)
           float4 kv[2], wv[2];
 #pragma unroll
@@ -415,7 +498,9 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
           for (int u = 0; u < 2; ++u) cst4(hrs, ((rowb + trow) * D + 4 * lane + 256 * u) * 4, hacc[u]);
         }
       }
-      cluster_barrier(cnt, tmo, ++bar);
+      TP_MARK(2)
+      cluster_barrier<G>(cnt, tmo, ++bar);
+      TP_MARK(3)
       // ------------------------------------------------------------------------------------------------ post (all 18 rows, every workgroup)
       {
         const int64_t hoff = (int64_t)step * p.head_stride;
@@ -464,21 +549,26 @@ __global__ __launch_bounds__(NTH, 2) void tacc_persist_kernel(const PK p) {
               yv.x = a1 * yv.x + a2 * xv[u].x; yv.y = a1 * yv.y + a2 * xv[u].y;
               yv.z = a1 * yv.z + a2 * xv[u].z; yv.w = a1 * yv.w + a2 * xv[u].w;
             }
-            *reinterpret_cast<float4*>(ylds + r * D + 4 * lane + 256 * u) = yv;
+            *reinterpret_cast<float4*>(ylds + r * YP + 4 * lane + 256 * u) = yv;
             if (last && g == 0 && s + 1 < p.n_steps && p.c1 != nullptr)   // X(s+1), read by every workgroup of the image at the end of step s+1
               cst4(xrs, (((s + 1) & 1) * M * D + o + 256 * u) * 4, yv);
           }
         }
         __syncthreads();   // y complete in LDS before the next projection reads it
       }
+      TP_MARK(4)
     }
   }
   // result: the leader's copy of y (= x after the last step).  Every workgroup has finished READING xio long ago unless the chain
   // had a single step (x(0) is read in the last post): one more barrier keeps that case safe.
-  cluster_barrier(cnt, tmo, ++bar);
+#ifdef VSP_TP_TIMING
+  if (wid == 0 && tid == 0)
+    for (int i = 0; i < 5; ++i) p.sync[40 + i] = (unsigned)(tph[i] >> 6);   // units of 64 cycles of the 100 MHz counter... (s_memtime: constant clock)
+#endif
+  cluster_barrier<G>(cnt, tmo, ++bar);
   if (g == 0)
     for (int i = tid; i < NTOK * D / 4; i += NTH)
-      reinterpret_cast<float4*>(p.xio + (int64_t)rowb * D)[i] = reinterpret_cast<const float4*>(ylds)[i];
+      reinterpret_cast<float4*>(p.xio + (int64_t)rowb * D)[i] = *reinterpret_cast<const float4*>(ylds + (i >> 7) * YP + (i & 127) * 4);
 }
 
 }  // namespace
@@ -492,14 +582,20 @@ size_t vsp_tacc_chain_persistent_work_floats(int B) {
 }
 
 int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
+  return vsp_tacc_chain_cluster_f32(pp, 16, stream);
+}
+
+int vsp_tacc_chain_cluster_f32(const vsp_tacc_chain_params* pp, int cluster, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "tacc_chain_persistent: null params");
+  VSP_REQUIRE(cluster == 16 || cluster == 8 || cluster == 4 || cluster == 2 || cluster == 1,
+              "tacc_chain_persistent: cluster size must be 1, 2, 4, 8 or 16 workgroups per image (got %d)", cluster);
   const vsp_tacc_chain_params& p = *pp;
   VSP_REQUIRE(p.n_tok == NTOK && p.dim == D, "tacc_chain_persistent: built for 18 tokens x 512 channels (got %d x %d)", p.n_tok, p.dim);
   VSP_REQUIRE(p.B >= 0 && p.n_blocks >= 0 && p.n_steps >= 0, "tacc_chain_persistent: negative size");
   if (p.B == 0 || p.n_blocks == 0 || p.n_steps == 0) return VSP_OK;
-  if (p.B > 16 || p.n_blocks > 4)
-    return vsp::fail(VSP_ENOTSUP, "tacc_chain_persistent: at most 16 images (one workgroup per CU, 16 per image) and 4 blocks (got %d, %d)",
-                     p.B, p.n_blocks);
+  if (p.B * cluster > vsp::kNumCU || p.B > 32 || p.n_blocks > 4)   // (32: the arrival counters of the sync area)
+    return vsp::fail(VSP_ENOTSUP, "tacc_chain_persistent: at most %d images (one workgroup per CU, %d per image; 32 in any case) and 4 blocks (got %d, %d)",
+                     vsp::kNumCU / cluster, cluster, p.B, p.n_blocks);
   VSP_REQUIRE(p.blocks && p.x && p.work && p.step, "tacc_chain_persistent: null pointer");
   VSP_REQUIRE(p.work_floats >= vsp_tacc_chain_persistent_work_floats(p.B), "tacc_chain_persistent: work buffer too small");
   VSP_REQUIRE(p.t_div > 0.f, "tacc_chain_persistent: t_div must be positive");
@@ -509,11 +605,16 @@ int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* pp, vsp_stream_t 
     const vsp_tacc_block& k = p.blocks[i];
     VSP_REQUIRE(k.wcat && k.eQ && k.ek && k.wq && k.wk && k.gamma && k.beta, "tacc_chain_persistent: block %d has a null pointer", i);
     VSP_REQUIRE(vsp::aligned16(k.wcat) && vsp::aligned16(k.eQ) && vsp::aligned16(k.ek) && vsp::aligned16(k.wq) &&
-                    vsp::aligned16(k.wk) && vsp::aligned16(k.gamma) && vsp::aligned16(k.beta),
+                    vsp::aligned16(k.wk) && vsp::aligned16(k.gamma) && vsp::aligned16(k.beta) && vsp::aligned16(k.wcat_frag),
                 "tacc_chain_persistent: block %d operands must be 16-byte aligned", i);
   }
-  static vsp::LdsAttrOnce attr;
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(tacc_persist_kernel), (int)LDS_BYTES, "tacc_chain_persistent")) return rc;
+  static vsp::LdsAttrOnce attr[5];
+  const void* kfn = cluster == 16 ? reinterpret_cast<const void*>(tacc_persist_kernel<16>)
+                    : cluster == 8 ? reinterpret_cast<const void*>(tacc_persist_kernel<8>)
+                    : cluster == 4 ? reinterpret_cast<const void*>(tacc_persist_kernel<4>)
+                    : cluster == 2 ? reinterpret_cast<const void*>(tacc_persist_kernel<2>)
+                                   : reinterpret_cast<const void*>(tacc_persist_kernel<1>);
+  if (int rc = attr[cluster == 16 ? 0 : cluster == 8 ? 1 : cluster == 4 ? 2 : cluster == 2 ? 3 : 4].ensure(kfn, (int)LDS_BYTES, "tacc_chain_persistent")) return rc;
   hipStream_t st = vsp::as_stream(stream);
   const size_t M = (size_t)p.B * NTOK;
   PK q{};
@@ -540,7 +641,13 @@ int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* pp, vsp_stream_t 
       q.cidx[s] = (short)ci;
     }
     if (hipMemsetAsync(q.sync, 0, 64 * sizeof(unsigned), st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "tacc_chain_persistent: memset failed");
-    tacc_persist_kernel<<<G * p.B, NTH, LDS_BYTES, st>>>(q);
+    switch (cluster) {
+      case 16: tacc_persist_kernel<16><<<16 * p.B, NTH, LDS_BYTES, st>>>(q); break;
+      case 8: tacc_persist_kernel<8><<<8 * p.B, NTH, LDS_BYTES, st>>>(q); break;
+      case 4: tacc_persist_kernel<4><<<4 * p.B, NTH, LDS_BYTES, st>>>(q); break;
+      case 2: tacc_persist_kernel<2><<<2 * p.B, NTH, LDS_BYTES, st>>>(q); break;
+      default: tacc_persist_kernel<1><<<p.B, NTH, LDS_BYTES, st>>>(q); break;
+    }
   }
   return vsp::check_launch("tacc_chain_persistent");
 }

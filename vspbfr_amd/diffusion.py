@@ -134,9 +134,17 @@ class Code_diffuser(nn.Module):
         stamp = tuple((w.data_ptr(), w._version) for w in srcs)
         hit = store.get(id(blk))
         if hit is None or hit[0] != stamp:
-            hit = (stamp, torch.cat([w.detach() for w in srcs], 0).contiguous())
+            wc = torch.cat([w.detach() for w in srcs], 0).contiguous()
+            # the same matrix in MFMA fragment order (include/vspbfr_hip.h vsp_tacc_block.wcat_frag): [n / 16][k / 16][k % 16 / 4][n % 16][k % 4]
+            n, k = wc.shape
+            frag = wc.view(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous() if n % 16 == 0 and k % 16 == 0 else None
+            hit = (stamp, wc, frag)
             store[id(blk)] = hit
         return hit[1]
+
+    def _wcat_frag(self, blk):
+        self._wcat(blk)
+        return self.__dict__["_wcat_cache"][id(blk)][2]
 
     def _tcols(self, blk):
         """The t-columns of the two Linear(513) layers as contiguous vectors (constant: cached like the concatenated matrix)."""
@@ -167,7 +175,7 @@ class Code_diffuser(nn.Module):
                 heads.append(H.linear(pre, seq[3].weight, seq[3].bias, act=seq.last).view(steps, B, 18, 512))
             wq, wk = self._tcols(blk)
             state.append({"eQ": e["Q"].reshape(M, 512), "ek": e["k"].reshape(M, 512), "gamma": heads[0], "beta": heads[1],
-                          "wq": wq, "wk": wk, "wcat": self._wcat(blk)})
+                          "wq": wq, "wk": wk, "wcat": self._wcat(blk), "wcat_frag": self._wcat_frag(blk)})
         return state
 
     def chain_step(self, x, pn, state, i, c1=None, c2=None, coef_idx=None):

@@ -995,10 +995,14 @@ def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=Non
 # costs more than the three launch boundaries it removes (the guide's verdict on fused GEMM chains at this size).  It also holds
 # 16 B CUs for the whole chain, which the two-stream batch loop needs for the convolutions.  So: OFF unless asked for
 # (True / `persistent=True`); batches above 16 always take the launched chain.
-TACC_PERSISTENT = False
+TACC_PERSISTENT = os.environ.get("VSP_TACC_PERSISTENT", "0") == "1"
+# workgroups per image of the persistent form (16: latency form; 4: throughput form for the two-stream batch loop, see
+# include/vspbfr_hip.h vsp_tacc_chain_cluster_f32)
+TACC_CLUSTER = int(os.environ.get("VSP_TACC_CLUSTER", "16"))
+_TACC_LAST_WORK = None
 
 
-def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None, persistent=None):
+def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None, persistent=None, cluster=None):
     """Run the whole sampler chain in place on x (B,18,512): for each t in `steps` (host ints, execution order) x <- c1[k] *
     denoiser(x, t) + c2[k] * x with k = coef_idx[s] (default t); c1 = c2 = None: x <- denoiser(x, t).  `blocks`: one dict per
     TACC block with device tensors wcat, eQ, ek, wq, wk, gamma, beta (gamma/beta: (head_steps, B, 18, 512))."""
@@ -1013,11 +1017,18 @@ def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, hea
             t = _req(blk[name], name)
             keep.append(t)
             setattr(arr[i], name, t.data_ptr())
+        if blk.get("wcat_frag") is not None:   # optional: the projection matrix in MFMA fragment order (coalesced loads)
+            t = _req(blk["wcat_frag"], "wcat_frag")
+            if t.numel() != blk["wcat"].numel():
+                raise RuntimeError("tacc_chain: wcat_frag must hold the same elements as wcat")
+            keep.append(t)
+            arr[i].wcat_frag = t.data_ptr()
     if head_steps is None:
         head_steps = blocks[0]["gamma"].shape[0] if n else 0
     if persistent is None:
         persistent = TACC_PERSISTENT
-    persistent = bool(persistent) and 0 < B <= 16 and n <= 4
+    cluster = int(TACC_CLUSTER if cluster is None else cluster)
+    persistent = bool(persistent) and 0 < B <= min(32, 256 // cluster) and n <= 4
     nfl = lib.vsp_tacc_chain_persistent_work_floats(B) if persistent else lib.vsp_tacc_chain_work_floats(B)
     work = torch.empty(nfl, device=x.device, dtype=torch.float32)
     steps = [int(s) for s in steps]
@@ -1033,7 +1044,9 @@ def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, hea
     p.c2 = _opt(c2, "c2").data_ptr() if c2 is not None else None
     p.t_div, p.head_steps = float(t_div), int(head_steps)
     if persistent:
-        check(lib.vsp_tacc_chain_persistent_f32(C.byref(p), _stream()), "tacc_chain_persistent")
+        check(lib.vsp_tacc_chain_cluster_f32(C.byref(p), cluster, _stream()), "tacc_chain_persistent")
+        global _TACC_LAST_WORK
+        _TACC_LAST_WORK = work   # (tuning builds read the phase counters of the sync area: tools/tacc_phase_times.py)
     else:
         check(lib.vsp_tacc_chain_f32(C.byref(p), _stream()), "tacc_chain")
     return x
