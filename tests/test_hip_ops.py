@@ -388,6 +388,19 @@ def test_row_helpers(H):
     close(H.demod_coefs(dev(st), dev(wsq), 0.1), torch.rsqrt(0.01 * (st ** 2) @ wsq.t() + 1e-8), 2e-5, 1e-6)
 
 
+def test_linear_many_rows_is_row_independent(H):
+    """The small-GEMM kernel's wide form (M >= 1024: four row blocks per workgroup share the B fragments): against float64, and
+    BIT-identical to the same rows computed in slices that take the one-block form (an image's result must not depend on the batch)."""
+    g_ = torch.Generator().manual_seed(43)
+    M, K, N = 1300, 512, 96
+    x, w, b = torch.randn(M, K, generator=g_), torch.randn(N, K, generator=g_) * 0.05, torch.randn(N, generator=g_)
+    ref = torch.sigmoid(x.double() @ w.double().t() + b.double()).float()
+    y = H.linear(dev(x), dev(w), dev(b), act=2)
+    close(y, ref, 1e-5, 1e-6, "wide form")
+    parts = torch.cat([H.linear(dev(x[i:i + 900]), dev(w), dev(b), act=2) for i in range(0, M, 900)], 0)
+    assert torch.equal(y, parts)
+
+
 def test_conv2d_true_groups_and_batched_head_gemm(H):
     """Grouped convolution with per-group input slices (the batched map2style heads) + the batched per-head linear."""
     for G in (3, 5):

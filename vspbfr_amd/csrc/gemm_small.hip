@@ -37,58 +37,72 @@ struct GemmK {
 constexpr int NBL = 2;  // 16-column blocks per workgroup tile
 constexpr int KW = 4;   // waves splitting K
 
-template <bool VEC>
+// MBK = 16-row blocks per workgroup.  1: the latency form above.  4 (round 3, M >= 1024 rows: the [7200 x 512] x [512 x 512] head GEMMs of
+// the sampler's prepare step): the B fragments of a k-step are loaded once and multiply four A blocks -- with one block per workgroup
+// every 16 x 32 tile streams both operands from L2 (690 MB for that GEMM: 84.7 us, L2-bound at 42 TFLOP/s).  The arithmetic per output
+// element (k order, the 4-wave split, the LDS reduction order) is the same for every MBK: results do not depend on M.
+template <bool VEC, int MBK>
 __global__ __launch_bounds__(64 * KW) void gemm_nt_kernel(const GemmK p) {
-  __shared__ float red[(KW - 1) * NBL * 4 * 64];
+  __shared__ float red[(KW - 1) * MBK * NBL * 4 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lr = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * 16 * NBL;
-  const int m0 = blockIdx.y * 16;
+  const int m0 = blockIdx.y * 16 * MBK;
   const int z = blockIdx.z;
 
-  const int am = min(m0 + lr, p.M - 1);
-  const float* arow = p.A + z * p.a_zs + am * p.a_ms;
+  const float* arow[MBK];
+#pragma unroll
+  for (int mb = 0; mb < MBK; ++mb) arow[mb] = p.A + z * p.a_zs + (int64_t)min(m0 + mb * 16 + lr, p.M - 1) * p.a_ms;
   const float* brow[NBL];
 #pragma unroll
   for (int j = 0; j < NBL; ++j) brow[j] = p.Bm + z * p.b_zs + (int64_t)min(n0 + j * 16 + lr, p.N - 1) * p.b_ns;
 
-  f32x4 acc[NBL];
+  f32x4 acc[MBK][NBL];
 #pragma unroll
-  for (int j = 0; j < NBL; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+    for (int j = 0; j < NBL; ++j) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int kdone = 0;  // columns [0, kdone) are covered by the vector loop
   if (VEC) {
     kdone = p.K & ~15;
-    auto step = [&](const float4& a, const float4 (&b)[NBL]) {
+    auto step = [&](const float4 (&a)[MBK], const float4 (&b)[NBL]) {
 #pragma unroll
-      for (int j = 0; j < NBL; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j].x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[j].y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[j].z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[j].w, acc[j], 0, 0, 0);
-      }
+      for (int mb = 0; mb < MBK; ++mb)
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) {
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].x, b[j].x, acc[mb][j], 0, 0, 0);
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].y, b[j].y, acc[mb][j], 0, 0, 0);
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].z, b[j].z, acc[mb][j], 0, 0, 0);
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb].w, b[j].w, acc[mb][j], 0, 0, 0);
+        }
     };
     int k0 = wave * 16;
     // two k-steps in flight: the loads of step s+1 are issued before the MFMAs of step s
-    float4 a0, b0[NBL];
+    float4 a0[MBK], b0[NBL];
     if (k0 < kdone) {
-      a0 = *reinterpret_cast<const float4*>(arow + k0 + 4 * kq);
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) a0[mb] = *reinterpret_cast<const float4*>(arow[mb] + k0 + 4 * kq);
 #pragma unroll
       for (int j = 0; j < NBL; ++j) b0[j] = *reinterpret_cast<const float4*>(brow[j] + k0 + 4 * kq);
     }
     for (; k0 < kdone; k0 += 16 * KW) {
       const int k1 = k0 + 16 * KW;
-      float4 a1 = a0, b1[NBL];
+      float4 a1[MBK], b1[NBL];
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) a1[mb] = a0[mb];
 #pragma unroll
       for (int j = 0; j < NBL; ++j) b1[j] = b0[j];
       if (k1 < kdone) {
-        a1 = *reinterpret_cast<const float4*>(arow + k1 + 4 * kq);
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) a1[mb] = *reinterpret_cast<const float4*>(arow[mb] + k1 + 4 * kq);
 #pragma unroll
         for (int j = 0; j < NBL; ++j) b1[j] = *reinterpret_cast<const float4*>(brow[j] + k1 + 4 * kq);
       }
       step(a0, b0);
-      a0 = a1;
+#pragma unroll
+      for (int mb = 0; mb < MBK; ++mb) a0[mb] = a1[mb];
 #pragma unroll
       for (int j = 0; j < NBL; ++j) b0[j] = b1[j];
     }
@@ -98,46 +112,55 @@ __global__ __launch_bounds__(64 * KW) void gemm_nt_kernel(const GemmK p) {
     const int k = k0 + kq;
     const bool ok = k < p.K;
     const int kc = ok ? k : 0;
-    const float a = ok ? arow[kc * p.a_ks] : 0.f;
+    float b[NBL];
 #pragma unroll
-    for (int j = 0; j < NBL; ++j) {
-      const float b = ok ? brow[j][kc * p.b_ks] : 0.f;
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    for (int j = 0; j < NBL; ++j) b[j] = ok ? brow[j][kc * p.b_ks] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MBK; ++mb) {
+      const float a = ok ? arow[mb][kc * p.a_ks] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NBL; ++j) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[mb][j], 0, 0, 0);
     }
   }
 
   // K-slice reduction through LDS
   if (wave > 0) {
 #pragma unroll
-    for (int j = 0; j < NBL; ++j)
+    for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(((wave - 1) * NBL + j) * 4 + r) * 64 + lane] = acc[j][r];
+      for (int j = 0; j < NBL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((((wave - 1) * MBK + mb) * NBL + j) * 4 + r) * 64 + lane] = acc[mb][j][r];
   }
   __syncthreads();
   if (wave > 0) return;
 #pragma unroll
   for (int w = 1; w < KW; ++w)
 #pragma unroll
-    for (int j = 0; j < NBL; ++j)
+    for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[j][r] += red[(((w - 1) * NBL + j) * 4 + r) * 64 + lane];
+      for (int j = 0; j < NBL; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mb][j][r] += red[((((w - 1) * MBK + mb) * NBL + j) * 4 + r) * 64 + lane];
 
   // D layout: lane holds column lr, rows kq*4 + r
 #pragma unroll
-  for (int j = 0; j < NBL; ++j) {
-    const int n = n0 + j * 16 + lr;
-    if (n >= p.N) continue;
-    const float bv = p.bias ? p.bias[z * p.bias_zs + n] * p.bias_scale : 0.f;
+  for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + kq * 4 + r;
-      if (m >= p.M) continue;
-      float v = acc[j][r] * p.alpha + bv;
-      if (p.act == 1) v = (v > 0.f ? v : v * p.slope) * p.gain;
-      else if (p.act == 2) v = 1.f / (1.f + expf(-v));
-      p.C[z * p.c_zs + m * p.c_ms + n] = v;
+    for (int j = 0; j < NBL; ++j) {
+      const int n = n0 + j * 16 + lr;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[z * p.bias_zs + n] * p.bias_scale : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mb * 16 + kq * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[mb][j][r] * p.alpha + bv;
+        if (p.act == 1) v = (v > 0.f ? v : v * p.slope) * p.gain;
+        else if (p.act == 2) v = 1.f / (1.f + expf(-v));
+        p.C[z * p.c_zs + m * p.c_ms + n] = v;
+      }
     }
-  }
 }
 
 
@@ -230,11 +253,14 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
       return vsp::check_launch("gemm");
     }
   }
-  dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + 15) / 16), (unsigned)p.Z);
+  const bool wide = vec && p.M >= 1024;   // four row blocks per workgroup share the B fragments (same arithmetic per element)
+  dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + (wide ? 63 : 15)) / (wide ? 64 : 16)), (unsigned)p.Z);
   VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");
-  if (vec)
-    gemm_nt_kernel<true><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
+  if (wide)
+    gemm_nt_kernel<true, 4><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
+  else if (vec)
+    gemm_nt_kernel<true, 1><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
   else
-    gemm_nt_kernel<false><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
+    gemm_nt_kernel<false, 1><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
   return vsp::check_launch("gemm");
 }
