@@ -253,10 +253,16 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
       return vsp::check_launch("gemm");
     }
   }
-  const bool wide = vec && p.M >= 1024;   // four row blocks per workgroup share the B fragments (same arithmetic per element)
-  dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + (wide ? 63 : 15)) / (wide ? 64 : 16)), (unsigned)p.Z);
+  const bool wide = vec && p.M >= 1024;   // several row blocks per workgroup share the B fragments (same arithmetic per element)
+  static const int wide_mbk = getenv("VSP_GEMM_MBK") ? atoi(getenv("VSP_GEMM_MBK")) : 4;
+  const int mrows = wide ? 16 * wide_mbk : 16;
+  dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + mrows - 1) / mrows), (unsigned)p.Z);
   VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");
-  if (wide)
+  if (wide && wide_mbk == 8)
+    gemm_nt_kernel<true, 8><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
+  else if (wide && wide_mbk == 2)
+    gemm_nt_kernel<true, 2><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
+  else if (wide)
     gemm_nt_kernel<true, 4><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
   else if (vec)
     gemm_nt_kernel<true, 1><<<grid, 64 * KW, 0, vsp::as_stream(stream)>>>(q);
