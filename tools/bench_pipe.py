@@ -20,6 +20,7 @@ SHAPES = {  # name: B, Cin, Cout, H, W, stride, pad, G (4 = dilation groups 1,2,
     "up512": (8, 64, 32, 512, 512, 1, 0, 1, True),
     "up32": (8, 512, 512, 32, 32, 1, 0, 1, True),
     "s1_512": (8, 512, 512, 64, 64, 1, 1, 1, False),
+    "narrow1024": (8, 32, 32, 1024, 1024, 1, 1, 1, False),
 }
 
 

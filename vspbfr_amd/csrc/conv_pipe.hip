@@ -590,6 +590,8 @@ extern const Cfg kCfgsP[] = {
     VSP_CFGPDF(2, 8, 4, 8, 4),         // 4 x 16 co x 256 pix
     VSP_CFGPDF(2, 8, 4, 8, 2),
     VSP_CFGPDF(2, 8, 8, 16, 1),
+    // (narrow layers -- 32 output channels x 512 / 256 pixels, 8 waves along the pixels: VSP_CFGP(2, 4, 1, 8, 8, 10, 1 | 2), (2, 2, 1, 8, 8, 6, 2) --
+    //  were built and measured on 32 -> 32 at 1024^2, batch 8: 1604 us = 96 TFLOP/s against 1420 us of the Winograd kernel; not kept)
     // the data gradient of the four dilation groups (appended: earlier indices keep their meaning)
     VSP_CFGPK(2, 8, 4, 8, 2),          // 64 co x 256 pix, two workgroups per CU
     VSP_CFGPK(2, 8, 8, 16, 1),
