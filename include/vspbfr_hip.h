@@ -297,6 +297,12 @@ int vsp_demod_weight_f32(float* out, float* wsq, const float* style, const float
                          float eps, vsp_stream_t stream);
 int vsp_demod_weight_bwd_f32(float* dstyle, float* dw, const float* g, const float* out, const float* style, const float* wsq,
                              const float* w, int B, int Cin, int Cout, int K, float wscale, vsp_stream_t stream);
+/* ... with a row pitch for g AND out (column windows of wider [B, g_stride] tensors: the four branches of a SMART layer share one
+ * concatenated demodulation tensor) and `accumulate` = 1: dstyle / dw are ADDED to what the buffers hold (the convolution's own style and
+ * weight gradients), so that one tensor per operand leaves the layer's backward. */
+int vsp_demod_weight_bwd_acc_f32(float* dstyle, float* dw, const float* g, int g_stride, const float* out, const float* style,
+                                 const float* wsq, const float* w, int B, int Cin, int Cout, int K, float wscale, int accumulate,
+                                 vsp_stream_t stream);
 /* 2x2 mean pooling of [planes, 2*OH, 2*OW] (F.interpolate bilinear 512->256 with align_corners=False is
  * exactly this, Loss/e4e_embedding.py:97; AdaptiveAvgPool2d 1024->512, e4e/models/psp.py:246). */
 int vsp_avgpool2x2_f32(float* out, const float* x, int64_t planes, int OH, int OW, vsp_stream_t stream);

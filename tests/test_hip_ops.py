@@ -1076,6 +1076,14 @@ def test_demod_weight_and_gradient(H, B, cin, cout, k):
     assert dw.shape == w.shape
     ds2, dw2 = H.demod_weight_bwd(dev(gy), out, dev(s), wsq, dev(w), scale, need_style=False)
     assert ds2 is None and torch.equal(dw2, dw)
+    # column windows of wider tensors (one row pitch for g and out) + accumulation into existing buffers
+    wide_g, wide_o = torch.randn(B, cout + 7, generator=g_), torch.rand(B, cout + 7, generator=g_)
+    wide_g[:, 3:3 + cout], wide_o[:, 3:3 + cout] = gy, out.cpu()
+    ds0, dw0 = torch.randn(B, cin, generator=g_), torch.randn(w.shape, generator=g_)
+    dsa, dwa = dev(ds0).clone(), dev(dw0).clone()
+    H.demod_weight_bwd(dev(wide_g)[:, 3:3 + cout], dev(wide_o)[:, 3:3 + cout], dev(s), wsq, dev(w), scale, ds_out=dsa, dw_out=dwa, accumulate=True)
+    close(dsa, ds0 + ds.cpu(), 2e-5, 2e-5 * float((ds0 + ds.cpu()).abs().max()), "accumulated dstyle")
+    close(dwa, dw0 + dw.cpu(), 2e-5, 2e-5 * float((dw0 + dw.cpu()).abs().max()), "accumulated dweight")
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(3, 16, (32, 32)), (3, 40, (23, 27)), (1, 5, (7, 9)), (4, 64, (64, 48))])

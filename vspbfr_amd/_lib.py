@@ -104,6 +104,7 @@ SIGNATURES = {
     "vsp_demod_f32": [_p, _p, _p, _i, _i, _i, _f, _f, _p],
     "vsp_demod_weight_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "vsp_demod_weight_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "vsp_demod_weight_bwd_acc_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
     "vsp_avgpool2x2_f32": [_p, _p, _i64, _i, _i, _p],
     "vsp_upsample_add_f32": [_p, _p, _p, _i64, _i, _i, _i, _i, _p],
     "vsp_e4e_codes_f32": [_p, _p, _p, _i, _i, _i, _p],

@@ -164,41 +164,57 @@ __global__ __launch_bounds__(256) void demod_weight_kernel(float* __restrict__ o
     out[(int64_t)b * Cout + co] = rsqrtf((red[0][b] + red[1][b] + red[2][b] + red[3][b]) * wscale2 + eps);
   }
 }
-// t[b, co] = -0.5 wscale^2 out^3 g  (d out / d (sum s^2 wsq));  dw[co, ci, k] = 2 w[co, ci, k] sum_b t[b, co] s[b, ci]^2: one thread per (co, ci)
-__global__ __launch_bounds__(256) void demod_weight_bwd_w_kernel(float* __restrict__ dw, const float* __restrict__ g, const float* __restrict__ out,
-                                                                  const float* __restrict__ style, const float* __restrict__ w, int B, int Cin,
-                                                                  int Cout, int K, float c) {
+// t[b, co] = -0.5 wscale^2 out^3 g  (d out / d (sum s^2 wsq));  dw[co, ci, k] (+)= 2 w[co, ci, k] sum_b t[b, co] s[b, ci]^2: one thread per (co, ci).
+// `acc`: add to what dw holds (the convolution's own weight gradient: one tensor leaves the layer's backward, autograd adds nothing).
+__global__ __launch_bounds__(256) void demod_weight_bwd_w_kernel(float* __restrict__ dw, const float* __restrict__ g, int gs,
+                                                                  const float* __restrict__ out, const float* __restrict__ style,
+                                                                  const float* __restrict__ w, int B, int Cin, int Cout, int K, float c, int acc) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)Cout * Cin) return;
   const int co = (int)(i / Cin), ci = (int)(i - (int64_t)co * Cin);
   float d = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float o = out[(int64_t)b * Cout + co], st = style[(int64_t)b * Cin + ci];
-    d = fmaf(c * g[(int64_t)b * Cout + co] * o * o * o, st * st, d);
+    const float o = out[(int64_t)b * gs + co], st = style[(int64_t)b * Cin + ci];
+    d = fmaf(c * g[(int64_t)b * gs + co] * o * o * o, st * st, d);
   }
   d *= 2.f;
   const float* wp = w + i * K;
   float* dp = dw + i * K;
-  for (int k = 0; k < K; ++k) dp[k] = wp[k] * d;
-}
-// dstyle[b, ci] = 2 s[b, ci] sum_co t[b, co] wsq[co, ci]: a workgroup = one sample x 64 input channels, the output channels in 4 quarters
-__global__ __launch_bounds__(256) void demod_weight_bwd_s_kernel(float* __restrict__ ds, const float* __restrict__ g, const float* __restrict__ out,
-                                                                  const float* __restrict__ style, const float* __restrict__ wsq, int Cin,
-                                                                  int Cout, float c) {
-  const int b = blockIdx.y, ci = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (ci < Cin) {
-    for (int co = q; co < Cout; co += 4) {
-      const float o = out[(int64_t)b * Cout + co];
-      acc = fmaf(c * g[(int64_t)b * Cout + co] * o * o * o, wsq[(int64_t)co * Cin + ci], acc);
-    }
+  if (acc) {
+    for (int k = 0; k < K; ++k) dp[k] = fmaf(wp[k], d, dp[k]);
+  } else {
+    for (int k = 0; k < K; ++k) dp[k] = wp[k] * d;
   }
-  __shared__ float red[4][64];
-  red[q][threadIdx.x & 63] = acc;
+}
+// dstyle[b, ci] (+)= 2 s[b, ci] sum_co t[b, co] wsq[co, ci]: a workgroup = one sample x 64 input channels; t of the sample goes to LDS once
+// (the first version recomputed it from three global loads per (co, ci): 16 us per launch), the output channels run in 4 quarters with the
+// wsq loads independent of each other
+__global__ __launch_bounds__(256) void demod_weight_bwd_s_kernel(float* __restrict__ ds, const float* __restrict__ g, int gs,
+                                                                  const float* __restrict__ out, const float* __restrict__ style,
+                                                                  const float* __restrict__ wsq, int Cin, int Cout, float c, int acc) {
+  extern __shared__ float dw_t[];   // [Cout] t, then [4][64] partial sums
+  const int b = blockIdx.y, ci = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  for (int co = threadIdx.x; co < Cout; co += 256) {
+    const float o = out[(int64_t)b * gs + co];
+    dw_t[co] = c * g[(int64_t)b * gs + co] * o * o * o;
+  }
+  __syncthreads();
+  float a0 = 0.f, a1 = 0.f;
+  if (ci < Cin) {
+    int co = q;
+    for (; co + 4 < Cout; co += 8) {
+      a0 = fmaf(dw_t[co], wsq[(int64_t)co * Cin + ci], a0);
+      a1 = fmaf(dw_t[co + 4], wsq[(int64_t)(co + 4) * Cin + ci], a1);
+    }
+    for (; co < Cout; co += 4) a0 = fmaf(dw_t[co], wsq[(int64_t)co * Cin + ci], a0);
+  }
+  float* red = dw_t + Cout;
+  red[q * 64 + (threadIdx.x & 63)] = a0 + a1;
   __syncthreads();
   if (q == 0 && ci < Cin) {
     const int l = threadIdx.x;
-    ds[(int64_t)b * Cin + ci] = 2.f * style[(int64_t)b * Cin + ci] * (red[0][l] + red[1][l] + red[2][l] + red[3][l]);
+    const float v = 2.f * style[(int64_t)b * Cin + ci] * ((red[l] + red[64 + l]) + (red[128 + l] + red[192 + l]));
+    ds[(int64_t)b * Cin + ci] = acc ? ds[(int64_t)b * Cin + ci] + v : v;
   }
 }
 
@@ -445,16 +461,26 @@ int vsp_demod_weight_f32(float* out, float* wsq, const float* style, const float
 
 int vsp_demod_weight_bwd_f32(float* dstyle, float* dw, const float* g, const float* out, const float* style, const float* wsq, const float* w,
                              int B, int Cin, int Cout, int K, float wscale, vsp_stream_t stream) {
+  return vsp_demod_weight_bwd_acc_f32(dstyle, dw, g, Cout, out, style, wsq, w, B, Cin, Cout, K, wscale, 0, stream);
+}
+
+int vsp_demod_weight_bwd_acc_f32(float* dstyle, float* dw, const float* g, int g_stride, const float* out, const float* style, const float* wsq,
+                                 const float* w, int B, int Cin, int Cout, int K, float wscale, int accumulate, vsp_stream_t stream) {
   VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && K >= 1, "demod_weight_bwd: bad dims");
   VSP_REQUIRE(g && out && style && (!dstyle || wsq) && (!dw || w), "demod_weight_bwd: null pointer");
-  VSP_REQUIRE(B <= 65535, "demod_weight_bwd: batch too large");
+  VSP_REQUIRE(B <= 65535 && g_stride >= Cout, "demod_weight_bwd: batch too large / gradient row pitch below Cout");
   const float c = -0.5f * wscale * wscale;
   hipStream_t st = vsp::as_stream(stream);
   if (dw) {
     const int64_t n = (int64_t)Cout * Cin;
-    demod_weight_bwd_w_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dw, g, out, style, w, B, Cin, Cout, K, c);
+    demod_weight_bwd_w_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(dw, g, g_stride, out, style, w, B, Cin, Cout, K, c, accumulate ? 1 : 0);
   }
-  if (dstyle && B > 0) demod_weight_bwd_s_kernel<<<dim3((unsigned)((Cin + 63) / 64), (unsigned)B), 256, 0, st>>>(dstyle, g, out, style, wsq, Cin, Cout, c);
+  if (dstyle && B > 0) {
+    const size_t lds = (size_t)(Cout + 256) * sizeof(float);
+    VSP_REQUIRE(lds <= 64 * 1024, "demod_weight_bwd: too many output channels (%d)", Cout);
+    demod_weight_bwd_s_kernel<<<dim3((unsigned)((Cin + 63) / 64), (unsigned)B), 256, lds, st>>>(dstyle, g, g_stride, out, style, wsq, Cin, Cout, c,
+                                                                                                   accumulate ? 1 : 0);
+  }
   return vsp::check_launch("demod_weight_bwd");
 }
 

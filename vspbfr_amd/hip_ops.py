@@ -784,15 +784,28 @@ def demod_weight(style, weight, wscale, eps=1e-8):
     return out, wsq
 
 
-def demod_weight_bwd(g, out, style, wsq, weight, wscale, need_style=True, need_weight=True):
-    """Gradient of a loss through demod_weight's `out`: (dstyle (B, Cin) or None, dweight shaped like weight or None)."""
-    g, out, style, wsq, weight = _req(g, "g"), _req(out, "out"), _req(style, "style"), _req(wsq, "wsq"), _req(weight, "weight")
+def demod_weight_bwd(g, out, style, wsq, weight, wscale, need_style=True, need_weight=True, ds_out=None, dw_out=None, accumulate=False):
+    """Gradient of a loss through demod_weight's `out`: (dstyle (B, Cin) or None, dweight shaped like weight or None).  `g` and `out` may be
+    column windows of wider row-major tensors with the SAME row pitch (slices [:, a:b]).  `ds_out` / `dw_out` + `accumulate`: add the
+    result to existing contiguous buffers (the convolution's own style / weight gradient) instead of allocating."""
+    style, wsq, weight = _req(style, "style"), _req(wsq, "wsq"), _req(weight, "weight")
     B, Cin = style.shape
     Cout, K = wsq.shape[0], weight.numel() // wsq.numel()
-    ds = torch.empty_like(style) if need_style else None
-    dw = torch.empty_like(weight) if need_weight else None
-    check(lib.vsp_demod_weight_bwd_f32(_ptr(ds), _ptr(dw), _ptr(g), _ptr(out), _ptr(style), _ptr(wsq), _ptr(weight), B, Cin, Cout, K,
-                                       float(wscale), _stream()), "demod_weight_bwd")
+    for t, nm in ((g, "g"), (out, "out")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape == (B, Cout) and t.stride(1) == 1):
+            raise RuntimeError(f"demod_weight_bwd: {nm} must be a float32 device (B, Cout) row-major window")
+    if g.stride(0) != out.stride(0) and B > 1:
+        raise RuntimeError("demod_weight_bwd: g and out must share their row pitch")
+    gs = int(g.stride(0)) if B > 1 else Cout
+    ds = (ds_out if ds_out is not None else torch.empty_like(style)) if need_style else None
+    dw = (dw_out if dw_out is not None else torch.empty_like(weight)) if need_weight else None
+    for t, nm, ref in ((ds, "ds_out", style), (dw, "dw_out", weight)):
+        if t is not None and not (t.is_contiguous() and t.numel() == ref.numel() and t.dtype == torch.float32 and t.is_cuda):
+            raise RuntimeError(f"demod_weight_bwd: {nm} must be a contiguous float32 device tensor with the operand's element count")
+    if accumulate and ((need_style and ds_out is None) or (need_weight and dw_out is None)):
+        raise RuntimeError("demod_weight_bwd: accumulate needs the buffers to add to")
+    check(lib.vsp_demod_weight_bwd_acc_f32(_ptr(ds), _ptr(dw), C.c_void_p(g.data_ptr()), gs, C.c_void_p(out.data_ptr()), _ptr(style), _ptr(wsq),
+                                           _ptr(weight), B, Cin, Cout, K, float(wscale), int(bool(accumulate)), _stream()), "demod_weight_bwd")
     return ds, dw
 
 

@@ -129,22 +129,31 @@ def _adjoint_pack(layer):
 
 
 class _ModConv(Function):
+    """`inner_demod` (training default): the demodulation coefficients are computed HERE from (weight, s) and their gradient is
+    ADDED to the convolution's own style / weight gradients inside the backward kernels (vsp_demod_weight_bwd_acc_f32), so the layer
+    is one autograd node with one gradient per operand -- as a separate node (`_Demod`) the engine added two pairs of tensors per
+    layer and copied a strided slice (148 adds and 60 copies per iteration)."""
+
     @staticmethod
-    def forward(ctx, x, weight, s, demod, layer):
+    def forward(ctx, x, weight, s, demod, layer, inner_demod=False):
         x, s = x.contiguous(), s.contiguous()
+        wsq = None
+        if inner_demod:
+            demod, wsq = H.demod_weight(s, weight, layer.scale)
         demod = None if demod is None else demod.contiguous()
+        ctx.inner = bool(inner_demod)
         if layer.upsample:
             y = H.conv_transpose2d_s2_fused(x, layer.packed(), in_scale=s, out_scale=demod)
         else:
             y = H.conv2d_packed(x, layer.packed(), in_scale=s, out_scale=demod)
         ctx.layer = layer
-        ctx.save_for_backward(x, s, demod, y if demod is not None else None)
+        ctx.save_for_backward(x, s, demod, y if demod is not None else None, wsq, weight if inner_demod else None)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, s, demod, y = ctx.saved_tensors
+        x, s, demod, y, wsq, weight = ctx.saved_tensors
         layer = ctx.layer
         g = g.contiguous()
         B, cin, cout, k = x.shape[0], layer.in_channel, layer.out_channel, layer.kernel_size
@@ -167,7 +176,21 @@ class _ModConv(Function):
                 dw = H.conv2d_wgrad(x, g, (cout, cin, k, k), 2 if layer.downsample else 1, 0 if layer.downsample else layer.padding,
                                     layer.dilation, 1, x_scale=s, dy_scale=demod, scale=layer.scale)
             dw = dw.unsqueeze(0)   # (the equalized-lr factor is folded into the kernel's store)
-        return dx, dw, ds, d_demod, None
+        if ctx.inner:   # the demodulation's share of d/ds and d/dW, added in place
+            need_s, need_w = ctx.needs_input_grad[2], ctx.needs_input_grad[1]
+            if dw is not None and not dw.is_contiguous():
+                dw = dw.contiguous()                                   # (up-sampling layers: the exchanged-roles gradient is a transposed view)
+            if (not need_s or ds is not None) and (not need_w or dw is not None):
+                H.demod_weight_bwd(d_demod, demod, s, wsq, weight, layer.scale, need_s, need_w, ds_out=ds if need_s else None,
+                                   dw_out=dw if need_w else None, accumulate=True)
+            else:   # (a gradient the convolution did not produce: weight gradients disabled)
+                ds2, dw2 = H.demod_weight_bwd(d_demod, demod, s, wsq, weight, layer.scale, need_s, need_w)
+                if need_s:
+                    ds = ds2 if ds is None else ds + ds2
+                if need_w:
+                    dw = dw2 if dw is None else dw + dw2
+            return dx, dw, ds, None, None, None
+        return dx, dw, ds, d_demod, None, None
 
 
 class _Demod(Function):
@@ -201,17 +224,20 @@ def _demod(conv, s):
 def modulated_conv(x, conv, style, modulation=None):
     """ModulatedConv2d.forward (reference models/RestoreNet.py:373-416) in the fused form above."""
     s = equal_linear(style, modulation if modulation is not None else conv.modulation)
-    demod = _demod(conv, s) if conv.demodulate else None
+    inner = bool(conv.demodulate and H.FUSED_DEMOD_GRAD and s.is_cuda and s.shape[0] <= 16)
+    demod = _demod(conv, s) if (conv.demodulate and not inner) else None
     if conv.downsample:
         x = _blur(x, conv.blur)
     if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or s.requires_grad):
-        out = _ModConv.apply(x, conv.weight, s, demod, conv)
+        out = _ModConv.apply(x, conv.weight, s, demod, conv, inner)
     else:
-        out = _ModConv.forward(_NoCtx(), x, conv.weight, s, demod, conv)
+        out = _ModConv.forward(_NoCtx(), x, conv.weight, s, demod, conv, inner)
     return _blur(out, conv.blur) if conv.upsample else out
 
 
 class _NoCtx:
+    inner = False
+
     def save_for_backward(self, *a):
         pass
 
@@ -246,19 +272,34 @@ def _smart_adjoint_pack(layer, hw=None):
 
 
 class _SmartBranches(Function):
+    """demod = None: the four demodulation vectors are computed here and their gradients are added inside the backward kernels (see _ModConv)."""
+
     @staticmethod
     def forward(ctx, x, s, demod, layer, *weights):
-        x, s, demod = x.contiguous(), s.contiguous(), demod.contiguous()
+        x, s = x.contiguous(), s.contiguous()
+        ctx.inner = demod is None
+        wsqs = []
+        if demod is None:
+            parts = []
+            for m in layer.ModulatedConv2ds:
+                dm, wq = H.demod_weight(s, m.weight, m.scale)
+                parts.append(dm)
+                wsqs.append(wq)
+            demod = torch.cat(parts, 1)
+        demod = demod.contiguous()
+        ctx.n_w = len(weights)
         pc, _ = layer._branch_pack()
         y = H.conv2d_packed(x, pc, in_scale=s, out_scale=demod)
         ctx.layer = layer
-        ctx.save_for_backward(x, s, demod, y)
+        ctx.save_for_backward(x, s, demod, y, *wsqs, *(weights if wsqs else ()))
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, s, demod, y = ctx.saved_tensors
+        x, s, demod, y = ctx.saved_tensors[:4]
+        wsqs = ctx.saved_tensors[4:4 + ctx.n_w] if ctx.inner else ()
+        wts = ctx.saved_tensors[4 + ctx.n_w:] if ctx.inner else ()
         layer = ctx.layer
         g = g.contiguous()
         B, cin, Hh, Ww = x.shape
@@ -282,12 +323,25 @@ class _SmartBranches(Function):
                                 x_scale=s, dy_scale=demod, x_shared=True, scale=ms[0].scale)   # (equal shapes: one factor)
             for i, m in enumerate(ms):
                 dws[i] = dw[i * cg:(i + 1) * cg].unsqueeze(0)
+        if ctx.inner:
+            for i, m in enumerate(layer.ModulatedConv2ds):
+                need_s, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[4 + i]
+                gi, oi = d_demod[:, i * cg:(i + 1) * cg], demod[:, i * cg:(i + 1) * cg]
+                if (ds is not None or not need_s) and (dws[i] is not None or not need_w):
+                    H.demod_weight_bwd(gi, oi, s, wsqs[i], wts[i], m.scale, need_s, need_w, ds_out=ds if need_s else None,
+                                       dw_out=dws[i] if need_w else None, accumulate=True)
+                else:   # (a gradient the convolution did not produce: weight gradients disabled)
+                    ds2, dw2 = H.demod_weight_bwd(gi, oi, s, wsqs[i], wts[i], m.scale, need_s, need_w)
+                    ds = ds2 if (need_s and ds is None) else (ds + ds2 if need_s else ds)
+                    dws[i] = dw2 if (need_w and dws[i] is None) else (dws[i] + dw2 if need_w else dws[i])
+            return (dx, ds, None, None, *dws)
         return (dx, ds, d_demod, None, *dws)
 
 
 def smart_branches(x, layer, style):
     s = equal_linear(style, layer.modulation)
-    demod = torch.cat([_demod(m, s) for m in layer.ModulatedConv2ds], 1)
+    inner = bool(H.FUSED_DEMOD_GRAD and s.is_cuda and s.shape[0] <= 16)
+    demod = None if inner else torch.cat([_demod(m, s) for m in layer.ModulatedConv2ds], 1)
     ws = [m.weight for m in layer.ModulatedConv2ds]
     if torch.is_grad_enabled() and (x.requires_grad or s.requires_grad or any(w.requires_grad for w in ws)):
         return _SmartBranches.apply(x, s, demod, layer, *ws)
