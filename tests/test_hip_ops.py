@@ -946,7 +946,7 @@ def test_torch_extension_modules(golden):
 
 
 # ------------------------------------------------------------------------------------------------ loss-network operators
-@pytest.mark.parametrize("k,s,p,hw", [(2, 2, 0, (20, 14)), (2, 2, 0, (9, 7)), (3, 2, 1, (56, 56)), (3, 2, 1, (13, 10))])
+@pytest.mark.parametrize("k,s,p,hw", [(2, 2, 0, (20, 14)), (2, 2, 0, (9, 7)), (2, 2, 0, (20, 16)), (2, 2, 0, (64, 128)), (3, 2, 1, (56, 56)), (3, 2, 1, (13, 10))])
 def test_maxpool2d_forward_backward(H, k, s, p, hw):
     """vsp_maxpool2d_f32 / _bwd against F.max_pool2d and its autograd (VGG16 2x2/2, ResNet 3x3/2 pad 1), ties included: the
     input is quantised to a few levels so that many windows hold their maximum more than once."""
