@@ -959,7 +959,7 @@ def test_maxpool2d_forward_backward(H, k, s, p, hw):
     assert torch.equal(H.maxpool2d(dev(x), k, s, p), got[0])
 
 
-@pytest.mark.parametrize("C_,hw", [(64, (24, 20)), (512, (5, 3)), (7, (33, 1))])
+@pytest.mark.parametrize("C_,hw", [(64, (24, 20)), (128, (13, 9)), (256, (7, 5)), (512, (5, 3)), (7, (33, 1))])
 def test_lpips_layer_forward_backward(H, C_, hw):
     """vsp_lpips_layer_f32 / _bwd against the reference's formula (my_lpips/__init__.py:44-46, networks_basic.py:73-83) evaluated by
     torch autograd in float64, including a pixel whose features are all zero (ReLU outputs) in either map."""

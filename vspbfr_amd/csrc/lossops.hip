@@ -145,6 +145,84 @@ __global__ __launch_bounds__(256) void lpips_layer_bwd_kernel(float* __restrict_
   }
 }
 
+// Register forms of the two kernels above for C = 64 * LPP, LPP = 1, 2, 4 (the first three LPIPS levels: 94 % of the bytes): LPP lanes share
+// a pixel, each keeps its 64 channels of BOTH maps in registers, so every element is read ONCE (the generic kernels walk the channels two
+// / three times: 2.4 GB through L2 for the 805 MB of the 64-channel 512^2 level, 533 us).  Lane = pixel + (64 / LPP) * part: the lanes of a
+// part read consecutive pixels of one channel plane; channel sums meet through xor-shuffles across the parts.
+template <int LPP>
+__device__ __forceinline__ float part_sum(float v) {
+#pragma unroll
+  for (int o = 64 / LPP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPP, bool BWD>
+__global__ __launch_bounds__(256) void lpips_layer_reg_kernel(float* __restrict__ outp, const float* __restrict__ f0, const float* __restrict__ f1,
+                                                               const float* __restrict__ w, const float* __restrict__ gout, int HW, float eps) {
+  constexpr int PXW = 64 / LPP;                       // pixels per wave
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int part = lane / PXW, pl = lane % PXW;
+  const int C = 64 * LPP;
+  const float* a = f0 + ((int64_t)b * C + 64 * part) * HW;
+  const float* c = f1 + ((int64_t)b * C + 64 * part) * HW;
+  const float* wp = w + 64 * part;
+  float acc = 0.f;
+  const float go = BWD ? gout[b] / (float)HW : 0.f;
+  for (int px0 = (blockIdx.x * 4 + wave) * PXW; px0 < HW; px0 += gridDim.x * 4 * PXW) {
+    const int px = px0 + pl;
+    const bool ok = px < HW;
+    const int pc = ok ? px : HW - 1;
+    float u[64], v[64];
+#pragma unroll
+    for (int ch = 0; ch < 64; ++ch) {
+      u[ch] = a[(int64_t)ch * HW + pc];
+      v[ch] = c[(int64_t)ch * HW + pc];
+    }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 64; ++ch) {
+      s0 = fmaf(u[ch], u[ch], s0);
+      s1 = fmaf(v[ch], v[ch], s1);
+    }
+    s0 = part_sum<LPP>(s0);
+    s1 = part_sum<LPP>(s1);
+    const float n1 = sqrtf(s1);
+    const float r0 = 1.f / (sqrtf(s0) + eps), r1 = 1.f / (n1 + eps);
+    if constexpr (!BWD) {
+      float d = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 64; ++ch) {
+        const float e = u[ch] * r0 - v[ch] * r1;
+        d = fmaf(wp[ch] * e, e, d);
+      }
+      acc += ok ? d : 0.f;
+    } else {
+      float dot = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < 64; ++ch) {
+        const float e = u[ch] * r0 - v[ch] * r1;
+        dot = fmaf(-2.f * wp[ch] * e, v[ch], dot);
+      }
+      dot = part_sum<LPP>(dot);
+      const float k2 = n1 > 0.f ? dot * r1 * r1 / n1 : 0.f;
+      float* o = outp + ((int64_t)b * C + 64 * part) * HW;
+      if (ok) {
+#pragma unroll
+        for (int ch = 0; ch < 64; ++ch) {
+          const float e = u[ch] * r0 - v[ch] * r1;
+          o[(int64_t)ch * HW + px] = go * (-2.f * wp[ch] * e * r1 - v[ch] * k2);
+        }
+      }
+    }
+  }
+  if constexpr (!BWD) {
+    __shared__ float red[4];
+    acc = wave_sum(acc);   // (all parts: every lane holds its share of the channels)
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(outp + b, (red[0] + red[1] + red[2] + red[3]) / (float)HW);
+  }
+}
+
 // adjoint of resize_bilinear_kernel (rowops.hip): scatter of each output gradient onto its four source pixels
 __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, int64_t planes,
                                                                    int IH, int IW, int OH, int OW, float sy, float sx) {
@@ -265,6 +343,15 @@ int vsp_lpips_layer_f32(float* out, const float* f0, const float* f1, const floa
   VSP_REQUIRE(out && f0 && f1 && w, "lpips_layer: null pointer");
   hipStream_t st = vsp::as_stream(stream);
   if (hipMemsetAsync(out, 0, sizeof(float) * B, st) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "lpips_layer: memset failed");
+  if (C == 64 || C == 128 || C == 256) {   // register form: every element read once
+    const int lpp = C / 64, pxb = 4 * (64 / lpp);
+    int bx = (HW + pxb - 1) / pxb;
+    if (bx > 2048) bx = 2048;
+    if (lpp == 1) lpips_layer_reg_kernel<1, false><<<dim3(bx, B), 256, 0, st>>>(out, f0, f1, w, nullptr, HW, 1e-10f);
+    else if (lpp == 2) lpips_layer_reg_kernel<2, false><<<dim3(bx, B), 256, 0, st>>>(out, f0, f1, w, nullptr, HW, 1e-10f);
+    else lpips_layer_reg_kernel<4, false><<<dim3(bx, B), 256, 0, st>>>(out, f0, f1, w, nullptr, HW, 1e-10f);
+    return vsp::check_launch("lpips_layer");
+  }
   int bx = (HW + 255) / 256;
   if (bx > 1024) bx = 1024;
   lpips_layer_fwd_kernel<<<dim3(bx, B), 256, 0, st>>>(out, f0, f1, w, C, HW, 1e-10f);
@@ -276,6 +363,16 @@ int vsp_lpips_layer_bwd_f32(float* df1, const float* f0, const float* f1, const 
   VSP_REQUIRE(B >= 0 && C >= 1 && HW >= 1, "lpips_layer_bwd: bad dims");
   if (B == 0) return VSP_OK;
   VSP_REQUIRE(df1 && f0 && f1 && w && gout, "lpips_layer_bwd: null pointer");
+  if (C == 64 || C == 128 || C == 256) {
+    const int lpp = C / 64, pxb = 4 * (64 / lpp);
+    int bx = (HW + pxb - 1) / pxb;
+    if (bx > 4096) bx = 4096;
+    hipStream_t st = vsp::as_stream(stream);
+    if (lpp == 1) lpips_layer_reg_kernel<1, true><<<dim3(bx, B), 256, 0, st>>>(df1, f0, f1, w, gout, HW, 1e-10f);
+    else if (lpp == 2) lpips_layer_reg_kernel<2, true><<<dim3(bx, B), 256, 0, st>>>(df1, f0, f1, w, gout, HW, 1e-10f);
+    else lpips_layer_reg_kernel<4, true><<<dim3(bx, B), 256, 0, st>>>(df1, f0, f1, w, gout, HW, 1e-10f);
+    return vsp::check_launch("lpips_layer_bwd");
+  }
   int bx = (HW + 255) / 256;
   if (bx > 4096) bx = 4096;
   lpips_layer_bwd_kernel<<<dim3(bx, B), 256, 0, vsp::as_stream(stream)>>>(df1, f0, f1, w, gout, C, HW, 1e-10f);
