@@ -120,6 +120,94 @@ class _SkipConvAdd(Function):
         return dxb, dw, g if ctx.needs_input_grad[2] else None, None
 
 
+def _blur_run(t, blur):
+    from .op.upfirdn2d import _run
+    p = blur.pad
+    return _run(t, blur.kernel, (1, 1), (1, 1), (p[0], p[1], p[0], p[1]))
+
+
+def _blur_adjoint(g, blur, in_hw):
+    """Gradient of _blur_run with respect to its input of spatial size in_hw (the flipped kernel is cached on the module)."""
+    from .op.upfirdn2d import _run
+    k = blur.kernel
+    fk = blur.__dict__.get("_vsp_flipped")
+    if fk is None or fk[0] != (k.data_ptr(), k._version):
+        fk = blur.__dict__["_vsp_flipped"] = ((k.data_ptr(), k._version), torch.flip(k, [0, 1]).contiguous())
+    kh, kw = k.shape
+    p0 = blur.pad[0]
+    oh, ow = g.shape[2:]
+    return _run(g, fk[1], (1, 1), (1, 1), (kw - p0 - 1, in_hw[1] - ow + p0, kh - p0 - 1, in_hw[0] - oh + p0))
+
+
+class _ResBlockFO(Function):
+    """A whole ResBlock of the first-order passes as ONE autograd node (models/RestoreNet.py:1183-1202): conv1 + lrelu, blur, stride-2
+    conv2 + lrelu (gain 1: the 1 / sqrt 2 folded in), blur + 1x1 stride-2 skip with the sum in its epilogue.  What the single node buys
+    is the BACKWARD's last step: the gradient of the skip path is handed to conv1's data-gradient convolution as a residual operand,
+    so the two gradients of the block input meet in that kernel's epilogue instead of an activation-sized autograd add (the largest
+    ATen kernels of the iteration: 268 MB operands at the first block)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ws, blk):
+        x = x.contiguous()
+        c1, c2, cs = blk.conv1[0], blk.conv2[1], blk.skip[1]
+        blur2, blurs = blk.conv2[0], blk.skip[0]
+        ci, co = w1.shape[1], w2.shape[0]
+        p1 = _cached_pack(c1, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(w1, scale=c1.scale), 1, ci, ci, 3, 3, 1, (1,), (c1.padding,)))
+        y1 = hip_ops.conv2d_packed(x, p1, act2=1, bias2=b1, gain2=2 ** 0.5)
+        y1b = _blur_run(y1, blur2)
+        p2 = _cached_pack(c2, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(w2, scale=c2.scale), 1, co, ci, 3, 3, 2, (1,), (0,)))
+        main = hip_ops.conv2d_packed(y1b, p2, act2=1, bias2=b2, gain2=1.0)
+        xb = _blur_run(x, blurs)
+        sc = cs.scale / math.sqrt(2)
+        ps = _cached_pack(cs, "fwd", lambda: hip_ops.PackedConv(hip_ops.pack_weight(ws, scale=sc), 1, co, ci, 1, 1, 2, (1,), (0,)))
+        y = hip_ops.conv2d_packed(xb, ps, res1=main)
+        ctx.blk = blk
+        ctx.save_for_backward(x, y1, y1b, main, xb, w1, w2, ws)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y1, y1b, main, xb, w1, w2, ws = ctx.saved_tensors
+        blk = ctx.blk
+        c1, c2, cs = blk.conv1[0], blk.conv2[1], blk.skip[1]
+        blur2, blurs = blk.conv2[0], blk.skip[0]
+        ci, co = w1.shape[1], w2.shape[0]
+        sc = cs.scale / math.sqrt(2)
+        g = g.contiguous()
+        no_w = conv2d_gradfix.weight_gradients_disabled
+        need = ctx.needs_input_grad
+        dx = dw1 = db1 = dw2 = db2 = dws = None
+        # ---- skip path: the 1x1 adjoint lands on the even pixels of the blurred input, then the blur's adjoint
+        dx_skip = None
+        if need[0]:
+            adjs = _cached_pack(cs, "adj", lambda: hip_ops.PackedConv(hip_ops.pack_weight(ws, adjoint=True, scale=sc), 1, ci, co, 1, 1, 1, (1,), (0,)))
+            dxb = torch.zeros_like(xb)
+            hip_ops.conv2d_packed(g, adjs, out=dxb, out_stride=(2, 2))
+            dx_skip = _blur_adjoint(dxb, blurs, x.shape[2:])
+        if need[5] and not no_w:
+            dws = hip_ops.conv2d_wgrad(xb, g, tuple(ws.shape), 2, 0, 1, 1, scale=sc)
+        # ---- main path, last layer first
+        g2 = hip_ops.fused_bias_act(g, g.new_empty(0), main, 3, 1, 0.2, 1.0)
+        if need[3] and not no_w:
+            dw2 = hip_ops.conv2d_wgrad(y1b, g2, tuple(w2.shape), 2, 0, 1, 1, scale=c2.scale)
+        if need[4]:
+            db2 = hip_ops.channel_sum(g2)
+        adj2 = _cached_pack(c2, "adj", lambda: hip_ops.PackedConv(hip_ops.pack_weight(w2, adjoint=True, scale=c2.scale), 1, ci, co, 3, 3, 1, (1,), (1,)))
+        dy1b = hip_ops.conv_transpose2d_s2_into(g2, adj2, y1b.shape[2:])
+        dy1 = _blur_adjoint(dy1b, blur2, y1.shape[2:])
+        g1 = hip_ops.fused_bias_act(dy1, dy1.new_empty(0), y1, 3, 1, 0.2, 2 ** 0.5)
+        if need[1] and not no_w:
+            dw1 = hip_ops.conv2d_wgrad(x, g1, tuple(w1.shape), 1, c1.padding, 1, 1, scale=c1.scale)
+        if need[2]:
+            db1 = hip_ops.channel_sum(g1)
+        if need[0]:
+            adj1 = _cached_pack(c1, "adj", lambda: hip_ops.PackedConv(
+                hip_ops.pack_weight(w1, adjoint=True, flip=True, scale=c1.scale), 1, ci, ci, 3, 3, 1, (1,), (3 - 1 - c1.padding,)))
+            dx = hip_ops.conv2d_packed(g1, adj1, res1=dx_skip)   # d/dx of the main path + the skip path's gradient in the epilogue
+        return dx, dw1, db1, dw2, db2, dws, None
+
+
 class ConvLayer(nn.Sequential):
     """[Blur,] EqualConv2d [, FusedLeakyReLU] with the reference's child indices (models/RestoreNet.py:1137-1179)."""
 
@@ -160,6 +248,9 @@ class ResBlock(nn.Module):
     def forward(self, x):
         if _FIRST_ORDER and torch.is_grad_enabled():
             # first-order passes: the 1 / sqrt 2 rides in conv2's activation gain and the skip's weight scale, the sum in the skip's epilogue
+            if hip_ops.RESBLOCK_ONE_NODE and x.is_cuda:
+                return _ResBlockFO.apply(x, self.conv1[0].weight, self.conv1[1].bias, self.conv2[1].weight, self.conv2[2].bias,
+                                         self.skip[1].weight, self)
             main = self.conv2(self.conv1(x), gain=1.0)
             blur, conv = self.skip[0], self.skip[1]
             return _SkipConvAdd.apply(upfirdn2d(x, blur.kernel, pad=blur.pad), conv.weight, main, conv)

@@ -110,6 +110,8 @@ BF16_FORCE = 0
 SMART_ADJOINT_ONE_PASS = os.environ.get("VSP_SMART_ADJOINT_ONE_PASS", "1") != "0"
 # training: demodulation coefficients and their gradient on the fused kernels (vsp_demod_weight_f32) instead of torch autograd
 FUSED_DEMOD_GRAD = os.environ.get("VSP_FUSED_DEMOD_GRAD", "1") != "0"
+# training: a discriminator ResBlock of the first-order passes as one autograd node (discriminator._ResBlockFO)
+RESBLOCK_ONE_NODE = os.environ.get("VSP_RESBLOCK_ONE_NODE", "1") != "0"
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
