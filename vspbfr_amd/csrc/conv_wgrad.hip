@@ -6,7 +6,7 @@
 //
 // As a GEMM: M = output channels, N = (input channel, tap), K = every output pixel of the batch.  One 4-wave workgroup owns a
 // (16 WCO) x (16 NB WCI) block of (co, ci) with all KH*KW taps of one group -- wave (wco, wci) its 16 co x 16 NB ci -- and walks a
-// strided share of K in chunks of one output-row segment (64 pixels):
+// consecutive run of K (down one column segment) in chunks of one output-row segment (64 pixels; 2 x 32 / 4 x 16 on small maps):
 //   * tile shapes: 64 co x 32 ci (WCO 4, NB 2) for ordinary layers, 32 x 64 (WCO 2, WCI 2, NB 2) and 16 x 64 (WCI 4) for the
 //     narrow dilated branches of a SMART layer (16 / 32 output channels per group: a 64-co tile would be 3/4 empty);
 //   * the dY slab [co][64 px] and the X slab [ci][KH rows][row segment + halo] of chunk i+1 are fetched into REGISTERS (16-byte
@@ -15,8 +15,12 @@
 //     under ~150 MFMAs per wave; the per-sample scales of a modulated layer (modulate-input / demodulate-output form) are folded
 //     in at the LDS write;
 //   * a k-step = 4 pixels: one A fragment (dY) serves all taps and ci blocks, B fragments are the tap-shifted views of the X slab;
-//   * the partial sums of the workgroups that share a (co, ci) block meet through fp32 atomics (dW is a few MB; the order of
-//     the additions is not fixed: ~1e-6 relative).
+//     3x3 layers run the chunk's MFMA loop FULLY UNROLLED (round 3; template arguments S = stride, TCL = chunk shape): one LDS base
+//     register per (ci block, tap), the pixel offset an immediate, the nine B fragments of unit u + 1 read under the MFMAs of unit u;
+//   * the partial sums of the workgroups that share a (co, ci) block go to private copies of dW in a caller-provided workspace and a
+//     second kernel adds them (sliced over the copies when dW is small); without a workspace: fp32 atomics (order not fixed, ~1e-6);
+//     the split matches the RESIDENT workgroups (2 per CU at 208 registers) so that the grid is one round;
+//   * 1x1 layers with at most 4 input channels (FromRGB) are a stream, not a GEMM: wgrad_fewin_kernel.
 // Groups: true groups (x channels g Cin_g ...), or a SHARED input with per-group dilation / padding (the four SMART branches in
 // one launch).  LDS pitches: channel rows 2 (mod 32) words apart: the 16 x 2 lanes of an access group hit 32 distinct banks.
 #include "vsp_common.h"

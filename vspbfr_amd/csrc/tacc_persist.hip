@@ -1,7 +1,8 @@
 // The Code_diffuser sampler chain as ONE persistent launch (round 3; VERDICT r2 "missing" item 1).
 //
 // Reference: ldm/ddpm.py:400-429 (p_sample_loop) around models/CodeDiffuser.py:86-140 (four TACC blocks per denoiser call).
-// tacc_chain.hip enqueues three launches per block (600 per batch at T = 50); here a CLUSTER of 16 workgroups owns one image for
+// tacc_chain.hip enqueues three launches per block (600 per batch at T = 50); here a CLUSTER of G workgroups (template argument:
+// 16 = the latency form described below; 8 / 4 / 2 / 1: each workgroup takes 16 / G slices, see the note at the kernel) owns one image for
 // the whole chain -- all T x n_blocks block evaluations and the sampler updates -- and the only things that cross workgroups are
 // the three all-to-all tensors of a block, exchanged through L2-bypassing (sc0 sc1) stores and loads behind a cluster barrier:
 //
@@ -20,8 +21,8 @@
 // tacc_proj_kernel (XCD x only ever touches rows [256 x, 256 x + 256) of a block's 2048 x 512 weight): speed only.  Every
 // cross-workgroup word is written with sc0 sc1 stores and read with sc0 sc1 loads (MI355X_MICROARCH.md, valid forms), the
 // barrier is one relaxed agent-scope counter per image behind a per-wave vmcnt(0) drain; spins are bounded (a timeout word stops
-// every later wait, the caller's parity tests see the garbage).  The grid must be co-resident: 16 B workgroups of 512 threads
-// with 146 KB of LDS, one per CU -> B <= 16 (the entry refuses larger batches; callers fall back to vsp_tacc_chain_f32).
+// every later wait, the caller's parity tests see the garbage).  The grid must be co-resident: G B workgroups of 512 threads
+// with 145 KB of LDS, one per CU -> G B <= 256 (the entry refuses larger batches; callers fall back to vsp_tacc_chain_f32).
 #include "tacc_kernels.h"
 #include <cstdlib>
 
