@@ -132,25 +132,37 @@ __global__ __launch_bounds__(256) void demod_kernel(float* out, const float* sty
 //      rsqrt(linear(s^2, w^2.sum(taps)) * c + eps) is 7 launches forward and ~14 backward per modulated layer (61 layers per iteration,
 //      every one a few microseconds of a 2 MB tensor); here: one launch forward, two backward.
 constexpr int kDemodMaxB = 16;
-// one workgroup per output channel: wsq[co, :] = sum_taps w^2 (kept for the backward), out[b, co] for every sample
+// one workgroup per output channel: wsq[co, :] = sum_taps w^2 (kept for the backward), out[b, co] for every sample.  The channel's
+// Cin x K weights are one contiguous run: it is staged through LDS with coalesced 4-byte loads (a thread reading its own K taps at
+// stride K touched 18 cache lines per load instruction), then every thread sums the taps of its input channels from LDS.
 __global__ __launch_bounds__(256) void demod_weight_kernel(float* __restrict__ out, float* __restrict__ wsq, const float* __restrict__ style,
                                                             const float* __restrict__ w, int B, int Cin, int Cout, int K, float wscale2,
                                                             float eps) {
+  extern __shared__ float dmw[];   // [chunk of 256 input channels][K] (+1 per row: odd pitch, conflict-free tap walks)
   const int co = blockIdx.x;
+  const int KP = K | 1;
   float acc[kDemodMaxB];
 #pragma unroll
   for (int b = 0; b < kDemodMaxB; ++b) acc[b] = 0.f;
-  for (int ci = threadIdx.x; ci < Cin; ci += 256) {
-    const float* wp = w + ((int64_t)co * Cin + ci) * K;
-    float q = 0.f;
-    for (int k = 0; k < K; ++k) q = fmaf(wp[k], wp[k], q);
-    wsq[(int64_t)co * Cin + ci] = q;
+  for (int c0 = 0; c0 < Cin; c0 += 256) {
+    const int nc = Cin - c0 < 256 ? Cin - c0 : 256;
+    const float* src = w + ((int64_t)co * Cin + c0) * K;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc * K; i += 256) dmw[(i / K) * KP + i % K] = src[i];
+    __syncthreads();
+    const int ci = c0 + threadIdx.x;
+    if ((int)threadIdx.x < nc) {
+      const float* wp = dmw + threadIdx.x * KP;
+      float q = 0.f;
+      for (int k = 0; k < K; ++k) q = fmaf(wp[k], wp[k], q);
+      wsq[(int64_t)co * Cin + ci] = q;
 #pragma unroll
-    for (int b = 0; b < kDemodMaxB; ++b)
-      if (b < B) {
-        const float st = style[(int64_t)b * Cin + ci];
-        acc[b] = fmaf(st * st, q, acc[b]);
-      }
+      for (int b = 0; b < kDemodMaxB; ++b)
+        if (b < B) {
+          const float st = style[(int64_t)b * Cin + ci];
+          acc[b] = fmaf(st * st, q, acc[b]);
+        }
+    }
   }
   __shared__ float red[4][kDemodMaxB];
 #pragma unroll
@@ -455,7 +467,9 @@ int vsp_demod_weight_f32(float* out, float* wsq, const float* style, const float
   VSP_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && K >= 1, "demod_weight: bad dims");
   if (B > kDemodMaxB) return vsp::fail(VSP_ENOTSUP, "demod_weight: at most %d samples per call (got %d)", kDemodMaxB, B);
   VSP_REQUIRE(out && wsq && style && w, "demod_weight: null pointer");
-  demod_weight_kernel<<<(unsigned)Cout, 256, 0, vsp::as_stream(stream)>>>(out, wsq, style, w, B, Cin, Cout, K, wscale * wscale, eps);
+  VSP_REQUIRE(K <= 49, "demod_weight: at most 49 taps (got %d)", K);
+  demod_weight_kernel<<<(unsigned)Cout, 256, (size_t)256 * (K | 1) * sizeof(float), vsp::as_stream(stream)>>>(out, wsq, style, w, B, Cin, Cout, K,
+                                                                                                        wscale * wscale, eps);
   return vsp::check_launch("demod_weight");
 }
 
