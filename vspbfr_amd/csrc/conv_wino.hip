@@ -42,9 +42,9 @@ __device__ __forceinline__ float uload(const float* base, int idx) {
 }
 
 // (round 3, tried: delaying the second half of the first generation of workgroups by 4-15 us so that the two resident workgroups of a
-//  CU run out of phase -- prologue / epilogue of one under the MFMA intervals of the other: no effect on 64 / 128 / 512 channels.
-//  The same build was 10-18 % slower than the production kernel for the few extra instructions at the kernel's entry: the schedule
-//  of this kernel is that sensitive to what the compiler does around the pinned steady state.)
+//  CU run out of phase -- prologue / epilogue of one under the MFMA intervals of the other: no effect on 64 / 128 / 512 channels
+//  (1029 / 868 / 771 us with and without, tools/wino_ablate.py).  Scheduler strategies of the compiler (-mllvm -amdgpu-sched-strategy=
+//  max-ilp | max-memory-clause | iterative-ilp | iterative-maxocc) and -O2: within 2 % of -O3 either way on the five judged shapes.)
 #ifndef VSP_WINO_PIN
 #define VSP_WINO_PIN 1   // pinned steady-state schedule for the undilated kernel (measured +1.5..3.5 %); dilated: slower, off
 #endif
