@@ -895,6 +895,8 @@ def test_conv2d_wgrad_scales_and_plane_dot(H):
     close(H.plane_dot(dev(gy), dev(y.detach().float())) / dev(dm), dd.grad.float(), 3e-5, 3e-5, "d demod")
     dxs = F.conv_transpose2d(gy.double() * dm.double()[:, :, None, None], w.double(), padding=1).float()
     close(H.plane_dot(dev(dxs), dev(x)), sd.grad.float(), 3e-5, 3e-5, "d style")
+    dws = H.conv2d_wgrad(dev(x), dev(gy), w.shape, 1, 1, 1, 1, x_scale=dev(s), dy_scale=dev(dm), scale=0.37)   # dw_scale: the equalized-lr factor
+    close(dws, 0.37 * dw.cpu(), 2e-5, 2e-5 * float(dw.abs().max()), "scaled dw")
     assert H.conv2d_wgrad(dev(x[:0]), dev(gy[:0]), w.shape, 1, 1).abs().max().item() == 0.0     # empty batch: zeros
     with pytest.raises(RuntimeError):
         H.conv2d_wgrad(dev(x), dev(gy), (cout, cin, 5, 5), 1, 2)
@@ -1400,6 +1402,12 @@ def test_conv_dilation_by_input_quarter(H, cin, cout, hw):
     close(y, ref, 2e-5, 2e-5 * float(ref.abs().max()), "y")
     with pytest.raises(RuntimeError):   # the Winograd / bf16 entries do not serve it
         H.conv2d_packed(dev(x), pc, winograd=True)
+    if cin == 64 and cout == 64:   # what the entry refuses: input channels that do not split into quarters of whole chunks, the transposed form
+        bad = H.PackedConv(w4[:, :, :40].contiguous(), 4, cout // 4, 40, 3, 3, 1, rates, rates, dil_by_input_quarter=True)
+        with pytest.raises(RuntimeError):
+            H.conv2d_packed(dev(x[:, :40].contiguous()), bad)
+        with pytest.raises(RuntimeError):
+            H.conv2d_packed(dev(x), pc, transposed=True)
 
 
 def test_conv_pipelined_refuses_what_it_does_not_serve(H):
