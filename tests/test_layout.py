@@ -177,3 +177,25 @@ def test_bf16_weight_lds_image_layout_cpu():
     assert not H.bf16_eligible(pc(G=8), 64, 64, 64, 64)                    # > 4 groups over one shared input
     assert H.bf16_eligible(pc(G=8, xgs=64), 64, 64, 64, 64)                # true groups
     assert not H.bf16_profitable(pc(), 8, 8, 8, 8) and H.bf16_profitable(pc(), 16, 16, 16, 16)
+
+
+def test_tacc_projection_fragment_layout():
+    """vsp_tacc_block.wcat_frag (include/vspbfr_hip.h): the concatenated [4D, D] projection matrix in MFMA fragment order --
+    frag[n / 16][k / 16][lane = 16 (k % 16 / 4) + n % 16][k % 4] = W[n][k] -- as diffusion.Code_diffuser builds it (host logic, CPU)."""
+    import torch
+    from vspbfr_amd.diffusion import Code_diffuser
+    net = Code_diffuser(timesteps=4)
+    blk = net.att_mapper[0]
+    W = net._wcat(blk)
+    F_ = net._wcat_frag(blk)
+    n_, k_ = W.shape
+    assert (n_, k_) == (2048, 512) and F_.numel() == W.numel() and F_.is_contiguous()
+    flat = F_.reshape(n_ // 16, k_ // 16, 64, 4)
+    g = torch.Generator().manual_seed(0)
+    for n, k in zip(torch.randint(0, n_, (200,), generator=g).tolist(), torch.randint(0, k_, (200,), generator=g).tolist()):
+        lane = 16 * ((k % 16) // 4) + n % 16
+        assert flat[n // 16, k // 16, lane, k % 4] == W[n, k]
+    # the rows are the four projections in the order the kernels slice them: k, v, q2, v2
+    srcs = [blk.k_matrix.weight, blk.v_matrix.weight, blk.attention_layer.q_matrix.weight, blk.attention_layer.v_matrix.weight]
+    assert torch.equal(W, torch.cat([w.detach() for w in srcs], 0))
+
