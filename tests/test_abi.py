@@ -4,6 +4,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -87,3 +89,23 @@ def test_torch_extension_modules_load_and_keep_the_reference_signatures():
         fused.fused_bias_act(torch.zeros(2, 3), torch.zeros(3), torch.zeros(0), 3, 0, 0.2, 1.0)
     with pytest.raises(RuntimeError):
         upfirdn2d_op.upfirdn2d(torch.zeros(1, 4, 4, 1), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0)
+
+
+def test_operand_device_refusal_logic():
+    """Host side of the device guard (reference op/fused_bias_act.cpp:25, op/upfirdn2d.cpp:23): one device per launch.  CPU tensors stand
+    in for devices here; `meta` is a second device type that needs no hardware."""
+    import torch
+    from vspbfr_amd import hip_ops as H
+    a, b = torch.zeros(2), torch.zeros(3)
+    assert H.operand_device((a, 1, None, [b, (a,)]), {"k": b}) == torch.device("cpu")
+    assert H.operand_device((1, "x"), {}) is None
+    m = torch.zeros(2, device="meta")
+    with pytest.raises(RuntimeError, match="different devices"):
+        H.operand_device((a, m), {})
+    with pytest.raises(RuntimeError, match="different devices"):
+        H.operand_device((a,), {"res": [m]})
+    # every public operator is wrapped, helpers without tensors are not
+    assert hasattr(H.fused_bias_act, "__wrapped_op__") and hasattr(H.conv2d_packed, "__wrapped_op__") and hasattr(H.tacc_chain, "__wrapped_op__")
+    assert not hasattr(H.conv_key, "__wrapped_op__")
+    with pytest.raises(RuntimeError, match="different devices"):
+        H.fused_bias_act(a, m, torch.zeros(0), 3, 0, 0.2, 1.0)

@@ -912,6 +912,35 @@ def test_resize_bilinear_matches_interpolate(H, ish, osh):
         close(H.resize_bilinear(dev(x), osh), H.avgpool2x2(dev(x)), 1e-6, 1e-6)
 
 
+def test_device_guard_second_device(golden):
+    """Device guard at the boundary (reference op/fused_bias_act.cpp:25, op/upfirdn2d.cpp:23): tensors on cuda:1 while cuda:0 is the
+    current device launch on cuda:1, through the pybind11 modules and through the ctypes path; mixed-device operands are refused.
+    Needs two visible devices (the round-end box has one: skipped there; the refusal logic itself is CPU-tested in tests/test_abi.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible device")
+    from vspbfr_amd.op import native
+    from vspbfr_amd.op.fused_act import fused_leaky_relu
+    fused, upfirdn2d_op = native.load()
+    d1 = torch.device("cuda:1")
+    name = next(n for n in cases.LRELU_CASES if cases.lrelu_inputs(n)[1] is not None)
+    x, b = cases.lrelu_inputs(name)
+    torch.cuda.set_device(0)
+    y = fused_leaky_relu(x.to(d1), b.to(d1))
+    assert y.device == d1 and torch.cuda.current_device() == 0
+    close(y, golden("ops")[name], 1e-6, 1e-6, name)
+    y = fused.fused_bias_act(x.to(d1), b.to(d1), torch.empty(0, device=d1), 3, 0, 0.2, math.sqrt(2))
+    assert y.device == d1 and torch.cuda.current_device() == 0
+    close(y, golden("ops")[name], 1e-6, 1e-6, name)
+    xf, k, up, down, pad = cases.fir_inputs("fir_blur_after_up")
+    B, C_, Hh, Ww = xf.shape
+    y = upfirdn2d_op.upfirdn2d(xf.to(d1).reshape(-1, Hh, Ww, 1), k.to(d1), up[0], up[1], down[0], down[1], pad[0], pad[1], pad[2], pad[3])
+    close(y.view(B, C_, y.shape[1], y.shape[2]), golden("ops")["fir_blur_after_up"], 1e-6, 1e-6, "fir on cuda:1")
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(x.to(d1), b.to("cuda:0"), torch.empty(0, device=d1), 3, 0, 0.2, 1.0)
+    with pytest.raises(RuntimeError, match="different devices"):
+        H.fused_bias_act(x.to(d1), b.to("cuda:0"), torch.empty(0, device=d1), 3, 0, 0.2, 1.0)
+
+
 def test_torch_extension_modules(golden):
     """The AOT pybind11 modules `fused` / `upfirdn2d` (vspbfr_amd/csrc/torch_ext) with the reference's native signatures
     (op/fused_bias_act.cpp:18-31, op/upfirdn2d.cpp:17-31) against the reference's golden outputs and the ctypes path."""

@@ -299,6 +299,21 @@ def gen_discriminator64():
     print("discriminator64.npz: d_loss %.4f r1 %.4e g_loss %.4f, %d parameters, %.1fs" % (d_loss.item(), r1.item(), g_loss.item(), len(names), time.time() - t))
 
 
+def gen_ada_draws():
+    """Seeded draws of the REFERENCE's sample_affine / sample_color (non_leaking.py:660-760): the host-side matrices of ADA, including the
+    quarter-turn categories (0, 3) of :673.  vspbfr_amd.non_leaking follows the same torch RNG call sequence, so the same seed must
+    give the same matrices (tests/test_ada_draws.py, CPU)."""
+    import non_leaking as NL
+    out = {}
+    for seed, p_aug, size in ((5, 0.8, 64), (23, 0.35, 256)):
+        torch.manual_seed(seed)
+        out[f"G_{seed}"] = np_(NL.sample_affine(p_aug, 32, size, size))
+        out[f"C_{seed}"] = np_(NL.sample_color(p_aug, 32))
+    out["cases"] = np.array([[5, 0.8, 64], [23, 0.35, 256]])
+    np.savez_compressed(os.path.join(GOLD, "ada_draws.npz"), **out)
+    print("ada_draws.npz:", {k: v.shape for k, v in out.items()})
+
+
 def gen_ada():
     """ADA augmentation (non_leaking.py:857-934) of the REFERENCE with pinned transformation matrices: G = the inverse of a
     sample_affine draw, C = a sample_color draw (both stored), the augmented batch, and the gradient of <augmented, R> w.r.t.
@@ -679,7 +694,7 @@ def gen_real512(ckpt_dir=None, lq_dir=None, n=2, out_name="real512.npz", stride=
 
 
 ALL = {"specs": gen_specs, "ops": gen_ops, "layers": gen_layers, "diffuser": gen_diffuser, "ddim": gen_ddim, "restorenet64": gen_restorenet64,
-       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "lpips": gen_lpips, "idloss": gen_idloss, "diffuser_train": gen_diffuser_train}
+       "generator64": gen_generator64, "encoder": gen_encoder, "pipeline512": gen_pipeline512, "loader": gen_loader, "restorenet64_grad": gen_restorenet64_grad, "discriminator64": gen_discriminator64, "ada": gen_ada, "ada_draws": gen_ada_draws, "lpips": gen_lpips, "idloss": gen_idloss, "diffuser_train": gen_diffuser_train}
 OPTIONAL = {"real512": gen_real512}   # needs the published checkpoints: not part of the default set
 
 if __name__ == "__main__":

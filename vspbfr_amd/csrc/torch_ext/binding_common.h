@@ -6,6 +6,7 @@
 #pragma once
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include "../../../include/vspbfr_hip.h"
 
 // Element types: the reference's modules dispatch over float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
@@ -20,6 +21,12 @@
               #x " must be float32, float16 or float64")
 
 inline torch::Tensor vsp_f32(const torch::Tensor& x) { return x.scalar_type() == at::kFloat ? x : x.to(at::kFloat); }
+
+// Device guard on the input's device, as the reference's front ends do (op/fused_bias_act.cpp:25, op/upfirdn2d.cpp:23
+// `const at::cuda::OptionalCUDAGuard device_guard(device_of(input))`): the launch goes to the TENSOR's device and that device's current
+// stream, whatever the caller's current device is; the previous device is restored on return.  Operands on another device are refused.
+#define VSP_DEVICE_GUARD(x) const c10::hip::OptionalHIPGuardMasqueradingAsCUDA vsp_device_guard(at::device_of(x))
+#define VSP_CHECK_SAME_DEVICE(x, ref) TORCH_CHECK((x).device() == (ref).device(), #x " is on ", (x).device(), ", expected ", (ref).device())
 
 inline void* vsp_current_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
 inline void vsp_raise(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", vsp_last_error()); }

@@ -4,8 +4,9 @@
 torch::Tensor fused_bias_act(const torch::Tensor& input, const torch::Tensor& bias, const torch::Tensor& refer, int act, int grad,
                              float alpha, float scale) {
   VSP_CHECK_INPUT(input);
-  if (bias.numel()) { VSP_CHECK_INPUT(bias); }
-  if (refer.numel()) { VSP_CHECK_INPUT(refer); }
+  if (bias.numel()) { VSP_CHECK_INPUT(bias); VSP_CHECK_SAME_DEVICE(bias, input); }
+  if (refer.numel()) { VSP_CHECK_INPUT(refer); VSP_CHECK_SAME_DEVICE(refer, input); }
+  VSP_DEVICE_GUARD(input);   // reference op/fused_bias_act.cpp:25
   TORCH_CHECK(!bias.numel() || bias.scalar_type() == input.scalar_type(), "bias must have the input's dtype");
   TORCH_CHECK(!refer.numel() || refer.scalar_type() == input.scalar_type(), "refer must have the input's dtype");
   const auto x = vsp_f32(input.contiguous());

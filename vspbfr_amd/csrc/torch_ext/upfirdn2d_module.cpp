@@ -6,6 +6,8 @@ torch::Tensor upfirdn2d(const torch::Tensor& input, const torch::Tensor& kernel,
                         int pad_x1, int pad_y0, int pad_y1) {
   VSP_CHECK_INPUT(input);
   VSP_CHECK_INPUT(kernel);
+  VSP_CHECK_SAME_DEVICE(kernel, input);
+  VSP_DEVICE_GUARD(input);   // reference op/upfirdn2d.cpp:23
   TORCH_CHECK(input.dim() == 4 && kernel.dim() == 2, "upfirdn2d expects input [major,H,W,minor] and a 2-D kernel");
   const int major = (int)input.size(0), in_h = (int)input.size(1), in_w = (int)input.size(2), minor = (int)input.size(3);
   const int kh = (int)kernel.size(0), kw = (int)kernel.size(1);

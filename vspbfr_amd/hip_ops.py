@@ -123,6 +123,44 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def operand_device(args, kwargs=None):
+    """Device index shared by every tensor among an operator's arguments (tensors inside lists / tuples included), None when there is
+    no tensor; RuntimeError when they lie on different devices.  Pure host logic (CPU-testable): the C ABI takes raw pointers and one
+    stream, so operands on two devices cannot be served by one launch -- the reference's extensions would fault on the foreign pointer,
+    this refuses."""
+    dev = None
+    stack = list(args) + (list(kwargs.values()) if kwargs else [])
+    while stack:
+        a = stack.pop()
+        if isinstance(a, torch.Tensor):
+            if dev is None:
+                dev = a.device
+            elif a.device != dev:
+                raise RuntimeError(f"operands on different devices: {dev} and {a.device}")
+        elif isinstance(a, (list, tuple)):
+            stack.extend(a)
+    return dev
+
+
+def device_guarded(fn):
+    """The reference's `at::cuda::OptionalCUDAGuard device_guard(device_of(input))` (op/fused_bias_act.cpp:25, op/upfirdn2d.cpp:23) for the
+    ctypes path: the launch goes to the TENSORS' device and that device's current stream (`_stream()` is evaluated inside the guard), not
+    to whatever device is current in the calling thread; the previous device comes back on return.  One process per GPU never takes the
+    slow branch."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        dev = operand_device(args, kwargs)
+        if dev is None or dev.type != "cuda" or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    guarded.__wrapped_op__ = fn
+    return guarded
+
+
 def _req(t, name, bf16_ok=False):
     if not isinstance(t, torch.Tensor):
         raise RuntimeError(f"{name} must be a tensor")
@@ -1230,3 +1268,16 @@ def plane_dot(a, b):
     planes = a.shape[0] * a.shape[1]
     check(lib.vsp_plane_dot_f32(_ptr(out), _ptr(a), _ptr(b), planes, a.numel() // max(planes, 1), _stream()), "plane_dot")
     return out
+
+
+def _guard_public_ops():
+    """every public operator of this module runs under `device_guarded` (helpers without tensor arguments pass straight through)"""
+    import types
+    skip = {"conv_key", "fir_out_size", "fir_bf16_ok", "conv2d_out_size", "operand_device", "device_guarded", "check"}
+    g = globals()
+    for name, obj in list(g.items()):
+        if isinstance(obj, types.FunctionType) and not name.startswith("_") and name not in skip and obj.__module__ == __name__:
+            g[name] = device_guarded(obj)
+
+
+_guard_public_ops()

@@ -28,6 +28,7 @@ SYM6 = (0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.04
 
 
 # ------------------------------------------------------------------------------------------------ device primitives
+@hip_ops.device_guarded
 def _affine_sample_raw(x, theta, out_hw):
     x = hip_ops._req(x.contiguous(), "x")
     theta = hip_ops._req(theta.contiguous(), "theta")
@@ -38,6 +39,7 @@ def _affine_sample_raw(x, theta, out_hw):
     return out
 
 
+@hip_ops.device_guarded
 def _affine_sample_adjoint_raw(g, theta, in_hw):
     g = hip_ops._req(g.contiguous(), "g")
     theta = hip_ops._req(theta.contiguous(), "theta")
@@ -83,6 +85,7 @@ def affine_sample(x, theta, out_hw):
     return _affine_sample_raw(x, theta, out_hw)
 
 
+@hip_ops.device_guarded
 def _color_raw(x, M, t):
     x = hip_ops._req(x.contiguous(), "x")
     B, C, Hh, Ww = x.shape
@@ -142,7 +145,9 @@ def sample_affine(p, size, height, width):
     G = _eye(3, size)
     flip = torch.randint(0, 2, (size,)).float()
     G = _maybe(p, _mat2({(0, 0): 1 - 2 * flip}, size), G)                                         # x-flip
-    th = -math.pi / 2 * torch.randint(0, 4, (size,)).float()
+    # the reference draws the quarter-turn count from the two categories (0, 3) (non_leaking.py:673 `category_sample(size, (0, 3))`), not
+    # from {0, 1, 2, 3}: one randint(high=2) index into that list
+    th = -math.pi / 2 * torch.tensor((0.0, 3.0))[torch.randint(high=2, size=(size,))]
     G = _maybe(p, _mat2({(0, 0): th.cos(), (0, 1): -th.sin(), (1, 0): th.sin(), (1, 1): th.cos()}, size), G)   # 90-degree rotations
     t = torch.empty(2, size).uniform_(-0.125, 0.125)
     G = _maybe(p, _mat2({(0, 2): torch.round(t[1] * width), (1, 2): torch.round(t[0] * height)}, size), G)     # integer translation
