@@ -339,13 +339,14 @@ def main():
         every batch is complete when the closing synchronize returns."""
         res, pending = None, None
 
-        def exchange(restored):
-            """start this batch's all-gather behind its kernels, then collect the PREVIOUS batch's (which ran under this batch's C + D)"""
+        def exchange(restored, reused=False):
+            """start this batch's all-gather behind its kernels, then collect the PREVIOUS batch's (which ran under this batch's C + D);
+            reused = `restored` is a buffer the next batch overwrites (a captured graph's static output): gathered from an owned copy"""
             nonlocal res, pending
             if world == 1:
                 res = restored
                 return
-            h = gatherer.start(restored)
+            h = gatherer.start(restored, stage=reused)
             if pending is not None:
                 res = pending.result()
             pending = h
@@ -354,7 +355,7 @@ def main():
                 exchange(pipe(x, image_index0=i0)["restored"])
         elif args.graphs:
             for o in pipe.run_batches_graphed(batches(n)):
-                exchange(o["restored"])
+                exchange(o["restored"], reused=True)
         else:
             for o in pipe.run_batches(batches(n)):
                 exchange(o["restored"])

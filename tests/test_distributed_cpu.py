@@ -108,6 +108,66 @@ def test_sharded_restoration_equals_single_rank(tmp_path):
         assert f"rank {r} ok" in o
 
 
+REUSE_WORKER = textwrap.dedent("""
+    import os, sys, time, torch
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    from vspbfr_amd.pipeline import RestoredGather
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    g = RestoredGather()
+    static = torch.empty(2, 3, 8, 8)           # ONE buffer reused for every batch, like a captured graph's static output
+    pending, got = None, []
+    for i in range(5):
+        static.fill_(100.0 * i + rank)          # "replay" of batch i overwrites the buffer
+        h = g.start(static, stage=True)         # gathered from a copy the gatherer owns
+        if rank == 0:
+            time.sleep(0.05)                    # a straggling peer: rank 1 runs ahead and overwrites `static` before gather i completes
+        if pending is not None:
+            got.append(pending.result().clone())
+        pending = h
+    got.append(pending.result().clone())
+    for i, out in enumerate(got):
+        assert out.shape == (2 * world, 3, 8, 8)
+        for r in range(world):
+            assert torch.all(out[2 * r:2 * r + 2] == 100.0 * i + r), (i, r, out[2 * r, 0, 0, 0].item())
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""" % ROOT)
+
+
+def test_restored_gather_reused_buffer_world2(tmp_path):
+    """the all-gather of a buffer the caller overwrites for the next batch (bench.py --graphs hands the graph's static
+    output to the asynchronous RestoredGather) must read an owned copy: `start(..., stage=True)`."""
+    script = tmp_path / "reuse_worker.py"
+    script.write_text(REUSE_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
+
+
+def test_bench_self_launch_world8_ragged():
+    """World size 8 (the driver's `bench.py --gpus 8`, BASELINE configs[3]): self-launch + the exchange loop with a ragged last batch over
+    eight gloo ranks.  Control path only (--launch-check): the RCCL leg itself has never run on hardware."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "3",
+                        "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["launch_check"] == "ok"
+
+
 def test_bench_self_launch_world4_ragged():
     """World size 4 through the same self-launch: the launch check also runs bench.py's exchange loop -- full batches and a RAGGED
     last one (the last ranks get fewer images) through the preallocated asynchronous RestoredGather, one batch behind."""
@@ -209,6 +269,7 @@ FROZEN_WORKER = textwrap.dedent("""
     requires_grad(net, False)                      # a module left frozen by whoever used it last (an inference pipeline, another trainer)
     red = OverlappedGradientReducer(list(net.parameters()), bucket_bytes=512)
     assert len(red.buckets) >= 2 and sum(len(b) for b in red.buckets) == 4, "every parameter must be bucketed"
+    assert not any(p.requires_grad for p in net.parameters()), "the reducer must not thaw the caller's module"
     requires_grad(net, True)
     x = torch.randn(5, 19, generator=torch.Generator().manual_seed(7 + rank))
     net(x).pow(2).mean().backward()

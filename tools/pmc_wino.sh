@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes for one Winograd conv shape (GPU box).  usage: tools/pmc_wino.sh <outdir> Cin Cout S [G]
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
 OUT=$1; shift
 mkdir -p $OUT
 P="python3 tools/run_one_wino.py $*"
@@ -8,11 +9,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU -d $OUT/p2 -o p2 --output-format csv -- $P > $OUT/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC -d $OUT/p3 -o p3 --output-format csv -- $P > $OUT/p3.log 2>&1
 python3 - <<PY
-import csv, collections, glob
+import csv, collections, glob, sys
+missing = False
 print("== conv_wino_kernel  $*")
 for pth in ("p1","p2","p3"):
     fs = glob.glob("$OUT/%s/**/*counter_collection.csv" % pth, recursive=True)
-    if not fs: print(pth, "no csv"); continue
+    if not fs: print(pth, "no csv"); missing = True; continue
     rows=list(csv.DictReader(open(fs[0])))
     agg=collections.defaultdict(list); dur=[]; name=""
     for r in rows:
@@ -21,4 +23,5 @@ for pth in ("p1","p2","p3"):
             dur.append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
     for k,v in agg.items(): print(pth, k, "%.5g"%(sum(v)/len(v)))
     print(pth, name, "duration us (min over dispatches)", min(dur) if dur else None)
+sys.exit(1 if missing else 0)   # a pass without a counter file is a failed run, not evidence
 PY

@@ -254,7 +254,10 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
     }
   }
   const bool wide = vec && p.M >= 1024;   // several row blocks per workgroup share the B fragments (same arithmetic per element)
-  static const int wide_mbk = getenv("VSP_GEMM_MBK") ? atoi(getenv("VSP_GEMM_MBK")) : 4;
+  static const int wide_mbk = [] {   // tuning switch; only the instantiated forms (the grid below is sized for the SAME value)
+    const int v = getenv("VSP_GEMM_MBK") ? atoi(getenv("VSP_GEMM_MBK")) : 4;
+    return (v == 2 || v == 4 || v == 8) ? v : 4;
+  }();
   const int mrows = wide ? 16 * wide_mbk : 16;
   dim3 grid((unsigned)((p.N + 16 * NBL - 1) / (16 * NBL)), (unsigned)((p.M + mrows - 1) / mrows), (unsigned)p.Z);
   VSP_REQUIRE(grid.y <= 65535, "gemm: M too large");

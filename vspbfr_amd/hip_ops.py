@@ -1081,6 +1081,8 @@ def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, hea
     if persistent is None:
         persistent = TACC_PERSISTENT
     cluster = int(TACC_CLUSTER if cluster is None else cluster)
+    if cluster not in (1, 2, 4, 8, 16):
+        raise RuntimeError(f"tacc_chain: cluster must be 1, 2, 4, 8 or 16 workgroups per image (got {cluster})")
     persistent = bool(persistent) and 0 < B <= min(32, 256 // cluster) and n <= 4
     nfl = lib.vsp_tacc_chain_persistent_work_floats(B) if persistent else lib.vsp_tacc_chain_work_floats(B)
     work = torch.empty(nfl, device=x.device, dtype=torch.float32)

@@ -314,7 +314,13 @@ class RestoredGather:
     (W B, 3, 512, 512) tensor is allocated per step: two output buffers alternate (a handle's buffer is reused two starts later --
     consume or copy the result before that).  Ragged splits (`counts` = per-rank batch sizes, equal on every rank) pad every
     rank's share to the largest one in a preallocated staging tensor and return a view of the gathered rows in rank order.
-    Single-rank / uninitialised process group: `result()` returns `local` unchanged."""
+    Single-rank / uninitialised process group: `result()` returns `local` unchanged.
+
+    Lifetime of `local`: the collective READS it asynchronously, so it must not be overwritten before `result()` of that handle.  A
+    fresh tensor per batch (the eager paths) is kept alive by the handle and is safe.  A buffer that the caller REUSES for the next batch
+    -- the static output of a captured graph (`run_batches_graphed`) -- must be passed with `stage=True`: `start` then copies it on the
+    current stream into a staging buffer this object owns (one per slot) before the collective is enqueued, so the next replay may
+    overwrite `local` at once (without it a rank that runs ahead sends batch i+1's pixels into gather i)."""
 
     def __init__(self, group=None):
         self.group = group
@@ -337,7 +343,7 @@ class RestoredGather:
             rows = self.out.view((len(self.counts), self.mx) + tuple(self.out.shape[1:]))
             return torch.cat([rows[r, :c] for r, c in enumerate(self.counts)], 0)
 
-    def start(self, local, counts=None):
+    def start(self, local, counts=None, stage=False):
         import torch.distributed as dist
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return RestoredGather.Handle(None, None, None, local, 0)
@@ -350,7 +356,7 @@ class RestoredGather:
         if out is None:
             out = self._out[key] = torch.empty((world * mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
         src = local.contiguous()
-        if src.shape[0] != mx:          # this rank's share is shorter than the longest one: stage it in the padded buffer
+        if src.shape[0] != mx or stage:  # a shorter share than the longest one, or a buffer the caller will overwrite: owned staging copy
             pad = self._pad.get(key)
             if pad is None:
                 pad = self._pad[key] = torch.zeros((mx,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)

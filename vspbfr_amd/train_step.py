@@ -87,7 +87,10 @@ class OverlappedGradientReducer:
         if frozen and len(frozen) < len(params):
             raise ValueError(f"OverlappedGradientReducer: {len(frozen)} of {len(params)} parameters are frozen at construction; pass the "
                              "trainable subset explicitly or thaw the module first (requires_grad_(True))")
-        for p in frozen:          # an entirely frozen module (its owner toggles requires_grad per step): hooks need a grad-requiring leaf
+        # an entirely frozen module (its owner toggles requires_grad per step): a hook can only be registered on a grad-requiring leaf,
+        # and it survives later toggles -- so the flag is raised for the registration only and put back: the caller's module is not
+        # silently thawed (a generator shared with an inference pipeline stays frozen until its owner thaws it)
+        for p in frozen:
             p.requires_grad_(True)
         self.params = params
         self.buckets, cur, size = [], [], 0
@@ -104,6 +107,8 @@ class OverlappedGradientReducer:
         self.launched = 0
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
+        for p in frozen:
+            p.requires_grad_(False)
 
     def _world(self):
         import torch.distributed as dist
