@@ -183,14 +183,29 @@ int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
  * `w` must hold the TRANSFORMED weights U = G g G^T (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]) in the kernel's
  * fragment order.  With CK = vsp_conv2d_winograd_chunk() input channels per chunk, MB = vsp_conv2d_winograd_mbw(cout_g)
  * 16-channel blocks per workgroup, Cin zero-padded to a multiple of CK and cout_g to a multiple of 16*MB:
- *     w[((((((g * ntile + tile) * nchunk + chunk) * 8 + wave) * 64 + lane) * 2 + pp) * MB + mb]
+ *     w[((((((g * ntile + tile) * nchunk + chunk) * 8 + wave) * 2 + pp) * 64 + lane) * MB + mb]
  *         = U_g[position 2*wave + pp][ci = CK*chunk + (lane >> 4)][co = 16*MB*tile + 16*mb + (lane & 15)]
- * (a wave owns two Winograd positions and reads its MFMA A fragments of a chunk as contiguous bytes per lane).
+ * (a wave owns two Winograd positions; its A fragments of one position and chunk are one contiguous run: a wave-wide load reads
+ * consecutive memory).
  * Every prologue / epilogue field of vsp_conv_params keeps its meaning, tile_hint is ignored.  16 multiplies per 2x2
  * output tile instead of 36; fp32 error ~1e-6 relative on top of the direct kernel's summation-order noise. */
 int vsp_conv2d_winograd_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_chunk(void);
 int vsp_conv2d_winograd_mbw(int cout_g);
+/* The same contract through Winograd F(4x4,3x3) for the DEEP stride-1 3x3 layers (one group, dilation 1, padding 1, no in_shift;
+ * Cin a multiple of 4, H and W multiples of 4, dense 16-byte aligned output / noise / residual planes: VSP_ENOTSUP otherwise --
+ * reference layers models/RestoreNet.py:213-244,410-416, e4e/models/stylegan2/model.py:268-276 at 256 / 512 channels): 36 multiplies
+ * per 4x4 output tile instead of 144.  Two launches: the input transform V = B^T d B (in_scale applied) into `work`
+ * (vsp_conv2d_winograd4_work_floats(p) floats, fragment order of the GEMM), then a barrier-free GEMM with both operands fetched from
+ * L2 straight into MFMA fragments and the fused epilogue of vsp_conv2d_f32.  Interpolation points 0, +-3/4, +-3/2, infinity: all
+ * transform constants are dyadic, fp32 error = the direct kernel's (rms 1.5e-6 at unit scale).  `w` = vsp_winograd4_weight_f32:
+ *     w[((((tile * nchunk + chunk) * 12 + wave) * 3 + q) * 64 + lane) * 4 + mb]
+ *         = U[position 3*wave + q][ci = 4*chunk + (lane >> 4)][co = 64*tile + 16*mb + (lane & 15)],   U = G g G^T
+ * (one wave-wide 16-byte load = 1 KiB of consecutive memory). */
+int vsp_conv2d_winograd4_f32(const vsp_conv_params* p, float* work, size_t work_floats, vsp_stream_t stream);
+size_t vsp_conv2d_winograd4_work_floats(const vsp_conv_params* p);
+size_t vsp_winograd4_weight_floats(int cin, int cout);
+int vsp_winograd4_weight_f32(float* U, const float* wp, int cin, int cout, vsp_stream_t stream);
 /* 1x1 convolution, stride 1, on small maps as one GEMM (the bottleneck 1x1 layers of the identity loss network at 7x7 / 4x4,
  * Loss/id_loss.py:13,27-41): y[b][co][p] = act(sum_ci w[co][ci] x[b][ci][p] + bias[co]); w row-major (Cout, Cin) = the OIHW
  * weight as it lies; Cin a multiple of 16; bias may be NULL; act: 0 none, 1 leaky relu (slope) times gain. */

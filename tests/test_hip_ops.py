@@ -1247,7 +1247,7 @@ def test_winograd_weight_kernel(H, ng, cin, cout):
     nch, nct = (cin + ck - 1) // ck, (cout + 16 * mb - 1) // (16 * mb)
     Up = U.new_zeros(ng, 16, nch * ck, nct * 16 * mb)
     Up[:, :, :cin, :cout] = U
-    ref = Up.view(ng, 8, 2, nch, 4, nct, mb, 16).permute(0, 5, 3, 1, 4, 7, 2, 6).float().contiguous().view(-1)
+    ref = Up.view(ng, 8, 2, nch, 4, nct, mb, 16).permute(0, 5, 3, 1, 2, 4, 7, 6).float().contiguous().view(-1)
     got = H.winograd_weight(dev(wp)).cpu()
     assert got.numel() == ref.numel() == H.lib.vsp_winograd_weight_floats(ng, cin, cout)
     close(got, ref, 1e-7, 1.2e-7, "winograd weight")

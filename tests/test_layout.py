@@ -89,7 +89,7 @@ def test_winograd_weight_fragment_layout():
             tile, rem = co // (16 * mb), co % (16 * mb)
             m, lr = rem // 16, rem % 16
             lane = kq * 16 + lr
-            return frag[(((((g * ntile + tile) * nch + chunk) * 8 + wave) * 64 + lane) * 2 + pp) * mb + m]
+            return frag[((((((g * ntile + tile) * nch + chunk) * 8 + wave) * 2 + pp) * 64 + lane) * mb + m)]
 
         Bt = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
         At = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], np.float64)

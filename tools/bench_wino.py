@@ -22,6 +22,8 @@ for (B, Cin, Cout, S) in [(8, 64, 64, 512), (8, 128, 128, 256), (8, 256, 256, 12
     err = (H.conv2d_packed(x, pc, in_scale=sc, winograd=True) - H.conv2d_packed(x, pc, in_scale=sc, winograd=False)).abs().max().item()
     print(f"{Cin}->{Cout} @{S}: direct {ud:.0f} us {fl/ud/1e6:.1f} TF | winograd {uw:.0f} us {fl/uw/1e6:.1f} eff. TF | x{ud/uw:.2f} | max diff {err:.2e}")
 
+if len(sys.argv) > 1 and sys.argv[1] == "plain":
+    sys.exit(0)
 print("dilation groups (1, 2, 4, 8):")
 for (B, Cin, Cg, S) in [(8, 64, 16, 512), (8, 128, 32, 256), (8, 256, 64, 128), (8, 512, 128, 64), (8, 512, 128, 32)]:
     x = torch.randn(B, Cin, S, S, device="cuda")

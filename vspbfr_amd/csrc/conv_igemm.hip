@@ -366,6 +366,45 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
   return vsp::check_launch("conv2d_winograd");
 }
 
+extern "C" size_t vsp_winograd4_weight_floats(int cin, int cout) { return vspconv::wino4_weight_floats(cin, cout); }
+
+extern "C" int vsp_winograd4_weight_f32(float* U, const float* wp, int cin, int cout, vsp_stream_t stream) {
+  VSP_REQUIRE(U && wp && cin >= 1 && cout >= 1, "winograd4_weight: bad arguments");
+  if (int rc = vspconv::wino4_weight_launch(U, wp, cin, cout, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("winograd4_weight");
+}
+
+extern "C" size_t vsp_conv2d_winograd4_work_floats(const vsp_conv_params* pp) {
+  return pp ? vspconv::wino4_work_floats(pp->B, pp->Cin, pp->H, pp->W) : 0;
+}
+
+extern "C" int vsp_conv2d_winograd4_f32(const vsp_conv_params* pp, float* work, size_t work_floats, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr && work != nullptr, "conv2d_winograd4: null params / work buffer");
+  const vsp_conv_params& p = *pp;
+  VSP_REQUIRE(!p.transposed && p.G == 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 && p.dil[0] == 1 &&
+                  p.pad_y[0] == 1 && p.pad_x[0] == 1,
+              "conv2d_winograd4: one group, 3x3, stride 1, dilation 1, padding 1");
+  VSP_REQUIRE(p.io_bf16 == 0 && p.dil_by_input_quarter == 0 && p.in_shift == nullptr, "conv2d_winograd4: fp32, no affine input shift");
+  VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.OH == p.H && p.OW == p.W, "conv2d_winograd4: dense same-size output");
+  VSP_REQUIRE(vsp::aligned16(p.w) && vsp::aligned16(work), "conv2d_winograd4: weights and work buffer must be 16-byte aligned");
+  VSP_REQUIRE(work_floats >= vspconv::wino4_work_floats(p.B, p.Cin, p.H, p.W), "conv2d_winograd4: work buffer too small");
+  VSP_REQUIRE((int64_t)vspconv::wino4_work_floats(1, p.Cin, p.H, p.W) * 4 < ((int64_t)1 << 40), "conv2d_winograd4: image too large");
+  int x_ch = 0;
+  bool empty = false;
+  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  if (empty) return VSP_OK;
+  ConvK q{};
+  if (int rc = fill_convk(p, x_ch, q)) return rc;
+  {
+    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    q.dbg = dbg;
+  }
+  if (!vspconv::wino4_eligible(q))
+    return vsp::fail(VSP_ENOTSUP, "conv2d_winograd4: needs Cin %% 4 == 0, H, W %% 4 == 0, dense 16-byte aligned output / noise / residual planes");
+  if (int rc = vspconv::wino4_launch(q, work, p.in_scale, p.in_scale ? p.in_scale_bstride : 0, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("conv2d_winograd4");
+}
+
 static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split);
 extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false); }
 extern "C" int vsp_conv2d_bf16x3(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, true); }

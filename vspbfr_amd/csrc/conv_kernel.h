@@ -618,6 +618,14 @@ int wino_launch(ConvK q, hipStream_t stream);
 // conv_smallmap.hip: K-split GEMM form for layers with few output positions (q filled by fill_convk: no tile plan needed)
 bool smallmap_eligible(const ConvK& q, bool transposed);
 int smallmap_launch(const ConvK& q, hipStream_t stream);
+int wino_ro_launch(ConvK q, int mbw, int ivc, hipStream_t stream);
+bool wino_ro_eligible(const ConvK& q);   // conv_wino_ro.hip: row-owner form, undilated groups
+// conv_wino4.hip: Winograd F(4x4,3x3) as input transform + barrier-free GEMM (deep layers)
+bool wino4_eligible(const ConvK& q);
+size_t wino4_weight_floats(int cin, int cout);
+size_t wino4_work_floats(int B, int cin, int H, int W);
+int wino4_weight_launch(float* U, const float* wp, int cin, int cout, hipStream_t stream);
+int wino4_launch(ConvK q, float* V, const float* scale, int scale_bs, hipStream_t stream);
 int wino_chunk();           // input channels per chunk the transformed-weight layout is built for
 int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout) for a layer with cout_g channels per group
 

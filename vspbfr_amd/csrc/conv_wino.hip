@@ -12,8 +12,8 @@
 // the transform 5 %, and nothing of it overlapped the MFMAs because three barriers per chunk kept the eight waves in lock
 // step):
 //   * U never touches LDS.  No two waves share a position, so the host stores U in FRAGMENT order
-//     [group][co tile][chunk][wave][lane][pp][mb] and a wave fetches its A fragments of a chunk as one contiguous run per
-//     lane, one chunk ahead, straight into the registers the MFMAs read.
+//     [group][co tile][chunk][wave][pp][lane][mb] and a wave fetches its A fragments of a chunk as one contiguous run per
+//     position, one chunk ahead, straight into the registers the MFMAs read.
 //   * the input patch is prefetched two chunks ahead (it streams from MALL/HBM) and double-buffered in LDS, V is
 //     double-buffered too: the transform of chunk i+1, the MFMAs of chunk i and the patch write of chunk i+2 share ONE
 //     barrier interval (4 input channels per chunk keep all of it inside 128 VGPRs: two workgroups per CU).
@@ -219,19 +219,18 @@ __global__ __launch_bounds__(NTHR, 4) void conv_wino_kernel(const ConvK p) {
         Pdst[PADROW ? p_dst[e] : p_dst[0] + PTH * e] = (((p_in >> e) & 1u) && chok) ? fmaf(preg[e], sc, sh) : 0.f;
   };
 
-  // ---- U fragments: [group][co tile][chunk][wave][lane][pp 2][mb MBW] floats
-  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk4 * 8 + wave) * 64 + lane) * UF;
+  // ---- U fragments: [group][co tile][chunk][wave][pp 2][lane][mb MBW] floats (round 4: one contiguous run per wave-wide load)
+  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk4 * 8 + wave) * 2 * 64 + lane) * MBW;
   auto load_u = [&](int c, float (&u)[UF]) {
     const float* src = ufr + (int64_t)c * (8 * 64 * UF);
-    if constexpr (UF == 8) {
-      const float4 a = reinterpret_cast<const float4*>(src)[0], bq = reinterpret_cast<const float4*>(src)[1];
+    if constexpr (MBW == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(src), bq = *reinterpret_cast<const float4*>(src + 64 * 4);
       u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w; u[4] = bq.x; u[5] = bq.y; u[6] = bq.z; u[7] = bq.w;
-    } else if constexpr (UF == 4) {
-      const float4 a = reinterpret_cast<const float4*>(src)[0];
-      u[0] = a.x; u[1] = a.y; u[2] = a.z; u[3] = a.w;
+    } else if constexpr (MBW == 2) {
+      const float2 a = *reinterpret_cast<const float2*>(src), bq = *reinterpret_cast<const float2*>(src + 64 * 2);
+      u[0] = a.x; u[1] = a.y; u[2] = bq.x; u[3] = bq.y;
     } else {
-      const float2 a = reinterpret_cast<const float2*>(src)[0];
-      u[0] = a.x; u[1] = a.y;
+      u[0] = src[0]; u[1] = src[64];
     }
   };
 
@@ -576,6 +575,11 @@ int wino_launch(ConvK q, hipStream_t stream) {
   int dmax = 1;
   for (int g = 0; g < q.G; ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
   if (dmax == 1) {
+    // row-owner form (conv_wino_ro.hip) wherever it serves the launch; maps up to 16 x 16 measured equal or slower (512 -> 512 at 16^2:
+    // 99 vs 102 us) and stay here.  VSP_WINO_RO = 0 keeps this file's kernel everywhere, 1 / 2 / 4 = barrier period of the other one
+    // (8-channel sub-stages; 2 and 4 measured within 1 % of 1 on the deep layers, slower on the shallow ones).
+    static const int ro = getenv("VSP_WINO_RO") ? atoi(getenv("VSP_WINO_RO")) : 1;
+    if ((ro == 1 || ro == 2 || ro == 4) && q.H * q.W > 256 && wino_ro_eligible(q)) return wino_ro_launch(q, wino_mbw(q.cout_g), ro, stream);
     switch (wino_mbw(q.cout_g)) {
       case 4: return launch_variant<4, 1>(q, stream);
       case 2: return launch_variant<2, 1>(q, stream);

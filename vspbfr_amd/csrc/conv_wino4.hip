@@ -1,0 +1,421 @@
+// Winograd F(4x4, 3x3) on fp32 MFMA for the deep stride-1 3x3 layers (round 4): 36 multiplies per 4x4 output tile where the direct
+// form has 144 and F(2x2, 3x3) has 64 -- the matrix pipe executes 1/4 of the algorithmic count.
+//
+// Why a second Winograd kernel, and why it looks nothing like conv_wino.hip: the F(2x2) kernels are bound by what sits BETWEEN their
+// MFMAs (input transform, V hand-over, barriers: 68-77 % pipe busy); on a layer with Cout >= 256 every one of the
+// Cout / 64 channel-tile workgroups repeats the same transform of the same patch.  Here the transform runs ONCE per layer as its own
+// streaming kernel and writes V = B^T d B in the GEMM's FRAGMENT order (2.25 x the input, it stays in the 256 MB Infinity Cache); the
+// GEMM kernel then has no LDS, no barrier and no VALU work in its main loop at all: both operands come straight from L2 into the
+// registers the MFMAs read (U like conv_wino.hip, V the same way), three k-steps ahead, every wave for itself.  The extra HBM /
+// cache traffic pays only where the transform is shared by >= 4 channel tiles, so the launcher takes Cin, Cout >= 256 layers only.
+//
+// Interpolation points 0, +-3/4, +-3/2, infinity (not the textbook 0, +-1, +-2): every constant of B^T and A^T is a dyadic rational
+// (exact in fp32) and the fp32 error of the whole convolution is that of the direct kernel (rms 1.5e-6 at unit scale, K = 256; the
+// textbook points: 4.4e-6, max 1.1e-4 -- tools/wino4_points.py).  With a = 3/4, b = 3/2:
+//   B^T rows:  [a2b2, 0, -(a2+b2), 0, 1, 0]            (a2b2 = 81/64, a2+b2 = 45/16)
+//              (d4 - b2 d2) +- a (d3 - b2 d1)           (b2 = 9/4)
+//              (d4 - a2 d2) +- b (d3 - a2 d1)           (a2 = 9/16)
+//              [0, a2b2, 0, -(a2+b2), 0, 1]
+//   A^T rows:  [1, 1, 1, 1, 1, 0], [0, a, -a, b, -b, 0], [0, a2, a2, b2, b2, 0], [0, a3, -a3, b3, -b3, 1]
+//   G rows  :  [64/81, 0, 0], [-128/243, -+32/81, -8/27], [32/243, +-16/81, 8/27], [0, 0, 1]      (U = G g G^T in fp64, rounded once)
+//
+// Geometry: a workgroup (12 waves) owns 64 output channels x 32 tiles (16 rows x 32 columns of one image); wave w owns the three
+// Winograd positions 3 w .. 3 w + 2 (position = 6 xi + nu) with 4 x 2 MFMA blocks each: 96 accumulator registers, one workgroup per CU
+// (the 36 accumulators per output are 295 KB: more than half of the CU's register file).
+//   U4 [co tile][chunk][wave 12][p 3][lane 64][mb 4]     lane = (kq, lr): ci = 4 chunk + kq, co = 64 tile + 16 mb + lr
+//   V  [image][pixel tile][chunk][wave 12]{[lane 64][p 0..1][nb 2], [lane 64][p = 2][nb 2]}     tile = 16 nb + lr -> (ty, tx) = (tile / 8, tile % 8)
+// Every wave-wide load instruction reads ONE contiguous run (1 KiB / 512 B): with the lane's operands of a k-step back to back
+// ([lane][p][mb]: 48-byte lane stride) an instruction touched three times the cache lines it used and the GEMM ran at 60 % pipe busy.
+// Epilogue: four passes (one 16-channel block each), the 36 position planes meet in LDS, one thread per (channel, tile) applies
+// A^T . A and the fused operand chain of the other conv kernels, 16-byte stores.
+#include "conv_kernel.h"
+
+namespace vspconv {
+
+namespace {
+
+constexpr float W4_A = 0.75f, W4_B = 1.5f, W4_A2 = 0.5625f, W4_B2 = 2.25f, W4_A2B2 = 1.265625f, W4_SUM2 = 2.8125f;
+constexpr float W4_A3 = 0.421875f, W4_B3 = 3.375f;
+constexpr int W4_TLX = 8, W4_TLY = 4;          // tiles of 4 x 4 outputs per workgroup: 32 columns x 16 rows
+constexpr int W4_NT = W4_TLX * W4_TLY;         // 32 tiles
+constexpr int W4_THR = 768;
+
+// ------------------------------------------------------------------------------------------------------------ weights: U = G g G^T
+// one wavefront per (co tile, chunk): lane = (kq, lr) -> ci = 4 chunk + kq, co = 64 tile + 16 mb + lr; fp64 sums rounded once
+__global__ __launch_bounds__(256) void wino4_weight_kernel(float* __restrict__ U, const float* __restrict__ wp, int cin, int cout, int nct, int nch,
+                                                          int64_t units) {
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int lane = threadIdx.x & 63, kq = lane >> 4, lr = lane & 15;
+  const int ch = (int)(unit % nch);
+  const int t = (int)(unit / nch);
+  const int ci = 4 * ch + kq;
+  const double Gm[6][3] = {{64.0 / 81.0, 0.0, 0.0},           {-128.0 / 243.0, -32.0 / 81.0, -8.0 / 27.0}, {-128.0 / 243.0, 32.0 / 81.0, -8.0 / 27.0},
+                           {32.0 / 243.0, 16.0 / 81.0, 8.0 / 27.0}, {32.0 / 243.0, -16.0 / 81.0, 8.0 / 27.0},  {0.0, 0.0, 1.0}};
+  float* dst = U + unit * (int64_t)(12 * 64 * 12) + (int64_t)lane * 4;
+  for (int mb = 0; mb < 4; ++mb) {
+    const int co = 64 * t + 16 * mb + lr;
+    const bool in = ci < cin && co < cout;
+    double gk[3][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) gk[tap / 3][tap % 3] = in ? (double)wp[((int64_t)tap * cin + ci) * cout + co] : 0.0;
+    double r[6][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int x = 0; x < 3; ++x) r[i][x] = Gm[i][0] * gk[0][x] + Gm[i][1] * gk[1][x] + Gm[i][2] * gk[2][x];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const double u = r[i][0] * Gm[j][0] + r[i][1] * Gm[j][1] + r[i][2] * Gm[j][2];
+        const int pos = 6 * i + j;
+        dst[(int64_t)(pos / 3) * (64 * 12) + (pos % 3) * 256 + mb] = (float)u;
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------- input transform: V = B^T d B
+__device__ __forceinline__ void w4_bt(const float (&d)[6], float (&o)[6]) {   // one 6-vector through B^T
+  const float e1 = fmaf(-W4_B2, d[2], d[4]), o1 = fmaf(-W4_B2, d[1], d[3]);
+  const float e2 = fmaf(-W4_A2, d[2], d[4]), o2 = fmaf(-W4_A2, d[1], d[3]);
+  o[0] = fmaf(W4_A2B2, d[0], fmaf(-W4_SUM2, d[2], d[4]));
+  o[1] = fmaf(W4_A, o1, e1);
+  o[2] = fmaf(-W4_A, o1, e1);
+  o[3] = fmaf(W4_B, o2, e2);
+  o[4] = fmaf(-W4_B, o2, e2);
+  o[5] = fmaf(W4_A2B2, d[1], fmaf(-W4_SUM2, d[3], d[5]));
+}
+
+// One workgroup (4 waves) per (image, pixel tile, 16 input channels).  The 18 x 40 patch of every channel (rows oy0 - 1 .. oy0 + 16,
+// columns ox0 - 4 .. ox0 + 35: whole 16-byte segments, inside the image or outside as a whole since W % 4 == 0) goes through LDS as
+// coalesced 16-byte loads -- the first version gathered each lane's 2 x 36 window words straight from global memory, 72 strided
+// loads per lane: the texture-address path, not HBM, set its time.  Wave w then owns chunk 4 cg + w: lane = (kq, lr) transforms the
+// windows of tiles lr and lr + 16 of channel 4 chunk + kq and writes its 2 x 36 values as the GEMM's fragment runs.
+constexpr int W4_PROW = 4 * W4_TLY + 2, W4_PCOL = 4 * W4_TLX + 8;      // 18 rows x 40 columns
+constexpr int W4_PSEG = W4_PCOL / 4;                                    // 10 segments per row
+constexpr int W4_PCH = W4_PROW * W4_PCOL + 16;                          // channel pitch: 736 words (== 32 mod 64: the four channels of a wave spread over the banks)
+__global__ __launch_bounds__(256) void wino4_input_kernel(float* __restrict__ V, const float* __restrict__ x, const float* __restrict__ scale,
+                                                         int scale_bs, int B, int Cin, int x_ch, int H, int W, int tiles_x, int tiles_y,
+                                                         int nch) {
+  __shared__ __attribute__((aligned(16))) float patch[16 * W4_PCH];
+  const int ncg = (nch + 3) / 4;
+  const int cg = blockIdx.x % ncg;
+  const int pt = (blockIdx.x / ncg) % (tiles_x * tiles_y);
+  const int b = blockIdx.x / (ncg * tiles_x * tiles_y);
+  const int ty_i = pt / tiles_x, tx_i = pt - ty_i * tiles_x;
+  const int oy0 = ty_i * (4 * W4_TLY), ox0 = tx_i * (4 * W4_TLX);
+  const int tid = threadIdx.x;
+  {
+    constexpr int NSEG = 16 * W4_PROW * W4_PSEG;          // 2880 segments
+    constexpr int NLD = (NSEG + 255) / 256;
+    float4 val[NLD];
+    float sc[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (W4_PROW * W4_PSEG), rem = e - ch * (W4_PROW * W4_PSEG);
+      const int r = rem / W4_PSEG, sg = rem - r * W4_PSEG;
+      const int ci = 16 * cg + ch;
+      const int iy = oy0 - 1 + r, ix = ox0 - 4 + 4 * sg;
+      const bool ok = e < NSEG && ci < Cin && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int cc = ci < Cin ? ci : Cin - 1;
+      // (clamped address, zero factor: no load behind a divergent branch)
+      const float* src = x + (((int64_t)b * x_ch + cc) * H + (ok ? iy : 0)) * W + (ok ? ix : 0);
+      val[i] = *reinterpret_cast<const float4*>(src);
+      sc[i] = ok ? (scale ? scale[(int64_t)b * scale_bs + cc] : 1.f) : 0.f;
+      dst[i] = e < NSEG ? ch * W4_PCH + r * W4_PCOL + 4 * sg : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if (dst[i] >= 0) *reinterpret_cast<float4*>(patch + dst[i]) = make_float4(val[i].x * sc[i], val[i].y * sc[i], val[i].z * sc[i], val[i].w * sc[i]);
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = 4 * cg + wave;
+  if (chunk >= nch) return;
+  const int lane = tid & 63, kq = lane >> 4, lr = lane & 15;
+  float v[2][36];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int tile = 16 * nb + lr, ty = tile / W4_TLX, tx = tile - ty * W4_TLX;
+    // window rows 4 ty .. 4 ty + 5, columns 4 tx + 3 .. 4 tx + 8 of the patch: [3] of one aligned segment, the next segment, [0] of the third
+    const float* wp = patch + (4 * wave + kq) * W4_PCH + (4 * ty) * W4_PCOL + 4 * tx;
+    float d[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const float4 s1 = *reinterpret_cast<const float4*>(wp + r * W4_PCOL + 4);
+      d[r][0] = wp[r * W4_PCOL + 3];
+      d[r][1] = s1.x; d[r][2] = s1.y; d[r][3] = s1.z; d[r][4] = s1.w;
+      d[r][5] = wp[r * W4_PCOL + 8];
+    }
+    // columns first (B^T d), then rows ((B^T d) B)
+    float t[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float col[6] = {d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]};
+      float o[6];
+      w4_bt(col, o);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t[r][c] = o[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float o[6];
+      w4_bt(t[r], o);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) v[nb][6 * r + c] = o[c];
+    }
+  }
+  const int64_t unit = ((int64_t)b * tiles_x * tiles_y + pt) * nch + chunk;
+  float* dst = V + unit * (int64_t)(12 * 64 * 6);
+#pragma unroll
+  for (int wv = 0; wv < 12; ++wv) {
+    const float4 o01 = make_float4(v[0][3 * wv], v[1][3 * wv], v[0][3 * wv + 1], v[1][3 * wv + 1]);
+    const float2 o2 = make_float2(v[0][3 * wv + 2], v[1][3 * wv + 2]);
+    *reinterpret_cast<float4*>(dst + (int64_t)wv * (64 * 6) + lane * 4) = o01;
+    *reinterpret_cast<float2*>(dst + (int64_t)wv * (64 * 6) + 256 + lane * 2) = o2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ GEMM + epilogue
+constexpr int W4_EP = W4_NT + 4;                  // epilogue row pitch (the two 16-tile halves of a store group land 16 banks apart)
+constexpr int W4_LDS = 36 * 16 * W4_EP;           // floats: one 16-channel block, all 36 positions
+
+struct W4Regs {      // the operands of one k-step of one wave: U [p][mb], V [p][nb]
+  float4 u[3];
+  float4 v01;        // p0.nb0, p0.nb1, p1.nb0, p1.nb1
+  float2 v2;         // p2.nb0, p2.nb1
+};
+
+__global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, const float* __restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, kq = lane >> 4;
+  // XCD-aware work order: every XCD walks a contiguous range of (image, pixel tile, channel tile), channel tiles of one pixel tile adjacent
+  // (they stream the same V slice out of one L2)
+  const int GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z, GT = GX * GY * GZ;
+  const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
+  const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+  const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+  const int GN = GX * GY;
+  const int b = lid / GN;
+  const int lrem = lid - b * GN;
+  // GX = pixel tiles per image, GY = channel tiles.  The 32 workgroups an XCD runs at a time stream U slices (64 co x Cin x 36: 4.7 MB at
+  // 512 channels) and V slices (32 tiles x Cin x 36: 2.4 MB) through its 4 MB L2: 8 pixel tiles x 4 channel tiles fill it with
+  // 4 U + 8 V = 38 MB per pass, 4 x 8 with 47 MB -> channel tiles go in groups of CG = 4 inside a pixel tile
+  const int CG = (GY % 4 == 0 && !(p.dbg & 64)) ? 4 : GY;
+  const int cgrp = lrem / (GX * CG), l2 = lrem - cgrp * (GX * CG);
+  const int pt = l2 / CG, ct = cgrp * CG + (l2 - pt * CG);
+  const int nch = (p.Cin + 3) / 4;
+
+  const float* up = p.w + ((int64_t)ct * nch * 12 + wave) * (64 * 12) + lane * 4;
+  const float* vp = V + (((int64_t)b * GX + pt) * nch * 12 + wave) * (64 * 6);
+  constexpr int USTEP = 12 * 64 * 12, VSTEP = 12 * 64 * 6;   // floats per chunk
+#ifdef VSP_WINO_ABLATE   // tuning only (VSP_CONV_DBG): 1 operands always from chunk 0, 2 no epilogue, 4 no loads in the main loop, 8 no MFMAs
+  const int ab = p.dbg;
+#else
+  constexpr int ab = 0;
+#endif
+  auto load = [&](int c, W4Regs& r) {
+    if ((ab & 4) && c >= 3) return;
+    const int cc = (ab & 1) ? 0 : (c < nch ? c : nch - 1);
+    const float* us = up + (int64_t)cc * USTEP;
+    const float* vs = vp + (int64_t)cc * VSTEP;
+    r.u[0] = *reinterpret_cast<const float4*>(us);
+    r.u[1] = *reinterpret_cast<const float4*>(us + 256);
+    r.u[2] = *reinterpret_cast<const float4*>(us + 512);
+    r.v01 = *reinterpret_cast<const float4*>(vs + lane * 4);
+    r.v2 = *reinterpret_cast<const float2*>(vs + 256 + lane * 2);
+  };
+
+  f32x4 acc[3][4][2];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) acc[q][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one k-step: the 8 MFMAs of position q read u[q] and the B pair of q; the register that was read LAST by a group is re-loaded (for
+  // k-step c + 3) right behind that group -- at most two loads per issue point.  (All five behind the 24 MFMAs: the twelve waves of
+  // the CU queue 60 wave-wide loads at once and every wave waits at its first one while the matrix pipe drains: 403 -> see DESIGN.)
+  constexpr int SB = 0x2 | 0x4 | 0x80 | 0x100 | 0x200;   // VALU, SALU and LDS operations may cross; MFMAs and vector-memory instructions may not
+  auto kstep = [&](int cn, W4Regs& r) {     // cn = the k-step the registers are re-loaded for (clamped)
+    const bool ld = !((ab & 4) && cn >= 3);
+    const int cc = (ab & 1) ? 0 : (cn < nch ? cn : nch - 1);
+    const float* us = up + (int64_t)cc * USTEP;
+    const float* vs = vp + (int64_t)cc * VSTEP;
+    const float bv[3][2] = {{r.v01.x, r.v01.y}, {r.v01.z, r.v01.w}, {r.v2.x, r.v2.y}};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float av[4] = {r.u[q].x, r.u[q].y, r.u[q].z, r.u[q].w};
+      if (!(ab & 8)) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[q][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb], bv[q][nb], acc[q][mb][nb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(SB);
+      if (ld) {
+        r.u[q] = *reinterpret_cast<const float4*>(us + 256 * q);
+        if (q == 1) r.v01 = *reinterpret_cast<const float4*>(vs + lane * 4);
+        if (q == 2) r.v2 = *reinterpret_cast<const float2*>(vs + 256 + lane * 2);
+      }
+      __builtin_amdgcn_sched_barrier(SB);
+    }
+  };
+
+  // ---- main loop: three register sets
+  W4Regs r0, r1, r2;
+  load(0, r0);
+  load(1, r1);
+  load(2, r2);
+  int c = 0;
+  for (; c + 3 <= nch; c += 3) {
+    kstep(c + 3, r0);
+    kstep(c + 4, r1);
+    kstep(c + 5, r2);
+  }
+  if (c < nch) kstep(nch, r0);
+  if (c + 1 < nch) kstep(nch, r1);
+
+  if (ab & 2) {
+    if (acc[0][0][0][0] == 123.456f) p.y[0] = 1.f;
+    return;
+  }
+  // ---- epilogue: per 16-channel block the 36 position planes through LDS; threads 0 .. 511 = (channel, tile)
+  float* Ml = smem;   // [36][16][W4_EP]
+  const int Cout = p.cout_g;
+  const float* osp = p.osp + (int64_t)b * Cout * p.oss;
+  const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW * p.nzs;
+  const float nw = p.nwp[0];
+  float* yb = p.y + ((int64_t)b * p.y_ch + p.y_coff) * p.y_h * p.y_w;
+  const float* r1b = p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r1s;
+  const float* r2b = p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * p.y_h * p.y_w * p.r2s;
+  const int y_plane = p.y_h * p.y_w;
+  const int tiles_x = (p.W + 4 * W4_TLX - 1) / (4 * W4_TLX);
+  const int ty_i = pt / tiles_x, tx_i = pt - ty_i * tiles_x;
+  const int e_co = tid >> 5, e_t = tid & 31;                      // (threads >= 512: e_co >= 16, no work in the read phase)
+  const int oy = (ty_i * W4_TLY + e_t / W4_TLX) * 4, ox = (tx_i * W4_TLX + e_t % W4_TLX) * 4;
+  typedef float f32x4u __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) {
+    if (mb > 0) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ml[((3 * wave + q) * 16 + kq * 4 + r) * W4_EP + nb * 16 + lr] = acc[q][mb][nb][r];
+    __syncthreads();
+    if (e_co < 16) {
+      float m[36];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) m[q] = Ml[(q * 16 + e_co) * W4_EP + e_t];
+      // Y = A^T M A: rows (xi) first, then columns (nu)
+      float z[4][6];
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) {
+        const float s1 = m[6 + nu] + m[12 + nu], d1 = m[6 + nu] - m[12 + nu];
+        const float s2 = m[18 + nu] + m[24 + nu], d2 = m[18 + nu] - m[24 + nu];
+        z[0][nu] = m[nu] + s1 + s2;
+        z[1][nu] = fmaf(W4_B, d2, W4_A * d1);
+        z[2][nu] = fmaf(W4_B2, s2, W4_A2 * s1);
+        z[3][nu] = fmaf(W4_B3, d2, fmaf(W4_A3, d1, m[30 + nu]));
+      }
+      float yv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s1 = z[i][1] + z[i][2], d1 = z[i][1] - z[i][2];
+        const float s2 = z[i][3] + z[i][4], d2 = z[i][3] - z[i][4];
+        yv[i][0] = z[i][0] + s1 + s2;
+        yv[i][1] = fmaf(W4_B, d2, W4_A * d1);
+        yv[i][2] = fmaf(W4_B2, s2, W4_A2 * s1);
+        yv[i][3] = fmaf(W4_B3, d2, fmaf(W4_A3, d1, z[i][5]));
+      }
+      const int cgi = ct * 64 + mb * 16 + e_co;
+      const bool cok = cgi < Cout;
+      const int cg = cok ? cgi : Cout - 1;
+      const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
+      const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
+      auto fin = [&](float v, float nz, float r1v, float r2v) {
+        v = v * os * cs + cb + b1;
+        v = (v > 0.f ? v : v * p.s1) * p.g1;
+        v += nz * nw + b2;
+        v = (v > 0.f ? v : v * sl2) * p.g2;
+        return v + r1v + r2v;
+      };
+      // (W % 4 == 0 and 16-byte aligned planes, checked by the launcher: a tile's row of four pixels is one aligned vector, inside the
+      //  image or outside as a whole; coordinates are clamped for the operand loads, only the store is predicated)
+      const bool colok = ox < p.OW;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oyi = oy + i;
+        const bool inside = cok && colok && oyi < p.OH;
+        const int oyc = min(oyi, p.OH - 1), oxc = min(ox, p.OW - 4);
+        const int ro = cg * y_plane + oyc * p.y_w + oxc;
+        f32x4u nz = {0.f, 0.f, 0.f, 0.f}, r1v = {0.f, 0.f, 0.f, 0.f}, r2v = {0.f, 0.f, 0.f, 0.f};
+        if (p.nzs) nz = *reinterpret_cast<const f32x4u*>(nzp + oyc * p.OW + oxc);
+        if (p.r1s) r1v = *reinterpret_cast<const f32x4u*>(r1b + ro);
+        if (p.r2s) r2v = *reinterpret_cast<const f32x4u*>(r2b + ro);
+        const f32x4u o4 = {fin(yv[i][0], nz[0], r1v[0], r2v[0]), fin(yv[i][1], nz[1], r1v[1], r2v[1]), fin(yv[i][2], nz[2], r1v[2], r2v[2]),
+                           fin(yv[i][3], nz[3], r1v[3], r2v[3])};
+        if (inside) *reinterpret_cast<f32x4u*>(yb + ro) = o4;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// layers the F(4x4) pair serves: one group, dilation 1, no affine input shift, whole 4 x 4 tiles and 16-byte rows, dense output, deep enough
+bool wino4_eligible(const ConvK& q) {
+  if (q.G != 1 || q.dil[0] != 1 || q.Cin % 4 != 0) return false;
+  if (q.H % 4 != 0 || q.W % 4 != 0 || q.W < 16 || q.H < 8) return false;
+  if (q.y_w != q.OW || q.y_h != q.OH) return false;
+  if (reinterpret_cast<uintptr_t>(q.x) & 15) return false;
+  if ((reinterpret_cast<uintptr_t>(q.y) & 15) || (q.r1s > 1) || (q.r2s > 1) || (q.nzs > 1)) return false;
+  if ((q.r1s && (reinterpret_cast<uintptr_t>(q.r1p) & 15)) || (q.r2s && (reinterpret_cast<uintptr_t>(q.r2p) & 15)) ||
+      (q.nzs && (reinterpret_cast<uintptr_t>(q.nzp) & 15)))
+    return false;
+  return true;
+}
+
+size_t wino4_weight_floats(int cin, int cout) {
+  const int64_t nch = (cin + 3) / 4, nct = (cout + 63) / 64;
+  return (size_t)(nct * nch * 12 * 64 * 12);
+}
+
+size_t wino4_work_floats(int B, int cin, int H, int W) {
+  const int64_t nch = (cin + 3) / 4;
+  const int64_t tiles_x = (W + 4 * W4_TLX - 1) / (4 * W4_TLX), tiles_y = (H + 4 * W4_TLY - 1) / (4 * W4_TLY);
+  return (size_t)(B * tiles_x * tiles_y * nch * 12 * 64 * 6);
+}
+
+int wino4_weight_launch(float* U, const float* wp, int cin, int cout, hipStream_t stream) {
+  const int nch = (cin + 3) / 4, nct = (cout + 63) / 64;
+  const int64_t units = (int64_t)nct * nch;
+  wino4_weight_kernel<<<(unsigned)((units + 3) / 4), 256, 0, stream>>>(U, wp, cin, cout, nct, nch, units);
+  return VSP_OK;
+}
+
+// q.w = U4 (wino4_weight_launch); V = work buffer of wino4_work_floats floats; scale = per-(image, input channel) factor or null
+int wino4_launch(ConvK q, float* V, const float* scale, int scale_bs, hipStream_t stream) {
+  const int nch = (q.Cin + 3) / 4;
+  const int tiles_x = (q.W + 4 * W4_TLX - 1) / (4 * W4_TLX), tiles_y = (q.H + 4 * W4_TLY - 1) / (4 * W4_TLY);
+  const int64_t wgs = (int64_t)q.B * tiles_x * tiles_y * ((nch + 3) / 4);
+  if (!(q.dbg & 32))   // (tuning: VSP_CONV_DBG 32 = GEMM only, 16 = input transform only)
+    wino4_input_kernel<<<(unsigned)wgs, 256, 0, stream>>>(V, q.x, scale, scale_bs, q.B, q.Cin, q.x_ch, q.H, q.W, tiles_x, tiles_y, nch);
+  if (q.dbg & 16) return VSP_OK;
+  static vsp::LdsAttrOnce attr;
+  const size_t lds = (size_t)W4_LDS * sizeof(float);
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(wino4_gemm_kernel), (int)lds, "conv2d_winograd4")) return rc;
+  dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)((q.cout_g + 63) / 64), (unsigned)q.B);
+  wino4_gemm_kernel<<<grid, W4_THR, lds, stream>>>(q, V);
+  return VSP_OK;
+}
+
+}  // namespace vspconv

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void pack_weight_adjoint_kernel(float* __restr
 }
 
 // One wavefront per (group, co tile, chunk): lane = (kq, lr) holds input channel 4 chunk + kq and, for each of the MB 16-channel
-// blocks, output channel 16 MB tile + 16 mb + lr; it writes [wave 8][lane][pp 2][mb MB], position = 2 wave + pp = 4 a + b.
+// blocks, output channel 16 MB tile + 16 mb + lr; it writes [wave 8][pp 2][lane][mb MB], position = 2 wave + pp = 4 a + b.
 template <int MB>
 __global__ __launch_bounds__(256) void winograd_weight_kernel(float* __restrict__ U, const float* __restrict__ wp, int cin, int cout_g,
                                                               int nct, int nch, int64_t units) {
@@ -94,13 +94,15 @@ __global__ __launch_bounds__(256) void winograd_weight_kernel(float* __restrict_
       u[mb][4 * a + 3] = r[a][2];
     }
   }
-  float* dst = U + unit * (int64_t)(1024 * MB) + (int64_t)lane * 2 * MB;
+  // [wave 8][pp 2][lane 64][mb MB]: a wave's A fragments of one position are ONE contiguous run (a 16-byte load per lane = 1 KiB of
+  // consecutive memory; with [lane][pp][mb] each wave-wide load touched twice the cache lines it used)
+  float* dst = U + unit * (int64_t)(1024 * MB) + (int64_t)lane * MB;
 #pragma unroll
   for (int wv = 0; wv < 8; ++wv)
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) dst[(int64_t)wv * 128 * MB + pp * MB + mb] = (float)u[mb][2 * wv + pp];
+      for (int mb = 0; mb < MB; ++mb) dst[(int64_t)(wv * 2 + pp) * 64 * MB + mb] = (float)u[mb][2 * wv + pp];
 }
 
 }  // namespace
