@@ -16,6 +16,7 @@
 #include "vsp_common.h"
 #include "vsp_bf16.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -60,10 +61,7 @@ constexpr int TOW = VSP_FIR_TOW;          // output tile cols
 #define VSP_FIR_RPT 2
 #endif
 constexpr int RPT = VSP_FIR_RPT;          // output rows per thread (x 4 columns)
-#ifndef VSP_FIR_NTB
-#define VSP_FIR_NTB 1
-#endif
-constexpr int NTB = VSP_FIR_NTB;          // tiles per block
+// tiles per block: template argument of the kernel (1 ships; see the launcher)
 constexpr int TOH = RPT * (256 / (TOW / 4)); // output tile rows
 
 // 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
@@ -76,7 +74,7 @@ using vsp::f32x4u;
 // 16-byte stores.
 // T = float or vsp::bf16_t: element type of x, out and the two residuals (arithmetic is fp32 either way; bf16: 2 B read + 2 B
 // written per output element, four elements per 8-byte access at halfword alignment).
-template <int KH, int KW, typename T>
+template <int KH, int KW, typename T, int NTB>
 __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, const T* __restrict__ x,
                                                         const float* __restrict__ kern, int in_h, int in_w,
                                                         int out_h, int out_w, int pad_x0, int pad_y0, int tiles_x,
@@ -326,15 +324,22 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
     VSP_REQUIRE(blocks < ((int64_t)1 << 31), "upfirdn2d: grid too large");
-    if (kh == 4)
-      fir_tile_kernel<4, 4, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
-    else if (kh == 3)
-      fir_tile_kernel<3, 3, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
-    else
-      fir_tile_kernel<2, 2, T><<<(unsigned)((blocks + NTB - 1) / NTB), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0,
-                                                                            pad_y0, tiles_x, tiles_y, (int)blocks, e);
+    // One tile per block.  Two (both windows requested up front; VSP_FIR_NTB = 2, tuning) measured SLOWER on bf16 planes too (round 4:
+    // 32 ch at 1024^2, B = 16: 2.50 -> 2.24 TB/s, C3 402 -> 391 img/s): half the bytes per tile is not what holds the bf16 blur at
+    // 2.3-2.9 TB/s -- its 8-byte window loads sit at halfword alignment on the (2H+1)-wide rows.
+    static const int ntb_env = getenv("VSP_FIR_NTB") ? atoi(getenv("VSP_FIR_NTB")) : 0;
+    const int ntb = ntb_env == 2 ? 2 : 1;
+#define VSP_FIR_LAUNCH(KH_, NTB_)                                                                                                     \
+  fir_tile_kernel<KH_, KH_, T, NTB_><<<(unsigned)((blocks + NTB_ - 1) / NTB_), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, \
+                                                                                         pad_x0, pad_y0, tiles_x, tiles_y, (int)blocks, e)
+    if (kh == 4) {
+      if (ntb == 2) VSP_FIR_LAUNCH(4, 2); else VSP_FIR_LAUNCH(4, 1);
+    } else if (kh == 3) {
+      VSP_FIR_LAUNCH(3, 1);
+    } else {
+      VSP_FIR_LAUNCH(2, 1);
+    }
+#undef VSP_FIR_LAUNCH
     return vsp::check_launch("upfirdn2d(tile)");
   }
   if constexpr (BF) {
