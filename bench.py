@@ -96,6 +96,7 @@ def train_bench(args, world, rank, dev):
     hip_ops.PROFILER = None
     sync()
     fl, conv_ms, n_launch = prof.summary()
+    ex_fl = prof.executed_flops()      # what the matrix pipe ran: Winograd launches at 16/36 (F(2x2)) or 36/144 (F(4x4)) of their algorithmic count
     # The R1 pass (a double backward through D) runs on every d_reg_every-th iteration: the timed region starts right after a
     # multiple of it, so that K timed iterations contain exactly floor(K / d_reg_every) of them -- one in sixteen with the default
     # K = 16 of this preset, as in the schedule being priced; the count is stated in the line.
@@ -125,6 +126,7 @@ def train_bench(args, world, rank, dev):
                    "note": "the timed region starts right after a multiple of d_reg_every; K a multiple of it prices the schedule exactly"},
             "roofline": {"bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(fl / conv_ms / 1e9 / 157.3, 3), "traffic": None,
+                         "executed_tflops": round(ex_fl / conv_ms / 1e9, 1), "executed_frac": round(ex_fl / conv_ms / 1e9 / 157.3, 3),
                          "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks); "
                                    "EFFECTIVE rate: algorithmic direct-conv FLOPs of every launch (Winograd launches execute 16/36 of theirs) / kernel time",
                          "launches": n_launch, "kernel_ms": round(conv_ms, 1),
@@ -216,6 +218,13 @@ def cpu_baseline(T, threads, sample_steps=2):
             r = json.load(f)
         ref = {"what": r["what"], "threads": r["threads"],
                "B4_T10_img_per_s": r.get("c1", {}).get("img_per_s"), "B1_T50_img_per_s": r.get("b1t50", {}).get("img_per_s")}
+    ref4_path = os.path.join(ROOT, "profiles", "r04_reference_cpu_timing.json")
+    if os.path.exists(ref4_path):  # round 4: the reference at the configuration the metric is quoted on (BASELINE configs[1]: B = 8, T = 50)
+        with open(ref4_path) as f:
+            r4 = json.load(f)
+        ref = dict(ref or {"what": r4["what"], "threads": r4["threads"]})
+        ref["C2_B8_T50_img_per_s"] = r4.get("c2", {}).get("img_per_s")
+        ref["C2_B8_T50_s_per_batch"] = r4.get("c2", {}).get("s_per_batch")
     return {"value": round(1.0 / total, 5), "unit": "img/s", "cores": threads, "kind": "port",
             "sample": f"1 image 512x512: stages A, C (to 1024^2), D in full + {sample_steps} of {T} DDPM steps ({measured:.1f} s "
                       f"measured), chain extrapolated linearly to T={T} -> {total:.1f} s/image",
