@@ -429,19 +429,9 @@ typedef struct vsp_tacc_chain_params {
 
 size_t vsp_tacc_chain_work_floats(int B);
 int vsp_tacc_chain_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
-/* The same chain as ONE persistent launch per 64 steps (tacc_persist.hip): a cluster of 16 workgroups owns an image for the whole
- * loop (reference ldm/ddpm.py:421-429 x models/CodeDiffuser.py:86-116,133-140), two cluster barriers per block instead of three
- * launch boundaries.  Same parameter block and results as vsp_tacc_chain_f32 (summation orders are identical); `work` must hold
- * vsp_tacc_chain_persistent_work_floats(B) floats.  B <= 16 and n_blocks <= 4 (one 512-thread workgroup per CU must be resident
- * for every (image, slice) pair): VSP_ENOTSUP otherwise -- callers fall back to vsp_tacc_chain_f32. */
-size_t vsp_tacc_chain_persistent_work_floats(int B);
-int vsp_tacc_chain_persistent_f32(const vsp_tacc_chain_params* p, vsp_stream_t stream);
-/* ... with `cluster` = 1, 2, 4, 8 or 16 workgroups per image (vsp_tacc_chain_persistent_f32 = 16, the latency form).  Small clusters are
- * the THROUGHPUT forms: in a batch loop that hides the chain under the previous batch's convolutions (restoration_test.py's
- * `for batch in loader`, vspbfr_amd/pipeline.py run_batches) the chain costs the CU-time it holds, not its latency -- cluster 4 runs the
- * same arithmetic in the same order (bit-identical results) on 4 B CUs for ~2x the wall time of the launched chain.  B * cluster <= 256
- * and B <= 32: VSP_ENOTSUP otherwise. */
-int vsp_tacc_chain_cluster_f32(const vsp_tacc_chain_params* p, int cluster, vsp_stream_t stream);
+/* (A persistent single-launch form of this chain -- clusters of 1 ... 16 workgroups per image, two cluster barriers per block --
+ * was built and parity-tested in round 3 and measured SLOWER than the three launches per block (46 vs 27.5 us per block at batch 8):
+ * retired to the branch `experiments/persistent-chain` in round 4; DESIGN section 4 keeps the accounting.) */
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 activations in HBM (BASELINE configs[2] "bf16 kernels"; the fp32 path above is the parity path).  A bf16 tensor is

@@ -84,31 +84,18 @@ def test_diffuser_ddpm_golden(golden, name):
         got, _ = net.chain_step(dev(x), H.pixelnorm_dim1(dev(x)), state, i, ddpm.posterior_mean_coef1,
                                 ddpm.posterior_mean_coef2)                                  # per-launch fused kernels
         assert maxerr(got, nxt) < 2e-4, i
-        for pers in (False, True):   # the C chain entries (sampler path): three launches per block / one persistent launch
-            got = H.tacc_chain(dev(x).clone(), state, [i], c1=ddpm.posterior_mean_coef1, c2=ddpm.posterior_mean_coef2,
-                               t_div=T, persistent=pers)
-            assert maxerr(got, nxt) < 2e-4, (i, pers)
+        got = H.tacc_chain(dev(x).clone(), state, [i], c1=ddpm.posterior_mean_coef1, c2=ddpm.posterior_mean_coef2, t_div=T)   # the C chain entry (sampler path)
+        assert maxerr(got, nxt) < 2e-4, i
         x = nxt
-    for pers in (False, True):
-        x0 = H.tacc_chain(dev(x_T).clone(), state, [T - 1], t_div=T, persistent=pers)        # no mixing: plain denoiser call
-        assert maxerr(x0, g[name + "/x0_first"]) < 2e-4, pers
-        with pytest.raises(RuntimeError):
-            H.tacc_chain(dev(x_T).clone(), state, [T], t_div=T, persistent=pers)             # step outside the prepared heads
-    # the whole chain behind each entry: same arithmetic in the same order -> the same bits; repeated runs of the persistent kernel
-    # (its cross-workgroup exchange is the only new thing) must not differ either
+    x0 = H.tacc_chain(dev(x_T).clone(), state, [T - 1], t_div=T)        # no mixing: plain denoiser call
+    assert maxerr(x0, g[name + "/x0_first"]) < 2e-4
+    with pytest.raises(RuntimeError):
+        H.tacc_chain(dev(x_T).clone(), state, [T], t_div=T)             # step outside the prepared heads
+    # the whole chain behind the entry is deterministic: repeated runs give the same bits
     steps = list(reversed(range(T)))
     kw = dict(c1=ddpm.posterior_mean_coef1, c2=ddpm.posterior_mean_coef2, t_div=T)
-    launched = H.tacc_chain(dev(x_T).clone(), state, steps, persistent=False, **kw)
-    for rep in range(3):
-        pers = H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, **kw)
-        assert torch.isfinite(pers).all()
-        assert maxerr(pers, launched.cpu().numpy()) < 1e-5, rep
-    for cluster in (8, 4, 2, 1):   # the throughput forms: fewer, fatter workgroups, the same arithmetic in the same order
-        pers = H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=cluster, **kw)
-        assert torch.equal(pers, H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=16, **kw)), cluster
-        assert maxerr(pers, launched.cpu().numpy()) < 1e-5, cluster
-    with pytest.raises(RuntimeError):
-        H.tacc_chain(dev(x_T).clone(), state, steps, persistent=True, cluster=3, **kw)
+    launched = H.tacc_chain(dev(x_T).clone(), state, steps, **kw)
+    assert torch.equal(launched, H.tacc_chain(dev(x_T).clone(), state, steps, **kw))
     # free-running chain (the sampler's own call)
     final = ddpm(x=dev(cond), condi_in=dev(cond), training=False, x_T=dev(x_T))
     sd64 = {k: v.double() for k, v in sd.items()}

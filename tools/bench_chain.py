@@ -10,20 +10,14 @@ torch.manual_seed(0)
 net = Code_diffuser(timesteps=T).to(dev).eval()
 ddpm = My_DDPM(denoise=net, linear_start=0.1, linear_end=0.99, timesteps=T).to(dev)
 cond = torch.randn(B, 18, 512, device=dev)
-from vspbfr_amd import hip_ops as H
-for pers, cluster in ((False, 16), (True, 16), (True, 8), (True, 4), (True, 2), (True, 1)):   # three launches per block / one persistent launch, G workgroups per image
-    H.TACC_PERSISTENT, H.TACC_CLUSTER = pers, cluster
-    for _ in range(2):
-        ddpm(x=cond, condi_in=cond, training=False)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    N = 5
-    for _ in range(N):
-        ddpm(x=cond, condi_in=cond, training=False)
-    e.record(); torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / N
-    cus = 256 if not pers else B * cluster
-    print(f"chain B={B} T={T} {('persistent, cluster %2d' % cluster) if pers else 'launched              '}: {ms:.3f} ms  "
-          f"({ms * 1000 / (4 * T):.1f} us per TACC block incl. prepare; {B * cluster if pers else '<= 256'} CUs"
-          + (f", {cus * ms / 256:.2f} ms of the whole chip" if pers else "") + ")")
+for _ in range(2):
+    ddpm(x=cond, condi_in=cond, training=False)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+N = 5
+for _ in range(N):
+    ddpm(x=cond, condi_in=cond, training=False)
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / N
+print(f"chain B={B} T={T} (three launches per TACC block): {ms:.3f} ms  ({ms * 1000 / (4 * T):.1f} us per TACC block incl. prepare)")

@@ -1,5 +1,5 @@
 """What the sampler chain costs the batch loop: stages C + D of one batch on the caller's stream, alone and with ONLY the chain of the
-next batch on a second stream, in its launched form and as persistent clusters of G workgroups per image.
+next batch on a second stream (round 3 also timed persistent clusters here: branch experiments/persistent-chain).
 usage: python tools/bench_chain_overlap.py [K]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,6 @@ with torch.no_grad():
             if chain is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    H.TACC_PERSISTENT, H.TACC_CLUSTER = chain
                     pipe.diffusion(x=lat, condi_in=lat, training=False)
             pipe.decode(lq, lat, pre)
             if chain is not None:
@@ -34,6 +33,5 @@ with torch.no_grad():
 
     base = run(None)
     print(f"C + D alone: {base:.2f} ms")
-    for chain in ((False, 16), (True, 16), (True, 8), (True, 4), (True, 2)):
-        t = run(chain)
-        print(f"+ chain {'launched' if not chain[0] else 'cluster %d' % chain[1]}: {t:.2f} ms (+{t - base:.2f})")
+    t = run(True)
+    print(f"+ chain (launched): {t:.2f} ms (+{t - base:.2f})")

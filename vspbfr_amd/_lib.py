@@ -121,8 +121,6 @@ SIGNATURES = {
     "vsp_tacc_tail_f32": [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "vsp_tacc_head_pre_f32": [_p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _p],
     "vsp_tacc_chain_f32": [_p, _p],
-    "vsp_tacc_chain_persistent_f32": [_p, _p],
-    "vsp_tacc_chain_cluster_f32": [_p, _i, _p],
     "vsp_conv2d_winograd_f32": [_p, _p],
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
@@ -155,7 +153,7 @@ SIGNATURES = {
     "vsp_conv2d_winograd_mbw": [_i],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
-_SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_tacc_chain_persistent_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)],
+_SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)],
           "vsp_winograd_weight_floats": [_i, _i, _i], "vsp_winograd4_weight_floats": [_i, _i],
           "vsp_conv2d_winograd4_work_floats": [_p]}
 

@@ -1083,22 +1083,7 @@ def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=Non
     return y
 
 
-# The sampler chain as ONE persistent launch (vsp_tacc_chain_persistent_f32: a cluster of 16 workgroups per image runs the whole loop,
-# two cluster barriers per block) instead of three launches per block.  Built, parity-tested (same bits as the launched chain) and
-# MEASURED SLOWER on MI355X: 46 us per block against 27.5 us at batch 8 / T = 50 (9.2 vs 5.5 ms per chain), 61 vs 46 us at batch 16,
-# 62 vs 54 us at batch 1 (tools/bench_chain.py) -- every phase of a block starts with L2-bypassing loads of what the other
-# workgroups just wrote (a memory round trip each: five dependent ones per block) and the barrier drains write-through stores, which
-# costs more than the three launch boundaries it removes (the guide's verdict on fused GEMM chains at this size).  It also holds
-# 16 B CUs for the whole chain, which the two-stream batch loop needs for the convolutions.  So: OFF unless asked for
-# (True / `persistent=True`); batches above 16 always take the launched chain.
-TACC_PERSISTENT = os.environ.get("VSP_TACC_PERSISTENT", "0") == "1"
-# workgroups per image of the persistent form (16: latency form; 4: throughput form for the two-stream batch loop, see
-# include/vspbfr_hip.h vsp_tacc_chain_cluster_f32)
-TACC_CLUSTER = int(os.environ.get("VSP_TACC_CLUSTER", "16"))
-_TACC_LAST_WORK = None
-
-
-def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None, persistent=None, cluster=None):
+def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None):
     """Run the whole sampler chain in place on x (B,18,512): for each t in `steps` (host ints, execution order) x <- c1[k] *
     denoiser(x, t) + c2[k] * x with k = coef_idx[s] (default t); c1 = c2 = None: x <- denoiser(x, t).  `blocks`: one dict per
     TACC block with device tensors wcat, eQ, ek, wq, wk, gamma, beta (gamma/beta: (head_steps, B, 18, 512))."""
@@ -1121,13 +1106,7 @@ def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, hea
             arr[i].wcat_frag = t.data_ptr()
     if head_steps is None:
         head_steps = blocks[0]["gamma"].shape[0] if n else 0
-    if persistent is None:
-        persistent = TACC_PERSISTENT
-    cluster = int(TACC_CLUSTER if cluster is None else cluster)
-    if cluster not in (1, 2, 4, 8, 16):
-        raise RuntimeError(f"tacc_chain: cluster must be 1, 2, 4, 8 or 16 workgroups per image (got {cluster})")
-    persistent = bool(persistent) and 0 < B <= min(32, 256 // cluster) and n <= 4
-    nfl = lib.vsp_tacc_chain_persistent_work_floats(B) if persistent else lib.vsp_tacc_chain_work_floats(B)
+    nfl = lib.vsp_tacc_chain_work_floats(B)
     work = torch.empty(nfl, device=x.device, dtype=torch.float32)
     steps = [int(s) for s in steps]
     st = (C.c_int * len(steps))(*steps)
@@ -1141,12 +1120,7 @@ def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, hea
     p.c1 = _opt(c1, "c1").data_ptr() if c1 is not None else None
     p.c2 = _opt(c2, "c2").data_ptr() if c2 is not None else None
     p.t_div, p.head_steps = float(t_div), int(head_steps)
-    if persistent:
-        check(lib.vsp_tacc_chain_cluster_f32(C.byref(p), cluster, _stream()), "tacc_chain_persistent")
-        global _TACC_LAST_WORK
-        _TACC_LAST_WORK = work   # (tuning builds read the phase counters of the sync area: tools/tacc_phase_times.py)
-    else:
-        check(lib.vsp_tacc_chain_f32(C.byref(p), _stream()), "tacc_chain")
+    check(lib.vsp_tacc_chain_f32(C.byref(p), _stream()), "tacc_chain")
     return x
 
 
