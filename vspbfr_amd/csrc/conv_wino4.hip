@@ -268,6 +268,10 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
     }
   };
 
+  if (p.dbg & 0x2000) {   // (tuning: static priorities by dispatch age)
+    if (wave >= 8) __builtin_amdgcn_s_setprio(2);
+    else if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  }
   // ---- main loop: three register sets
   W4Regs r0, r1, r2;
   load(0, r0);
@@ -310,6 +314,12 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
       for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) Ml[((3 * wave + q) * 16 + kq * 4 + r) * W4_EP + nb * 16 + lr] = acc[q][mb][nb][r];
+    // (the per-channel operands of this pass leave before the barrier: they do not depend on the exchange)
+    const int cgi = ct * 64 + mb * 16 + (e_co & 15);
+    const bool cok = cgi < Cout;
+    const int cg = cok ? cgi : Cout - 1;
+    const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
+    const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
     __syncthreads();
     if (e_co < 16) {
       float m[36];
@@ -336,11 +346,6 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
         yv[i][2] = fmaf(W4_B2, s2, W4_A2 * s1);
         yv[i][3] = fmaf(W4_B3, d2, fmaf(W4_A3, d1, z[i][5]));
       }
-      const int cgi = ct * 64 + mb * 16 + e_co;
-      const bool cok = cgi < Cout;
-      const int cg = cok ? cgi : Cout - 1;
-      const float os = osp[cg * p.oss], cs = p.csp[cg * p.css], cb = p.cbp[cg * p.cbs];
-      const float b1 = p.b1p[cg * p.b1s], b2 = p.b2p[cg * p.b2s], sl2 = p.s2p[cg * p.s2s];
       auto fin = [&](float v, float nz, float r1v, float r2v) {
         v = v * os * cs + cb + b1;
         v = (v > 0.f ? v : v * p.s1) * p.g1;

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   }
   load_plane(M, preg);
   __syncthreads();
+  if ((p.dbg & 0x1000) && wave >= 4) __builtin_amdgcn_s_setprio(1);   // (tuning: static priority for the younger half of the workgroup)
   int rcur = 0, rnxt = M % R;   // ring slots of sub-stage j and j + M
   for (int j = 0; j < nstage; ++j) {
     const float* Pcur = Pl + rcur * LDS_P;
@@ -275,6 +276,12 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   }
   if (M > 1) __syncthreads();   // (the epilogue reuses the ring)
 
+#ifdef VSP_WINO_ABLATE
+  if (ab & 512) {   // no epilogue (one word keeps the accumulators alive)
+    if (acc[0][0][0][0] == 123.456f) p.y[0] = 1.f;
+    return;
+  }
+#endif
   // ---- epilogue (conv_wino.hip): per 16-channel block(s), all sixteen positions through LDS, one thread per (channel, tile)
   constexpr int ETILE = Gm::ETILE, ENB = ETILE / 16, EP = Gm::EP;
   float* Ml = smem;
@@ -289,6 +296,14 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   constexpr int EMB = Gm::EMB, ECO = 16 * EMB;
   constexpr int EPT = ECO * ETILE / RO_NTHR;
   typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+  constexpr int TP = ETILE / 2;                       // horizontal tile pairs per pass
+  constexpr int EPT2 = ECO * TP / RO_NTHR;            // (channel, tile pair) items per thread and pass
+  static_assert(ECO * TP % RO_NTHR == 0 && TLX % 2 == 0, "tile pairs");
+  struct QOps { float os, cs, cb, b1, b2, sl2; int cbase; };
+  // 16-byte form: dense rows of whole quads, every operand plane 16-byte aligned (uniform)
+  const bool quads = p.r1s <= 1 && p.r2s <= 1 && p.nzs <= 1 && (p.OW & 3) == 0 && p.y_w == p.OW && (y_plane & 3) == 0 &&
+                     !(reinterpret_cast<uintptr_t>(yb) & 15) && !(p.r1s && (reinterpret_cast<uintptr_t>(r1b) & 15)) &&
+                     !(p.r2s && (reinterpret_cast<uintptr_t>(r2b) & 15)) && !(p.nzs && (reinterpret_cast<uintptr_t>(nzp) & 15)) && !(p.dbg & 0x4000);
   const bool vec2 = p.r1s <= 1 && p.r2s <= 1;
   const bool pairs = vec2 && (p.OW & 1) == 0 && p.OW >= 2;
 #pragma unroll
@@ -296,6 +311,18 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
 #pragma unroll
     for (int th = 0; th < NTILE / ETILE; ++th) {
       if (mb0 + th > 0) __syncthreads();
+      QOps qops[EPT2];
+      if (quads) {
+#pragma unroll
+        for (int it = 0; it < EPT2; ++it) {
+          const int e_co = (tid + it * RO_NTHR) / TP;
+          const int cgi = co0 + mb0 * 16 + e_co;
+          const int cg = g * p.cout_g + (cgi < p.cout_g ? cgi : p.cout_g - 1);
+          qops[it].os = osp[cg * p.oss]; qops[it].cs = p.csp[cg * p.css]; qops[it].cb = p.cbp[cg * p.cbs];
+          qops[it].b1 = p.b1p[cg * p.b1s]; qops[it].b2 = p.b2p[cg * p.b2s]; qops[it].sl2 = p.s2p[cg * p.s2s];
+          qops[it].cbase = cg * y_plane;
+        }
+      }
 #pragma unroll
       for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
@@ -306,6 +333,69 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
             for (int r = 0; r < 4; ++r)
               Ml[((2 * wave + pp) * ECO + m2 * 16 + kq * 4 + r) * EP + nb * 16 + lr] = acc[pp][mb0 + m2][th * ENB + nb][r];
       __syncthreads();
+      if (quads) {
+        // (uniform) two horizontally adjacent tiles per thread: the 2 x 4 output pixels leave as two 16-byte stores, the sixteen
+        // position values of both tiles come as 8-byte LDS reads, and a thread keeps ONE channel per pass (its six per-channel
+        // operands were requested before the exchange).  Measured on 64 -> 64 at 512^2: the 8-byte-per-lane form spent 200 of the
+        // kernel's 870 us here.
+#pragma unroll
+        for (int it = 0; it < EPT2; ++it) {
+          const int dp = tid + it * RO_NTHR;
+          const int e_co = dp / TP, tp = dp - e_co * TP;
+          const int e_t = (tp / (TLX / 2)) * TLX + 2 * (tp % (TLX / 2));      // first tile of the pair
+          const int e_tile = th * ETILE + e_t;
+          const int sy = oy0 + 2 * (e_tile / TLX), sx = ox0 + 2 * (e_tile % TLX);
+          float2 m[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) m[q] = *reinterpret_cast<const float2*>(Ml + (q * ECO + e_co) * EP + e_t);
+          float yv[2][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+              const float m0 = h ? m[nu].y : m[nu].x, m1 = h ? m[4 + nu].y : m[4 + nu].x;
+              const float m2 = h ? m[8 + nu].y : m[8 + nu].x, m3 = h ? m[12 + nu].y : m[12 + nu].x;
+              t0[nu] = m0 + m1 + m2;
+              t1[nu] = m1 - m2 - m3;
+            }
+            yv[0][2 * h] = t0[0] + t0[1] + t0[2]; yv[0][2 * h + 1] = t0[1] - t0[2] - t0[3];
+            yv[1][2 * h] = t1[0] + t1[1] + t1[2]; yv[1][2 * h + 1] = t1[1] - t1[2] - t1[3];
+          }
+          const int cgi = co0 + mb0 * 16 + e_co;
+          const bool cok = cgi < p.cout_g;
+          const QOps& o = qops[it];
+          auto fin = [&](float v, float nz, float r1v, float r2v) {
+            v = v * o.os * o.cs + o.cb + o.b1;
+            v = (v > 0.f ? v : v * p.s1) * p.g1;
+            v += nz * nw + o.b2;
+            v = (v > 0.f ? v : v * o.sl2) * p.g2;
+            return v + r1v + r2v;
+          };
+          typedef float f32x4q __attribute__((ext_vector_type(4)));
+          f32x4q nz[2], r1v[2], r2v[2];
+          int ro[2];
+          bool inside[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int oy = sy + i;
+            inside[i] = cok && oy < p.OH && sx < p.OW;
+            const int oyc = min(oy, p.OH - 1), oxc = min(sx, p.OW - 4);
+            ro[i] = o.cbase + oyc * p.y_w + oxc;
+            nz[i] = r1v[i] = r2v[i] = f32x4q{0.f, 0.f, 0.f, 0.f};
+            if (p.nzs) nz[i] = *reinterpret_cast<const f32x4q*>(nzp + oyc * p.OW + oxc);
+            if (p.r1s) r1v[i] = *reinterpret_cast<const f32x4q*>(r1b + ro[i]);
+            if (p.r2s) r2v[i] = *reinterpret_cast<const f32x4q*>(r2b + ro[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const f32x4q o4 = {fin(yv[i][0], nz[i][0], r1v[i][0], r2v[i][0]), fin(yv[i][1], nz[i][1], r1v[i][1], r2v[i][1]),
+                               fin(yv[i][2], nz[i][2], r1v[i][2], r2v[i][2]), fin(yv[i][3], nz[i][3], r1v[i][3], r2v[i][3])};
+            if (inside[i]) *reinterpret_cast<f32x4q*>(yb + ro[i]) = o4;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int it = 0; it < EPT; ++it) {
         const int pair = tid + it * RO_NTHR;
