@@ -10,8 +10,8 @@
 // cache traffic pays only where the transform is shared by >= 4 channel tiles, so the launcher takes Cin, Cout >= 256 layers only.
 //
 // Interpolation points 0, +-3/4, +-3/2, infinity (not the textbook 0, +-1, +-2): every constant of B^T and A^T is a dyadic rational
-// (exact in fp32) and the fp32 error of the whole convolution is that of the direct kernel (rms 1.5e-6 at unit scale, K = 256; the
-// textbook points: 4.4e-6, max 1.1e-4 -- tools/wino4_points.py).  With a = 3/4, b = 3/2:
+// (exact in fp32) and the fp32 error of the whole convolution is that of the direct kernel (rms 1.55e-6, max 8.7e-6 at unit scale, K = 256; the
+// textbook points: 3.2e-6, max 4.1e-5 -- tools/wino4_points.py).  With a = 3/4, b = 3/2:
 //   B^T rows:  [a2b2, 0, -(a2+b2), 0, 1, 0]            (a2b2 = 81/64, a2+b2 = 45/16)
 //              (d4 - b2 d2) +- a (d3 - b2 d1)           (b2 = 9/4)
 //              (d4 - a2 d2) +- b (d3 - a2 d1)           (a2 = 9/16)
