@@ -504,7 +504,7 @@ def test_upfirdn2d_autograd_any_order(H, up, down, pad, k):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 8, 64, 16, 16), (1, 20, 36, 13, 29), (2, 64, 64, 32, 32), (1, 256, 128, 16, 24),
-                                               (1, 3, 4, 7, 5)])
+                                               (1, 3, 4, 7, 5), (1, 24, 40, 20, 36), (2, 16, 32, 40, 24), (1, 12, 96, 34, 52)])
 def test_conv2d_winograd(H, B, Cin, Cout, Hh, Ww):
     """F(2x2,3x3) kernel against F.conv2d, with the whole prologue / epilogue chain of a StyledConv."""
     x = torch.randn(B, Cin, Hh, Ww)
@@ -527,6 +527,91 @@ def test_conv2d_winograd(H, B, Cin, Cout, Hh, Ww):
     close(y2, ref2, 5e-5, 5e-5)
     with pytest.raises(RuntimeError):
         H.conv2d_packed(dev(x), H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 2, (1,), (1,)), winograd=True)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 64, 64, 32, 32), (1, 20, 40, 36, 48), (2, 8, 72, 16, 64), (1, 256, 128, 24, 40),
+                                               (3, 12, 200, 8, 16)])
+def test_conv2d_winograd4(H, B, Cin, Cout, Hh, Ww):
+    """F(4x4,3x3) pair (vsp_conv2d_winograd4_f32: input transform + barrier-free GEMM) against float64 F.conv2d: plain, and with the whole
+    prologue / epilogue chain of a StyledConv; partial pixel tiles (H, W not multiples of 16 / 32), partial channel tiles and chunks."""
+    g_ = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g_)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    assert H.winograd4_eligible(pc, Hh, Ww, Hh, Ww)
+    close(H.conv2d_packed(dev(x), pc, winograd=4), F.conv2d(x.double(), w.double(), padding=1).float(), 5e-5, 5e-5)
+    s_in, demod, bias = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, Cout, generator=g_) + 0.5, torch.randn(Cout, generator=g_)
+    nz, nw = torch.randn(B, 1, Hh, Ww, generator=g_), torch.tensor([0.7])
+    r1, r2 = torch.randn(B, Cout, Hh, Ww, generator=g_), torch.randn(B, Cout, Hh, Ww, generator=g_)
+    ref = F.conv2d((x * s_in.view(B, Cin, 1, 1)).double(), w.double(), padding=1) * demod.view(B, Cout, 1, 1).double() + (nz * nw).double()
+    ref = (F.leaky_relu(ref + bias.view(1, -1, 1, 1).double(), 0.2) * math.sqrt(2) + r1.double() + r2.double()).float()
+    kw = dict(in_scale=dev(s_in), out_scale=dev(demod), noise=dev(nz), noise_w=dev(nw), act2=1, bias2=dev(bias), res1=dev(r1), res2=dev(r2))
+    y = H.conv2d_packed(dev(x), pc, winograd=4, **kw)
+    close(y, ref, 6e-5, 6e-5)
+    # written into a channel window of a wider tensor
+    out = torch.full((B, Cout + 5, Hh, Ww), 7.0, device=DEV)
+    H.conv2d_packed(dev(x), pc, out=out, y_coff=3, winograd=4)
+    close(out[:, 3:3 + Cout], F.conv2d(x, w, padding=1), 6e-5, 6e-5)
+    assert bool((out[:, :3] == 7.0).all()) and bool((out[:, 3 + Cout:] == 7.0).all())
+    # what the deep-layer form does not serve goes to F(2x2,3x3): an affine input shift, maps that are not whole 4 x 4 tiles
+    a, sh = torch.rand(Cin) + 0.5, torch.randn(Cin)
+    y2 = H.conv2d_packed(dev(x), pc, in_scale=dev(a), in_scale_per_sample=False, in_shift=dev(sh), winograd=4)
+    close(y2, F.conv2d(x * a.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), w, padding=1), 5e-5, 5e-5)
+    x3 = torch.randn(1, Cin, 18, 22)
+    assert not H.winograd4_eligible(pc, 18, 22, 18, 22)
+    close(H.conv2d_packed(dev(x3), pc, winograd=4), F.conv2d(x3, w, padding=1), 5e-5, 5e-5)
+
+
+def test_conv2d_winograd4_refusals(H):
+    """The C entry refuses what it cannot serve (VSP_ENOTSUP / VSP_EINVAL through RuntimeError), it does not compute something else."""
+    from vspbfr_amd import _lib
+    x = dev(torch.randn(1, 8, 16, 32))
+    w = dev(torch.randn(64, 8, 3, 3))
+    pc = H.PackedConv(H.pack_weight(w), 1, 64, 8, 3, 3, 1, (1,), (1,))
+    u4 = pc.winograd4_weight()
+    assert u4.numel() == _lib.lib.vsp_winograd4_weight_floats(8, 64)
+    p = _lib.ConvParams()
+    out = torch.empty(1, 64, 16, 32, device=DEV)
+    p.x, p.w, p.y = x.data_ptr(), u4.data_ptr(), out.data_ptr()
+    p.B, p.Cin, p.H, p.W, p.G, p.cout_g, p.OH, p.OW, p.KH, p.KW = 1, 8, 16, 32, 1, 64, 16, 32, 3, 3
+    p.stride_y = p.stride_x = 1
+    for g in range(4):
+        p.dil[g], p.pad_y[g], p.pad_x[g] = 1, 1, 1
+    p.y_ch, p.y_h, p.y_w, p.osy, p.osx, p.x_ch = 64, 16, 32, 1, 1, 8
+    import ctypes as C
+    nfl = _lib.lib.vsp_conv2d_winograd4_work_floats(C.byref(p))
+    work = torch.empty(nfl, device=DEV)
+    assert _lib.lib.vsp_conv2d_winograd4_f32(C.byref(p), work.data_ptr(), nfl, None) == 0
+    torch.cuda.synchronize()
+    close(out, F.conv2d(x.cpu(), w.cpu(), padding=1), 5e-5, 5e-5)
+    assert _lib.lib.vsp_conv2d_winograd4_f32(C.byref(p), work.data_ptr(), nfl - 1, None) != 0          # work buffer too small
+    p.dil[0] = p.pad_y[0] = p.pad_x[0] = 2
+    assert _lib.lib.vsp_conv2d_winograd4_f32(C.byref(p), work.data_ptr(), nfl, None) != 0              # dilation
+    p.dil[0] = p.pad_y[0] = p.pad_x[0] = 1
+    p.stride_y = p.stride_x = 2
+    assert _lib.lib.vsp_conv2d_winograd4_f32(C.byref(p), work.data_ptr(), nfl, None) != 0              # stride
+    p.stride_y = p.stride_x = 1
+    p.y = out.data_ptr() + 4
+    assert _lib.lib.vsp_conv2d_winograd4_f32(C.byref(p), work.data_ptr(), nfl, None) == -3             # VSP_ENOTSUP: output not 16-byte aligned
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (6, 3), (30, 72), (130, 40)])
+def test_winograd4_weight_kernel(H, cin, cout):
+    """vsp_winograd4_weight_f32 against U = G g G^T in float64 (points 0, +-3/4, +-3/2, inf) in the fragment order include/vspbfr_hip.h
+    states for vsp_conv2d_winograd4_f32, zero padding included."""
+    g_ = torch.Generator().manual_seed(17)
+    wp = torch.randn(1, 9, cin, cout, generator=g_)
+    Gm = torch.tensor(((64 / 81, 0, 0), (-128 / 243, -32 / 81, -8 / 27), (-128 / 243, 32 / 81, -8 / 27), (32 / 243, 16 / 81, 8 / 27),
+                       (32 / 243, -16 / 81, 8 / 27), (0, 0, 1)), dtype=torch.float64)
+    U = torch.einsum("ay,bx,yxio->abio", Gm, Gm, wp[0].double().view(3, 3, cin, cout)).reshape(36, cin, cout)
+    nch, nct = (cin + 3) // 4, (cout + 63) // 64
+    Up = U.new_zeros(36, nch * 4, nct * 64)
+    Up[:, :cin, :cout] = U
+    # [tile][chunk][wave 12][q 3][lane = kq 4 x lr 16][mb 4]  <-  U[pos = 3 wave + q][ci = 4 chunk + kq][co = 64 tile + 16 mb + lr]
+    ref = Up.view(12, 3, nch, 4, nct, 4, 16).permute(4, 2, 0, 1, 3, 6, 5).float().contiguous().view(-1)
+    got = H.winograd4_weight(dev(wp)).cpu()
+    assert got.numel() == ref.numel() == H.lib.vsp_winograd4_weight_floats(cin, cout)
+    close(got, ref, 1e-7, 1.2e-7, "winograd4 weight")
 
 
 @pytest.mark.parametrize("B,Cin,Cg,Hh,Ww", [(2, 16, 8, 24, 24), (1, 24, 16, 37, 21), (2, 64, 32, 32, 32), (1, 40, 64, 16, 48), (1, 32, 128, 19, 19)])

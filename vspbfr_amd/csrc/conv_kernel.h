@@ -619,7 +619,9 @@ int wino_launch(ConvK q, hipStream_t stream);
 bool smallmap_eligible(const ConvK& q, bool transposed);
 int smallmap_launch(const ConvK& q, hipStream_t stream);
 int wino_ro_launch(ConvK q, int mbw, int ivc, hipStream_t stream);
-bool wino_ro_eligible(const ConvK& q);   // conv_wino_ro.hip: row-owner form, undilated groups
+bool wino_ro_eligible(const ConvK& q);
+int wino_rod_launch(ConvK q, int mbw, hipStream_t stream);            // conv_wino_rod.hip: row-owner form, dilation groups
+bool wino_rod_eligible(const ConvK& q);   // conv_wino_ro.hip: row-owner form, undilated groups
 // conv_wino4.hip: Winograd F(4x4,3x3) as input transform + barrier-free GEMM (deep layers)
 bool wino4_eligible(const ConvK& q);
 size_t wino4_weight_floats(int cin, int cout);

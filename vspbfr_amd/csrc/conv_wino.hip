@@ -586,6 +586,13 @@ int wino_launch(ConvK q, hipStream_t stream) {
       default: return launch_variant<1, 1>(q, stream);
     }
   }
+  {   // dilation groups: row-owner form (conv_wino_rod.hip) where it measured faster -- 128 -> 4 x 32 at 256^2 1099 -> 1070 us, 256 -> 4 x 64 at
+      // 128^2 793 -> 762, 512 -> 4 x 128 at 32^2 302 -> 291; 512 -> 4 x 128 at 64^2 753 -> 768: stays here.  VSP_WINO_ROD = 0 / 2: never / always.
+    static const int rod = getenv("VSP_WINO_ROD") ? atoi(getenv("VSP_WINO_ROD")) : 1;
+    const bool deep_large = q.Cin >= 512 && q.H * q.W >= 4096;
+    if (rod && (rod == 2 || !deep_large) && wino_mbw(q.cout_g) >= 2 && wino_rod_eligible(q))
+      return wino_rod_launch(q, wino_mbw(q.cout_g), stream);
+  }
   switch (wino_mbw(q.cout_g)) {
     case 4: return launch_variant<4, 8>(q, stream);
     case 2: return launch_variant<2, 8>(q, stream);
