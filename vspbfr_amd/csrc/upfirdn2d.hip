@@ -326,7 +326,9 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     VSP_REQUIRE(blocks < ((int64_t)1 << 31), "upfirdn2d: grid too large");
     // One tile per block.  Two (both windows requested up front; VSP_FIR_NTB = 2, tuning) measured SLOWER on bf16 planes too (round 4:
     // 32 ch at 1024^2, B = 16: 2.50 -> 2.24 TB/s, C3 402 -> 391 img/s): half the bytes per tile is not what holds the bf16 blur at
-    // 2.3-2.9 TB/s -- its 8-byte window loads sit at halfword alignment on the (2H+1)-wide rows.
+    // 2.3-2.9 TB/s.  Nor is the halfword alignment of its 8-byte window loads on the (2H+1)-wide rows: the same quads fetched as aligned
+    // dwords + a 16-bit funnel shift measured 2-3 % slower (2.51 -> 2.45 TB/s; tried and removed).  Per element the bf16 blur already runs
+    // 1.5 x the fp32 one (0.62 vs 0.40 outputs / ns): what is left is its instruction count per output, not its bytes.
     static const int ntb_env = getenv("VSP_FIR_NTB") ? atoi(getenv("VSP_FIR_NTB")) : 0;
     const int ntb = ntb_env == 2 ? 2 : 1;
 #define VSP_FIR_LAUNCH(KH_, NTB_)                                                                                                     \
