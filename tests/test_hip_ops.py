@@ -1475,6 +1475,30 @@ def test_conv_pipelined_kernels(H, case):
                ch_bias=dev(torch.randn(cout, generator=g_)), act2=2, prelu=dev(torch.rand(cout, generator=g_)))
     base = dict(transposed=tr, winograd=False, bf16=False)
     want, want2 = H.conv2d_packed(x, pc, **base, **kw), H.conv2d_packed(x, pc, **base, **kw2)
+
+    # The same two operand chains restated in float64 torch from the contract of include/vspbfr_hip.h (the pipelined
+    # kernels' operands were only checked against the tiled kernel): y = act2(act1(conv(x * in_scale) * out_scale * ch_scale + ch_bias + bias1)
+    # + noise * noise_w + bias2) + res1 + res2
+    def conv64(xs):
+        if tr:
+            return F.conv_transpose2d(xs, ws[0].double().transpose(0, 1), stride=2)
+        outs = []
+        for gi in range(G):
+            xi = xs[:, gi * cin:(gi + 1) * cin] if true_groups else xs
+            outs.append(F.conv2d(xi, ws[gi].double(), None, st, pad[gi], dil[gi]))
+        return torch.cat(outs, 1)
+    c64 = lambda t: t.cpu().double()
+    v = conv64(c64(x) * c64(kw["in_scale"]).view(B, xc, 1, 1)) * c64(kw["out_scale"]).view(B, cout, 1, 1) + c64(kw["bias1"]).view(1, -1, 1, 1)
+    v = F.leaky_relu(v, 0.2) * math.sqrt(2)
+    if "noise" in kw:
+        v = v + c64(kw["noise"]) * 0.3
+    v = F.leaky_relu(v + c64(kw["bias2"]).view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    if "res1" in kw:
+        v = v + c64(kw["res1"]) + c64(kw["res2"])
+    close(want, v.float(), 5e-5, 5e-5, "tiled kernel, epilogue chain vs float64")
+    v2 = conv64(c64(x) * c64(kw2["in_scale"]).view(1, xc, 1, 1)) * c64(kw2["ch_scale"]).view(1, -1, 1, 1) + c64(kw2["ch_bias"]).view(1, -1, 1, 1)
+    v2 = torch.where(v2 > 0, v2, v2 * c64(kw2["prelu"]).view(1, -1, 1, 1))
+    close(want2, v2.float(), 5e-5, 5e-5, "tiled kernel, per-channel operands vs float64")
     ran = 0
     for i in range(lib.vsp_conv2d_num_configs()):
         name = lib.vsp_conv2d_config_name(i).decode()
@@ -1486,8 +1510,8 @@ def test_conv_pipelined_kernels(H, case):
             continue   # this configuration does not serve the launch (mode, patch rows, chunk size)
         ran += 1
         close(y, ref, 2e-5, 2e-5, name + " plain")
-        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw), want, 3e-5, 3e-5, name + " epilogue")
-        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw2), want2, 3e-5, 3e-5, name + " per-channel operands")
+        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw), v.float(), 5e-5, 5e-5, name + " epilogue vs float64")
+        close(H.conv2d_packed(x, pc, tile_hint=i + 1, **base, **kw2), v2.float(), 5e-5, 5e-5, name + " per-channel operands vs float64")
         if not tr and st == 1 and G == 1:   # strided placement into a larger tensor, channel window
             out_a = torch.zeros(B, cout + 3, 2 * OH + 1, 2 * OW + 2, device=x.device)
             out_b = torch.zeros_like(out_a)
