@@ -490,7 +490,9 @@ bool wino_ro_eligible(const ConvK& q) {
   return q.cout_g > 16 && q.W % 4 == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 && ((int64_t)q.H * q.W) % 4 == 0;
 }
 
-// m = barrier period in 8-channel sub-stages (1, 2 or 4)
+// m = barrier period in 8-channel sub-stages (1, 2 or 4).  (A half tile -- 64 channels x 16 tiles, 75 VGPRs, three workgroups per CU -- for the
+// launches that fill only half of the chip's workgroup slots was measured and removed: 256 -> 256 at 32^2 60 vs 58 us, every larger layer
+// 8-15 % slower: the small layers are bound by their K chain of 32 sub-stages, not by occupancy.)
 int wino_ro_launch(ConvK q, int mbw, int m, hipStream_t stream) {
   if (mbw == 4) return m == 4 ? launch_ro<4, 4>(q, stream) : (m == 2 ? launch_ro<4, 2>(q, stream) : launch_ro<4, 1>(q, stream));
   return m == 4 ? launch_ro<2, 4>(q, stream) : (m == 2 ? launch_ro<2, 2>(q, stream) : launch_ro<2, 1>(q, stream));
