@@ -31,13 +31,14 @@ constexpr int RO_NTHR = 512;
 
 constexpr int IVC = 8;   // input channels per sub-stage: one channel plane per wave
 
-template <int MBW>
-struct RG {  // geometry (undilated): MBW 16-channel blocks x NBW 16-tile blocks per wave and position, MBW * NBW = 8
+template <int MBW, int TLX_ = 8>
+struct RG {  // geometry (undilated): MBW 16-channel blocks x NBW 16-tile blocks per wave and position, MBW * NBW = 8; TLX_ tile columns
+             // per workgroup (8: 16 x 16 pixels at 32 tiles; 16: 32 x 8 pixels -- 128-byte output row segments)
   static constexpr int KS = IVC / 4;
   static constexpr int NBW = 8 / MBW;
   static constexpr int WCO = 16 * MBW;
   static constexpr int NTILE = 16 * NBW;
-  static constexpr int TLX = NBW == 8 ? 16 : 8;
+  static constexpr int TLX = NBW == 8 ? 16 : TLX_;
   static constexpr int TLY = NTILE / TLX;
   static constexpr int PR = 2 * TLY + 2;
   // Patch rows are staged as ALIGNED 16-byte segments: image columns ox0 - 4 ... ox0 + 2 TLX + 3 (W % 4 == 0: a segment lies inside the
@@ -64,9 +65,9 @@ struct RG {  // geometry (undilated): MBW 16-channel blocks x NBW 16-tile blocks
 // ring[s % R], the planes of sub-stage s + M are committed during sub-stage s (into the slot sub-stage s - M was read from), and a
 // barrier closes every M-th sub-stage: between the commit of a sub-stage and its first read, and between the last read of a slot and
 // its overwrite, lies at least one barrier.  M = 1 is the plain double buffer.
-template <int MBW, int M>
+template <int MBW, int M, int TLXV = 8>
 __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p) {
-  using Gm = RG<MBW>;
+  using Gm = RG<MBW, TLXV>;
   constexpr int NBW = Gm::NBW, WCO = Gm::WCO, NTILE = Gm::NTILE, TLX = Gm::TLX, TLY = Gm::TLY, PR = Gm::PR, PCP = Gm::PCP, SEG = Gm::SEG;
   constexpr int PPITCH = Gm::PPITCH, LDS_P = Gm::LDS_P, UF = Gm::UF, KS = Gm::KS, NLD = Gm::NLD;
   constexpr int R = 2 * M;
@@ -466,18 +467,18 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   }
 }
 
-template <int MBW, int M>
+template <int MBW, int M, int TLXV = 8>
 int launch_ro(ConvK q, hipStream_t stream) {
-  using Gm = RG<MBW>;
+  using Gm = RG<MBW, TLXV>;
   static vsp::LdsAttrOnce attr;
   const size_t lds = (size_t)Gm::lds_floats(M) * sizeof(float);
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino_ro_kernel<MBW, M>), (int)lds, "conv2d_winograd (row-owner)")) return rc;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino_ro_kernel<MBW, M, TLXV>), (int)lds, "conv2d_winograd (row-owner)")) return rc;
   q.co_tiles = (q.cout_g + Gm::WCO - 1) / Gm::WCO;
   const int blocks = ((q.W + 2 * Gm::TLX - 1) / (2 * Gm::TLX)) * ((q.H + 2 * Gm::TLY - 1) / (2 * Gm::TLY));
   q.wg_order = 1;
   if (q.dbg & 0x300) q.wg_order = ((q.dbg >> 8) & 3) == 1 ? 1 : 0;
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_wino_ro_kernel<MBW, M><<<grid, RO_NTHR, lds, stream>>>(q);
+  conv_wino_ro_kernel<MBW, M, TLXV><<<grid, RO_NTHR, lds, stream>>>(q);
   return VSP_OK;
 }
 
@@ -494,7 +495,13 @@ bool wino_ro_eligible(const ConvK& q) {
 // launches that fill only half of the chip's workgroup slots was measured and removed: 256 -> 256 at 32^2 60 vs 58 us, every larger layer
 // 8-15 % slower: the small layers are bound by their K chain of 32 sub-stages, not by occupancy.)
 int wino_ro_launch(ConvK q, int mbw, int m, hipStream_t stream) {
-  if (mbw == 4) return m == 4 ? launch_ro<4, 4>(q, stream) : (m == 2 ? launch_ro<4, 2>(q, stream) : launch_ro<4, 1>(q, stream));
+  if (mbw == 4) {
+    // 16 tile columns x 2 tile rows per workgroup (32 x 4 output pixels: 128-byte row segments on both the patch loads and the stores)
+    // wherever a row holds them: 0.5-2 % over the 8 x 4 form on every layer (128 -> 128 at 256^2: 769 -> 752 us); VSP_WINO_RO_WIDE = 0: off
+    static const int wide_env = getenv("VSP_WINO_RO_WIDE") ? atoi(getenv("VSP_WINO_RO_WIDE")) : 1;
+    if (wide_env && m == 1 && q.W >= 32) return launch_ro<4, 1, 16>(q, stream);
+    return m == 4 ? launch_ro<4, 4>(q, stream) : (m == 2 ? launch_ro<4, 2>(q, stream) : launch_ro<4, 1>(q, stream));
+  }
   return m == 4 ? launch_ro<2, 4>(q, stream) : (m == 2 ? launch_ro<2, 2>(q, stream) : launch_ro<2, 1>(q, stream));
 }
 
