@@ -441,7 +441,7 @@ def main():
                        "overlap": "none" if args.no_overlap else "A+B of batch i+1 on a second HIP stream under C+D of batch i",
                        "launch": "two captured HIP graphs (A+B, C+D) replayed per batch" if args.graphs else "eager (one host launch per kernel)",
                        "rng": "torch device RNG, one randn per consumer" if args.torch_rng else
-                              "keyed Philox draws by (seed, global image index): 2 launches per batch, world-size invariant (mixing = 0: no per-batch style-mixing coin)",
+                              "keyed Philox draws by (seed, global image index): 2 launches per batch; the DRAWS are world-size invariant (mixing = 0: no per-batch style-mixing coin), the kernels' summation orders follow the per-rank batch size",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),

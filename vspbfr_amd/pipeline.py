@@ -55,7 +55,12 @@ class RestorationPipeline:
         reference.  noise_seed=int: KEYED draws (hip_ops.keyed_fill): x_T, z and all 46 noise maps of a batch are functions of
         (noise_seed, global image index, tensor id) drawn by two launches (one per stage pair) -- with mixing = 0 (bench, CLI
         default of this repository's tests) the result for an image does not depend on the batch it travels in or on the rank that
-        computes it.  With mixing > 0 that invariance does NOT hold: the reference flips ONE style-mixing coin and draws
+        computes it -- up to the last bits of the kernels' summation orders, which are chosen per launch SHAPE: the few-row GEMM
+        form (M <= 16 rows: every style modulation at batch <= 16) sums K in another order than the MFMA tile form (M > 16), and the
+        conv tile / Winograd variant comes from a per-shape table keyed by the batch size, so an image restored inside a batch of 32
+        differs from the same image inside a batch of 4 by fp32 rounding noise (1e-6 relative per layer; the draws themselves are
+        bit-identical).  Ranks of one job run the same batch size, so the all-gathered result does not depend on the world size at a fixed
+        per-rank batch.  With mixing > 0 the invariance does NOT hold at all: the reference flips ONE style-mixing coin and draws
         ONE inject index per BATCH (restoration_test.py:77-82), which is kept here and keyed by the batch's first global image index,
         so an image's result then depends on which batch it is in; graph capture refuses mixing > 0 for the same reason (the coin
         would be frozen into the graph)."""
