@@ -22,6 +22,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the host driver of the GPU boxes supports dmabuf IPC only: without this RCCL's buffer exchange between the ranks of one node fails with
+# `hipIpcGetMemHandle: invalid argument` (exported on the boxes already; set here too for a rank started by a bare torchrun)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
