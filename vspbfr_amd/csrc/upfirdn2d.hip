@@ -349,8 +349,8 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     // 32 ch at 1024^2, B = 16: 2.50 -> 2.24 TB/s, C3 402 -> 391 img/s): half the bytes per tile is not what holds the bf16 blur at
     // 2.3-2.9 TB/s.  Nor is the halfword alignment of its 8-byte window loads on the (2H+1)-wide rows: the same quads fetched as aligned
     // dwords + a 16-bit funnel shift measured 2-3 % slower (2.51 -> 2.45 TB/s; tried and removed).  Per element the bf16 blur already runs
-    // 1.5 x the fp32 one (0.62 vs 0.40 outputs / ns).  PMC (32 channels at 1024^2, bf16, B = 16): 1.05 M wavefronts of ~2700 cycles, on
-    // average 1.4 resident per SIMD where registers and LDS admit 7, 394 VALU + 228 SALU instructions per wave.  PERSISTENT blocks (8 per
+    // 1.5 x the fp32 one (0.62 vs 0.40 outputs / ns).  PMC (32 channels at 1024^2, bf16, B = 16): 1.05 M wavefronts, 394 VALU +
+    // 228 SALU instructions per wave, 5.6 of the 7 admissible waves resident per SIMD (SQ_WAVE_CYCLES counts quad-cycles).  PERSISTENT blocks (8 per
     // CU walking the tile list with the next window requested one tile ahead, before or after the epilogue operands) measured 25-45 %
     // SLOWER on both element types (fp32 plain 4.08 -> 3.1 TB/s, bf16 2.36 -> 1.65): tried and removed -- two barriers per tile in a
     // resident block cost more than launching a fresh one.  The interior fast path below is what paid (fp32 3.0-3.5 -> 4.1-4.5 TB/s).
