@@ -131,12 +131,14 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
 #pragma unroll
     for (int i = 0; i < NLD; ++i) dst[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, p_voff[i], soff, 0));
   };
+  const float* wt_b = p.wtp + b * p.wt_bs;   // (per-image bases hoisted: the interval's scalar address arithmetic is part of its issue time)
+  const float* wc_b = p.wcp + b * p.wc_bs;
   auto commit_plane = [&](float* Pdst, int j, const f32x4v (&src)[NLD]) {   // style scale and (folded BatchNorm) affine ride on the patch
     const int ci = j * IVC + wave;
     const bool chok = ci < p.Cin;
     const int cc = chok ? ci : p.Cin - 1;
-    const float st = uload_ro(p.wtp, b * p.wt_bs + cc * p.wt_cs);
-    const float sc = uload_ro(p.wcp, b * p.wc_bs + cc * p.wc_cs) * st;
+    const float st = uload_ro(wt_b, cc * p.wt_cs);
+    const float sc = uload_ro(wc_b, cc * p.wc_cs) * st;
     const float sh = uload_ro(p.wshp, cc * p.wsh_cs) * st;
     float* dst = Pdst + wave * PPITCH;
 #pragma unroll
@@ -149,20 +151,26 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
     }
   };
 
-  // ---- U fragments: [group][co tile][chunk][wave][pp 2][lane][mb MBW] floats, one 4-channel chunk (k-step) and position per load
-  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk4 * 8 + wave) * 2 * 64 + lane) * MBW;
+  // ---- U fragments: [group][co tile][chunk][wave][pp 2][lane][mb MBW] floats, one 4-channel chunk (k-step) and position per load.
+  //      Buffer loads: resource = this channel tile's slice, scalar offset = chunk, lane offset fixed (a flat pointer costs a 64-bit VALU
+  //      add per load and a handful of scalar instructions for the 64-bit chunk offset: 56 SALU + 60 VALU per 32 MFMAs were measured).
+  const float* utile = p.w + ((int64_t)g * p.co_tiles + ct) * nchunk4 * (8 * 64 * UF);
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(utile), 0, nchunk4 * (8 * 64 * UF) * 4, 0x00020000);
+  const int u_voff = ((wave * 2 * 64 + lane) * MBW) * 4;
   auto load_u_half = [&](int c, int pp, float (&u)[UF]) {
     if (ab & 4) return;
     const int cc = (ab & 64) ? 0 : (c < nchunk4 ? c : nchunk4 - 1);
-    const float* src = ufr + (int64_t)cc * (8 * 64 * UF) + pp * 64 * MBW;
+    const int soff = cc * (8 * 64 * UF * 4);
     if constexpr (MBW == 4) {
-      const float4 a = reinterpret_cast<const float4*>(src)[0];
-      u[pp * 4 + 0] = a.x; u[pp * 4 + 1] = a.y; u[pp * 4 + 2] = a.z; u[pp * 4 + 3] = a.w;
+      typedef float f32x4b __attribute__((ext_vector_type(4)));
+      const f32x4b a = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff + pp * 64 * MBW * 4, soff, 0));
+      u[pp * 4 + 0] = a[0]; u[pp * 4 + 1] = a[1]; u[pp * 4 + 2] = a[2]; u[pp * 4 + 3] = a[3];
     } else if constexpr (MBW == 2) {
-      const float2 a = reinterpret_cast<const float2*>(src)[0];
-      u[pp * 2 + 0] = a.x; u[pp * 2 + 1] = a.y;
+      typedef float f32x2b __attribute__((ext_vector_type(2)));
+      const f32x2b a = __builtin_bit_cast(f32x2b, __builtin_amdgcn_raw_buffer_load_b64(ursrc, u_voff + pp * 64 * MBW * 4, soff, 0));
+      u[pp * 2 + 0] = a[0]; u[pp * 2 + 1] = a[1];
     } else {
-      u[pp] = src[0];
+      u[pp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ursrc, u_voff + pp * 64 * MBW * 4, soff, 0));
     }
   };
 
@@ -177,7 +185,8 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   const int woffA = kq * PPITCH + (2 * wty + rA) * PCP + 4 + 2 * wtx;
   const int woffB = kq * PPITCH + (2 * wty + rB) * PCP + 4 + 2 * wtx;
   typedef float f32x2a __attribute__((ext_vector_type(2)));
-  auto fragments = [&](const float* Psrc, int ks, float (&bv)[2][NBW]) {   // k-step ks of the stage (channels 4 ks + kq) -> B fragments
+  auto fragments = [&](const float* Psrc, int ks, float (&bv)[2][NBW], auto nuh_tag) {   // k-step ks of the stage (channels 4 ks + kq) -> B fragments
+    constexpr int NUHK = decltype(nuh_tag)::value;   // 0 / 1: compile-time column half (no selects, the unused fourth column is never combined); 2: run time
     if (ab & 2) return;
     const float* base = (ab & 128) ? smem + (lane & 1) * 4 : Psrc + ks * (4 * PPITCH);   // (128: every lane reads the same two words: LDS broadcast)
 #pragma unroll
@@ -194,11 +203,21 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const int nb = n0 + n;
-        const float w0 = fmaf(wb[n][0].x, sgn, wa[n][0].x), w1 = fmaf(wb[n][0].y, sgn, wa[n][0].y);
-        const float w2 = fmaf(wb[n][1].x, sgn, wa[n][1].x), w3 = fmaf(wb[n][1].y, sgn, wa[n][1].y);
+        const float w1 = fmaf(wb[n][0].y, sgn, wa[n][0].y), w2 = fmaf(wb[n][1].x, sgn, wa[n][1].x);
         // nu = 0: W0 - W2, 1: W1 + W2, 2: W2 - W1, 3: W1 - W3
-        bv[0][nb] = nuh ? w2 - w1 : w0 - w2;
-        bv[1][nb] = nuh ? w1 - w3 : w1 + w2;
+        if constexpr (NUHK == 1) {
+          const float w3 = fmaf(wb[n][1].y, sgn, wa[n][1].y);
+          bv[0][nb] = w2 - w1;
+          bv[1][nb] = w1 - w3;
+        } else if constexpr (NUHK == 0) {
+          const float w0 = fmaf(wb[n][0].x, sgn, wa[n][0].x);
+          bv[0][nb] = w0 - w2;
+          bv[1][nb] = w1 + w2;
+        } else {
+          const float w0 = fmaf(wb[n][0].x, sgn, wa[n][0].x), w3 = fmaf(wb[n][1].y, sgn, wa[n][1].y);
+          bv[0][nb] = nuh ? w2 - w1 : w0 - w2;
+          bv[1][nb] = nuh ? w1 - w3 : w1 + w2;
+        }
       }
     }
   };
@@ -239,10 +258,11 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
   __syncthreads();
   if ((p.dbg & 0x1000) && wave >= 4) __builtin_amdgcn_s_setprio(1);   // (tuning: static priority for the younger half of the workgroup)
   int rcur = 0, rnxt = M % R;   // ring slots of sub-stage j and j + M
+  auto main_loop = [&](auto nuh_tag) {
   for (int j = 0; j < nstage; ++j) {
     const float* Pcur = Pl + rcur * LDS_P;
     float* Pnxt = Pl + rnxt * LDS_P;
-    fragments(Pcur, 0, bva);
+    fragments(Pcur, 0, bva, nuh_tag);
     // The issue points of the vector-memory instructions are pinned inside the MFMA stream (fence mask: VALU, SALU and LDS operations may
     // cross, MFMAs and vector-memory instructions may not): left alone the compiler sinks the U loads to the end of the k-step in front
     // of their use (they then wait behind `vmcnt(0)` a few MFMAs later).
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
     if (!(ab & 16)) commit_plane(Pnxt, j + M, preg);
     if (!(ab & 8)) load_plane(j + M + 1, preg);
     __builtin_amdgcn_sched_barrier(SB);
-    fragments(Pcur, 1, bvb);
+    fragments(Pcur, 1, bvb, nuh_tag);
     multiply_pp(1, ua, bva);
     __builtin_amdgcn_sched_barrier(SB);
     // k-step 1
@@ -274,6 +294,13 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
     if (M == 1 || (j % M) == M - 1) {
       if (!(ab & 32)) __syncthreads();
     }
+  }
+  };
+  // (uniform) the loop is instantiated per column half where the registers allow it (the 32-channel variant spills with two copies)
+  if constexpr (MBW == 4) {
+    if (nuh) main_loop(std::integral_constant<int, 1>{}); else main_loop(std::integral_constant<int, 0>{});
+  } else {
+    main_loop(std::integral_constant<int, 2>{});
   }
   if (M > 1) __syncthreads();   // (the epilogue reuses the ring)
 

@@ -142,12 +142,14 @@ __global__ __launch_bounds__(RD_NTHR, 4) void conv_wino_rod_kernel(const ConvK p
 #pragma unroll
     for (int i = 0; i < NLD; ++i) preg[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, p_voff[i], soff, 0));
   };
+  const float* wt_b = p.wtp + b * p.wt_bs;
+  const float* wc_b = p.wcp + b * p.wc_bs;
   auto commit_plane = [&](float* Pdst, int j) {
     const int ci = j * IVC + wave;
     const bool chok = ci < p.Cin;
     const int cc = chok ? ci : p.Cin - 1;
-    const float st = uload_rod(p.wtp, b * p.wt_bs + cc * p.wt_cs);
-    const float sc = uload_rod(p.wcp, b * p.wc_bs + cc * p.wc_cs) * st;
+    const float st = uload_rod(wt_b, cc * p.wt_cs);
+    const float sc = uload_rod(wc_b, cc * p.wc_cs) * st;
     const float sh = uload_rod(p.wshp, cc * p.wsh_cs) * st;
     float* dst = Pdst + wave * PPITCH;
 #pragma unroll
@@ -159,19 +161,24 @@ __global__ __launch_bounds__(RD_NTHR, 4) void conv_wino_rod_kernel(const ConvK p
     }
   };
 
-  // ---- U fragments: [group][co tile][chunk][wave][pp 2][lane][mb MBW]
-  const float* ufr = p.w + ((((int64_t)g * p.co_tiles + ct) * nchunk4 * 8 + wave) * 2 * 64 + lane) * MBW;
+  // ---- U fragments: [group][co tile][chunk][wave][pp 2][lane][mb MBW]; buffer loads (resource = this channel tile's slice, scalar
+  //      offset = chunk, fixed lane offset: conv_wino_ro.hip)
+  const float* utile = p.w + ((int64_t)g * p.co_tiles + ct) * nchunk4 * (8 * 64 * UF);
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(utile), 0, nchunk4 * (8 * 64 * UF) * 4, 0x00020000);
+  const int u_voff = ((wave * 2 * 64 + lane) * MBW) * 4;
   auto load_u = [&](int c, float (&u)[UF]) {
     const int cc = c < nchunk4 ? c : nchunk4 - 1;
-    const float* src = ufr + (int64_t)cc * (8 * 64 * UF);
+    const int soff = cc * (8 * 64 * UF * 4);
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
       if constexpr (MBW == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(src + pp * 64 * MBW);
-        u[pp * 4 + 0] = a.x; u[pp * 4 + 1] = a.y; u[pp * 4 + 2] = a.z; u[pp * 4 + 3] = a.w;
+        typedef float f32x4b __attribute__((ext_vector_type(4)));
+        const f32x4b a = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(ursrc, u_voff + pp * 64 * MBW * 4, soff, 0));
+        u[pp * 4 + 0] = a[0]; u[pp * 4 + 1] = a[1]; u[pp * 4 + 2] = a[2]; u[pp * 4 + 3] = a[3];
       } else {
-        const float2 a = *reinterpret_cast<const float2*>(src + pp * 64 * MBW);
-        u[pp * 2 + 0] = a.x; u[pp * 2 + 1] = a.y;
+        typedef float f32x2b __attribute__((ext_vector_type(2)));
+        const f32x2b a = __builtin_bit_cast(f32x2b, __builtin_amdgcn_raw_buffer_load_b64(ursrc, u_voff + pp * 64 * MBW * 4, soff, 0));
+        u[pp * 2 + 0] = a[0]; u[pp * 2 + 1] = a[1];
       }
     }
   };
