@@ -212,9 +212,26 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
   const int pt = l2 / CG, ct = cgrp * CG + (l2 - pt * CG);
   const int nch = (p.Cin + 3) / 4;
 
-  const float* up = p.w + ((int64_t)ct * nch * 12 + wave) * (64 * 12) + lane * 4;
-  const float* vp = V + (((int64_t)b * GX + pt) * nch * 12 + wave) * (64 * 6);
+  // operands through buffer resources: resource = this workgroup's U / V slice, scalar offset = chunk, fixed lane offsets (flat pointers cost a
+  // 64-bit multiply-add per k-step on the vector pipe)
   constexpr int USTEP = 12 * 64 * 12, VSTEP = 12 * 64 * 6;   // floats per chunk
+  const float* uslice = p.w + (int64_t)ct * nch * USTEP;
+  const float* vslice = V + ((int64_t)b * GX + pt) * nch * VSTEP;
+  const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uslice), 0, nch * USTEP * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vslice), 0, nch * VSTEP * 4, 0x00020000);
+  const int u_voff = (wave * (64 * 12) + lane * 4) * 4;            // + 1024 bytes per position
+  const int v01_voff = (wave * (64 * 6) + lane * 4) * 4;
+  const int v2_voff = (wave * (64 * 6) + 256 + lane * 2) * 4;
+  typedef float f32x4b __attribute__((ext_vector_type(4)));
+  typedef float f32x2b __attribute__((ext_vector_type(2)));
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    const f32x4b t = __builtin_bit_cast(f32x4b, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(t[0], t[1], t[2], t[3]);
+  };
+  auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+    const f32x2b t = __builtin_bit_cast(f32x2b, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    return make_float2(t[0], t[1]);
+  };
 #ifdef VSP_WINO_ABLATE   // tuning only (VSP_CONV_DBG): 1 operands always from chunk 0, 2 no epilogue, 4 no loads in the main loop, 8 no MFMAs
   const int ab = p.dbg;
 #else
@@ -223,13 +240,11 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
   auto load = [&](int c, W4Regs& r) {
     if ((ab & 4) && c >= 3) return;
     const int cc = (ab & 1) ? 0 : (c < nch ? c : nch - 1);
-    const float* us = up + (int64_t)cc * USTEP;
-    const float* vs = vp + (int64_t)cc * VSTEP;
-    r.u[0] = *reinterpret_cast<const float4*>(us);
-    r.u[1] = *reinterpret_cast<const float4*>(us + 256);
-    r.u[2] = *reinterpret_cast<const float4*>(us + 512);
-    r.v01 = *reinterpret_cast<const float4*>(vs + lane * 4);
-    r.v2 = *reinterpret_cast<const float2*>(vs + 256 + lane * 2);
+    r.u[0] = ld4(ursrc, u_voff, cc * (USTEP * 4));
+    r.u[1] = ld4(ursrc, u_voff + 1024, cc * (USTEP * 4));
+    r.u[2] = ld4(ursrc, u_voff + 2048, cc * (USTEP * 4));
+    r.v01 = ld4(vrsrc, v01_voff, cc * (VSTEP * 4));
+    r.v2 = ld2(vrsrc, v2_voff, cc * (VSTEP * 4));
   };
 
   f32x4 acc[3][4][2];
@@ -246,8 +261,7 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
   auto kstep = [&](int cn, W4Regs& r) {     // cn = the k-step the registers are re-loaded for (clamped)
     const bool ld = !((ab & 4) && cn >= 3);
     const int cc = (ab & 1) ? 0 : (cn < nch ? cn : nch - 1);
-    const float* us = up + (int64_t)cc * USTEP;
-    const float* vs = vp + (int64_t)cc * VSTEP;
+    const int usoff = cc * (USTEP * 4), vsoff = cc * (VSTEP * 4);
     const float bv[3][2] = {{r.v01.x, r.v01.y}, {r.v01.z, r.v01.w}, {r.v2.x, r.v2.y}};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -260,9 +274,9 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
       }
       __builtin_amdgcn_sched_barrier(SB);
       if (ld) {
-        r.u[q] = *reinterpret_cast<const float4*>(us + 256 * q);
-        if (q == 1) r.v01 = *reinterpret_cast<const float4*>(vs + lane * 4);
-        if (q == 2) r.v2 = *reinterpret_cast<const float2*>(vs + 256 + lane * 2);
+        r.u[q] = ld4(ursrc, u_voff + 1024 * q, usoff);
+        if (q == 1) r.v01 = ld4(vrsrc, v01_voff, vsoff);
+        if (q == 2) r.v2 = ld2(vrsrc, v2_voff, vsoff);
       }
       __builtin_amdgcn_sched_barrier(SB);
     }

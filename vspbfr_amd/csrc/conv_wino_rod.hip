@@ -144,13 +144,17 @@ __global__ __launch_bounds__(RD_NTHR, 4) void conv_wino_rod_kernel(const ConvK p
   };
   const float* wt_b = p.wtp + b * p.wt_bs;
   const float* wc_b = p.wcp + b * p.wc_bs;
+  const bool affine = p.wc_cs != 0 || p.wsh_cs != 0 || p.wc_bs != 0;
   auto commit_plane = [&](float* Pdst, int j) {
     const int ci = j * IVC + wave;
     const bool chok = ci < p.Cin;
     const int cc = chok ? ci : p.Cin - 1;
     const float st = uload_rod(wt_b, cc * p.wt_cs);
-    const float sc = uload_rod(wc_b, cc * p.wc_cs) * st;
-    const float sh = uload_rod(p.wshp, cc * p.wsh_cs) * st;
+    float sc = st, sh = 0.f;
+    if (affine) {   // (uniform for the launch) folded-BatchNorm input of the IR-SE body; the modulated layers skip two scalar loads and their address arithmetic
+      sc = uload_rod(wc_b, cc * p.wc_cs) * st;
+      sh = uload_rod(p.wshp, cc * p.wsh_cs) * st;
+    }
     float* dst = Pdst + wave * PPITCH;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
