@@ -252,6 +252,18 @@ int vsp_conv2d_bf16(const vsp_conv_params* p, vsp_stream_t stream);
  *         part 0 = bf16(W), part 1 = bf16(W - float(bf16(W)))   (hip_ops.bf16x3_weight). */
 int vsp_conv2d_bf16x3(const vsp_conv_params* p, vsp_stream_t stream);
 
+/* The "row-vector K" form of vsp_conv2d_bf16 for the low-channel, large-map stride-1 layers of the bf16-activation
+ * configuration (32 -> 32 at 1024^2, 64 -> 64 at 512^2, 128 -> 128 at 256^2 ...; conv_bf16_rv.hip): a lane's eight k-values are two
+ * channels x four consecutive pixels of an input row (three horizontal taps + one zero weight), so the NCHW bf16 image is
+ * staged as it lies in HBM and the output leaves the accumulators as packed pixel pairs.  Serves io_bf16 = 1, G = 1, 3x3,
+ * stride 1, dilation = padding = 1, Cin % 8 == 0, Cout % 32 == 0, W % 64 == 0, 16-byte aligned x, images below 1 GiB; returns
+ * VSP_ENOTSUP for any other launch (the caller falls back to vsp_conv2d_bf16).  Same operands and epilogue as vsp_conv2d_bf16;
+ * `w` in this kernel's order (hip_ops.bf16rv_weight), nchunk = Cin / 8:
+ *     w[(((((chunk * 3 + ky) * 2 + quad) * 2 + half) * Cout + co) * 8 + e]              (uint16 bf16 bit patterns)
+ *         = bf16( W[tap = 3*ky + kx][ci = 8*chunk + 4*quad + 2*half + (e >> 2)][co] ),  kx = e & 3;  0 for kx = 3.
+ * tile_hint: 0 = automatic, 1 = 32-channel tiles (16 rows x 64 pixels), 2 = 64-channel tiles (8 rows x 64 pixels). */
+int vsp_conv2d_bf16rv(const vsp_conv_params* p, vsp_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Strided, batched small GEMM on fp32 MFMA -- replaces F.linear / torch.matmul of the path
  * (EqualLinear: models/RestoreNet.py:161-171; TACC_block / spatial_attention: models/CodeDiffuser.py:35-47,

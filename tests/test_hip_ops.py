@@ -904,6 +904,55 @@ def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww):
     assert H.conv2d_packed(x, pc, bf16=True, out=o32, **kw) is o32 and torch.equal(o32, H.conv2d_packed(x.float(), pc, bf16=True, **kw))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,hint", [(2, 32, 64, 64, 64, 0), (1, 64, 32, 40, 128, 0), (2, 16, 32, 16, 64, 1), (1, 24, 64, 9, 64, 2),
+                                                   (1, 128, 128, 64, 64, 2), (1, 64, 64, 70, 192, 1),
+                                                   (5, 64, 64, 256, 256, 0), (6, 32, 32, 256, 256, 1)])   # more tiles than resident workgroups: the persistent walk, two workgroups per CU
+def test_conv2d_bf16rv(H, B, Cin, Cout, Hh, Ww, hint):
+    """vsp_conv2d_bf16rv (row-vector K: two channels x four pixels per lane fragment) against vsp_conv2d_bf16 with fp32 output on the
+    same bf16-representable operands: same products, another summation order and ONE rounding at the store -- whole epilogue
+    (style scale, demodulation, noise, bias, activation, two residuals), both tile variants, ragged row counts, 1 and 3 chunks,
+    the affine (folded BatchNorm) prologue whose shift must not leak into the zero padding."""
+    x = _b16(torch.randn(B, Cin, Hh, Ww, device=DEV))
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV) / math.sqrt(Cin * 9)
+    s_in, demod, bias = torch.rand(B, Cin, device=DEV) + 0.5, torch.rand(B, Cout, device=DEV) + 0.5, torch.randn(Cout, device=DEV)
+    nz, nw = torch.randn(B, 1, Hh, Ww, device=DEV), torch.full((1,), 0.2, device=DEV)
+    r1, r2 = _b16(torch.randn(B, Cout, Hh, Ww, device=DEV)), _b16(torch.randn(B, Cout, Hh, Ww, device=DEV))
+    pc = H.PackedConv(H.pack_weight(w), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+
+    def close(got, ref):
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        err = (got.float() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all()), float(err.max())
+
+    kw = dict(in_scale=s_in, out_scale=demod, act2=1, bias2=bias, noise=nz, noise_w=nw)
+    close(H.conv2d_packed(x, pc, bf16="rv", tile_hint=hint, res1=r1, res2=r2, **kw), H.conv2d_packed(x.float(), pc, bf16=True, res1=r1.float(), res2=r2.float(), **kw))
+    close(H.conv2d_packed(x, pc, bf16="rv", tile_hint=hint), H.conv2d_packed(x.float(), pc, bf16=True))
+    close(H.conv2d_packed(x, pc, bf16="rv", tile_hint=hint, act1=True, bias1=bias, res1=r1), H.conv2d_packed(x.float(), pc, bf16=True, act1=True, bias1=bias, res1=r1.float()))
+    bn_s, bn_h = torch.rand(Cin, device=DEV) + 0.5, torch.randn(Cin, device=DEV)
+    kw2 = dict(in_scale=bn_s, in_scale_per_sample=False, in_shift=bn_h, act2=2, prelu=torch.rand(Cout, device=DEV) * 0.5)
+    close(H.conv2d_packed(x, pc, bf16="rv", tile_hint=hint, **kw2), H.conv2d_packed(x.float(), pc, bf16=True, **kw2))
+
+
+def test_conv2d_bf16rv_refusals(H):
+    """Launches the row-vector kernel does not serve: VSP_ENOTSUP at the C entry (the automatic path then uses vsp_conv2d_bf16),
+    an error when it is forced."""
+    w = torch.randn(32, 32, 3, 3, device=DEV) / 17
+    pc = H.PackedConv(H.pack_weight(w), 1, 32, 32, 3, 3, 1, (1,), (1,))
+    x = _b16(torch.randn(1, 32, 32, 48, device=DEV))            # W % 64 != 0
+    with pytest.raises(RuntimeError, match="row-vector"):
+        H.conv2d_packed(x, pc, bf16="rv")
+    H.BF16_CONV, H.ACT_BF16 = True, True
+    try:
+        y = H.conv2d_packed(x, pc)                               # automatic: the general bf16 kernel
+        x2 = _b16(torch.randn(1, 32, 128, 128, device=DEV))
+        y2 = H.conv2d_packed(x2, pc)                             # automatic: eligible and profitable -> the row-vector kernel
+    finally:
+        H.BF16_CONV, H.ACT_BF16 = False, False
+    assert y.dtype == torch.bfloat16 and y2.dtype == torch.bfloat16
+    ref2 = H.conv2d_packed(x2.float(), pc, bf16=True)
+    assert float((y2.float() - ref2).abs().max()) <= float(ref2.abs().max()) * 2.0 ** -7
+
+
 # ------------------------------------------------------------------------------------------------ convolution backward
 def _grads(fn, *tensors):
     with torch.enable_grad():   # (this module switches autograd off globally)

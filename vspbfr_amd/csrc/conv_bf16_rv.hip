@@ -1,0 +1,465 @@
+// 3x3 stride-1 convolution on the bf16 matrix pipe for the LOW-CHANNEL, LARGE-MAP layers of the bf16-activation configuration
+// (32 -> 32 at 1024^2, 64 -> 64 at 512^2, 128 -> 128 at 256^2 ...: BASELINE configs[2]).  Those layers sit near the HBM roofline
+// on paper (64 -> 64 at 512^2: 1 byte per 36 bf16 MACs) and the general kernel (conv_bf16.hip) spends its time on the way the
+// operands get into fragment order: a lane's MFMA fragment there is 8 CHANNELS of one pixel, so an NCHW image is transposed
+// element by element (one 16-bit load per element, pack, ds_write) and the output goes back through an LDS transpose.
+//
+// "Row-vector K": the reduction index of v_mfma_f32_32x32x16_bf16 is (channel, tap) in any order both operands agree on.  Here a
+// lane's eight k-values are TWO channels x FOUR consecutive pixels of one input row, [x-1, x, x+1, x+2] -- the three horizontal
+// taps of that row plus one zero weight -- i.e. two 8-byte reads of the image AS IT LIES in HBM.  So
+//   * the patch in LDS is a straight copy of the NCHW bf16 rows (16-byte loads, 16-byte ds_writes, the per-sample style scale
+//     applied on the way: bf16(x * s) exactly as conv_bf16.hip rounds it); nothing is transposed;
+//   * a B fragment is two ds_read_b64 at 2-byte granularity (gfx950 LDS takes unaligned b64), lanes 4 bytes apart;
+//   * the 32 pixels of an N-block are the EVEN or the ODD pixels of a 64-pixel row segment, so a lane ends up with both
+//     pixels of a pair (2j, 2j+1) for 16 channels: the epilogue packs the pair into one dword and stores it to the NCHW bf16
+//     output directly from the accumulators -- a wave store covers two whole 128-byte lines, no LDS transpose, no barrier;
+//   * a B fragment (input row r) feeds the three output rows r-1, r, r+1 of the wave, the A fragment of (dy, channel quad) every
+//     output row and both parities: 6-8 LDS fragment reads per 48 MFMAs and k-chunk instead of 1 per MFMA.
+// The price is 4/3 of the MFMAs (the zero tap), which these layers have to spare.
+// Workgroup = 4 waves, wave = MB 32-channel blocks x RWV output rows x 64 pixels: 64 channels x 8 rows (MB = 2, RWV = 2), 32 x 8, 32 x 16.
+// K runs in chunks of 8 channels (two MFMA k-steps per vertical tap), patch and weights double-buffered, one barrier per chunk;
+// weights [chunk][dy][quad][half][co][8] bf16 (hip_ops.bf16rv_weight) come in by LDS-DMA.
+// Numerics: as conv_bf16.hip (bf16 operands, exact products, fp32 accumulation, fp32 epilogue chain) in another summation order.
+#include "conv_kernel.h"
+#include "vsp_bf16.h"
+
+namespace vspconv {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2h __attribute__((ext_vector_type(2), aligned(2)));
+
+constexpr int RV_TW = 64;           // pixels per tile row
+constexpr int RV_SEG = 10;          // 16-byte segments per patch row: columns x0 - 8 ... x0 + 71
+constexpr int RV_ROWB = RV_SEG * 16;
+constexpr int RV_CK = 8;            // channels per chunk
+constexpr int RV_MAXC = 256;        // input channels the LDS scale table holds
+
+template <int MB, int RWV>   // 32-channel blocks and output rows per wave
+__global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, const int ntiles) {
+  constexpr int TH = 4 * RWV, PR = TH + 2, CO_T = 32 * MB;
+  constexpr int SPC = (PR * RV_SEG + 63) / 64;      // staging slots per channel; a wave stages two channels of every chunk
+  constexpr int PT = 2 * SPC;
+  constexpr int PCH = PR * RV_ROWB;                 // bytes per channel of the patch image
+  constexpr int PBUF = RV_CK * PCH;
+  constexpr int WROWS = 12;                         // [dy 3][quad 2][half 2] rows of CO_T fragments per chunk
+  constexpr int WBUF = WROWS * CO_T * 16;
+  constexpr int NGRP = 2 * (RWV + 2);               // (quad, input row) groups per chunk
+  static_assert(PT <= NGRP, "one commit per fragment group");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Wl = smem;                  // 2 x WBUF
+  unsigned char* Pl = smem + 2 * WBUF;       // 2 x PBUF
+  float4* Ep = reinterpret_cast<float4*>(smem + 2 * WBUF + 2 * PBUF);   // [tile parity][channel of the tile]: scale, bias, bias2, slope2
+  float2* Sc = reinterpret_cast<float2*>(smem + 2 * WBUF + 2 * PBUF + 2 * CO_T * 16);   // [tile parity][input channel]: style scale, shift
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, kh = lane >> 5;
+
+  // PERSISTENT workgroups: the grid is what the chip holds (two per CU); a workgroup walks a contiguous range of the logical tile
+  // order co tile (same patch) -> tile column -> tile row -> image, and every XCD (own L2; the dispatcher deals workgroups
+  // round-robin over the eight) gets a contiguous range of workgroups.  A tile lives ~40 us, of which launch, first loads and
+  // the epilogue were a third (tuning build: 237 of 790 us with everything else switched off): the first loads of tile t + 1 are
+  // issued BEFORE the epilogue of tile t.
+  const int tiles_x = p.W / RV_TW, tiles_y = (p.H + TH - 1) / TH, co_tiles = p.co_tiles;
+  int t_begin, t_end;
+  {
+    const int GT = gridDim.x, wgid = blockIdx.x;
+    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+    const int g = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+    t_begin = (int)((int64_t)g * ntiles / GT);
+    t_end = (int)((int64_t)(g + 1) * ntiles / GT);
+  }
+  if (t_begin >= t_end) return;
+  struct Tile { int b, oy0, x0, co0; };
+  auto decode = [&](int lid) {
+    Tile t;
+    const int ct = lid % co_tiles; lid /= co_tiles;
+    const int tx = lid % tiles_x; lid /= tiles_x;
+    const int ty = lid % tiles_y;
+    t.b = lid / tiles_y; t.oy0 = ty * TH; t.x0 = tx * RV_TW; t.co0 = ct * CO_T;
+    return t;
+  };
+  const int chw = p.H * p.W;
+  const int nchunk = p.Cin / RV_CK;
+  const int Cout = p.cout_g;     // (host: a multiple of CO_T)
+
+  // ---- patch staging: slot e of wave w = channel 2w + e / SPC of the chunk, 16-byte segment (e % SPC) * 64 + lane of its PR x 10.
+  // State of the tile being STAGED (from the moment its first loads are issued, i.e. before the previous tile's epilogue):
+  const bool affine = p.bf_isc_s != 0 || p.bf_ish_s != 0;   // (uniform) absent: the patch is a plain copy
+  const bool shifted = p.bf_ish_s != 0;
+  typedef const float __attribute__((address_space(4))) * cfp4;   // uniform loads through the scalar cache
+  const float slope_c = ((cfp4)(uintptr_t)p.s2p)[0];
+  const bool fast = p.s1 == 1.f && p.g1 == 1.f && p.s2s == 0 && slope_c >= 0.f && slope_c <= 1.f;   // (uniform) the lean epilogue below
+  int poff[PT];
+  unsigned pwr = 0, pin = 0;
+  int st_xoff = 0, st_co0 = 0, st_b = 0;   // byte offset of the image in x, first channel of the tile, image
+  const float* iscp = p.in_scale;
+  const int pdst0 = 2 * wave * PCH + lane * 16;   // slot e lands at + (e / SPC) PCH + (e % SPC) 1024: a patch row is exactly its ten segments
+#pragma unroll
+  for (int e = 0; e < PT; ++e) pwr |= lane + 64 * (e % SPC) < PR * RV_SEG ? (1u << e) : 0u;
+  auto stage_tile = [&](const Tile& t) {
+    pin = 0;
+#pragma unroll
+    for (int e = 0; e < PT; ++e) {
+      const int chl = e / SPC, tt = lane + 64 * (e % SPC);
+      const int row = tt / RV_SEG, seg = tt - row * RV_SEG;
+      const int iy = t.oy0 - 1 + row, ix = t.x0 - 8 + 8 * seg;
+      const bool in = tt < PR * RV_SEG && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      poff[e] = in ? (chl * chw + iy * p.W + ix) * 2 : 0x7fffffff;   // (past the buffer: the load returns zeros)
+      pin |= in ? (1u << e) : 0u;
+    }
+    st_xoff = t.b * p.x_ch * chw * 2;
+    st_co0 = t.co0;
+    iscp = p.in_scale + (int64_t)t.b * p.in_scale_bstride;
+    st_b = t.b;
+  };
+  float4 epv;
+  float2 scv[RV_MAXC / 256];
+  auto ep_load = [&]() {   // epilogue operands of the staged tile's channels (threads 0 .. CO_T - 1), written to LDS by first_commit
+    if (affine) {
+#pragma unroll
+      for (int k = 0; k < RV_MAXC / 256; ++k) {
+        const int ci = tid + 256 * k;
+        scv[k] = ci < p.Cin ? float2{iscp[ci * p.bf_isc_s], p.in_shift[ci * p.bf_ish_s]} : float2{0.f, 0.f};
+      }
+    }
+    if (tid < CO_T) {
+      const int co = st_co0 + tid;
+      const float os = p.osp[((int64_t)st_b * Cout + co) * p.oss] * p.csp[co * p.css];
+      const float cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
+      const float b2 = p.b2p[co * p.b2s];
+      epv = fast ? float4{os * p.g2, (cb + b2) * p.g2, 0.f, 0.f} : float4{os, cb, b2, p.s2p[co * p.s2s]};
+    }
+  };
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, 0x7ffffff0, 0x00020000);
+  u32x4 pregA[PT], pregB[PT];
+  auto issue_p = [&](u32x4 (&pr)[PT], int c) {
+#ifdef VSP_BF16_ABLATE  // tuning build only (VSP_CONV_DBG): 1 no patch loads after the first chunk, 2 no weight DMA, 4 no stores, 8 no MFMAs, 16 no commits, 32 no B fragment reads, 64 no epilogue, 128 no A fragment reads
+    if ((p.dbg & 1) && c > 0) return;
+#endif
+    const int soff = st_xoff + (c * RV_CK + 2 * wave) * chw * 2;
+#pragma unroll
+    for (int e = 0; e < PT; ++e) pr[e] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, poff[e], soff, 0);
+  };
+  // the per-channel input scale / shift of the staged image: fetched ONCE per tile with the first loads and kept in LDS (a scalar
+  // load per chunk missed the scalar cache every other chunk -- a memory round trip in front of every commit)
+  int sc_par = 0;
+  auto load_scales = [&](int c, float (&sc)[2], float (&sh)[2]) {
+    const float2* src = Sc + sc_par * RV_MAXC + c * RV_CK + 2 * wave;
+    const float2 v0 = src[0], v1 = src[1];
+    sc[0] = v0.x; sh[0] = v0.y; sc[1] = v1.x; sh[1] = v1.y;
+  };
+  auto commit_one = [&](unsigned char* Pdst, const u32x4 (&pr)[PT], const float (&sc)[2], const float (&sh)[2], int e) {
+    if (!((pwr >> e) & 1u)) return;
+#ifdef VSP_BF16_ABLATE
+    if (p.dbg & 16) return;
+#endif
+    u32x4 v = pr[e];
+    if (affine) {
+      const float s = sc[e / SPC], h = sh[e / SPC];
+      const bool in = (pin >> e) & 1u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float lo = fmaf(vsp::bf16_lo(v[k]), s, h), hi = fmaf(vsp::bf16_hi(v[k]), s, h);
+        const unsigned w = vsp::bf16_pack(lo, hi);
+        v[k] = (!shifted || in) ? w : 0u;   // (a shift must not leak into the zero padding)
+      }
+    }
+    *reinterpret_cast<u32x4*>(Pdst + pdst0 + (e / SPC) * PCH + (e % SPC) * 1024) = v;
+  };
+
+  // ---- weight slab by LDS-DMA: 12 rows of CO_T 16-byte fragments, 64 per wave instruction
+  constexpr int NDMA = WROWS * CO_T / 64;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w);
+  auto issue_w = [&](unsigned char* Wdst, int c) {
+#ifdef VSP_BF16_ABLATE
+    if ((p.dbg & 2) && c > 0) return;
+#endif
+    const u32x4* src = wsrc + (int64_t)c * WROWS * Cout;
+#pragma unroll
+    for (int k = 0; k < (NDMA + 3) / 4; ++k) {
+      const int i = wave + 4 * k;
+      const int L = i * 64 + lane;
+      const int row = L / CO_T, co = L - row * CO_T;
+      if (i < NDMA) __builtin_amdgcn_global_load_lds(src + row * Cout + st_co0 + co, reinterpret_cast<u32x4*>(Wdst) + i * 64, 16, 0, 0);
+    }
+  };
+
+  // ---- fragments
+  const int b_lane = kh * 2 * PCH + 12 + 4 * l32;       // byte of pixel pair l32 - 1 (pixels x0 + 2 l32 - 2, - 1) in row 0 of the half's first channel
+  const int a_lane = (kh * CO_T + l32) * 16;
+  const int wr0 = wave * RWV;                            // first output row of the wave inside the tile
+
+  f32x16 acc[MB][RWV][2];
+
+  auto interval = [&](int c, u32x4 (&prLoad)[PT], u32x4 (&prCommit)[PT]) {
+    const int cur = c & 1, nxt = cur ^ 1;
+    float sc[2], sh[2];
+    if (affine) load_scales(c + 1 < nchunk ? c + 1 : c, sc, sh);
+    if (c + 2 < nchunk) issue_p(prLoad, c + 2);
+    const unsigned char* Wc = Wl + cur * WBUF + a_lane;
+    const unsigned char* Pc = Pl + cur * PBUF + b_lane + wr0 * RV_ROWB;
+    unsigned char* Pn = Pl + nxt * PBUF;
+    // B fragments of one (quad, input row) group: per channel THREE aligned dwords E0 E1 E2 = pixel pairs j - 1, j, j + 1 of the row
+    // (ds_read_b32, lanes 4 bytes apart: 256 bytes per instruction and half); the odd pixels' window [2j .. 2j+3] is (E1, E2), the
+    // even pixels' window [2j-1 .. 2j+2] two funnel shifts -- 12 bytes of LDS per lane and channel for both parities (two
+    // overlapping ds_read_b64 per parity measured 10 clk each: with eight waves per CU the LDS, not the matrix pipe, was the bound)
+    auto load_b = [&](int grp, bf16x8 (&bf)[2]) {
+#ifdef VSP_BF16_ABLATE
+      if (p.dbg & 32) return;
+#endif
+      const int q = grp / (RWV + 2), ir = grp - q * (RWV + 2);
+      unsigned e[2][3];
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e[ch][k] = *reinterpret_cast<const unsigned*>(Pc + (4 * q + ch) * PCH + ir * RV_ROWB + 4 * k);
+      bf[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(e[0][1], e[0][0], 16), __builtin_amdgcn_alignbit(e[0][2], e[0][1], 16),
+                                               __builtin_amdgcn_alignbit(e[1][1], e[1][0], 16), __builtin_amdgcn_alignbit(e[1][2], e[1][1], 16)});
+      bf[1] = __builtin_bit_cast(bf16x8, u32x4{e[0][1], e[0][2], e[1][1], e[1][2]});
+    };
+    bf16x8 a[3][MB], bq[2][2];
+    load_b(0, bq[0]);
+#pragma unroll
+    for (int grp = 0; grp < NGRP; ++grp) {
+      const int q = grp / (RWV + 2), ir = grp - q * (RWV + 2);
+#ifdef VSP_BF16_ABLATE
+      if (!(p.dbg & 128))
+#endif
+      if (ir == 0) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            a[dy][mb] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Wc + ((dy * 2 + q) * 2 * CO_T + mb * 32) * 16));
+      }
+      const int cs = grp & 1;
+      if (grp + 1 < NGRP) load_b(grp + 1, bq[cs ^ 1]);
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int r = ir - dy;
+          if (r < 0 || r >= RWV) continue;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+#ifdef VSP_BF16_ABLATE
+            if (p.dbg & 8) continue;
+#endif
+            acc[mb][r][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][mb], bq[cs][pp], acc[mb][r][pp], 0, 0, 0);
+          }
+        }
+      if (c + 1 < nchunk) {
+        if (grp < PT) commit_one(Pn, prCommit, sc, sh, grp);
+        if (grp == PT - 1) issue_w(Wl + nxt * WBUF, c + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  };
+  auto first_loads = [&]() {
+    issue_p(pregA, 0);
+    if (nchunk > 1) issue_p(pregB, 1);
+    ep_load();
+    issue_w(Wl, 0);
+  };
+  auto first_commit = [&](int par) {
+    sc_par = par;
+    if (affine) {
+#pragma unroll
+      for (int k = 0; k < RV_MAXC / 256; ++k)
+        if (tid + 256 * k < p.Cin) Sc[par * RV_MAXC + tid + 256 * k] = scv[k];
+    }
+    if (tid < CO_T) Ep[par * CO_T + tid] = epv;
+    if (affine) __syncthreads();   // (the first chunk's own scales)
+    float sc[2] = {1.f, 1.f}, sh[2] = {0.f, 0.f};
+    if (affine) load_scales(0, sc, sh);
+#pragma unroll
+    for (int e = 0; e < PT; ++e) commit_one(Pl, pregA, sc, sh, e);
+    __syncthreads();
+  };
+
+  // ---- epilogue operands that do not depend on the tile
+  const int y_plane = p.y_h * p.y_w;
+  const bool has_nz = p.nzs != 0, has_r1 = p.r1s != 0, has_r2 = p.r2s != 0;
+  const bool act1 = !(p.s1 == 1.f && p.g1 == 1.f);
+  const float s1 = p.s1, g1 = p.g1, g2 = p.g2, nw = ((cfp4)(uintptr_t)p.nwp)[0];
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r1p), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.r2p), 0, 0x7ffffff0, 0x00020000);
+
+  Tile cur = decode(t_begin);
+  int par = 0;
+  stage_tile(cur);
+  first_loads();
+  first_commit(par);
+  for (int t = t_begin; t < t_end; ++t) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < RWV; ++r)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mb][r][pp][i] = 0.f;
+    // the noise of the wave's rows: requested before the chunk loop, long landed when the epilogue reads it
+    f32x2 nzv[RWV];
+    int voff[RWV];
+#pragma unroll
+    for (int r = 0; r < RWV; ++r) {
+      const int oy = cur.oy0 + wr0 + r;
+      const bool ok = oy < p.OH;
+      nzv[r] = f32x2{0.f, 0.f};
+      if (has_nz && ok) nzv[r] = *reinterpret_cast<const f32x2*>(p.nzp + (int64_t)cur.b * p.OH * p.OW + oy * p.OW + cur.x0 + 2 * l32);
+      voff[r] = ok ? ((kh * 4 * y_plane) + oy * p.y_w + cur.x0 + 2 * l32) * 2 : 0x7fffffff;   // (rows past the image: dropped by the range check)
+    }
+    for (int c = 0; c < nchunk; c += 2) {
+      interval(c, pregA, pregB);
+      if (c + 1 < nchunk) interval(c + 1, pregB, pregA);
+    }
+    const bool has_next = t + 1 < t_end;
+    const Tile done = cur;
+    if (has_next) {   // (every wave is past the last barrier of the chunk loop: both buffer pairs are free)
+      cur = decode(t + 1);
+      stage_tile(cur);
+      first_loads();
+    }
+    // ---- epilogue: lane = pixel pair (x0 + 2 l32, +1) of the wave's rows, channels 8 (i >> 2) + 4 kh + (i & 3) of every 32-block
+    const int y_img = (done.b * p.y_ch + p.y_coff) * y_plane * 2, r_img = (done.b * p.res_ch + p.res_coff) * y_plane * 2;
+#ifdef VSP_BF16_ABLATE
+    if (!(p.dbg & 64))
+#endif
+    if (fast) {
+      // StyledConv / plain-conv flavour (no first activation, constant slope in [0, 1]): gain folded into the per-channel pair
+      // (scale, bias) and the noise row, leaky ReLU = max(v, slope v): ~9 vector instructions per pixel pair and one 8-byte LDS
+      // read per channel, four channels requested at a time.  Plain floats on purpose: written on float2 vectors (v_pk_fma_f32
+      // with op_sel broadcasts of the freshly read pair) the even pixel of the last 16 lanes lost its bias term on a few row
+      // segments per launch whenever two workgroups shared a CU (never with one) -- see DESIGN.md, round-4 findings.
+      f32x2 nzg[RWV];
+#pragma unroll
+      for (int r = 0; r < RWV; ++r) nzg[r] = nzv[r] * (nw * g2);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+          f32x2 ab[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ab[k] = *reinterpret_cast<const f32x2*>(&Ep[par * CO_T + mb * 32 + 8 * ib + k + 4 * kh]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = 4 * ib + k;
+            const int cplane = (done.co0 + mb * 32 + 8 * ib + k) * y_plane * 2;
+#pragma unroll
+            for (int r = 0; r < RWV; ++r) {
+              float v[2] = {fmaf(acc[mb][r][0][i], ab[k][0], ab[k][1]), fmaf(acc[mb][r][1][i], ab[k][0], ab[k][1])};
+              if (has_nz) { v[0] += nzg[r][0]; v[1] += nzg[r][1]; }
+              v[0] = fmaxf(v[0], v[0] * slope_c);
+              v[1] = fmaxf(v[1], v[1] * slope_c);
+              if (has_r1) {
+                const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r1rsrc, voff[r], r_img + cplane, 0);
+                v[0] += vsp::bf16_lo(w); v[1] += vsp::bf16_hi(w);
+              }
+              if (has_r2) {
+                const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r2rsrc, voff[r], r_img + cplane, 0);
+                v[0] += vsp::bf16_lo(w); v[1] += vsp::bf16_hi(w);
+              }
+#ifdef VSP_BF16_ABLATE
+              if ((p.dbg & 4) && v[0] != 12345.f) continue;
+#endif
+              __builtin_amdgcn_raw_buffer_store_b32(vsp::bf16_pack(v[0], v[1]), yrsrc, voff[r], y_img + cplane, 0);
+            }
+          }
+        }
+      }
+    } else
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int col = mb * 32 + 8 * (i >> 2) + (i & 3);        // + 4 kh: the lane half
+        const float4 e4 = Ep[par * CO_T + col + 4 * kh];
+        const float os = e4.x, cb = e4.y, b2 = e4.z, pg = g2, ng = e4.w * g2;
+        const int cplane = (done.co0 + col) * y_plane * 2;
+#pragma unroll
+        for (int r = 0; r < RWV; ++r) {
+          float v[2] = {fmaf(acc[mb][r][0][i], os, cb), fmaf(acc[mb][r][1][i], os, cb)};
+          if (act1) {
+            v[0] = (v[0] > 0.f ? v[0] : v[0] * s1) * g1;
+            v[1] = (v[1] > 0.f ? v[1] : v[1] * s1) * g1;
+          }
+          v[0] += nzv[r][0] * nw + b2;
+          v[1] += nzv[r][1] * nw + b2;
+          v[0] *= v[0] > 0.f ? pg : ng;
+          v[1] *= v[1] > 0.f ? pg : ng;
+          if (has_r1) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r1rsrc, voff[r], r_img + cplane, 0);
+            v[0] += vsp::bf16_lo(w); v[1] += vsp::bf16_hi(w);
+          }
+          if (has_r2) {
+            const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(r2rsrc, voff[r], r_img + cplane, 0);
+            v[0] += vsp::bf16_lo(w); v[1] += vsp::bf16_hi(w);
+          }
+#ifdef VSP_BF16_ABLATE
+          if ((p.dbg & 4) && v[0] != 12345.f) continue;
+#endif
+          __builtin_amdgcn_raw_buffer_store_b32(vsp::bf16_pack(v[0], v[1]), yrsrc, voff[r], y_img + cplane, 0);
+        }
+      }
+    }
+    if (has_next) {
+      par ^= 1;
+      first_commit(par);
+    }
+  }
+}
+
+template <int MB, int RWV>
+int launch_rv(ConvK q, hipStream_t stream) {
+  constexpr int TH = 4 * RWV, PR = TH + 2, CO_T = 32 * MB;
+  constexpr size_t lds = 2 * (size_t)(12 * CO_T * 16) + 2 * (size_t)(RV_CK * PR * RV_ROWB) + 2 * CO_T * 16 + 2 * RV_MAXC * 8;
+  static vsp::LdsAttrOnce attr;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_rv_kernel<MB, RWV>), 150 * 1024, "conv2d_bf16rv")) return rc;
+  q.co_tiles = q.cout_g / CO_T;
+  const int64_t ntiles = (int64_t)(q.W / RV_TW) * ((q.H + TH - 1) / TH) * q.co_tiles * q.B;
+  if (ntiles > 0x7fffffff) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: grid too large");
+  static const int per_cu = getenv("VSP_BF16RV_WGS") ? atoi(getenv("VSP_BF16RV_WGS")) : 2;   // resident workgroups per CU (tuning)
+  const int64_t grid = ntiles < (int64_t)vsp::kNumCU * per_cu ? ntiles : (int64_t)vsp::kNumCU * per_cu;
+  conv_bf16_rv_kernel<MB, RWV><<<dim3((unsigned)grid), 256, lds, stream>>>(q, (int)ntiles);
+  return VSP_OK;
+}
+
+}  // namespace
+
+// What the row-vector kernel serves: G = 1, dilation 1, bf16 activations, Cin % 8 == 0, Cout % 32 == 0, W % 64 == 0, 16-byte
+// aligned image rows, tensors below 2 GiB (32-bit byte offsets from the tensor base).
+bool bf16rv_eligible(const ConvK& q) {
+  if (q.G != 1 || q.dil[0] != 1 || !q.io_bf16 || q.KH != 3 || q.KW != 3) return false;
+  if (q.Cin % RV_CK || q.Cin > RV_MAXC || q.cout_g % 32 || q.W % RV_TW || q.OH != q.H || q.OW != q.W) return false;
+  if ((reinterpret_cast<uintptr_t>(q.x) & 15) || (reinterpret_cast<uintptr_t>(q.y) & 3)) return false;
+  if ((q.r1s && (reinterpret_cast<uintptr_t>(q.r1p) & 3)) || (q.r2s && (reinterpret_cast<uintptr_t>(q.r2p) & 3))) return false;
+  if (q.nzs && (reinterpret_cast<uintptr_t>(q.nzp) & 7)) return false;
+  const int64_t lim = ((int64_t)1 << 31) - 64;   // 32-bit byte offsets from the tensor base; the padding marker 0x7fffffff lies above them
+  const int64_t plane = (int64_t)q.y_h * q.y_w;
+  if ((q.y_w & 1) || (int64_t)q.B * q.x_ch * q.H * q.W * 2 >= lim || (int64_t)q.B * q.y_ch * plane * 2 >= lim || (int64_t)q.B * q.res_ch * plane * 2 >= lim) return false;
+  return true;
+}
+
+// variant: 0 = automatic (64-channel tiles when Cout allows), 1 = 32 channels x 8 rows, 2 = 64 channels x 8 rows, 3 = 32 channels x 16 rows (x 64 pixels)
+int bf16rv_launch(const ConvK& q, int variant, hipStream_t stream) {
+  if (variant == 0) variant = q.cout_g % 64 == 0 ? 2 : 1;
+  if (variant == 2 && q.cout_g % 64) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: 64-channel tiles need Cout %% 64 == 0");
+  switch (variant) {
+    case 1: return launch_rv<1, 2>(q, stream);
+    case 2: return launch_rv<2, 2>(q, stream);
+    case 3: return launch_rv<1, 4>(q, stream);
+    default: return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: unknown variant %d", variant);
+  }
+}
+
+}  // namespace vspconv

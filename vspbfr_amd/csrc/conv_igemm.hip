@@ -405,11 +405,13 @@ extern "C" int vsp_conv2d_winograd4_f32(const vsp_conv_params* pp, float* work, 
   return vsp::check_launch("conv2d_winograd4");
 }
 
-static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split);
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, bool rv = false);
 extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false); }
 extern "C" int vsp_conv2d_bf16x3(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, true); }
+// the row-vector-K kernel (conv_bf16_rv.hip): same operands as vsp_conv2d_bf16 with io_bf16 = 1, its own weight order; VSP_ENOTSUP when the launch is not one it serves
+extern "C" int vsp_conv2d_bf16rv(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false, true); }
 
-static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split) {
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, bool rv) {
   VSP_REQUIRE(pp != nullptr, "conv2d_bf16: null params");
   vsp_conv_params pcopy = *pp;
   int mode = 0;
@@ -469,6 +471,11 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   {
     static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
     q.dbg = dbg;
+  }
+  if (rv) {
+    if (mode != 0 || !vspconv::bf16rv_eligible(q)) return VSP_ENOTSUP;
+    if (int rc = vspconv::bf16rv_launch(q, p.tile_hint, vsp::as_stream(stream))) return rc;
+    return vsp::check_launch("conv2d_bf16rv");
   }
   if (split) {
     if (int rc = vspconv::bf16_launch_split(q, mode, p.tile_hint, vsp::as_stream(stream))) return rc;

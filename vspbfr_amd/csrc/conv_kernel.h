@@ -634,6 +634,9 @@ int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout)
 // conv_bf16.hip: 3x3 stride-1 convolution on the bf16 matrix pipe (q.w = bf16 weights in LDS-image order)
 int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream);
 int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream);  // hi + lo bf16 operands ("bf16x3")
+// conv_bf16_rv.hip: the row-vector-K form for low-channel large-map stride-1 layers with bf16 activations
+bool bf16rv_eligible(const ConvK& q);
+int bf16rv_launch(const ConvK& q, int variant, hipStream_t stream);
 
 struct Cfg {
   int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;  // a name ending in "t" marks a transposed-conv kernel

@@ -290,7 +290,7 @@ class PackedConv:
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
-                 "_wino", "_wino4", "_bf16", "_bf16x3")
+                 "_wino", "_wino4", "_bf16", "_bf16x3", "_bf16rv")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -307,6 +307,7 @@ class PackedConv:
         self._wino4 = None
         self._bf16 = None
         self._bf16x3 = None
+        self._bf16rv = None
 
     @property
     def cout(self):
@@ -334,6 +335,13 @@ class PackedConv:
                 self._bf16 = bf16_weight(self.w)
         return self._bf16
 
+
+    def bf16rv_weight(self):
+        """The weight rounded to bf16 in the fragment order of vsp_conv2d_bf16rv, built on first use."""
+        if self._bf16rv is None:
+            with torch.no_grad():
+                self._bf16rv = bf16rv_weight(self.w)
+        return self._bf16rv
 
     def bf16x3_weight(self):
         """hi + lo bf16 parts of the weight in the LDS-image order of vsp_conv2d_bf16x3, built on first use."""
@@ -393,6 +401,49 @@ def bf16_weight(wp):
     Wz[:, :, :cin, :cout] = wp
     Wz = Wz.view(ng, T, nch, 2, 8, co_pad).permute(0, 2, 1, 3, 5, 4)
     return Wz.to(torch.bfloat16).contiguous().view(-1)
+
+
+def bf16rv_weight(wp):
+    """packed weights (1, 9, Cin, Cout) fp32 -> [chunk Cin/8][ky 3][quad 2][half 2][Cout][8] bf16 with element e = channel
+    8 chunk + 4 quad + 2 half + (e >> 2), horizontal tap kx = e & 3 (kx = 3: zero) -- the A fragments of vsp_conv2d_bf16rv."""
+    ng, T, cin, cout = wp.shape
+    if ng != 1 or T != 9 or cin % 8 or cout % 32:
+        raise RuntimeError("bf16rv_weight: G = 1, 3x3, Cin % 8 == 0, Cout % 32 == 0")
+    Wz = wp.new_zeros(3, 4, cin, cout)
+    Wz[:, :3] = wp[0].view(3, 3, cin, cout)
+    Wz = Wz.view(3, 4, cin // 8, 2, 2, 2, cout).permute(2, 0, 3, 4, 6, 5, 1)   # chunk, ky, quad, half, co, pair, kx
+    return Wz.to(torch.bfloat16).contiguous().view(-1)
+
+
+def bf16rv_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
+    """What vsp_conv2d_bf16rv serves (bf16 activations on top; the entry re-checks alignment and returns VSP_ENOTSUP)."""
+    return (not transposed and pc.G == 1 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.dil[0] == 1 and pc.pad_y[0] == 1
+            and pc.pad_x[0] == 1 and pc.cin % 8 == 0 and pc.cout % 32 == 0 and W % 64 == 0 and (OH, OW) == (H, W)
+            and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0) and not pc.dil_by_input_quarter)
+
+
+BF16_RV = os.environ.get("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
+
+
+def bf16rv_profitable(pc, H, W):
+    """Layers where the row-vector-K kernel beats vsp_conv2d_bf16 (tools/bench_bf16rv.py, batch 16: 64 -> 64 at 512^2 x1.53, at 256^2
+    x1.51, 64 -> 128 at 128^2 x1.46, 128 -> 128 at 256^2 x1.27, 32 -> 32 at 1024^2 x1.23, 256 -> 256 at 128^2 x1.10; 128 -> 128 at 64^2 x0.83)."""
+    return pc.cin <= 256 and H * W >= 128 * 128
+
+
+def _bf16rv_call(p, pc, keep, forced):
+    """One launch of vsp_conv2d_bf16rv on the filled parameter block; False = the entry does not serve it (alignment): the caller
+    goes on to vsp_conv2d_bf16."""
+    bw = pc.bf16rv_weight()
+    w0, h0 = p.w, p.tile_hint
+    p.w, p.tile_hint = bw.data_ptr(), (p.tile_hint if forced else 0)
+    rc = lib.vsp_conv2d_bf16rv(C.byref(p), _stream())
+    if rc == -3 and not forced:
+        p.w, p.tile_hint = w0, h0
+        return False
+    check(rc, "conv2d_bf16rv")
+    keep.append(bw)
+    return True
 
 
 def bf16x3_weight(wp):
@@ -511,6 +562,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     x3 = bf16 == "x3" or (bf16 is None and BF16_CONV == "x3")
+    rv = None          # the row-vector-K kernel (vsp_conv2d_bf16rv): "rv" forces it, None = where it is eligible and measured faster
+    if bf16 == "rv":
+        bf16, rv = True, True
     if bf16 is None:
         bf16 = bool(BF16_CONV) and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
         if x3 and bf16:  # split precision: doubled LDS images -- the layers where it beats the tuned fp32 kernels (tools/conv_breakdown.py)
@@ -518,6 +572,8 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
                 pc.stride == 1 or (pc.stride == 2 and pc.G == 1 and OW >= 32)))
     elif bf16 and not bf_ok:
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
+    if rv and not bf16rv_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset):
+        raise RuntimeError("conv2d: this layer is not eligible for the row-vector bf16 kernel (see bf16rv_eligible)")
     # bf16 activations: the bf16 kernel (not its split-precision form) reads and writes bf16 when the configuration asks for it or
     # the caller hands it a bf16 tensor; every other kernel is fp32 on both sides
     io_bf = bool(bf16) and not x3 and (x.dtype == BF or (ACT_BF16 and out is None)) and (out is None or out.dtype == BF)
@@ -596,6 +652,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
         else:
             check(rc, "conv2d_bf16x3")
+    elif bf16 and (rv or (rv is None and BF16_RV and tile_hint == 0 and not BF16_FORCE)) and io_bf and bf16rv_eligible(
+            pc, H, W, OH, OW, transposed, out_stride, out_offset) and (rv or bf16rv_profitable(pc, H, W)) and _bf16rv_call(p, pc, keep, rv):
+        pass
     elif bf16:
         bw = pc.bf16_weight()
         keep.append(bw)
