@@ -933,6 +933,27 @@ def test_conv2d_bf16rv(H, B, Cin, Cout, Hh, Ww, hint):
     close(H.conv2d_packed(x, pc, bf16="rv", tile_hint=hint, **kw2), H.conv2d_packed(x.float(), pc, bf16=True, **kw2))
 
 
+@pytest.mark.parametrize("B,Cin,Cg,Hh,Ww,dils", [(2, 32, 16, 40, 64, (1, 2, 4, 8)), (1, 64, 32, 64, 128, (1, 2, 4, 8)), (1, 16, 8, 19, 64, (2, 8)),
+                                                   (3, 64, 16, 128, 256, (8, 4, 2, 1))])
+def test_conv2d_bf16rv_dilation_groups(H, B, Cin, Cg, Hh, Ww, dils):
+    """The dilation groups of a SMART branch launch on vsp_conv2d_bf16rv (columns de-interleaved into d residue sub-rows in LDS, rows
+    polyphase) against vsp_conv2d_bf16 with fp32 output on the same bf16-representable operands: 16 / 32 / 8 channels per group (the
+    zero-padded half of a 32-row weight slab is never stored), ragged row counts, more tiles than resident workgroups."""
+    G = len(dils)
+    x = _b16(torch.randn(B, Cin, Hh, Ww, device=DEV))
+    wp = torch.stack([H.pack_weight(torch.randn(Cg, Cin, 3, 3, device=DEV) / math.sqrt(Cin * 9))[0] for _ in range(G)]).contiguous()
+    pc = H.PackedConv(wp, G, Cg, Cin, 3, 3, 1, dils, dils)
+    s_in, demod, bias = torch.rand(B, Cin, device=DEV) + 0.5, torch.rand(B, G * Cg, device=DEV) + 0.5, torch.randn(G * Cg, device=DEV)
+    r1 = _b16(torch.randn(B, G * Cg, Hh, Ww, device=DEV))
+    for kw in (dict(in_scale=s_in), dict(in_scale=s_in, out_scale=demod, act2=1, bias2=bias, res1=r1), dict()):
+        got = H.conv2d_packed(x, pc, bf16="rv", **kw)
+        kwf = {k: (v.float() if k == "res1" else v) for k, v in kw.items()}
+        ref = H.conv2d_packed(x.float(), pc, bf16=True, **kwf)
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape
+        err = (got.float() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all()), (float(err.max()), kw.keys())
+
+
 def test_conv2d_bf16rv_refusals(H):
     """Launches the row-vector kernel does not serve: VSP_ENOTSUP at the C entry (the automatic path then uses vsp_conv2d_bf16),
     an error when it is forced."""

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vspbfr_amd import hip_ops as H
 dev = torch.device("cuda", 0)
-shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.startswith("g")] or [
     (16, 64, 64, 512), (16, 32, 32, 1024), (16, 128, 128, 256), (16, 64, 64, 256), (16, 64, 64, 128), (16, 128, 128, 64), (16, 256, 256, 128), (16, 64, 128, 128)]
 hints = [int(v) for v in os.environ.get("HINTS", "0").split(",")]
 
@@ -22,6 +22,24 @@ def timed(fn, n=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 
+
+groups = [tuple(int(v) for v in a[1:].split(",")) for a in sys.argv[1:] if a.startswith("g")]
+shapes = [t for t in shapes if len(t) == 4]
+for B, Cin, Cg, S in groups or ([] if len(sys.argv) > 1 else [(16, 64, 16, 512), (16, 128, 32, 256), (16, 256, 64, 128)]):
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, S, S, device=dev).to(torch.bfloat16)
+    wp = torch.stack([H.pack_weight(torch.randn(Cg, Cin, 3, 3, device=dev) / math.sqrt(Cin * 9))[0] for _ in range(4)]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    kw = dict(in_scale=torch.rand(B, Cin, device=dev) + 0.5)
+    out = torch.empty(B, 4 * Cg, S, S, device=dev, dtype=torch.bfloat16)
+    H.BF16_RV = False
+    t0 = timed(lambda: H.conv2d_packed(x, pc, bf16=True, out=out, **kw))
+    y0 = out.float()
+    t1 = timed(lambda: H.conv2d_packed(x, pc, bf16="rv", out=out, **kw))
+    y1 = out.float()
+    nb = (x.numel() + out.numel()) * 2
+    fl = 2.0 * B * 4 * Cg * Cin * 9 * S * S
+    print(f"{Cin}->4x{Cg} dilated @{S} B{B}: bf16 {t0:.0f} us {nb / t0 / 1e6:.2f} TB/s {fl / t0 / 1e6:.0f} TF | rv {t1:.0f} us {nb / t1 / 1e6:.2f} TB/s {fl / t1 / 1e6:.0f} TF x{t0 / t1:.2f} maxdiff vs bf16 {float((y1 - y0).abs().max()):.3g} (range {float(y0.abs().max()):.2f})", flush=True)
 
 for B, Cin, Cout, S in shapes:
     torch.manual_seed(0)

@@ -39,12 +39,21 @@ constexpr int RV_ROWB = RV_SEG * 16;
 constexpr int RV_CK = 8;            // channels per chunk
 constexpr int RV_MAXC = 256;        // input channels the LDS scale table holds
 
-template <int MB, int RWV>   // 32-channel blocks and output rows per wave
+// DIL = 1, 2, 4, 8: one DILATION GROUP of a SMART branch launch (the host launches the groups one after the other).  Rows are polyphase
+// as in conv_bf16.hip (a tile = TH rows ry, ry + d, ... of the image).  Columns: the patch row is staged DE-INTERLEAVED into d residue
+// sub-rows (pixel c of the patch row -> sub-row c % d, entry c / d), so the three taps x - d, x, x + d of a pixel are again neighbours
+// in LDS and a lane's window [m-1 .. m+2] of its sub-row is read exactly as for d = 1 (three aligned dwords + a funnel shift by
+// the lane's own 0 / 16 bits); a lane still owns the ADJACENT pixels (2j, 2j+1) of the image row (its two N-blocks read different
+// sub-rows), so the epilogue and its packed stores do not change.
+template <int MB, int RWV, int DIL = 1>   // 32-channel blocks and output rows per wave, dilation of the group
 __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, const int ntiles) {
   constexpr int TH = 4 * RWV, PR = TH + 2, CO_T = 32 * MB;
-  constexpr int SPC = (PR * RV_SEG + 63) / 64;      // staging slots per channel; a wave stages two channels of every chunk
+  constexpr int SEGS = DIL == 8 ? 11 : RV_SEG;      // 16-byte segments per patch row: the window reaches 2 d pixels past the tile
+  constexpr int LROW = DIL == 8 ? 192 : RV_ROWB;    // bytes per patch row in LDS
+  constexpr int SP = LROW / DIL;                    // ... per residue sub-row (a multiple of 4)
+  constexpr int SPC = (PR * SEGS + 63) / 64;        // staging slots per channel; a wave stages two channels of every chunk
   constexpr int PT = 2 * SPC;
-  constexpr int PCH = PR * RV_ROWB;                 // bytes per channel of the patch image
+  constexpr int PCH = PR * LROW;                    // bytes per channel of the patch image
   constexpr int PBUF = RV_CK * PCH;
   constexpr int WROWS = 12;                         // [dy 3][quad 2][half 2] rows of CO_T fragments per chunk
   constexpr int WBUF = WROWS * CO_T * 16;
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   // round-robin over the eight) gets a contiguous range of workgroups.  A tile lives ~40 us, of which launch, first loads and
   // the epilogue were a third (tuning build: 237 of 790 us with everything else switched off): the first loads of tile t + 1 are
   // issued BEFORE the epilogue of tile t.
-  const int tiles_x = p.W / RV_TW, tiles_y = (p.H + TH - 1) / TH, co_tiles = p.co_tiles;
+  const int tiles_x = p.W / RV_TW, tiles_y = ((p.H + DIL - 1) / DIL + TH - 1) / TH, co_tiles = p.co_tiles;
   int t_begin, t_end;
   {
     const int GT = gridDim.x, wgid = blockIdx.x;
@@ -76,18 +85,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
     t_end = (int)((int64_t)(g + 1) * ntiles / GT);
   }
   if (t_begin >= t_end) return;
-  struct Tile { int b, oy0, x0, co0; };
+  struct Tile { int b, oy0, x0, co0, ry; };   // oy0: first row of the tile in the row-residue sub-image ry
   auto decode = [&](int lid) {
     Tile t;
     const int ct = lid % co_tiles; lid /= co_tiles;
     const int tx = lid % tiles_x; lid /= tiles_x;
-    const int ty = lid % tiles_y;
-    t.b = lid / tiles_y; t.oy0 = ty * TH; t.x0 = tx * RV_TW; t.co0 = ct * CO_T;
+    const int ty = lid % tiles_y; lid /= tiles_y;
+    t.ry = lid % DIL;
+    t.b = lid / DIL; t.oy0 = ty * TH; t.x0 = tx * RV_TW; t.co0 = ct * CO_T;
     return t;
   };
   const int chw = p.H * p.W;
   const int nchunk = p.Cin / RV_CK;
-  const int Cout = p.cout_g;     // (host: a multiple of CO_T)
+  const int Cout = p.cout_g;     // channels of the group (a multiple of 8); weights are padded to rv_copad rows
+  const int cbase = p.rv_cbase;  // first channel of the group in the layer's per-channel operands and in y
 
   // ---- patch staging: slot e of wave w = channel 2w + e / SPC of the chunk, 16-byte segment (e % SPC) * 64 + lane of its PR x 10.
   // State of the tile being STAGED (from the moment its first loads are issued, i.e. before the previous tile's epilogue):
@@ -100,17 +111,25 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   unsigned pwr = 0, pin = 0;
   int st_xoff = 0, st_co0 = 0, st_b = 0;   // byte offset of the image in x, first channel of the tile, image
   const float* iscp = p.in_scale;
-  const int pdst0 = 2 * wave * PCH + lane * 16;   // slot e lands at + (e / SPC) PCH + (e % SPC) 1024: a patch row is exactly its ten segments
+  const int pdst0 = 2 * wave * PCH + lane * 16;   // d = 1: slot e lands at + (e / SPC) PCH + (e % SPC) 1024: a patch row is exactly its ten segments
+  int pdstv[DIL > 1 ? PT : 1];                    // d > 1: first byte of the segment's entries in residue sub-row 0
 #pragma unroll
-  for (int e = 0; e < PT; ++e) pwr |= lane + 64 * (e % SPC) < PR * RV_SEG ? (1u << e) : 0u;
+  for (int e = 0; e < PT; ++e) {
+    const int tt = lane + 64 * (e % SPC);
+    pwr |= tt < PR * SEGS ? (1u << e) : 0u;
+    if constexpr (DIL > 1) {
+      const int row = tt / SEGS, seg = tt - row * SEGS;
+      pdstv[e] = ((2 * wave + e / SPC) * PR + row) * LROW + seg * (16 / DIL);
+    }
+  }
   auto stage_tile = [&](const Tile& t) {
     pin = 0;
 #pragma unroll
     for (int e = 0; e < PT; ++e) {
       const int chl = e / SPC, tt = lane + 64 * (e % SPC);
-      const int row = tt / RV_SEG, seg = tt - row * RV_SEG;
-      const int iy = t.oy0 - 1 + row, ix = t.x0 - 8 + 8 * seg;
-      const bool in = tt < PR * RV_SEG && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const int row = tt / SEGS, seg = tt - row * SEGS;
+      const int sy = t.oy0 - 1 + row, iy = sy * DIL + t.ry, ix = t.x0 - 8 + 8 * seg;
+      const bool in = tt < PR * SEGS && sy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       poff[e] = in ? (chl * chw + iy * p.W + ix) * 2 : 0x7fffffff;   // (past the buffer: the load returns zeros)
       pin |= in ? (1u << e) : 0u;
     }
@@ -130,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
       }
     }
     if (tid < CO_T) {
-      const int co = st_co0 + tid;
-      const float os = p.osp[((int64_t)st_b * Cout + co) * p.oss] * p.csp[co * p.css];
+      const int co = cbase + min(st_co0 + tid, Cout - 1);   // (channels past the group: clamped, never stored)
+      const float os = p.osp[((int64_t)st_b * p.rv_ctot + co) * p.oss] * p.csp[co * p.css];
       const float cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
       const float b2 = p.b2p[co * p.b2s];
       epv = fast ? float4{os * p.g2, (cb + b2) * p.g2, 0.f, 0.f} : float4{os, cb, b2, p.s2p[co * p.s2s]};
@@ -171,7 +190,28 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
         v[k] = (!shifted || in) ? w : 0u;   // (a shift must not leak into the zero padding)
       }
     }
-    *reinterpret_cast<u32x4*>(Pdst + pdst0 + (e / SPC) * PCH + (e % SPC) * 1024) = v;
+    if constexpr (DIL == 1) {
+      *reinterpret_cast<u32x4*>(Pdst + pdst0 + (e / SPC) * PCH + (e % SPC) * 1024) = v;
+    } else {   // de-interleave the eight pixels into the d residue sub-rows
+      unsigned char* dst = Pdst + pdstv[e];
+      constexpr unsigned LO = 0x05040100u, HI = 0x07060302u;   // v_perm_b32 selectors: the low / the high halves of (S1, S0)
+      if constexpr (DIL == 2) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_amdgcn_perm(v[1], v[0], LO), __builtin_amdgcn_perm(v[3], v[2], LO)};
+        *reinterpret_cast<u32x2*>(dst + SP) = u32x2{__builtin_amdgcn_perm(v[1], v[0], HI), __builtin_amdgcn_perm(v[3], v[2], HI)};
+      } else if constexpr (DIL == 4) {
+        *reinterpret_cast<unsigned*>(dst) = __builtin_amdgcn_perm(v[2], v[0], LO);
+        *reinterpret_cast<unsigned*>(dst + SP) = __builtin_amdgcn_perm(v[2], v[0], HI);
+        *reinterpret_cast<unsigned*>(dst + 2 * SP) = __builtin_amdgcn_perm(v[3], v[1], LO);
+        *reinterpret_cast<unsigned*>(dst + 3 * SP) = __builtin_amdgcn_perm(v[3], v[1], HI);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          *reinterpret_cast<unsigned short*>(dst + (2 * k) * SP) = (unsigned short)(v[k] & 0xffffu);
+          *reinterpret_cast<unsigned short*>(dst + (2 * k + 1) * SP) = (unsigned short)(v[k] >> 16);
+        }
+      }
+    }
   };
 
   // ---- weight slab by LDS-DMA: 12 rows of CO_T 16-byte fragments, 64 per wave instruction
@@ -181,13 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
 #ifdef VSP_BF16_ABLATE
     if ((p.dbg & 2) && c > 0) return;
 #endif
-    const u32x4* src = wsrc + (int64_t)c * WROWS * Cout;
+    const u32x4* src = wsrc + (int64_t)c * WROWS * p.rv_copad;
 #pragma unroll
     for (int k = 0; k < (NDMA + 3) / 4; ++k) {
       const int i = wave + 4 * k;
       const int L = i * 64 + lane;
       const int row = L / CO_T, co = L - row * CO_T;
-      if (i < NDMA) __builtin_amdgcn_global_load_lds(src + row * Cout + st_co0 + co, reinterpret_cast<u32x4*>(Wdst) + i * 64, 16, 0, 0);
+      if (i < NDMA) __builtin_amdgcn_global_load_lds(src + row * p.rv_copad + st_co0 + co, reinterpret_cast<u32x4*>(Wdst) + i * 64, 16, 0, 0);
     }
   };
 
@@ -195,6 +235,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   const int b_lane = kh * 2 * PCH + 12 + 4 * l32;       // byte of pixel pair l32 - 1 (pixels x0 + 2 l32 - 2, - 1) in row 0 of the half's first channel
   const int a_lane = (kh * CO_T + l32) * 16;
   const int wr0 = wave * RWV;                            // first output row of the wave inside the tile
+  int boffd[DIL > 1 ? 2 : 1], shd[DIL > 1 ? 2 : 1];      // d > 1: the lane's window in its residue sub-row, per pixel parity: first aligned dword, funnel shift
+  if constexpr (DIL > 1) {
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int c = 8 + 2 * l32 + pp;                    // column of the pixel in the patch row
+      const int bo = (c % DIL) * SP + 2 * (c / DIL - 1);
+      boffd[pp] = kh * 2 * PCH + (bo & ~3);
+      shd[pp] = (bo & 2) ? 16 : 0;
+    }
+  }
 
   f32x16 acc[MB][RWV][2];
 
@@ -204,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
     if (affine) load_scales(c + 1 < nchunk ? c + 1 : c, sc, sh);
     if (c + 2 < nchunk) issue_p(prLoad, c + 2);
     const unsigned char* Wc = Wl + cur * WBUF + a_lane;
-    const unsigned char* Pc = Pl + cur * PBUF + b_lane + wr0 * RV_ROWB;
+    const unsigned char* Pc = Pl + cur * PBUF + (DIL == 1 ? b_lane : 0) + wr0 * LROW;
     unsigned char* Pn = Pl + nxt * PBUF;
     // B fragments of one (quad, input row) group: per channel THREE aligned dwords E0 E1 E2 = pixel pairs j - 1, j, j + 1 of the row
     // (ds_read_b32, lanes 4 bytes apart: 256 bytes per instruction and half); the odd pixels' window [2j .. 2j+3] is (E1, E2), the
@@ -215,14 +265,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
       if (p.dbg & 32) return;
 #endif
       const int q = grp / (RWV + 2), ir = grp - q * (RWV + 2);
-      unsigned e[2][3];
+      if constexpr (DIL == 1) {
+        unsigned e[2][3];
 #pragma unroll
-      for (int ch = 0; ch < 2; ++ch)
+        for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) e[ch][k] = *reinterpret_cast<const unsigned*>(Pc + (4 * q + ch) * PCH + ir * RV_ROWB + 4 * k);
-      bf[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(e[0][1], e[0][0], 16), __builtin_amdgcn_alignbit(e[0][2], e[0][1], 16),
-                                               __builtin_amdgcn_alignbit(e[1][1], e[1][0], 16), __builtin_amdgcn_alignbit(e[1][2], e[1][1], 16)});
-      bf[1] = __builtin_bit_cast(bf16x8, u32x4{e[0][1], e[0][2], e[1][1], e[1][2]});
+          for (int k = 0; k < 3; ++k) e[ch][k] = *reinterpret_cast<const unsigned*>(Pc + (4 * q + ch) * PCH + ir * LROW + 4 * k);
+        bf[0] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(e[0][1], e[0][0], 16), __builtin_amdgcn_alignbit(e[0][2], e[0][1], 16),
+                                                 __builtin_amdgcn_alignbit(e[1][1], e[1][0], 16), __builtin_amdgcn_alignbit(e[1][2], e[1][1], 16)});
+        bf[1] = __builtin_bit_cast(bf16x8, u32x4{e[0][1], e[0][2], e[1][1], e[1][2]});
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          unsigned e[2][3];
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) e[ch][k] = *reinterpret_cast<const unsigned*>(Pc + boffd[pp] + (4 * q + ch) * PCH + ir * LROW + 4 * k);
+          bf[pp] = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(e[0][1], e[0][0], shd[pp]), __builtin_amdgcn_alignbit(e[0][2], e[0][1], shd[pp]),
+                                                    __builtin_amdgcn_alignbit(e[1][1], e[1][0], shd[pp]), __builtin_amdgcn_alignbit(e[1][2], e[1][1], shd[pp])});
+        }
+      }
     };
     bf16x8 a[3][MB], bq[2][2];
     load_b(0, bq[0]);
@@ -313,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
     int voff[RWV];
 #pragma unroll
     for (int r = 0; r < RWV; ++r) {
-      const int oy = cur.oy0 + wr0 + r;
+      const int oy = (cur.oy0 + wr0 + r) * DIL + cur.ry;
       const bool ok = oy < p.OH;
       nzv[r] = f32x2{0.f, 0.f};
       if (has_nz && ok) nzv[r] = *reinterpret_cast<const f32x2*>(p.nzp + (int64_t)cur.b * p.OH * p.OW + oy * p.OW + cur.x0 + 2 * l32);
@@ -331,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
       first_loads();
     }
     // ---- epilogue: lane = pixel pair (x0 + 2 l32, +1) of the wave's rows, channels 8 (i >> 2) + 4 kh + (i & 3) of every 32-block
-    const int y_img = (done.b * p.y_ch + p.y_coff) * y_plane * 2, r_img = (done.b * p.res_ch + p.res_coff) * y_plane * 2;
+    const int y_img = (done.b * p.y_ch + p.y_coff + cbase) * y_plane * 2, r_img = (done.b * p.res_ch + p.res_coff + cbase) * y_plane * 2;
 #ifdef VSP_BF16_ABLATE
     if (!(p.dbg & 64))
 #endif
@@ -351,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
           f32x2 ab[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) ab[k] = *reinterpret_cast<const f32x2*>(&Ep[par * CO_T + mb * 32 + 8 * ib + k + 4 * kh]);
+          if (done.co0 + mb * 32 + 8 * ib >= Cout) continue;   // (uniform: channel octets past the group; Cout is a multiple of 8)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int i = 4 * ib + k;
@@ -383,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int col = mb * 32 + 8 * (i >> 2) + (i & 3);        // + 4 kh: the lane half
+        if (done.co0 + mb * 32 + 8 * (i >> 2) >= Cout) continue;  // (uniform)
         const float4 e4 = Ep[par * CO_T + col + 4 * kh];
         const float os = e4.x, cb = e4.y, b2 = e4.z, pg = g2, ng = e4.w * g2;
         const int cplane = (done.co0 + col) * y_plane * 2;
@@ -419,28 +484,31 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   }
 }
 
-template <int MB, int RWV>
+template <int MB, int RWV, int DIL = 1>
 int launch_rv(ConvK q, hipStream_t stream) {
   constexpr int TH = 4 * RWV, PR = TH + 2, CO_T = 32 * MB;
-  constexpr size_t lds = 2 * (size_t)(12 * CO_T * 16) + 2 * (size_t)(RV_CK * PR * RV_ROWB) + 2 * CO_T * 16 + 2 * RV_MAXC * 8;
+  constexpr size_t lds = 2 * (size_t)(12 * CO_T * 16) + 2 * (size_t)(RV_CK * PR * (DIL == 8 ? 192 : RV_ROWB)) + 2 * CO_T * 16 + 2 * RV_MAXC * 8;
   static vsp::LdsAttrOnce attr;
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_rv_kernel<MB, RWV>), 150 * 1024, "conv2d_bf16rv")) return rc;
-  q.co_tiles = q.cout_g / CO_T;
-  const int64_t ntiles = (int64_t)(q.W / RV_TW) * ((q.H + TH - 1) / TH) * q.co_tiles * q.B;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_rv_kernel<MB, RWV, DIL>), 150 * 1024, "conv2d_bf16rv")) return rc;
+  q.co_tiles = (q.cout_g + CO_T - 1) / CO_T;
+  const int64_t ntiles = (int64_t)(q.W / RV_TW) * (((q.H + DIL - 1) / DIL + TH - 1) / TH) * DIL * q.co_tiles * q.B;
   if (ntiles > 0x7fffffff) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: grid too large");
   static const int per_cu = getenv("VSP_BF16RV_WGS") ? atoi(getenv("VSP_BF16RV_WGS")) : 2;   // resident workgroups per CU (tuning)
   const int64_t grid = ntiles < (int64_t)vsp::kNumCU * per_cu ? ntiles : (int64_t)vsp::kNumCU * per_cu;
-  conv_bf16_rv_kernel<MB, RWV><<<dim3((unsigned)grid), 256, lds, stream>>>(q, (int)ntiles);
+  conv_bf16_rv_kernel<MB, RWV, DIL><<<dim3((unsigned)grid), 256, lds, stream>>>(q, (int)ntiles);
   return VSP_OK;
 }
 
 }  // namespace
 
-// What the row-vector kernel serves: G = 1, dilation 1, bf16 activations, Cin % 8 == 0, Cout % 32 == 0, W % 64 == 0, 16-byte
-// aligned image rows, tensors below 2 GiB (32-bit byte offsets from the tensor base).
+// What the row-vector kernel serves: bf16 activations, 3x3, stride 1, G = 1 or 2-4 DILATION GROUPS over one input (dilations from
+// {1, 2, 4, 8}, padding = dilation), Cin % 8 == 0 (<= 256), channels per group % 32 == 0 (plain layers) / % 8 == 0 (groups), W % 64 == 0,
+// 16-byte aligned image rows, tensors below 2 GiB (32-bit byte offsets from the tensor base).
 bool bf16rv_eligible(const ConvK& q) {
-  if (q.G != 1 || q.dil[0] != 1 || !q.io_bf16 || q.KH != 3 || q.KW != 3) return false;
-  if (q.Cin % RV_CK || q.Cin > RV_MAXC || q.cout_g % 32 || q.W % RV_TW || q.OH != q.H || q.OW != q.W) return false;
+  if (!q.io_bf16 || q.KH != 3 || q.KW != 3 || q.G < 1 || q.G > 4 || (q.G > 1 && q.x_gs != 0)) return false;
+  for (int g = 0; g < q.G; ++g)
+    if (q.dil[g] != 1 && (q.G == 1 || (q.dil[g] != 2 && q.dil[g] != 4 && q.dil[g] != 8))) return false;
+  if (q.Cin % RV_CK || q.Cin > RV_MAXC || q.cout_g % (q.G == 1 ? 32 : 8) || q.W % RV_TW || q.OH != q.H || q.OW != q.W) return false;
   if ((reinterpret_cast<uintptr_t>(q.x) & 15) || (reinterpret_cast<uintptr_t>(q.y) & 3)) return false;
   if ((q.r1s && (reinterpret_cast<uintptr_t>(q.r1p) & 3)) || (q.r2s && (reinterpret_cast<uintptr_t>(q.r2p) & 3))) return false;
   if (q.nzs && (reinterpret_cast<uintptr_t>(q.nzp) & 7)) return false;
@@ -450,16 +518,40 @@ bool bf16rv_eligible(const ConvK& q) {
   return true;
 }
 
-// variant: 0 = automatic (64-channel tiles when Cout allows), 1 = 32 channels x 8 rows, 2 = 64 channels x 8 rows, 3 = 32 channels x 16 rows (x 64 pixels)
-int bf16rv_launch(const ConvK& q, int variant, hipStream_t stream) {
-  if (variant == 0) variant = q.cout_g % 64 == 0 ? 2 : 1;
-  if (variant == 2 && q.cout_g % 64) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: 64-channel tiles need Cout %% 64 == 0");
-  switch (variant) {
-    case 1: return launch_rv<1, 2>(q, stream);
-    case 2: return launch_rv<2, 2>(q, stream);
-    case 3: return launch_rv<1, 4>(q, stream);
-    default: return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: unknown variant %d", variant);
+// variant (plain layers): 0 = automatic (64-channel tiles when Cout allows), 1 = 32 channels x 8 rows, 2 = 64 channels x 8 rows,
+// 3 = 32 channels x 16 rows (x 64 pixels).  Dilation groups: one launch per group on the 32-channel x 8-row tile.
+int bf16rv_launch(const ConvK& q0, int variant, hipStream_t stream) {
+  ConvK q = q0;
+  q.rv_copad = (q.cout_g + 31) & ~31;
+  q.rv_ctot = q.G * q.cout_g;
+  q.rv_cbase = 0;
+  if (q.G == 1) {
+    if (variant == 0) variant = q.cout_g % 64 == 0 ? 2 : 1;
+    if (variant == 2 && q.cout_g % 64) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: 64-channel tiles need Cout %% 64 == 0");
+    switch (variant) {
+      case 1: return launch_rv<1, 2>(q, stream);
+      case 2: return launch_rv<2, 2>(q, stream);
+      case 3: return launch_rv<1, 4>(q, stream);
+      default: return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: unknown variant %d", variant);
+    }
   }
+  const int64_t wgroup = (int64_t)(q.Cin / RV_CK) * 12 * q.rv_copad * 8;   // bf16 elements of one group's weights
+  const vsp::bf16_t* w0 = reinterpret_cast<const vsp::bf16_t*>(q0.w);
+  const int G = q.G;
+  q.G = 1;
+  for (int g = 0; g < G; ++g) {
+    q.rv_cbase = g * q.cout_g;
+    q.w = reinterpret_cast<const float*>(w0 + g * wgroup);
+    int rc;
+    switch (q0.dil[g]) {
+      case 1: rc = launch_rv<1, 2, 1>(q, stream); break;
+      case 2: rc = launch_rv<1, 2, 2>(q, stream); break;
+      case 4: rc = launch_rv<1, 2, 4>(q, stream); break;
+      default: rc = launch_rv<1, 2, 8>(q, stream); break;
+    }
+    if (rc) return rc;
+  }
+  return VSP_OK;
 }
 
 }  // namespace vspconv

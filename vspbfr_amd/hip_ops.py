@@ -404,22 +404,29 @@ def bf16_weight(wp):
 
 
 def bf16rv_weight(wp):
-    """packed weights (1, 9, Cin, Cout) fp32 -> [chunk Cin/8][ky 3][quad 2][half 2][Cout][8] bf16 with element e = channel
-    8 chunk + 4 quad + 2 half + (e >> 2), horizontal tap kx = e & 3 (kx = 3: zero) -- the A fragments of vsp_conv2d_bf16rv."""
+    """packed weights (G, 9, Cin, cout_g) fp32 -> per group [chunk Cin/8][ky 3][quad 2][half 2][co_pad][8] bf16 with element e = channel
+    8 chunk + 4 quad + 2 half + (e >> 2), horizontal tap kx = e & 3 (kx = 3: zero), co_pad = cout_g rounded up to 32 (zero rows) --
+    the A fragments of vsp_conv2d_bf16rv (G > 1: the dilation groups of one launch, one after the other)."""
     ng, T, cin, cout = wp.shape
-    if ng != 1 or T != 9 or cin % 8 or cout % 32:
-        raise RuntimeError("bf16rv_weight: G = 1, 3x3, Cin % 8 == 0, Cout % 32 == 0")
-    Wz = wp.new_zeros(3, 4, cin, cout)
-    Wz[:, :3] = wp[0].view(3, 3, cin, cout)
-    Wz = Wz.view(3, 4, cin // 8, 2, 2, 2, cout).permute(2, 0, 3, 4, 6, 5, 1)   # chunk, ky, quad, half, co, pair, kx
+    if T != 9 or cin % 8 or cout % 8:
+        raise RuntimeError("bf16rv_weight: 3x3, Cin % 8 == 0, channels per group % 8 == 0")
+    co_pad = (cout + 31) // 32 * 32
+    Wz = wp.new_zeros(ng, 3, 4, cin, co_pad)
+    Wz[:, :, :3, :, :cout] = wp.view(ng, 3, 3, cin, cout)
+    Wz = Wz.view(ng, 3, 4, cin // 8, 2, 2, 2, co_pad).permute(0, 3, 1, 4, 5, 7, 6, 2)   # group, chunk, ky, quad, half, co, pair, kx
     return Wz.to(torch.bfloat16).contiguous().view(-1)
 
 
 def bf16rv_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0)):
-    """What vsp_conv2d_bf16rv serves (bf16 activations on top; the entry re-checks alignment and returns VSP_ENOTSUP)."""
-    return (not transposed and pc.G == 1 and pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.dil[0] == 1 and pc.pad_y[0] == 1
-            and pc.pad_x[0] == 1 and pc.cin % 8 == 0 and pc.cout % 32 == 0 and W % 64 == 0 and (OH, OW) == (H, W)
-            and tuple(out_stride) == (1, 1) and tuple(out_offset) == (0, 0) and not pc.dil_by_input_quarter)
+    """What vsp_conv2d_bf16rv serves (bf16 activations on top; the entry re-checks alignment and returns VSP_ENOTSUP): plain 3x3 layers
+    and the 2-4 dilation groups of a SMART branch launch (dilations from 1, 2, 4, 8 over one input)."""
+    if (transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.cin % 8 or pc.cin > 256 or W % 64 or (OH, OW) != (H, W)
+            or tuple(out_stride) != (1, 1) or tuple(out_offset) != (0, 0) or pc.dil_by_input_quarter):
+        return False
+    if pc.G == 1:
+        return pc.dil[0] == 1 and pc.pad_y[0] == 1 and pc.pad_x[0] == 1 and pc.cout_g % 32 == 0
+    return (2 <= pc.G <= 4 and pc.x_group_stride == 0 and pc.cout_g % 8 == 0
+            and all(pc.dil[g] in (1, 2, 4, 8) and pc.pad_y[g] == pc.dil[g] and pc.pad_x[g] == pc.dil[g] for g in range(pc.G)))
 
 
 BF16_RV = os.environ.get("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
@@ -428,6 +435,8 @@ BF16_RV = os.environ.get("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel 
 def bf16rv_profitable(pc, H, W):
     """Layers where the row-vector-K kernel beats vsp_conv2d_bf16 (tools/bench_bf16rv.py, batch 16: 64 -> 64 at 512^2 x1.53, at 256^2
     x1.51, 64 -> 128 at 128^2 x1.46, 128 -> 128 at 256^2 x1.27, 32 -> 32 at 1024^2 x1.23, 256 -> 256 at 128^2 x1.10; 128 -> 128 at 64^2 x0.83)."""
+    if pc.G > 1:   # dilation groups (served, tested, not chosen): every group stages the whole input patch for its few channels -- alone
+        return False   # 64 -> 4 x 16 at 512^2 x1.12, 128 -> 4 x 32 at 256^2 x1.03, 256 -> 4 x 64 at 128^2 x0.83; inside configs[2] no gain (400-415 img/s)
     return pc.cin <= 256 and H * W >= 128 * 128
 
 
