@@ -426,7 +426,8 @@ def main():
                        "F(2x2,3x3)) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers); "
                        "achieved / frac = ALGORITHMIC FLOPs / time, i.e. an effective rate on the Winograd layers; executed_tflops / "
                        "executed_frac = what the matrix pipe ran (F(2x2) launches at 16/36, F(4x4) launches at 36/144 of their algorithmic count)") if args.conv_dtype == "f32" else (
-            "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + the fp32 "
+            "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + conv_bf16_rv_kernel "
+            "(row-vector K: plain stride-1 layers with <= 256 channels on maps >= 128^2, bf16 activations) + the fp32 "
             "conv_igemm_kernel on small maps and 1x1 layers; achieved = algorithmic FLOPs / time against the dense bf16 MFMA peak; with "
             "fp32 activations in HBM the 512^2 / 256^2 layers are fabric-bound (DESIGN 9)")
         line = {
