@@ -55,6 +55,10 @@ for B, Cin, Cout, S in shapes:
     fl = 2.0 * B * Cout * Cin * 9 * S * S
     line = f"{Cin}->{Cout} @{S} B{B}: bf16 {t0:.0f} us {nb / t0 / 1e6:.2f} TB/s {fl / t0 / 1e6:.0f} TF"
     for h in hints:
+        if not H.bf16rv_eligible(pc, S, S, S, S):
+            line += " | rv: not eligible"
+            y1 = y0
+            break
         t1 = timed(lambda: H.conv2d_packed(x, pc, bf16="rv", tile_hint=h, out=out, **kw))
         y1 = out.float()
         line += f" | rv[{h}] {t1:.0f} us {nb / t1 / 1e6:.2f} TB/s {fl / t1 / 1e6:.0f} TF x{t0 / t1:.2f} maxdiff vs bf16 {float((y1 - y0).abs().max()):.3g}"

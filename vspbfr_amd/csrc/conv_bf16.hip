@@ -227,6 +227,10 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     const int cib = min(c * BCK + 8 * oct, p.Cin - 8);
     // constant address space: a uniform load from it goes through the scalar cache (a plain global pointer does not, the
     // compiler cannot know that nothing stores to it).  Absent operands: a device constant through stride 0 (host).
+    // (Round 4: the same operands from an LDS table filled once per workgroup -- what the row-vector kernel does per tile -- measured
+    //  2-7 % faster on the dilation-group launches and 7 % SLOWER on the plain 64- / 128-channel layers: one more barrier in the
+    //  prologue, four LDS reads and sixteen v_readfirstlane per interval; not kept.  Writing that variant turned up a compiler
+    //  trap: __builtin_bit_cast(int, t[k]) on the ELEMENT expression of an ext_vector read element 0 for every k.)
     typedef const float __attribute__((address_space(4))) * cfp4;
     cfp4 s0 = (cfp4)(uintptr_t)(iscp + cib * p.bf_isc_s);
     cfp4 h0 = (cfp4)(uintptr_t)(ishp + cib * p.bf_ish_s);
@@ -403,10 +407,20 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     }
     __syncthreads();
   };
+  // Epilogue operands of the tile's channels: ONE table in LDS (scale = out_scale x ch_scale, bias = ch_bias + bias1, bias2, slope2),
+  // filled while the first loads are in flight.  (Per row / per lane loads in the epilogue each cost a round trip through the scalar
+  // or vector cache: six dependent operands per output row -- the row-vector kernel's tuning build showed what that costs.)
+  float4* Ept = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(smem16) + p.bf_tab);
   {
     issue_w(Wl, 0);
     issue_p(pregA, 0);
     if (DEEP && nchunk > 1) issue_p(pregB, 1);
+    if (tid < CO_T) {
+      const int cgl = min(co0 + tid, p.cout_g - 1);   // (channels past the group: clamped, never stored)
+      const int co = g * p.cout_g + cgl;
+      const float* ospb = p.osp + (int64_t)b * (p.G * p.cout_g) * p.oss;
+      Ept[tid] = float4{ospb[co * p.oss] * p.csp[co * p.css], p.cbp[co * p.cbs] + p.b1p[co * p.b1s], p.b2p[co * p.b2s], p.s2p[co * p.s2s]};
+    }
     float sc[8], sh[8];
     const bool oct_ok = load_scales(0, sc, sh);
 #pragma unroll
@@ -427,8 +441,6 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   // tile is transposed through LDS, one 32-channel block row (mb) at a time: E[channel][pixel] fp32, then one lane owns 4
   // consecutive pixels of one channel -> 16-byte noise / residual loads and stores, and (256-pixel tiles) the channel is
   // wave-uniform, so its six operands come through the scalar cache.
-  const int Cout = p.G * p.cout_g;
-  const float* osp = p.osp + (int64_t)b * Cout * p.oss;
   const float* nzp = p.nzp + (int64_t)b * p.OH * p.OW;
   const float nw = p.nwp[0];
   const float s1 = p.s1, g1 = p.g1, g2 = p.g2;
@@ -462,8 +474,8 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           const bool ch_ok = cg_ < p.cout_g;
           const int cg = ch_ok ? cg_ : p.cout_g - 1;
           const int co = g * p.cout_g + cg;
-          const float os = osp[co * p.oss] * p.csp[co * p.css], cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
-          const float b2 = p.b2p[co * p.b2s], sl2 = p.s2p[co * p.s2s];
+          const float4 e4 = Ept[cg - co0];
+          const float os = e4.x, cb = e4.y, b2 = e4.z, sl2 = e4.w;
           AT* yc = yb + (int64_t)co * y_plane;
           auto fin = [&](float v) {
             v = v * os + cb;
@@ -505,11 +517,9 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     auto operands = [&](int row, int& co, float& os, float& cb, float& b2, float& sl2) -> bool {
       const int cg = co0 + ((row >> 5) * MB + mb) * 32 + (row & 31);
       const bool ok = cg < p.cout_g;
-      co = g * p.cout_g + (ok ? cg : p.cout_g - 1);   // (clamped: the loads below are unconditional, the store is not)
-      os = osp[co * p.oss] * p.csp[co * p.css];
-      cb = p.cbp[co * p.cbs] + p.b1p[co * p.b1s];
-      b2 = p.b2p[co * p.b2s];
-      sl2 = p.s2p[co * p.s2s];
+      co = g * p.cout_g + (ok ? cg : p.cout_g - 1);   // (clamped: the loads of the residuals are unconditional, the store is not)
+      const float4 e4 = Ept[cg - co0];                // (rows past the group hold the clamped channel's operands)
+      os = e4.x; cb = e4.y; b2 = e4.z; sl2 = e4.w;
       return ok;
     };
     const bool quads = (p.OW & 3) == 0 && p.OW >= 4;   // (uniform) a lane's four pixels are inside or outside the row together
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
 }
 
 struct BfGeom {
-  int twl, pitch, plane, pt;
+  int twl, pitch, plane, pt, tab;
   size_t lds;
 };
 
@@ -615,6 +625,8 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
   r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * npl * r.plane) * 16 * npart;
   const size_t epi = (size_t)erows * npix * sizeof(float);  // epilogue transpose buffer
   if (epi > r.lds) r.lds = epi;
+  r.tab = (int)r.lds;                                        // the per-channel epilogue operand table behind both (16 B per output channel of the tile)
+  r.lds += (size_t)co_t * 16;
   return r;
 }
 
@@ -629,6 +641,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   q.tw_log2 = gm.twl;
   q.bf_pitch = gm.pitch;
   q.bf_plane = gm.plane;
+  q.bf_tab = gm.tab;
   q.co_tiles = (q.cout_g + CO_T - 1) / CO_T;
   const int TW = 1 << gm.twl, TH = NPIX >> gm.twl;
   int blocks = 0;

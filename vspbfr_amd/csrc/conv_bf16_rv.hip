@@ -413,7 +413,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
         for (int ib = 0; ib < 4; ++ib) {
           f32x2 ab[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) ab[k] = *reinterpret_cast<const f32x2*>(&Ep[par * CO_T + mb * 32 + 8 * ib + k + 4 * kh]);
+          for (int k = 0; k < 4; ++k) {   // (read through the type it was written with: a float4 store read back as a float2 is undefined under TBAA)
+            const float4 t4 = Ep[par * CO_T + mb * 32 + 8 * ib + k + 4 * kh];
+            ab[k] = f32x2{t4.x, t4.y};
+          }
           if (done.co0 + mb * 32 + 8 * ib >= Cout) continue;   // (uniform: channel octets past the group; Cout is a multiple of 8)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {

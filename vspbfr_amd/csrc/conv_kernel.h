@@ -69,6 +69,7 @@ struct ConvK {
   const float* wcp; int wc_cs, wc_bs;
   const float* wshp; int wsh_cs;
   int io_bf16;                                   // conv_bf16.hip: x, y, res1, res2 are bf16 in HBM
+  int bf_tab;                                    // conv_bf16.hip: byte offset of the per-channel operand table in dynamic LDS
   int rv_copad, rv_cbase, rv_ctot;               // conv_bf16_rv.hip: channel rows of a weight slab (cout_g rounded up to 32); first channel of the
                                                  // launched dilation group in the layer's operands and in y; channels of the layer (G * cout_g)
 };
