@@ -64,6 +64,11 @@ constexpr int RPT = VSP_FIR_RPT;          // output rows per thread (x 4 columns
 // tiles per block: template argument of the kernel (1 ships; see the launcher)
 constexpr int TOH = RPT * (256 / (TOW / 4)); // output tile rows
 
+// (Round 4, bf16 planes: the window kept PACKED -- 8-byte loads, a tile of dwords in LDS, one 16-byte LDS read per window row and thread, two
+// horizontal taps as ONE v_dot2c_f32_bf16 on a pixel pair, i.e. 8 dot products + 3 funnel shifts per window row instead of 16 FMAs per output
+// + the unpacking; exact for the path's taps, results within one bf16 unit of the fp32 arithmetic on < 1 % of the elements -- measured 2.26-2.40
+// TB/s against 2.4-2.6: the bf16 blur is NOT bound by its arithmetic either.  A tile lives ~7 us with six workgroups per CU: what is in
+// flight per CU (6 x 6 KB of window) over that latency IS the 2.4 TB/s; removed.)
 // 4 floats that are only 4-byte aligned (image rows of odd width): gfx950 global loads/stores take any dword alignment
 using vsp::f32x4u;
 
