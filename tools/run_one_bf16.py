@@ -1,4 +1,5 @@
-"""Run one bf16 conv shape a few times (for rocprofv3 --pmc passes).  usage: run_one_bf16.py Cin Cout S variant [G] [iters]"""
+"""Run one bf16 conv shape a few times (for rocprofv3 --pmc passes).  usage: run_one_bf16.py Cin Cout S variant [G] [iters]
+env: IO_BF16=1 bf16 activations in HBM; RV=1 the row-vector-K kernel (vsp_conv2d_bf16rv); B=<batch> (default 8)"""
 import math, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,7 +7,7 @@ from vspbfr_amd import hip_ops as H
 Cin, Cout, S, v = (int(a) for a in sys.argv[1:5])
 G = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 3
-B = 8
+B = int(os.environ.get("B", "8"))
 x = torch.randn(B, Cin, S, S, device="cuda")
 if os.environ.get("IO_BF16"):
     x = x.to(torch.bfloat16)
@@ -19,6 +20,6 @@ else:
 sc = torch.rand(B, Cin, device="cuda") + 0.5
 out = torch.empty(B, Cout, S, S, device="cuda", dtype=x.dtype)
 for _ in range(iters):
-    H.conv2d_packed(x, pc, out=out, in_scale=sc, bf16=True, tile_hint=v)
+    H.conv2d_packed(x, pc, out=out, in_scale=sc, bf16=("rv" if os.environ.get("RV") else True), tile_hint=v)
 torch.cuda.synchronize()
 print("done")
