@@ -179,6 +179,44 @@ def test_bf16_weight_lds_image_layout_cpu():
     assert not H.bf16_profitable(pc(), 8, 8, 8, 8) and H.bf16_profitable(pc(), 16, 16, 16, 16)
 
 
+def test_bf16rv_weight_fragment_layout_cpu():
+    """hip_ops.bf16rv_weight against the documented index formula of vsp_conv2d_bf16rv (include/vspbfr_hip.h): every (tap, ci, co) is
+    found where the formula says, the fourth horizontal slot and the channel rows past cout_g are zero; eligibility and the choice rule of
+    the row-vector kernel (no GPU needed)."""
+    import numpy as np
+    import torch
+    from vspbfr_amd import hip_ops as H
+    rng = np.random.default_rng(11)
+    for G, cin, cout_g in ((1, 24, 64), (4, 16, 16), (2, 8, 40)):
+        w = rng.standard_normal((G, cout_g, cin, 3, 3)).astype(np.float32)
+        wp = torch.stack([H.pack_weight(torch.from_numpy(w[g]))[0] for g in range(G)])
+        packed = H.bf16rv_weight(wp)
+        co_pad, nch = (cout_g + 31) // 32 * 32, cin // 8
+        assert packed.dtype == torch.bfloat16 and packed.numel() == G * nch * 3 * 2 * 2 * co_pad * 8
+        flat = packed.float().numpy()
+
+        def W(g, ky, kx, ci, co):   # the header's formula, per group
+            chunk, quad, half, pair = ci // 8, (ci % 8) // 4, (ci % 4) // 2, ci % 2
+            return flat[g * (nch * 12 * co_pad * 8) + (((((chunk * 3 + ky) * 2 + quad) * 2 + half) * co_pad + co) * 8) + pair * 4 + kx]
+
+        for g in range(G):
+            back = np.array([[[[W(g, ky, kx, ci, co) for kx in range(3)] for ky in range(3)] for ci in range(cin)] for co in range(cout_g)], np.float32)
+            assert np.array_equal(back, torch.from_numpy(w[g]).to(torch.bfloat16).float().numpy())
+        full = flat.reshape(G, nch, 3, 2, 2, co_pad, 2, 4)
+        assert not full[..., 3].any() and not full[:, :, :, :, :, cout_g:].any()
+    pc = lambda **kw: H.PackedConv(torch.zeros(1), kw.get("G", 1), kw.get("cout_g", 64), kw.get("cin", 64), kw.get("k", 3), kw.get("k", 3),
+                                   kw.get("stride", 1), kw.get("dil", (1,)), kw.get("pad", (1,)), x_group_stride=kw.get("xgs", 0))
+    assert H.bf16rv_eligible(pc(), 128, 128, 128, 128) and H.bf16rv_eligible(pc(cin=32, cout_g=32), 1024, 1024, 1024, 1024)
+    assert H.bf16rv_eligible(pc(G=4, cout_g=16, dil=(1, 2, 4, 8), pad=(1, 2, 4, 8)), 512, 512, 512, 512)
+    assert not H.bf16rv_eligible(pc(), 128, 96, 128, 96)                                   # W % 64
+    assert not H.bf16rv_eligible(pc(cin=512), 64, 64, 64, 64)                              # more than 256 input channels
+    assert not H.bf16rv_eligible(pc(cout_g=48), 128, 128, 128, 128)                        # plain layers: channels % 32
+    assert not H.bf16rv_eligible(pc(stride=2), 128, 128, 64, 64) and not H.bf16rv_eligible(pc(dil=(2,), pad=(2,)), 128, 128, 128, 128)
+    assert not H.bf16rv_eligible(pc(G=4, cout_g=16, dil=(1, 2, 3, 8), pad=(1, 2, 3, 8)), 512, 512, 512, 512)   # dilations from {1, 2, 4, 8}
+    assert H.bf16rv_profitable(pc(), 128, 128) and not H.bf16rv_profitable(pc(), 64, 64)
+    assert not H.bf16rv_profitable(pc(G=4, cout_g=16, dil=(1, 2, 4, 8), pad=(1, 2, 4, 8)), 512, 512)    # served, not chosen
+
+
 def test_tacc_projection_fragment_layout():
     """vsp_tacc_block.wcat_frag (include/vspbfr_hip.h): the concatenated [4D, D] projection matrix in MFMA fragment order --
     frag[n / 16][k / 16][lane = 16 (k % 16 / 4) + n % 16][k % 4] = W[n][k] -- as diffusion.Code_diffuser builds it (host logic, CPU)."""
