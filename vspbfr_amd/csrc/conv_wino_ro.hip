@@ -147,6 +147,11 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
     float* dst = Pdst + wave * PPITCH;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
+      // (These 16-byte writes start at word 1 + 4 l: NOT 16-byte aligned, served as four dword passes with the lanes four banks apart --
+      //  14 conflict cycles per write, 27 % of the kernel's LDS-active cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.27; with the
+      //  commits switched off 0.008).  Writing the ALIGNED unit (d of segment l - 1 through DPP wave_shr:1, a, b, c) takes the ratio to
+      //  0.015 and the kernel from 605 to 630 us at 256 -> 256 / 128^2, 1211 to 1378 us at 32 -> 32 / 1024^2: the LDS is not what this
+      //  kernel waits for, the extra VALU on the commit path is.  Kept misaligned.)
       // (an invalid segment was loaded from offset 0 of the plane: finite data times a zero scale, no branch around the stores)
       const bool ok = ((p_ok >> i) & 1u) && chok;
       const float scm = ok ? sc : 0.f, shm = ok ? sh : 0.f;
