@@ -70,19 +70,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, kh = lane >> 5;
 
-  // PERSISTENT workgroups: the grid is what the chip holds (two per CU); a workgroup walks a contiguous range of the logical tile
-  // order co tile (same patch) -> tile column -> tile row -> image, and every XCD (own L2; the dispatcher deals workgroups
-  // round-robin over the eight) gets a contiguous range of workgroups.  A tile lives ~40 us, of which launch, first loads and
+  // PERSISTENT workgroups: the grid is what the chip holds (two per CU); the logical tile order is co tile (same patch) -> tile
+  // column -> tile row -> image, and every XCD (own L2; the dispatcher deals workgroups round-robin over the eight) gets a
+  // contiguous range of workgroups.  A tile lives ~40 us, of which launch, first loads and
   // the epilogue were a third (tuning build: 237 of 790 us with everything else switched off): the first loads of tile t + 1 are
   // issued BEFORE the epilogue of tile t.
   const int tiles_x = p.W / RV_TW, tiles_y = ((p.H + DIL - 1) / DIL + TH - 1) / TH, co_tiles = p.co_tiles;
-  int t_begin, t_end;
+  // Tile walk: INTERLEAVED -- in step k the resident workgroups take the tiles k G ... k G + G - 1 (G = grid size), workgroup g the
+  // g-th of them, every XCD a contiguous eighth.  Neighbouring tiles are then in flight at the SAME time and their shared lines (a
+  // 64-pixel row segment is exactly one 128-byte line: the one-pixel left and two-pixel right halo cost two more lines per row; the
+  // two halo rows) are L2 hits.  With a contiguous range of tiles per workgroup nothing that ran together shared anything: PMC
+  // FETCH_SIZE 1.87 GB for the 0.54 GB input of 64 -> 64 at 512^2 (B = 16), the launch moving 4.8 TB/s through the fabric -- bound by
+  // its own over-fetch (profiles/r04_conv_traffic_pmc_c3_bf16act.json).
+  int t_begin, t_end, t_step;
   {
     const int GT = gridDim.x, wgid = blockIdx.x;
     const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
     const int g = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
-    t_begin = (int)((int64_t)g * ntiles / GT);
-    t_end = (int)((int64_t)(g + 1) * ntiles / GT);
+    if (p.dbg & 0x10000) {   // (tuning: the contiguous ranges)
+      t_begin = (int)((int64_t)g * ntiles / GT);
+      t_end = (int)((int64_t)(g + 1) * ntiles / GT);
+      t_step = 1;
+    } else {
+      t_begin = g;
+      t_end = ntiles;
+      t_step = GT;
+    }
   }
   if (t_begin >= t_end) return;
   struct Tile { int b, oy0, x0, co0, ry; };   // oy0: first row of the tile in the row-residue sub-image ry
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
   stage_tile(cur);
   first_loads();
   first_commit(par);
-  for (int t = t_begin; t < t_end; ++t) {
+  for (int t = t_begin; t < t_end; t += t_step) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -386,10 +399,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
       interval(c, pregA, pregB);
       if (c + 1 < nchunk) interval(c + 1, pregB, pregA);
     }
-    const bool has_next = t + 1 < t_end;
+    const bool has_next = t + t_step < t_end;
     const Tile done = cur;
     if (has_next) {   // (every wave is past the last barrier of the chunk loop: both buffer pairs are free)
-      cur = decode(t + 1);
+      cur = decode(t + t_step);
       stage_tile(cur);
       first_loads();
     }
