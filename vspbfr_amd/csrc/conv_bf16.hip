@@ -103,11 +103,26 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   const int GX = gridDim.x, GY = gridDim.y, GN = GX * GY, GT = GN * gridDim.z;
   int b = blockIdx.z, xl = blockIdx.x, yy = blockIdx.y;
   int reg_ry = -1, reg_ty = 0, reg_tx = 0;
-  if (p.G == 1 || (MODE == M_CONV && p.wg_order == 3)) {
+  if (p.G == 1 || (MODE == M_CONV && p.wg_order == 3)) {   // (wg_order 2: G == 1 only)
     const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
     const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
     const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
-    if (p.G == 1) {
+    if (p.G == 1 && p.wg_order == 2) {
+      // weight-heavy layers (the 512 -> 5632 stem: 52 MB of bf16 weights, 88 channel tiles, 128 pixel tiles): with the channel tiles
+      // fastest every pixel tile streams ALL the weights through its XCD's 4 MB L2 -- PMC FETCH_SIZE 7.2 GB for 0.56 GB of operands,
+      // the launch moving 3.9 TB/s through the fabric.  Here a GROUP of p.tiles_x channel tiles (their weights fit the L2) sweeps every
+      // pixel tile of every image before the next group starts: the weights are fetched once per group, the (smaller) input once per
+      // group sweep.
+      const int cgs = p.tiles_x, npt = GX * (int)gridDim.z;         // channel tiles per group, pixel tiles of the batch
+      const int full = (GY / cgs) * cgs * npt;                      // workgroups of the whole groups
+      int cgrp, rem, cw;
+      if (lid < full) { cgrp = lid / (cgs * npt); rem = lid - cgrp * (cgs * npt); cw = cgs; }
+      else { cgrp = GY / cgs; rem = lid - full; cw = GY - cgrp * cgs; }   // the last, narrower group
+      const int pt = rem / cw;
+      yy = cgrp * cgs + (rem - pt * cw);
+      b = pt / GX;
+      xl = pt - b * GX;
+    } else if (p.G == 1) {
       b = lid / GN;
       const int lrem = lid - b * GN;
       xl = lrem / GY;
@@ -665,6 +680,16 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
       q.tiles_y = (q.H + 8 * TH - 1) / (8 * TH);
       q.tiles_x = ((q.W + TW - 1) / TW + 3) / 4;
       blocks = q.tiles_y * q.tiles_x * 32;
+    }
+  }
+  if (q.G == 1 && !(q.dbg & 0x20000)) {   // weight-heavy layers: channel-tile groups sweep the pixel tiles (see the kernel)
+    const int64_t wtile = (int64_t)q.Cin * 9 * CO_T * 2 * (SPLIT ? 2 : 1), wall = wtile * q.co_tiles;   // bf16 weight bytes of one channel tile / of the layer
+    const int64_t xall = (int64_t)q.B * q.Cin * q.H * q.W * (q.io_bf16 ? 2 : 4);
+    if (wall > 8 * 1024 * 1024 && q.co_tiles >= 4 && wall * 2 > xall / 8) {
+      int cgs = (int)((int64_t)(3 * 1024 * 1024 / 2) / wtile);     // half of an XCD's L2 for the group's weights
+      cgs = cgs < 1 ? 1 : (cgs > q.co_tiles ? q.co_tiles : cgs);
+      q.wg_order = 2;
+      q.tiles_x = cgs;
     }
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
