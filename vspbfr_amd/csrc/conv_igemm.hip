@@ -585,6 +585,15 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     if (int rc = raised[best.cfg].ensure(reinterpret_cast<const void*>(k.kern), (int)(k.PF == 3 ? kMaxLdsPipe : kMaxLds), "conv2d")) return rc;
   }
   q.wg_order = (q.dbg & 0x1000000) ? 0 : 1;   // XCD-aware order (conv_kernel.h); VSP_CONV_DBG = 16777216 keeps the dispatch order
+  if (k.PF == 3 && p.G == 1 && q.wg_order == 1 && !(q.dbg & 0x20000)) {   // conv_pipe.hip: channel-tile groups on weight-heavy layers
+    const int64_t wtile = (int64_t)p.Cin * p.KH * p.KW * CO_T * 4, wall = wtile * best.co_tiles;
+    const int64_t xall = (int64_t)p.B * p.Cin * p.H * p.W * 4;
+    if (wall > 16 * 1024 * 1024 && best.co_tiles >= 4 && wall * 2 > xall / 8) {
+      int cgs = (int)((int64_t)(2 * 1024 * 1024) / wtile);
+      q.wg_cgs = cgs < 1 ? 1 : (cgs > best.co_tiles ? best.co_tiles : cgs);
+      q.wg_order = 2;
+    }
+  }
   dim3 grid((unsigned)(best.tiles_x * best.tiles_y + (best.strip_col > 0 ? best.strip_col + best.strip_row : 0)), (unsigned)gy,
             (unsigned)p.B);
   dim3 block(64 * k.WM * k.WN * k.WK);

@@ -88,6 +88,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void conv_pipe_kernel(const Conv
     const int lrem = lid - bz * GN;
     tile = lrem / GY;
     by = lrem - tile * GY;
+  } else if (p.wg_order == 2) {
+    // weight-heavy layers (the 512 -> 5632 stem: 104 MB of weights): a GROUP of p.wg_cgs channel tiles sweeps every pixel tile of the
+    // batch before the next group starts -- the group's weights stay in the XCD's L2 and the (smaller) input is streamed once per
+    // sweep, instead of every pixel tile streaming all the weights (round 3: FETCH_SIZE 6.8 GB for this one launch).
+    const int GX = gridDim.x, GY = gridDim.y, GT = GX * GY * gridDim.z;
+    const int wgid = blockIdx.x + GX * (blockIdx.y + GY * blockIdx.z);
+    const int xcd = wgid & 7, xq = GT >> 3, xr = GT & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wgid >> 3);
+    const int cgs = p.wg_cgs, npt = GX * (int)gridDim.z;
+    const int full = (GY / cgs) * cgs * npt;
+    int cgrp, rem, cw;
+    if (lid < full) { cgrp = lid / (cgs * npt); rem = lid - cgrp * (cgs * npt); cw = cgs; }
+    else { cgrp = GY / cgs; rem = lid - full; cw = GY - cgrp * cgs; }
+    const int pt = rem / cw;
+    by = cgrp * cgs + (rem - pt * cw);
+    bz = pt / GX;
+    tile = pt - bz * GX;
   }
   const int tx_i = tile % p.tiles_x, ty_i = tile / p.tiles_x;
   const int g = DGS ? 0 : by / p.co_tiles;
