@@ -522,6 +522,10 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
     if ((named || preferred || guess) && !p.dil_by_input_quarter) {
       ConvK q{};
       if (int rc = fill_convk(p, x_ch, q)) return rc;
+      {
+        static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;   // tuning switches (0 in production)
+        q.dbg = dbg;
+      }
       if (vspconv::smallmap_eligible(q, p.transposed != 0)) return vspconv::smallmap_launch(q, vsp::as_stream(stream));
       VSP_REQUIRE(!named, "conv2d: configuration smallmap does not fit this problem (Cin %% 16 == 0, at most 8192 output positions, not transposed)");
     }
