@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rv_kernel(const ConvK p, con
             acc[mb][r][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dy][mb], bq[cs][pp], acc[mb][r][pp], 0, 0, 0);
           }
         }
+      // (Measured alternative: all commits + the weight DMA at the TOP of the interval, the patch loads of chunk c + 2 behind them and
+      //  `s_waitcnt vmcnt(PT)` + a bare s_barrier at the end, so that the prefetch flies across the barrier instead of being drained by
+      //  the vmcnt(0) the DMA needs: correct, and 520 against 514 us -- the drain is not what the 150 us of the patch loads are.)
       if (c + 1 < nchunk) {
         if (grp < PT) commit_one(Pn, prCommit, sc, sh, grp);
         if (grp == PT - 1) issue_w(Wl + nxt * WBUF, c + 1);
