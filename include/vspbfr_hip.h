@@ -187,7 +187,10 @@ int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
  *         = U_g[position 2*wave + pp][ci = CK*chunk + (lane >> 4)][co = 16*MB*tile + 16*mb + (lane & 15)]
  * (a wave owns two Winograd positions; its A fragments of one position and chunk are one contiguous run: a wave-wide load reads
  * consecutive memory).
- * Every prologue / epilogue field of vsp_conv_params keeps its meaning, tile_hint is ignored.  16 multiplies per 2x2
+ * Every prologue / epilogue field of vsp_conv_params keeps its meaning.  tile_hint names the kernel FORM (tests / tuning): 0 = the
+ * library chooses; 1 = task list (conv_wino.hip), 2 = row owner (conv_wino_ro.hip / conv_wino_rod.hip), 3 = register-resident U with
+ * polyphase staging (conv_wino_rs.hip: Cin <= 64, W % 4 == 0, no in_shift -- the 64 -> 4 x 16 dilation groups of the SMART layers,
+ * reference models/RestoreNet.py:179-244); a named form that does not serve the launch returns VSP_ENOTSUP.  16 multiplies per 2x2
  * output tile instead of 36; fp32 error ~1e-6 relative on top of the direct kernel's summation-order noise. */
 int vsp_conv2d_winograd_f32(const vsp_conv_params* p, vsp_stream_t stream);
 int vsp_conv2d_winograd_chunk(void);

@@ -18,6 +18,6 @@ else:
     wp = torch.randn(4, 9, Cin, Cout // 4, device="cuda") / math.sqrt(Cin * 9)
     pc = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
 for _ in range(iters):
-    H.conv2d_packed(x, pc, in_scale=sc, winograd=4 if os.environ.get("WINO") == "4" else True)
+    H.conv2d_packed(x, pc, in_scale=sc, winograd=4 if os.environ.get("WINO") == "4" else True, wino_form=int(os.environ.get("WINO_FORM", "0")))
 torch.cuda.synchronize()
 print("done", Cin, Cout, S, G)

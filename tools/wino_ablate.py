@@ -14,7 +14,7 @@ if G == 1:
 else:
     wp = torch.randn(4, 9, Cin, Cout // 4, device="cuda") / math.sqrt(Cin * 9)
     pc = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
-f = lambda: H.conv2d_packed(x, pc, in_scale=sc, winograd=True)
+f = lambda: H.conv2d_packed(x, pc, in_scale=sc, winograd=True, wino_form=int(os.environ.get("WINO_FORM", "0")))
 f(); f(); torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()

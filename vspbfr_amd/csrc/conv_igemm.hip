@@ -362,7 +362,8 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
     q.wc_bs = (p.in_scale && affine) ? p.in_scale_bstride : 0;
     q.wshp = affine ? p.in_shift : kc + 1;                         q.wsh_cs = affine ? 1 : 0;
   }
-  if (int rc = vspconv::wino_launch(q, vsp::as_stream(stream))) return rc;
+  VSP_REQUIRE(p.tile_hint >= 0 && p.tile_hint <= 3, "conv2d_winograd: tile_hint names the kernel form: 0 automatic, 1 task list, 2 row owner, 3 register-resident U");
+  if (int rc = vspconv::wino_launch(q, p.tile_hint, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_winograd");
 }
 

@@ -618,14 +618,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK, OCC) void conv_igemm_kernel(cons
 
 
 // conv_wino.hip: Winograd F(2x2,3x3) launch (q.w = transformed weights [16][Cin][Cout]); tiles are set inside
-int wino_launch(ConvK q, hipStream_t stream);
+int wino_launch(ConvK q, int form, hipStream_t stream);
 // conv_smallmap.hip: K-split GEMM form for layers with few output positions (q filled by fill_convk: no tile plan needed)
 bool smallmap_eligible(const ConvK& q, bool transposed);
 int smallmap_launch(const ConvK& q, hipStream_t stream);
 int wino_ro_launch(ConvK q, int mbw, int ivc, hipStream_t stream);
 bool wino_ro_eligible(const ConvK& q);
 int wino_rod_launch(ConvK q, int mbw, hipStream_t stream);            // conv_wino_rod.hip: row-owner form, dilation groups
-bool wino_rod_eligible(const ConvK& q);   // conv_wino_ro.hip: row-owner form, undilated groups
+bool wino_rod_eligible(const ConvK& q);
+int wino_rs_launch(ConvK q, hipStream_t stream);                      // conv_wino_rs.hip: register-resident U, polyphase staging (Cin <= 64)
+bool wino_rs_eligible(const ConvK& q);
+bool wino_rs_profitable(const ConvK& q);   // conv_wino_ro.hip: row-owner form, undilated groups
 // conv_wino4.hip: Winograd F(4x4,3x3) as input transform + barrier-free GEMM (deep layers)
 bool wino4_eligible(const ConvK& q);
 size_t wino4_weight_floats(int cin, int cout);

@@ -571,15 +571,28 @@ int wino_chunk() { return WCK; }
 // 16-channel blocks per workgroup for a layer with cout_g output channels per group (the weight layout depends on it)
 int wino_mbw(int cout_g) { return cout_g > 32 ? 4 : (cout_g > 16 ? 2 : 1); }
 
-int wino_launch(ConvK q, hipStream_t stream) {
+int wino_launch(ConvK q, int form, hipStream_t stream) {
+  // form (vsp_conv_params.tile_hint of the Winograd entry): 0 = automatic; 1 = the task-list kernel of this file; 2 = the row-owner forms
+  // (conv_wino_ro.hip / conv_wino_rod.hip); 3 = the register-resident-U form (conv_wino_rs.hip); a named form that does not serve the
+  // launch is VSP_ENOTSUP
   int dmax = 1;
   for (int g = 0; g < q.G; ++g) dmax = q.dil[g] > dmax ? q.dil[g] : dmax;
+  if (form == 3) {
+    if (!wino_rs_eligible(q)) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the register-resident-U form does not serve this launch");
+    return wino_rs_launch(q, stream);
+  }
+  if (form == 0) {
+    static const int rs = getenv("VSP_WINO_RS") ? atoi(getenv("VSP_WINO_RS")) : 1;   // 0: never, 2: wherever eligible
+    if (rs && wino_rs_eligible(q) && (rs == 2 || wino_rs_profitable(q))) return wino_rs_launch(q, stream);
+  }
   if (dmax == 1) {
     // row-owner form (conv_wino_ro.hip) wherever it serves the launch; maps up to 16 x 16 measured equal or slower (512 -> 512 at 16^2:
     // 99 vs 102 us) and stay here.  VSP_WINO_RO = 0 keeps this file's kernel everywhere, 1 / 2 / 4 = barrier period of the other one
     // (8-channel sub-stages; 2 and 4 measured within 1 % of 1 on the deep layers, slower on the shallow ones).
     static const int ro = getenv("VSP_WINO_RO") ? atoi(getenv("VSP_WINO_RO")) : 1;
-    if ((ro == 1 || ro == 2 || ro == 4) && q.H * q.W > 256 && wino_ro_eligible(q)) return wino_ro_launch(q, wino_mbw(q.cout_g), ro, stream);
+    if (form == 2 && !wino_ro_eligible(q)) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the row-owner form does not serve this launch");
+    if (form != 1 && (ro == 1 || ro == 2 || ro == 4) && (q.H * q.W > 256 || form == 2) && wino_ro_eligible(q))
+      return wino_ro_launch(q, wino_mbw(q.cout_g), ro == 0 ? 1 : ro, stream);
     switch (wino_mbw(q.cout_g)) {
       case 4: return launch_variant<4, 1>(q, stream);
       case 2: return launch_variant<2, 1>(q, stream);
@@ -590,8 +603,9 @@ int wino_launch(ConvK q, hipStream_t stream) {
       // 128^2 793 -> 762, 512 -> 4 x 128 at 32^2 302 -> 291; 512 -> 4 x 128 at 64^2 753 -> 768: stays here.  VSP_WINO_ROD = 0 / 2: never / always.
     static const int rod = getenv("VSP_WINO_ROD") ? atoi(getenv("VSP_WINO_ROD")) : 1;
     const bool deep_large = q.Cin >= 512 && q.H * q.W >= 4096;
-    if (rod && (rod == 2 || !deep_large) && wino_mbw(q.cout_g) >= 2 && wino_rod_eligible(q))
-      return wino_rod_launch(q, wino_mbw(q.cout_g), stream);
+    const bool rod_ok = wino_mbw(q.cout_g) >= 2 && wino_rod_eligible(q);
+    if (form == 2 && !rod_ok) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the row-owner form does not serve this launch");
+    if (form != 1 && rod_ok && (form == 2 || (rod && (rod == 2 || !deep_large)))) return wino_rod_launch(q, wino_mbw(q.cout_g), stream);
   }
   switch (wino_mbw(q.cout_g)) {
     case 4: return launch_variant<4, 8>(q, stream);

@@ -551,10 +551,11 @@ def conv2d_out_size(H, W, pc):
 def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out_offset=(0, 0), in_scale=None,
                   in_scale_per_sample=True, in_shift=None, out_scale=None, ch_scale=None, ch_bias=None, act1=False,
                   bias1=None, noise=None, noise_w=None, act2=0, bias2=None, prelu=None, slope2=0.2, gain2=SQRT2, res1=None,
-                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False, winograd=None, bf16=None):
+                  res2=None, res_coff=0, n_out=None, tile_hint=0, transposed=False, winograd=None, bf16=None, wino_form=0):
     """Launch vsp_conv2d_f32.  `out` (B, y_ch, y_h, y_w) is allocated when None.  `n_out` = (OH, OW) positions to
     compute (defaults to the standard conv output size).  `winograd`: True / False forces / forbids the F(2x2,3x3) kernel
-    (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape.  `bf16`: True runs the
+    (vsp_conv2d_winograd_f32) on an eligible layer; None = what the tuned table says for this shape; `wino_form` names the F(2x2) kernel
+    form (0 automatic, 1 task list, 2 row owner, 3 register-resident U: include/vspbfr_hip.h, tests / tuning).  `bf16`: True runs the
     layer on vsp_conv2d_bf16 (tile_hint = its variant), None = the module switch BF16_CONV on eligible layers."""
     x = _req(x, "x", bf16_ok=True)
     B, x_ch, H, W = x.shape
@@ -696,6 +697,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             uw = pc.winograd_weight()
             keep.append(uw)
             p.w = uw.data_ptr()
+            p.tile_hint = wino_form
             check(lib.vsp_conv2d_winograd_f32(C.byref(p), _stream()), "conv2d_winograd")
     else:
         check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
