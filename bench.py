@@ -127,11 +127,12 @@ def train_bench(args, world, rank, dev):
                                    "from inside backward (64 MB buckets)" % B, "global_batch": world * B},
             "r1": {"d_reg_every": tr.d_reg_every, "r1_iterations_in_timed_region": n_r1,
                    "note": "the timed region starts right after a multiple of d_reg_every; K a multiple of it prices the schedule exactly"},
-            "roofline": {"bound": "mfma", "achieved": round(fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(fl / conv_ms / 1e9 / 157.3, 3), "traffic": None,
-                         "executed_tflops": round(ex_fl / conv_ms / 1e9, 1), "executed_frac": round(ex_fl / conv_ms / 1e9 / 157.3, 3),
-                         "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks); "
-                                   "EFFECTIVE rate: algorithmic direct-conv FLOPs of every launch (Winograd launches execute 16/36 of theirs) / kernel time",
+            "roofline": {"bound": "mfma", "achieved": round(ex_fl / conv_ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(ex_fl / conv_ms / 1e9 / 157.3, 3), "traffic": None,
+                         "algorithmic_tflops": round(fl / conv_ms / 1e9, 1), "algorithmic_frac": round(fl / conv_ms / 1e9 / 157.3, 3),
+                         "kernel": "conv family of one iteration (forward, data gradient, weight gradient, loss networks); achieved / frac = FLOPs "
+                                   "the matrix pipe EXECUTED / kernel time (Winograd launches run 16/36 or 36/144 of their direct-form count); "
+                                   "algorithmic_* = direct-form FLOPs / time (an effective rate)",
                          "launches": n_launch, "kernel_ms": round(conv_ms, 1),
                          "measured": "HIP events per launch on the launch stream over one untimed iteration"},
             "cpu_baseline": None}))
@@ -399,7 +400,9 @@ def main():
             pipe(lq)
             hip_ops.PROFILER = None
             torch.cuda.synchronize()
-        prof = hip_ops.ConvProfiler()
+        # Per-launch events inside the timed region only for the serial loop (--no-overlap), where they ARE the kernel durations; the
+        # default overlapped loop takes every roofline figure from the `iso` step above and times K clean steps.
+        prof = hip_ops.ConvProfiler() if iso is None else None
         hip_ops.PROFILER = prof
         sync()
         t0 = time.perf_counter()
@@ -412,8 +415,12 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    conv_flops, conv_ms, conv_launches = prof.summary()
-    conv_bytes = prof.algorithmic_bytes()
+    if prof is not None:
+        conv_flops, conv_ms, conv_launches = prof.summary()
+        conv_exec = prof.executed_flops()
+    else:   # the serial measurement step, scaled to the K timed steps (the line's per-step fields divide by K again)
+        conv_flops, conv_ms, conv_launches = (v * args.steps for v in iso.summary())
+        conv_exec = iso.executed_flops() * args.steps
 
     if rank == 0:
         imgs = world * B * args.steps
@@ -421,11 +428,11 @@ def main():
         # bf16 configuration: the dense bf16 MFMA peak (MI355X_MICROARCH.md); the conv family then mixes bf16 (stride-1 3x3)
         # and fp32 (stride-2, transposed, small-map) launches, all priced against the bf16 peak
         PEAK = {"f32": PEAK_FP32_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.conv_dtype]  # bf16x3: three MFMAs per product
-        KERNEL_NOTE = ("conv family: conv_pipe_kernel (direct, double-buffered pipeline: stride-2 / transposed / dilation groups) + "
-                       "conv_igemm_kernel / conv_smallmap_kernel (direct, small maps and 1x1) + conv_wino_ro_kernel / conv_wino_kernel (Winograd "
-                       "F(2x2,3x3)) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers); "
-                       "achieved / frac = ALGORITHMIC FLOPs / time, i.e. an effective rate on the Winograd layers; executed_tflops / "
-                       "executed_frac = what the matrix pipe ran (F(2x2) launches at 16/36, F(4x4) launches at 36/144 of their algorithmic count)") if args.conv_dtype == "f32" else (
+        KERNEL_NOTE = ("conv family: conv_pipe_kernel (direct, double-buffered pipeline: stride-2 / transposed) + "
+                       "conv_igemm_kernel / conv_smallmap_kernel (direct, small maps and 1x1) + conv_wino_ro_kernel / conv_wino_rod_kernel / "
+                       "conv_wino_rs_kernel / conv_wino_kernel (Winograd F(2x2,3x3): row-owner, dilation groups, register-resident U) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers); "
+                       "achieved / frac = FLOPs the matrix pipe EXECUTED / kernel time (F(2x2) launches run 16/36, F(4x4) launches 36/144 of their "
+                       "direct-form count); algorithmic_tflops / algorithmic_frac = direct-form FLOPs / time, an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
             "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + conv_bf16_rv_kernel "
             "(row-vector K: plain stride-1 layers with <= 256 channels on maps >= 128^2, bf16 activations) + the fp32 "
             "conv_igemm_kernel on small maps and 1x1 layers; achieved = algorithmic FLOPs / time against the dense bf16 MFMA peak; with "
@@ -447,8 +454,12 @@ def main():
                        "rng": "torch device RNG, one randn per consumer" if args.torch_rng else
                               "keyed Philox draws by (seed, global image index): 2 launches per batch; the DRAWS are world-size invariant (mixing = 0: no per-batch style-mixing coin), the kernels' summation orders follow the per-rank batch size",
                        "sharding": f"dp{world}: batch split, weights replicated, all-gather of restored images" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK, 4), "traffic": conv_traffic(B, args),
+            # achieved / frac = what the matrix pipe EXECUTED per second (<= peak by construction: a Winograd F(2x2,3x3) launch runs 16/36, an
+            # F(4x4,3x3) launch 36/144 of its direct-form count); algorithmic_* = direct-form FLOPs / time, an effective rate that may exceed 1
+            "roofline": {"bound": "mfma", "achieved": round(conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0, 2), "peak": PEAK, "unit": "TFLOP/s",
+                         "frac": round((conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0) / PEAK, 4),
+                         "algorithmic_tflops": round(achieved, 2), "algorithmic_frac": round(achieved / PEAK, 4),
+                         "traffic": conv_traffic(B, args),
                          "kernel": KERNEL_NOTE, "launches_per_step": conv_launches // max(args.steps, 1),
                          "algorithmic_gflop_per_step": round(conv_flops / max(args.steps, 1) / 1e9, 1),
                          "kernel_ms_per_step": round(conv_ms / max(args.steps, 1), 2),
@@ -473,26 +484,21 @@ def main():
                        else "HIP events per launch inside the timed region (no second stream: --no-overlap)"})
             rl.pop("algorithmic_gflop_per_step", None)
         elif iso is not None:
+            # The roofline figures of the kernel are the per-launch HIP-event durations of ONE serial step taken right before the timed
+            # region: in the timed region two streams run at once (an event interval there would also contain the other stream's
+            # kernels), so it carries no per-launch events.  rocprofv3 serialises dispatches: its per-kernel durations (profiles/) agree
+            # with these.
             fl, ms, n = iso.summary()
-            # The roofline figures of the kernel are the per-launch HIP-event durations of the serial step: in the timed region
-            # two streams run at once, so an event interval there also contains the other stream's kernels (and a graph replay
-            # carries no per-launch events at all).  rocprofv3 serialises dispatches, so its per-kernel durations (profiles/)
-            # agree with these, not with the overlapped intervals, which stay in the line as `timed_region`.
-            rl = line["roofline"]
-            rl["timed_region"] = {"note": "per-launch event intervals inside the K timed steps (two streams overlap: an interval "
-                                          "also contains the side stream's kernels)",
-                                  "achieved": rl["achieved"], "frac": rl["frac"], "kernel_ms_per_step": rl["kernel_ms_per_step"],
-                                  "launches_per_step": rl["launches_per_step"]}
-            rl["achieved"], rl["frac"] = round(fl / (ms * 1e-3) / 1e12, 2), round(fl / (ms * 1e-3) / 1e12 / PEAK, 4)
-            rl["launches_per_step"], rl["algorithmic_gflop_per_step"], rl["kernel_ms_per_step"] = n, round(fl / 1e9, 1), round(ms, 2)
-            # `achieved` / `frac` count ALGORITHMIC work (2 Cin 9 FLOP per output): the Winograd layers execute 16/36 of
-            # theirs, so the figure is an effective rate there.  What the matrix pipe EXECUTED per second stands next to it.
             ex = iso.executed_flops()
-            rl["executed_tflops"], rl["executed_frac"] = round(ex / (ms * 1e-3) / 1e12, 2), round(ex / (ms * 1e-3) / 1e12 / PEAK, 4)
+            rl = line["roofline"]
+            rl["achieved"], rl["frac"] = round(ex / (ms * 1e-3) / 1e12, 2), round(ex / (ms * 1e-3) / 1e12 / PEAK, 4)
+            rl["algorithmic_tflops"], rl["algorithmic_frac"] = round(fl / (ms * 1e-3) / 1e12, 2), round(fl / (ms * 1e-3) / 1e12 / PEAK, 4)
+            rl["launches_per_step"], rl["algorithmic_gflop_per_step"], rl["kernel_ms_per_step"] = n, round(fl / 1e9, 1), round(ms, 2)
+            rl["executed_gflop_per_step"] = round(ex / 1e9, 1)
             rl["by_kernel_family"] = {k: {"algorithmic_tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "ms": round(v[1], 2), "launches": v[2]}
                                       for k, v in sorted(iso.by_kind().items()) if v[1] > 0}
             rl["measured"] = ("HIP events per launch on the launch stream over one serial step inside bench.py, right before the "
-                              "timed region (no second stream in flight)")
+                              "timed region (no second stream in flight; the timed region itself carries no per-launch events)")
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(args.timesteps, threads)

@@ -319,6 +319,26 @@ int vsp_axpby_idx_f32(float* out, const float* x, const float* y, const float* a
  * (models/RestoreNet.py:376-379 with the tap sum hoisted: wsq[co,ci] = sum_taps W[co,ci,:,:]^2). */
 int vsp_demod_f32(float* out, const float* style, const float* wsq, int B, int Cin, int Cout, float wscale,
                   float eps, vsp_stream_t stream);
+/* Every style modulation of a network for one latent in two launches (round 5): per modulated layer l the modulation vector
+ * mod_l[b, ci] = alpha_l * sum_k src[b * bstride + src_off_l + k] * w_l[ci, k] + bias_l[ci] * bias_scale_l   (EqualLinear,
+ * models/RestoreNet.py:142-171, evaluated at models/RestoreNet.py:211,467 once per layer) and, where wsq_l is given, the demodulation
+ * coefficients demod_l[b, co] = rsqrt(wscale2_l * sum_ci mod_l[b, ci]^2 * wsq_l[co, ci] + eps) (models/RestoreNet.py:376-379).  `table`
+ * is a DEVICE array of L entries; src_off is the element offset of the layer's style row inside the latent tensor (row b of the view
+ * latent[:, i] starts at src + b * bstride + src_off).  K a multiple of 256 (>= 512), B <= 16, 16-byte aligned rows.  Results are
+ * bit-identical to vsp_gemm_f32 (few-row form) followed by vsp_demod_f32 per layer. */
+typedef struct {
+  const float* w;      /* (cin, K) EqualLinear weight */
+  const float* bias;   /* (cin) or NULL */
+  const float* wsq;    /* (cout, cin) sum of squared taps, or NULL: no demodulation */
+  float* mod;          /* out (B, cin) */
+  float* demod;        /* out (B, cout) or NULL */
+  int64_t src_off;
+  int cin, cout;
+  float alpha, bias_scale, wscale2;
+  int pad_;
+} vsp_style_layer;
+int vsp_style_plan_f32(const vsp_style_layer* table, int L, const float* src, int B, int64_t bstride, int K, int max_cin, int max_cout,
+                       float eps, vsp_stream_t stream);
 /* The same coefficients under autograd (training rows; reference models/RestoreNet.py:376-379 differentiated by torch): forward from
  * the weight w[Cout, Cin, K] (K taps) -- wsq[co, ci] = sum_k w^2 is written for the backward -- and the gradient of a loss through
  * `out` with respect to the style and the weight:  t = -0.5 wscale^2 out^3 g;  dstyle[b, ci] = 2 style[b, ci] sum_co t[b, co] wsq[co, ci];

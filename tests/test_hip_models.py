@@ -158,6 +158,49 @@ def test_restorenet64_golden_and_oracle(golden):
     assert maxerr(out2, ref2) < 2e-4
 
 
+def test_style_plan_matches_layers():
+    """vsp_style_plan_f32 (all modulation / demodulation vectors of a network part in two launches, layers.StyleContext) against the
+    per-layer launches: the first forward records, the following ones replay the plan -- outputs BIT-identical to a run with the plans
+    switched off, for Restoration_net (encoder and decoder parts, K = 1024 / 1536) and the e4e Generator (K = 512), and again after the
+    batch size changes (the plan is rebuilt)."""
+    from vspbfr_amd import layers
+    from vspbfr_amd.e4e import Generator
+    from vspbfr_amd.restorenet import Restoration_net
+    size, case = 64, "restorenet64"
+    sd = weights.synth_state_dict("restorenet", weights.load_specs()["restorenet64"], cases.SEED)
+    net = load(Restoration_net(size, 512, 8), "restorenet", sd=sd)
+    gen = load(Generator(64, 512, 8), "e4e_decoder", "e4e_decoder64")
+
+    def run_net(B):
+        imgs = cases.image_batch(case + str(B), B, size)
+        enc_s, dec_s = OM.restoration_noise_shapes(size, B)
+        de_feats = [cases.tensor(case + str(B), f"de_feat{k}", (B, 512, 2 ** (k + 2), 2 ** (k + 2)), 0.5) for k in range(5)]
+        pre, z = cases.tensor(case + str(B), "pre_styles", (B, 18, 512)), cases.tensor(case + str(B), "z", (B, 512))
+        en, dn = cases.noise_list(case + str(B), "enc", enc_s), cases.noise_list(case + str(B), "dec", dec_s)
+        return net(dev(imgs), [dev(f) for f in de_feats], dev(pre), [dev(z)], enc_noise=[dev(n) for n in en], dec_noise=[dev(n) for n in dn])
+
+    def run_gen(B):
+        latent = cases.tensor("generator64" + str(B), "latent", (B, 10, 512))
+        noise = cases.noise_list("generator64" + str(B), "n", OM.generator_noise_shapes(64, B))
+        return gen([dev(latent)], input_is_latent=True, noise=[dev(n) for n in noise])[0]
+
+    for fn, mod, tags in ((run_net, net, ("enc", "dec")), (run_gen, gen, ("gen",))):
+        outs = {}
+        for B in (2, 2, 2, 3, 2):          # record, replay, replay, rebuild for another batch size, rebuild back
+            outs.setdefault(B, []).append(fn(B).clone())
+        for t in tags:
+            ctx = mod.__dict__["_style_ctx"][t]
+            assert ctx.recorded is not None and ctx.plan is not None and len(ctx.recorded) >= 5, t
+        layers.STYLE_PLANS = False
+        try:
+            for B, got in outs.items():
+                ref = fn(B)
+                for g in got:
+                    assert torch.equal(g, ref), (B, float((g - ref).abs().max()))
+        finally:
+            layers.STYLE_PLANS = True
+
+
 def test_restorenet_rejects_unusable_reference_flags():
     from vspbfr_amd.restorenet import Restoration_net
     net = Restoration_net(64, 512, 8).eval()

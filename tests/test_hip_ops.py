@@ -954,6 +954,37 @@ def test_conv2d_bf16rv_dilation_groups(H, B, Cin, Cg, Hh, Ww, dils):
         assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5 * ref.abs().max()).all()), (float(err.max()), kw.keys())
 
 
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,hint", [(5, 64, 64, 256, 256, 0), (6, 32, 32, 256, 256, 1)])
+def test_conv2d_bf16rv_repeat(H, B, Cin, Cout, Hh, Ww, hint):
+    """The fence around the packed-fp32 miscompare of round 4 (conv_bf16_rv.hip refuses to build with SLP vectorisation): more
+    tiles than resident workgroups, two workgroups per CU, 50 launches of the same operands -- every launch BIT-identical to the first
+    (the failure was sporadic: 0.01-0.05 % of the outputs, never the same ones) and the first one within one bf16 rounding of float64
+    F.conv2d on the bf16-rounded operands, DIRECTLY (not through vsp_conv2d_bf16)."""
+    g_ = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g_).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9)
+    s_in, demod, bias = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, Cout, generator=g_) + 0.5, torch.randn(Cout, generator=g_)
+    nz, nw = torch.randn(B, 1, Hh, Ww, generator=g_), torch.full((1,), 0.2)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+    xd = dev(x)
+    kw = dict(in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), noise=dev(nz), noise_w=dev(nw))
+    first = H.conv2d_packed(xd, pc, bf16="rv", tile_hint=hint, **kw)
+    first_bare = H.conv2d_packed(xd, pc, bf16="rv", tile_hint=hint)
+    for _ in range(50):
+        assert torch.equal(H.conv2d_packed(xd, pc, bf16="rv", tile_hint=hint, **kw), first)
+    for _ in range(10):
+        assert torch.equal(H.conv2d_packed(xd, pc, bf16="rv", tile_hint=hint), first_bare)
+    sel = [0, B - 1]
+    wb = w.to(torch.bfloat16).double()
+    xs = (x[sel].float() * s_in[sel].view(2, Cin, 1, 1)).to(torch.bfloat16).double()      # the kernel commits bf16(x * s)
+    ref = F.conv2d(xs, wb, padding=1) * demod[sel].double().view(2, Cout, 1, 1) + nz[sel].double() * 0.2
+    ref = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.2) * math.sqrt(2)
+    ref_bare = F.conv2d(x[sel].double(), wb, padding=1)
+    for got, r in ((first[sel], ref), (first_bare[sel], ref_bare)):
+        err = (got.double().cpu() - r).abs()
+        assert bool((err <= r.abs() * 2.0 ** -8 + 2e-5 * r.abs().max()).all()), float(err.max())
+
+
 def test_conv2d_bf16rv_refusals(H):
     """Launches the row-vector kernel does not serve: VSP_ENOTSUP at the C entry (the automatic path then uses vsp_conv2d_bf16),
     an error when it is forced."""

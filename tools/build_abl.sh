@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 src=$1; macro=$2; name=$3
 mkdir -p build/abl
 make -C vspbfr_amd/csrc -j8 > /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -D$macro $(grep -q "^\$(OBJDIR)/${src%.hip}.o: CXXFLAGS" vspbfr_amd/csrc/Makefile && echo -fno-slp-vectorize) -c vspbfr_amd/csrc/$src -o build/abl/${src%.hip}.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -D$macro $(sed -n "s/^\$(OBJDIR)\/${src%.hip}.o: CXXFLAGS += //p" vspbfr_amd/csrc/Makefile) -c vspbfr_amd/csrc/$src -o build/abl/${src%.hip}.o
 objs=$(ls build/csrc/*.o | grep -v "/${src%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/$name.so $objs build/abl/${src%.hip}.o
 echo build/abl/$name.so

@@ -1,6 +1,8 @@
-mkdir -p gpurun_out/r4ae
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r4ae/c64
+#!/bin/bash
+# PMC passes on the general bf16 kernel for one low-channel layer (64 -> 64 at 512^2, bf16 activations).  usage: tools/pmc_bf16_lowch.sh [outdir]
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT" || exit 1
+OUT=${1:-gpurun_out/pmc_bf16_lowch}
 mkdir -p $OUT
 P="python3 tools/run_one_bf16.py 64 64 512 0"
 export IO_BF16=1

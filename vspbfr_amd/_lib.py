@@ -102,6 +102,7 @@ SIGNATURES = {
     "vsp_film_f32": [_p, _p, _p, _p, _i64, _p],
     "vsp_axpby_idx_f32": [_p, _p, _p, _p, _p, _i, _i64, _p],
     "vsp_demod_f32": [_p, _p, _p, _i, _i, _i, _f, _f, _p],
+    "vsp_style_plan_f32": [_p, _i, _p, _i, _i64, _i, _i, _i, _f, _p],
     "vsp_demod_weight_f32": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "vsp_demod_weight_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "vsp_demod_weight_bwd_acc_f32": [_p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],

@@ -23,6 +23,15 @@
 #include "conv_kernel.h"
 #include "vsp_bf16.h"
 
+// This file must be compiled with -fno-slp-vectorize (Makefile; tools/build_abl.sh copies the flags of the Makefile rule): with the SLP
+// vectoriser on, hipcc turns the commit / epilogue arithmetic into v_pk_fma_f32 / v_pk_add_f32 with op_sel broadcasts of operands that
+// have just come back from LDS, and the kernel then miscomputes 0.01-0.05 % of its outputs when two of its workgroups share a CU
+// ("packed fp32"; tests/test_hip_ops.py::test_conv2d_bf16rv_repeat is the fence).  There is no pragma for the SLP
+// pass, so the build rule defines this macro next to the flag and any other build path stops here instead of dropping it silently.
+#ifndef VSP_BUILT_WITHOUT_SLP
+#error "conv_bf16_rv.hip: build with -fno-slp-vectorize -DVSP_BUILT_WITHOUT_SLP (see vspbfr_amd/csrc/Makefile)"
+#endif
+
 namespace vspconv {
 
 namespace {

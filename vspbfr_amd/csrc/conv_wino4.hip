@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(float* __restrict__ V,
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-      if (dst[i] >= 0) *reinterpret_cast<float4*>(patch + dst[i]) = make_float4(val[i].x * sc[i], val[i].y * sc[i], val[i].z * sc[i], val[i].w * sc[i]);
+      if (dst[i] >= 0) {   // padding by SELECT, not by a zero factor: an Inf / NaN at the clamped address must not leak into the border
+        const bool ok = sc[i] != 0.f;
+        *reinterpret_cast<float4*>(patch + dst[i]) = ok ? make_float4(val[i].x * sc[i], val[i].y * sc[i], val[i].z * sc[i], val[i].w * sc[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,7 +210,11 @@ __global__ __launch_bounds__(W4_THR, 3) void wino4_gemm_kernel(const ConvK p, co
   // GX = pixel tiles per image, GY = channel tiles.  The 32 workgroups an XCD runs at a time stream U slices (64 co x Cin x 36: 4.7 MB at
   // 512 channels) and V slices (32 tiles x Cin x 36: 2.4 MB) through its 4 MB L2: 8 pixel tiles x 4 channel tiles fill it with
   // 4 U + 8 V = 38 MB per pass, 4 x 8 with 47 MB -> channel tiles go in groups of CG = 4 inside a pixel tile
-  const int CG = (GY % 4 == 0 && !(p.dbg & 64)) ? 4 : GY;
+#ifdef VSP_WINO_ABLATE
+  const int CG = (GY % 4 == 0 && !(p.dbg & 64)) ? 4 : GY;   // (tuning: 64 = no channel-tile groups)
+#else
+  const int CG = GY % 4 == 0 ? 4 : GY;
+#endif
   const int cgrp = lrem / (GX * CG), l2 = lrem - cgrp * (GX * CG);
   const int pt = l2 / CG, ct = cgrp * CG + (l2 - pt * CG);
   const int nch = (p.Cin + 3) / 4;
@@ -426,9 +433,14 @@ int wino4_launch(ConvK q, float* V, const float* scale, int scale_bs, hipStream_
   const int nch = (q.Cin + 3) / 4;
   const int tiles_x = (q.W + 4 * W4_TLX - 1) / (4 * W4_TLX), tiles_y = (q.H + 4 * W4_TLY - 1) / (4 * W4_TLY);
   const int64_t wgs = (int64_t)q.B * tiles_x * tiles_y * ((nch + 3) / 4);
-  if (!(q.dbg & 32))   // (tuning: VSP_CONV_DBG 32 = GEMM only, 16 = input transform only)
+#ifdef VSP_WINO_ABLATE   // tuning build only (VSP_CONV_DBG): 32 = GEMM only, 16 = input transform only -- the production library always runs both
+  const int abl = q.dbg;
+#else
+  constexpr int abl = 0;
+#endif
+  if (!(abl & 32))
     wino4_input_kernel<<<(unsigned)wgs, 256, 0, stream>>>(V, q.x, scale, scale_bs, q.B, q.Cin, q.x_ch, q.H, q.W, tiles_x, tiles_y, nch);
-  if (q.dbg & 16) return VSP_OK;
+  if (abl & 16) return VSP_OK;
   static vsp::LdsAttrOnce attr;
   const size_t lds = (size_t)W4_LDS * sizeof(float);
   if (int rc = attr.ensure(reinterpret_cast<const void*>(wino4_gemm_kernel), (int)lds, "conv2d_winograd4")) return rc;

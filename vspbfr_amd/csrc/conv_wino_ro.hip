@@ -117,19 +117,20 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
     const int r = live ? l / SEG : 0, sg = live ? l - r * SEG : 0;
     const int iy = oy0 - 1 + r, ix = ox0 - 4 + 4 * sg;
     const bool in = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    p_voff[i] = in ? (iy * p.W + ix) * 4 : 0;
+    p_voff[i] = in ? (iy * p.W + ix) * 4 : 0x7ffffff0;   // padding: a lane offset past the resource, the load returns zeros
     p_ok |= in ? (1u << i) : 0u;
     p_dst[i] = 1 + r * PCP + 4 * sg;
   }
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.x_ch * chw * 4, 0x00020000);   // this image (the range check compares the lane offset with size - scalar offset)
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v preg[NLD];
   auto load_plane = [&](int j, f32x4v (&dst)[NLD]) {    // this wave's plane of sub-stage j (clamped: past the end the last one is loaded again)
     const int jj = j < nstage ? j : nstage - 1;
     const int ci = jj * IVC + wave;
-    const int soff = (ci < p.Cin ? ci : 0) * chw * 4;
+    const bool chin = ci < p.Cin;                                  // (a channel past the layer: every lane offset out of range -> zeros)
+    const int soff = (chin ? ci : 0) * chw * 4;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) dst[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, p_voff[i], soff, 0));
+    for (int i = 0; i < NLD; ++i) dst[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, chin ? p_voff[i] : 0x7ffffff0, soff, 0));
   };
   const float* wt_b = p.wtp + b * p.wt_bs;   // (per-image bases hoisted: the interval's scalar address arithmetic is part of its issue time)
   const float* wc_b = p.wcp + b * p.wc_bs;
@@ -152,11 +153,11 @@ __global__ __launch_bounds__(RO_NTHR, 4) void conv_wino_ro_kernel(const ConvK p)
       //  commits switched off 0.008).  Writing the ALIGNED unit (d of segment l - 1 through DPP wave_shr:1, a, b, c) takes the ratio to
       //  0.015 and the kernel from 605 to 630 us at 256 -> 256 / 128^2, 1211 to 1378 us at 32 -> 32 / 1024^2: the LDS is not what this
       //  kernel waits for, the extra VALU on the commit path is.  Kept misaligned.)
-      // (an invalid segment was loaded from offset 0 of the plane: finite data times a zero scale, no branch around the stores)
-      const bool ok = ((p_ok >> i) & 1u) && chok;
-      const float scm = ok ? sc : 0.f, shm = ok ? sh : 0.f;
+      // padding and absent channels arrive as ZEROS (out-of-range lane offset): only the affine shift still has to be masked, one select
+      // per segment -- no zero FACTOR that would turn an Inf / NaN at a clamped address into a NaN border
+      const float shm = (((p_ok >> i) & 1u) && chok) ? sh : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[p_dst[i] + e] = fmaf(src[i][e], scm, shm);
+      for (int e = 0; e < 4; ++e) dst[p_dst[i] + e] = fmaf(src[i][e], sc, shm);
     }
   };
 

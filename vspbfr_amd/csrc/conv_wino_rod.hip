@@ -128,19 +128,20 @@ __global__ __launch_bounds__(RD_NTHR, 4) void conv_wino_rod_kernel(const ConvK p
     const int sy = oy0 - 1 + r, ix = ox0 - hl + 4 * sg;
     const int iy = sy * d + ry;
     const bool in = sy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-    p_voff[i] = in ? (iy * p.W + ix) * 4 : 0;
+    p_voff[i] = in ? (iy * p.W + ix) * 4 : 0x7ffffff0;   // padding: a lane offset past the resource, the load returns zeros
     p_ok |= in ? (1u << i) : 0u;
     p_dst[i] = 1 + r * PCP + 4 * sg;
   }
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.x_ch * chw * 4, 0x00020000);   // this image (the range check compares the lane offset with size - scalar offset)
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   f32x4v preg[NLD];
   auto load_plane = [&](int j) {
     const int jj = j < nstage ? j : nstage - 1;
     const int ci = jj * IVC + wave;
-    const int soff = (ci < p.Cin ? ci : 0) * chw * 4;
+    const bool chin = ci < p.Cin;                                  // (a channel past the layer: every lane offset out of range -> zeros)
+    const int soff = (chin ? ci : 0) * chw * 4;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) preg[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, p_voff[i], soff, 0));
+    for (int i = 0; i < NLD; ++i) preg[i] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, chin ? p_voff[i] : 0x7ffffff0, soff, 0));
   };
   const float* wt_b = p.wtp + b * p.wt_bs;
   const float* wc_b = p.wcp + b * p.wc_bs;
@@ -158,10 +159,9 @@ __global__ __launch_bounds__(RD_NTHR, 4) void conv_wino_rod_kernel(const ConvK p
     float* dst = Pdst + wave * PPITCH;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const bool ok = ((p_ok >> i) & 1u) && chok;
-      const float scm = ok ? sc : 0.f, shm = ok ? sh : 0.f;
+      const float shm = (((p_ok >> i) & 1u) && chok) ? sh : 0.f;   // (padding / absent channels arrive as zeros: conv_wino_ro.hip)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[p_dst[i] + e] = fmaf(preg[i][e], scm, shm);
+      for (int e = 0; e < 4; ++e) dst[p_dst[i] + e] = fmaf(preg[i][e], sc, shm);
     }
   };
 

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(RS_NTHR, 2) void conv_wino_rs_kernel(const ConvK p,
       return slot_voff(i, gq.ry, gq.oy0, gq.X0);
     };
     f32x4r preg[RS_NLD];
-    // (the stage's channel offset rides in the LANE offset: the buffer range check does not see a scalar offset; the padding marker stays
-    //  above every buffer size: 0x7fffffff + offset < 2^32)
+    // (the stage's channel offset rides in the LANE offset, the scalar offset stays 0: the range check is then simply lane offset >= size;
+    //  the padding marker stays above every buffer size: 0x7fffffff + offset < 2^32)
     auto load_slot = [&](const ItemGeo& gq, int s, int i) {
       if (ab & 8) return;
       preg[i] = __builtin_bit_cast(f32x4r, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(geo_voff(gq, i) + (unsigned)(s * 8 * chw * 4)), 0, 0));

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import hip_ops as H
-from .layers import EqualLinear, NoiseInjection, PixelNorm, StyledConv, ToRGB, _Cached
+from .layers import EqualLinear, NoiseInjection, PixelNorm, StyledConv, ToRGB, _Cached, style_context
 
 IR50_BLOCKS = ((64, 64, 3), (64, 128, 4), (128, 256, 14), (256, 512, 3))
 
@@ -94,19 +94,20 @@ class Generator(nn.Module):
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         B = latent.shape[0]
-        out = self.conv1(self.input(B), latent[:, 0], noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
-        feats = [out] if return_features else None
-        i = 1
-        for j in range(self.log_size - 2):
-            if max_feature_res is not None and 2 ** (j + 3) > max_feature_res:
-                break
-            out = self.convs[2 * j](out, latent[:, i], noise[1 + 2 * j])
-            if return_features:
-                feats.append(out)
-            out = self.convs[2 * j + 1](out, latent[:, i + 1], noise[2 + 2 * j])
-            skip = self.to_rgbs[j](out, latent[:, i + 2], skip)
-            i += 2
+        with style_context(self, "gen", latent):   # (every layer's modulation / demodulation vector in two launches, layers.StyleContext)
+            out = self.conv1(self.input(B), latent[:, 0], noise[0])
+            skip = self.to_rgb1(out, latent[:, 1])
+            feats = [out] if return_features else None
+            i = 1
+            for j in range(self.log_size - 2):
+                if max_feature_res is not None and 2 ** (j + 3) > max_feature_res:
+                    break
+                out = self.convs[2 * j](out, latent[:, i], noise[1 + 2 * j])
+                if return_features:
+                    feats.append(out)
+                out = self.convs[2 * j + 1](out, latent[:, i + 1], noise[2 + 2 * j])
+                skip = self.to_rgbs[j](out, latent[:, i + 2], skip)
+                i += 2
         if return_latents:
             return skip, latent
         return skip, feats

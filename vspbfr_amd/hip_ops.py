@@ -584,6 +584,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
     if rv and not bf16rv_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset):
         raise RuntimeError("conv2d: this layer is not eligible for the row-vector bf16 kernel (see bf16rv_eligible)")
+    if rv and not (x.dtype == BF or (ACT_BF16 and out is None)) or (rv and out is not None and out.dtype != BF):
+        raise RuntimeError("conv2d: bf16='rv' names the row-vector kernel, which reads and writes bf16 activations: pass a bf16 input "
+                           "(and output) or switch ACT_BF16 on")
     # bf16 activations: the bf16 kernel (not its split-precision form) reads and writes bf16 when the configuration asks for it or
     # the caller hands it a bf16 tensor; every other kernel is fp32 on both sides
     io_bf = bool(bf16) and not x3 and (x.dtype == BF or (ACT_BF16 and out is None)) and (out is None or out.dtype == BF)
@@ -645,6 +648,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     prof = PROFILER
     if prof is not None:
         start = prof.begin()
+    ran_rv = False
     if bf16 and x3:
         bw = pc.bf16x3_weight()
         keep.append(bw)
@@ -664,7 +668,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             check(rc, "conv2d_bf16x3")
     elif bf16 and (rv or (rv is None and BF16_RV and tile_hint == 0 and not BF16_FORCE)) and io_bf and bf16rv_eligible(
             pc, H, W, OH, OW, transposed, out_stride, out_offset) and (rv or bf16rv_profitable(pc, H, W)) and _bf16rv_call(p, pc, keep, rv):
-        pass
+        ran_rv = True
     elif bf16:
         bw = pc.bf16_weight()
         keep.append(bw)
@@ -706,7 +710,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         n_out_el = B * pc.cout * ((2 * H + 1) * (2 * W + 1) if transposed else OH * OW)
         nbytes = (x.numel() + n_out_el * (1 + (res1 is not None) + (res2 is not None))) * es + pc.cout * Cin * pc.kh * pc.kw * (2 if bf16 else 4) + (
             B * OH * OW * 4 if noise is not None else 0)
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else "bf16") if bf16 else (("wino4" if (winograd == 4 and winograd is not True) else "wino") if winograd else ("tconv" if transposed else "direct")), key), nbytes)
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else ("bf16rv" if ran_rv else "bf16")) if bf16 else (("wino4" if (winograd == 4 and winograd is not True) else "wino") if winograd else ("tconv" if transposed else "direct")), key), nbytes)
     return out
 
 

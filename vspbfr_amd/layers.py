@@ -14,7 +14,9 @@ works on the published files; the forward passes do NOT follow the reference's o
   conv_transpose2d), followed by the FIR blur whose epilogue carries noise, bias, leaky-ReLU and the residual adds.
 Inference only (no autograd through the HIP ops).
 """
+import ctypes
 import math
+import os
 
 import torch
 from torch import nn
@@ -45,6 +47,135 @@ class _Cached(nn.Module):
                 hit = (stamp, fn())
             store[key] = hit
         return hit[1]
+
+
+# ---- all style modulations of a network up front (vsp_style_plan_f32: two launches instead of ~2 per modulated layer)
+STYLE_PLANS = os.environ.get("VSP_STYLE_PLAN", "1") != "0"
+_STYLE_CTX = None
+
+
+class _StyleLayerC(ctypes.Structure):   # vsp_style_layer (include/vspbfr_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("wsq", ctypes.c_void_p), ("mod", ctypes.c_void_p), ("demod", ctypes.c_void_p),
+                ("src_off", ctypes.c_int64), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("alpha", ctypes.c_float),
+                ("bias_scale", ctypes.c_float), ("wscale2", ctypes.c_float), ("pad_", ctypes.c_int)]
+
+
+class StyleContext:
+    """Per (network part, latent tensor): the first no-grad forward RECORDS which modulation layer reads which row view of `src`
+    (EqualLinear weight / bias, the conv's squared-tap sums), the following ones evaluate all of them with vsp_style_plan_f32 before the first
+    layer runs and hand the slices out.  A layer whose style is not the recorded row view of the current `src` (or whose parameters moved)
+    falls back to its own two launches; a plan is rebuilt when the batch size, a parameter or a derived tensor changes."""
+
+    def __init__(self):
+        self.recorded = None     # list of (owner id, eql, src_off, wsq, wscale) in call order
+        self.plan = None
+
+    def begin(self, src):
+        self.src, self.hits, self.rec = src, None, None
+        if not (STYLE_PLANS and src.is_cuda and src.dtype == torch.float32 and src.dim() == 3 and src.is_contiguous() and not torch.is_grad_enabled()):
+            return
+        B, K = src.shape[0], src.shape[2]
+        if B > 16 or K < 512 or K % 256 or src.data_ptr() % 16:
+            return
+        if self.recorded is None:
+            self.rec = []
+            return
+        plan = self.plan
+        stamp = (B, src.shape[1], K, src.device) + tuple(
+            (e[1].weight.data_ptr(), e[1].weight._version, None if e[3] is None else e[3].data_ptr()) for e in self.recorded)
+        if plan is None or plan["stamp"] != stamp:
+            plan = self.plan = self._build(B, K, src.device, stamp)
+        H.check(H.lib.vsp_style_plan_f32(plan["table"].data_ptr(), len(self.recorded), src.data_ptr(), B, src.stride(0), K, plan["max_cin"],
+                                         plan["max_cout"], 1e-8, H._stream()), "style_plan")
+        self.hits = plan["out"]
+
+    def _build(self, B, K, device, stamp):
+        n = sum(B * e[1].weight.shape[0] + (0 if e[3] is None else B * e[3].shape[0]) for e in self.recorded)
+        buf = torch.empty(n, device=device, dtype=torch.float32)
+        arr = (_StyleLayerC * len(self.recorded))()
+        out, off, max_cin, max_cout = {}, 0, 1, 0
+        for i, (oid, eql, src_off, wsq, wscale) in enumerate(self.recorded):
+            cin = eql.weight.shape[0]
+            mod = buf[off:off + B * cin].view(B, cin)
+            off += B * cin
+            demod = None
+            if wsq is not None:
+                cout = wsq.shape[0]
+                demod = buf[off:off + B * cout].view(B, cout)
+                off += B * cout
+                max_cout = max(max_cout, cout)
+            max_cin = max(max_cin, cin)
+            a = arr[i]
+            a.w, a.bias = eql.weight.data_ptr(), (eql.bias.data_ptr() if eql.bias is not None else None)
+            a.wsq, a.mod, a.demod = (wsq.data_ptr() if wsq is not None else None), mod.data_ptr(), (demod.data_ptr() if demod is not None else None)
+            a.src_off, a.cin, a.cout = src_off, cin, (wsq.shape[0] if wsq is not None else 0)
+            w32 = ctypes.c_float(wscale if wsq is not None else 0.0).value     # (vsp_demod_f32 squares its float argument IN float: the same bits here)
+            a.alpha, a.bias_scale, a.wscale2 = eql.scale, eql.lr_mul, ctypes.c_float(w32 * w32).value
+            out[oid] = (src_off, mod, demod)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        return {"stamp": stamp, "table": table, "buf": buf, "out": out, "max_cin": max_cin, "max_cout": max_cout}
+
+    def _row_offset(self, style):
+        """element offset of the row view `style` = src[:, i] inside src, or None"""
+        src = self.src
+        if style.dim() != 2 or style.shape != (src.shape[0], src.shape[2]) or style.stride(1) != 1 or (style.shape[0] > 1 and style.stride(0) != src.stride(0)):
+            return None
+        d = style.data_ptr() - src.data_ptr()
+        if d < 0 or d % (4 * src.shape[2]) or d // (4 * src.shape[2]) >= src.shape[1]:
+            return None
+        return d // 4
+
+    def terms(self, owner, eql, style, wsq, wscale):
+        off = self._row_offset(style)
+        if self.hits is not None and off is not None:
+            hit = self.hits.get(id(owner))
+            if hit is not None and hit[0] == off:
+                return hit[1], hit[2]
+        mod = eql(style)
+        demod = H.demod_coefs(mod, wsq, wscale) if wsq is not None else None
+        if self.rec is not None:
+            ok = (off is not None and eql.activation is None and eql.weight.shape[1] == self.src.shape[2] and eql.weight.is_contiguous()
+                  and eql.weight.data_ptr() % 16 == 0 and eql.weight.shape[0] <= 65535)
+            self.rec.append((id(owner), eql, off, wsq, wscale) if ok else None)
+        return mod, demod
+
+    def end(self):
+        if self.rec is not None and self.rec and all(e is not None for e in self.rec) and len({e[0] for e in self.rec}) == len(self.rec):
+            self.recorded = self.rec
+        self.rec = self.hits = self.src = None
+
+
+class style_context:
+    """with style_context(module, "tag", latent): ... -- the modulation layers called inside take their vectors from the module's plan"""
+
+    def __init__(self, module, tag, src):
+        store = module.__dict__.setdefault("_style_ctx", {})
+        self.ctx = store.get(tag)
+        if self.ctx is None:
+            self.ctx = store[tag] = StyleContext()
+        self.src = src
+
+    def __enter__(self):
+        global _STYLE_CTX
+        self.prev = _STYLE_CTX
+        self.ctx.begin(self.src)
+        _STYLE_CTX = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global _STYLE_CTX
+        self.ctx.end()
+        _STYLE_CTX = self.prev
+        return False
+
+
+def style_terms(owner, eql, style, wsq=None, wscale=None):
+    """(modulation vector, demodulation coefficients or None) of one modulated layer: from the active plan, else two launches."""
+    ctx = _STYLE_CTX
+    if ctx is not None:
+        return ctx.terms(owner, eql, style, wsq, wscale)
+    mod = eql(style)
+    return mod, (H.demod_coefs(mod, wsq, wscale) if wsq is not None else None)
 
 
 class PixelNorm(nn.Module):
@@ -164,8 +295,7 @@ class ModulatedConv2d(_Cached):
 
     def run(self, x, style, noise=None, noise_w=None, act_bias=None, ch_bias=None, res1=None, res2=None):
         """conv (+ the caller's fused tail).  `style` is the un-modulated style vector (B, style_dim)."""
-        mod = self.modulation(style)
-        demod = self.demod(mod)
+        mod, demod = style_terms(self, self.modulation, style, self.wsq() if self.demodulate else None, self.scale)
         x = x.contiguous()
         act = act_bias is not None
         if self.upsample:
@@ -224,7 +354,7 @@ class ToRGB(nn.Module):
                 up = dict(up_src=skip.contiguous(), up_kernel=u.kernel)
             else:
                 up = dict(res=u(skip))
-        return H.pointwise(x.contiguous(), w, in_scale=conv.modulation(style), ch_bias=self.bias.view(3), **up)
+        return H.pointwise(x.contiguous(), w, in_scale=style_terms(conv, conv.modulation, style)[0], ch_bias=self.bias.view(3), **up)
 
 
 class SMARTLayer(_Cached):
@@ -261,9 +391,8 @@ class SMARTLayer(_Cached):
 
     def forward(self, x, style, noise=None):
         x = x.contiguous()
-        mod = self.modulation(style)
         pc, wsq = self._branch_pack()
-        demod = H.demod_coefs(mod, wsq, self.ModulatedConv2ds[0].scale)
+        mod, demod = style_terms(self, self.modulation, style, wsq, self.ModulatedConv2ds[0].scale)
         mid = H.conv2d_packed(x, pc, in_scale=mod, out_scale=demod)
         nz = self.noise.draw(noise, (x.shape[0], 1, x.shape[2], x.shape[3]), x.device)
         return H.conv2d_packed(mid, self._fusion_pack(), act1=True, bias1=self.fusion[1].bias, noise=nz,

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import hip_ops as H
-from .layers import EqualLinear, LargeConvLayer, PixelNorm, SMARTLayer, StyledConv, ToRGB
+from .layers import EqualLinear, LargeConvLayer, PixelNorm, SMARTLayer, StyledConv, ToRGB, style_context
 
 
 def make_noise(batch, latent_dim, n_noise, device):
@@ -98,11 +98,12 @@ class Restoration_net(nn.Module):
         B = imgs.shape[0]
         out = self.down_from_big(imgs)
         feats = []
-        for ii in range(0, len(self.encoder_convs), 2):
-            sty = latent_cp[:, ii]
-            out = self.encoder_convs[ii](out, sty, enc_noise[ii])
-            feats.append(out)
-            out = self.encoder_convs[ii + 1](out, sty, enc_noise[ii + 1])  # same latent index as the SMART layer
+        with style_context(self, "enc", latent_cp):   # every modulation / demodulation vector of the encoder in two launches (layers.StyleContext)
+            for ii in range(0, len(self.encoder_convs), 2):
+                sty = latent_cp[:, ii]
+                out = self.encoder_convs[ii](out, sty, enc_noise[ii])
+                feats.append(out)
+                out = self.encoder_convs[ii + 1](out, sty, enc_noise[ii + 1])  # same latent index as the SMART layer
         out = self.final_layer(out)
         x_global = self.final_linear[0](out.view(B, -1))
         if self.training:   # Dropout2d(0.5) of final_linear (models/RestoreNet.py:907-909): the training loop samples fakes in train mode
@@ -152,16 +153,17 @@ class Restoration_net(nn.Module):
         def sty(i):
             return sty_all[:, i]
 
-        out = self.conv1(feats[0], sty(0), dec_noise[0])
-        skip = self.to_rgb1(out, sty(1))
-        i = 1
-        for j in range(self.log_size - 2):
-            k = (i + 1) // 2
-            # up-conv; `out + feat + sty_de_feat` (models/RestoreNet.py:1035) rides in the blur epilogue
-            out = self.convs[2 * j](out, sty(i), dec_noise[1 + 2 * j], res1=feats[k], res2=de_feats[k].contiguous())
-            out = self.convs[2 * j + 1](out, sty(i + 1), dec_noise[2 + 2 * j])
-            skip = self.to_rgbs[j](out, sty(i + 2), skip)
-            i += 2
+        with style_context(self, "dec", sty_all):   # (the decoder's modulation / demodulation vectors: two launches, layers.StyleContext)
+            out = self.conv1(feats[0], sty(0), dec_noise[0])
+            skip = self.to_rgb1(out, sty(1))
+            i = 1
+            for j in range(self.log_size - 2):
+                k = (i + 1) // 2
+                # up-conv; `out + feat + sty_de_feat` (models/RestoreNet.py:1035) rides in the blur epilogue
+                out = self.convs[2 * j](out, sty(i), dec_noise[1 + 2 * j], res1=feats[k], res2=de_feats[k].contiguous())
+                out = self.convs[2 * j + 1](out, sty(i + 1), dec_noise[2 + 2 * j])
+                skip = self.to_rgbs[j](out, sty(i + 2), skip)
+                i += 2
         if return_latents:
             return skip, latent
         return skip
