@@ -23,6 +23,10 @@ LAYERS = [  # Cin, channels per group, H = W, dilations
     (64, 64, 128, (1,)),
     (64, 16, 256, (1, 2, 4, 8)),
     (128, 32, 256, (1, 2, 4, 8)),
+    (256, 64, 128, (1, 2, 4, 8)),
+    (512, 128, 64, (1, 2, 4, 8)),
+    (512, 128, 32, (1, 2, 4, 8)),
+    (512, 128, 16, (1, 2, 4, 8)),
 ]
 
 
@@ -43,12 +47,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--check", action="store_true")
-    ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--only", type=str, default="")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B = args.batch
     for li, (cin, cg, hw, dils) in enumerate(LAYERS):
-        if args.only >= 0 and li != args.only:
+        if args.only and str(li) not in args.only.split(","):
             continue
         G = len(dils)
         g_ = torch.Generator().manual_seed(li)

@@ -599,13 +599,15 @@ int wino_launch(ConvK q, int form, hipStream_t stream) {
       default: return launch_variant<1, 1>(q, stream);
     }
   }
-  {   // dilation groups: row-owner form (conv_wino_rod.hip) where it measured faster -- 128 -> 4 x 32 at 256^2 1099 -> 1070 us, 256 -> 4 x 64 at
-      // 128^2 793 -> 762, 512 -> 4 x 128 at 32^2 302 -> 291; 512 -> 4 x 128 at 64^2 753 -> 768: stays here.  VSP_WINO_ROD = 0 / 2: never / always.
+  {   // dilation groups: row-owner form (conv_wino_rod.hip) wherever it serves the launch (>= 32 channels per group) -- round 5, one box, forms
+      // named through tile_hint (profiles/r05_ab_rod_dense.log): 128 -> 4 x 32 at 256^2 1066 -> 952 us, 256 -> 4 x 64 at 128^2 774 -> 704,
+      // 512 -> 4 x 128 at 64^2 740 -> 667 (round 4 had measured that one equal and kept it here), at 32^2 296 -> 261.  VSP_WINO_ROD = 0: never.
+      // (A dense epilogue -- the tile's scattered pixels through LDS, 16-byte stores -- was measured on this kernel in round 5: no difference,
+      //  not kept; its workgroups live 16-64 stages and the epilogue of one hides under the main loop of the other.)
     static const int rod = getenv("VSP_WINO_ROD") ? atoi(getenv("VSP_WINO_ROD")) : 1;
-    const bool deep_large = q.Cin >= 512 && q.H * q.W >= 4096;
     const bool rod_ok = wino_mbw(q.cout_g) >= 2 && wino_rod_eligible(q);
     if (form == 2 && !rod_ok) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the row-owner form does not serve this launch");
-    if (form != 1 && rod_ok && (form == 2 || (rod && (rod == 2 || !deep_large)))) return wino_rod_launch(q, wino_mbw(q.cout_g), stream);
+    if (form != 1 && rod_ok && (form == 2 || rod)) return wino_rod_launch(q, wino_mbw(q.cout_g), stream);
   }
   switch (wino_mbw(q.cout_g)) {
     case 4: return launch_variant<4, 8>(q, stream);
