@@ -266,6 +266,12 @@ int vsp_conv2d_bf16x3(const vsp_conv_params* p, vsp_stream_t stream);
  *         = bf16( W[tap = 3*ky + kx][ci = 8*chunk + 4*quad + 2*half + (e >> 2)][co] ),  kx = e & 3;  0 for kx = 3.
  * tile_hint: 0 = automatic, 1 = 32-channel tiles (16 rows x 64 pixels), 2 = 64-channel tiles (8 rows x 64 pixels). */
 int vsp_conv2d_bf16rv(const vsp_conv_params* p, vsp_stream_t stream);
+/* The dilation groups of a SMART branch launch with bf16 activations (io_bf16 = 1; reference models/RestoreNet.py:179-244, 270-418): up to four
+ * groups (dilation = padding = 1, 2, 4, 8) of at most 16 output channels over ONE shared input of at most 64 channels (a multiple of 8), W a
+ * multiple of 8, no in_shift.  `w` is the PACKED FP32 weight of vsp_conv2d_f32 (the kernel rounds w * in_scale to bf16 once per image and keeps
+ * it in registers); patch channel-last and polyphase in LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation and epilogue chain, bf16 output.
+ * VSP_ENOTSUP when the launch is not one it serves (conv_bf16_dg.hip). */
+int vsp_conv2d_bf16dg(const vsp_conv_params* p, vsp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Strided, batched small GEMM on fp32 MFMA -- replaces F.linear / torch.matmul of the path

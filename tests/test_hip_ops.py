@@ -897,7 +897,11 @@ def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww):
     if Cout % 4 == 0 and Cout // 4 >= 8:
         wp = torch.stack([H.pack_weight(torch.randn(Cout // 4, Cin, 3, 3, device=DEV) / math.sqrt(Cin * 9))[0] for _ in range(4)]).contiguous()
         pc4 = H.PackedConv(wp, 4, Cout // 4, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
-        assert torch.equal(H.conv2d_packed(x, pc4, bf16=True, in_scale=s_in), _b16(H.conv2d_packed(x.float(), pc4, bf16=True, in_scale=s_in)))
+        H.BF16_DG = False   # (this test is about vsp_conv2d_bf16's own I/O forms; with bf16 input the launch would go to vsp_conv2d_bf16dg,
+        try:                #  which rounds the style scale into the weight: test_conv2d_bf16dg)
+            assert torch.equal(H.conv2d_packed(x, pc4, bf16=True, in_scale=s_in), _b16(H.conv2d_packed(x.float(), pc4, bf16=True, in_scale=s_in)))
+        finally:
+            H.BF16_DG = True
     # a bf16 tensor handed to a layer that runs on an fp32 kernel is converted, the result is fp32
     assert H.conv2d_packed(x, pc, bf16=False, winograd=False).dtype == torch.float32
     o32 = torch.empty(B, Cout, Hh, Ww, device=DEV)                    # an fp32 `out` keeps the launch on fp32 I/O
@@ -983,6 +987,56 @@ def test_conv2d_bf16rv_repeat(H, B, Cin, Cout, Hh, Ww, hint):
     for got, r in ((first[sel], ref), (first_bare[sel], ref_bare)):
         err = (got.double().cpu() - r).abs()
         assert bool((err <= r.abs() * 2.0 ** -8 + 2e-5 * r.abs().max()).all()), float(err.max())
+
+
+@pytest.mark.parametrize("B,Cin,Cg,Hh,Ww,dils", [(2, 64, 16, 64, 64, (1, 2, 4, 8)), (1, 32, 16, 37, 24, (1, 2, 4, 8)), (3, 64, 8, 40, 64, (2, 8)),
+                                                   (1, 16, 16, 9, 8, (4,)), (2, 48, 12, 19, 40, (8, 1, 2)), (2, 64, 16, 256, 256, (1, 2, 4, 8))])
+def test_conv2d_bf16dg(H, B, Cin, Cg, Hh, Ww, dils):
+    """vsp_conv2d_bf16dg (the dilation groups of a SMART branch launch on v_mfma_f32_16x16x32_bf16: patch channel-last and polyphase in LDS,
+    weights as register-resident A fragments) DIRECTLY against float64 F.conv2d(dilation = d) on the operands the kernel multiplies: bf16
+    activations and bf16(w * style scale) -- the scale is rounded into the WEIGHT here -- exact products, fp32 accumulation, one bf16 rounding
+    at the store.  Ragged maps, partial channel blocks, fewer groups, the whole epilogue chain with both residuals, repeat launches
+    bit-identical, and the automatic choice for a bf16 input."""
+    g_ = torch.Generator().manual_seed(Hh * 7 + Ww)
+    G = len(dils)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g_).to(torch.bfloat16)
+    ws = [torch.randn(Cg, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9) for _ in dils]
+    s_in, demod, bias = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, G * Cg, generator=g_) + 0.5, torch.randn(G * Cg, generator=g_)
+    nz, nw = torch.randn(B, 1, Hh, Ww, generator=g_), torch.full((1,), 0.3)
+    r1 = torch.randn(B, G * Cg, Hh, Ww, generator=g_).to(torch.bfloat16)
+    r2 = torch.randn(B, G * Cg, Hh, Ww, generator=g_).to(torch.bfloat16)
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, G, Cg, Cin, 3, 3, 1, dils, dils)
+    sel = [0, B - 1] if Hh * Ww >= 65536 else list(range(B))
+
+    def ref(scale, full):
+        outs = []
+        for b in sel:
+            sb = scale[b].view(1, Cin, 1, 1) if scale is not None else torch.ones(1, Cin, 1, 1)
+            y = torch.cat([F.conv2d(x[b:b + 1].double(), (w_ * sb).to(torch.bfloat16).double(), padding=d, dilation=d) for w_, d in zip(ws, dils)], 1)
+            if full:
+                y = y * demod[b].double().view(1, -1, 1, 1) + nz[b:b + 1].double() * 0.3
+                y = F.leaky_relu(y + bias.double().view(1, -1, 1, 1), 0.2) * math.sqrt(2) + r1[b:b + 1].double() + r2[b:b + 1].double()
+            outs.append(y)
+        return torch.cat(outs)
+
+    def close(got, want):
+        assert got.dtype == torch.bfloat16
+        err = (got[sel].double().cpu() - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -8 + 2e-5 * want.abs().max()).all()), float(err.max())
+
+    xd = dev(x)
+    bare = H.conv2d_packed(xd, pc, bf16="dg")
+    close(bare, ref(None, False))
+    kw = dict(in_scale=dev(s_in), out_scale=dev(demod), noise=dev(nz), noise_w=dev(nw), act2=1, bias2=dev(bias), res1=dev(r1), res2=dev(r2))
+    full = H.conv2d_packed(xd, pc, bf16="dg", **kw)
+    close(full, ref(s_in, True))
+    for _ in range(5):
+        assert torch.equal(H.conv2d_packed(xd, pc, bf16="dg", **kw), full)
+    if G > 1:   # a bf16 input to a dilation-group launch takes this kernel by itself
+        assert torch.equal(H.conv2d_packed(xd, pc, bf16=True, **kw), full)
+    with pytest.raises(RuntimeError):   # an affine input shift is not served
+        H.conv2d_packed(xd, pc, bf16="dg", in_scale=dev(torch.rand(Cin)), in_scale_per_sample=False, in_shift=dev(torch.randn(Cin)))
 
 
 def test_conv2d_bf16rv_refusals(H):

@@ -33,12 +33,17 @@ for B, Cin, Cg, S in groups or ([] if len(sys.argv) > 1 else [(16, 64, 16, 512),
     kw = dict(in_scale=torch.rand(B, Cin, device=dev) + 0.5)
     out = torch.empty(B, 4 * Cg, S, S, device=dev, dtype=torch.bfloat16)
     H.BF16_RV = False
+    H.BF16_DG = False
     t0 = timed(lambda: H.conv2d_packed(x, pc, bf16=True, out=out, **kw))
     y0 = out.float()
     t1 = timed(lambda: H.conv2d_packed(x, pc, bf16="rv", out=out, **kw))
     y1 = out.float()
     nb = (x.numel() + out.numel()) * 2
     fl = 2.0 * B * 4 * Cg * Cin * 9 * S * S
+    if H.bf16dg_eligible(pc, S, S, S, S):   # round 5: the dilation-group kernel (conv_bf16_dg.hip)
+        t2 = timed(lambda: H.conv2d_packed(x, pc, bf16="dg", out=out, **kw))
+        y2 = out.float()
+        print(f"{Cin}->4x{Cg} dilated @{S} B{B}: dg {t2:.0f} us {nb / t2 / 1e6:.2f} TB/s {fl / t2 / 1e6:.0f} TF x{t0 / t2:.2f} vs bf16, maxdiff vs bf16 {float((y2 - y0).abs().max()):.3g}", flush=True)
     print(f"{Cin}->4x{Cg} dilated @{S} B{B}: bf16 {t0:.0f} us {nb / t0 / 1e6:.2f} TB/s {fl / t0 / 1e6:.0f} TF | rv {t1:.0f} us {nb / t1 / 1e6:.2f} TB/s {fl / t1 / 1e6:.0f} TF x{t0 / t1:.2f} maxdiff vs bf16 {float((y1 - y0).abs().max()):.3g} (range {float(y0.abs().max()):.2f})", flush=True)
 
 for B, Cin, Cout, S in shapes:

@@ -126,6 +126,7 @@ SIGNATURES = {
     "vsp_conv2d_bf16": [_p, _p],
     "vsp_conv2d_bf16x3": [_p, _p],
     "vsp_conv2d_bf16rv": [_p, _p],
+    "vsp_conv2d_bf16dg": [_p, _p],
     "vsp_affine_sample_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "vsp_affine_sample_bwd_f32": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "vsp_color_affine_f32": [_p, _p, _p, _p, _i, _i64, _p],

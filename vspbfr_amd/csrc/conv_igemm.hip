@@ -406,13 +406,15 @@ extern "C" int vsp_conv2d_winograd4_f32(const vsp_conv_params* pp, float* work, 
   return vsp::check_launch("conv2d_winograd4");
 }
 
-static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, bool rv = false);
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, int rv = 0);   // rv: 1 = conv_bf16_rv.hip, 2 = conv_bf16_dg.hip
 extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false); }
 extern "C" int vsp_conv2d_bf16x3(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, true); }
 // the row-vector-K kernel (conv_bf16_rv.hip): same operands as vsp_conv2d_bf16 with io_bf16 = 1, its own weight order; VSP_ENOTSUP when the launch is not one it serves
-extern "C" int vsp_conv2d_bf16rv(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false, true); }
+extern "C" int vsp_conv2d_bf16rv(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false, 1); }
+// the dilation-group kernel (conv_bf16_dg.hip): bf16 activations, `w` = the PACKED FP32 weights of vsp_conv2d_f32 (converted in the kernel); VSP_ENOTSUP when it does not serve the launch
+extern "C" int vsp_conv2d_bf16dg(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false, 2); }
 
-static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, bool rv) {
+static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, int rv) {
   VSP_REQUIRE(pp != nullptr, "conv2d_bf16: null params");
   vsp_conv_params pcopy = *pp;
   int mode = 0;
@@ -472,6 +474,11 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   {
     static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
     q.dbg = dbg;
+  }
+  if (rv == 2) {
+    if (mode != 0 || !vspconv::bf16dg_eligible(q)) return VSP_ENOTSUP;
+    if (int rc = vspconv::bf16dg_launch(q, p.act1 != 0 || p.act2 != 0 || p.noise != nullptr, vsp::as_stream(stream))) return rc;
+    return vsp::check_launch("conv2d_bf16dg");
   }
   if (rv) {
     if (mode != 0 || !vspconv::bf16rv_eligible(q)) return VSP_ENOTSUP;

@@ -644,6 +644,8 @@ int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream)
 // conv_bf16_rv.hip: the row-vector-K form for low-channel large-map stride-1 layers with bf16 activations
 bool bf16rv_eligible(const ConvK& q);
 int bf16rv_launch(const ConvK& q, int variant, hipStream_t stream);
+bool bf16dg_eligible(const ConvK& q);                                 // conv_bf16_dg.hip: dilation groups of <= 16 channels, bf16 activations, Cin <= 64
+int bf16dg_launch(const ConvK& q, bool full, hipStream_t stream);
 
 struct Cfg {
   int MB, NB, WM, WN, CK, WK, PMAX, PF, OCC;  // a name ending in "t" marks a transposed-conv kernel

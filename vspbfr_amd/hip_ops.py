@@ -290,7 +290,7 @@ class PackedConv:
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
-                 "_wino", "_wino4", "_bf16", "_bf16x3", "_bf16rv")
+                 "_wino", "_wino4", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -308,6 +308,7 @@ class PackedConv:
         self._bf16 = None
         self._bf16x3 = None
         self._bf16rv = None
+        self._bf16dg = None
 
     @property
     def cout(self):
@@ -342,6 +343,13 @@ class PackedConv:
             with torch.no_grad():
                 self._bf16rv = bf16rv_weight(self.w)
         return self._bf16rv
+
+    def bf16dg_weight(self):
+        """The fp32 weight in the A-fragment order of vsp_conv2d_bf16dg, built on first use."""
+        if self._bf16dg is None:
+            with torch.no_grad():
+                self._bf16dg = bf16dg_weight(self.w)
+        return self._bf16dg
 
     def bf16x3_weight(self):
         """hi + lo bf16 parts of the weight in the LDS-image order of vsp_conv2d_bf16x3, built on first use."""
@@ -429,6 +437,29 @@ def bf16rv_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_o
             and all(pc.dil[g] in (1, 2, 4, 8) and pc.pad_y[g] == pc.dil[g] and pc.pad_x[g] == pc.dil[g] for g in range(pc.G)))
 
 
+def bf16dg_weight(wp):
+    """packed weights (G, 9, Cin, cout_g) fp32 -> fp32 [group][stage Cin/32][tap 9][lane 64][8] with lane = 16 kb + co, element e = input
+    channel 32 stage + 8 kb + e (zero-padded: Cin to 32 stages, cout_g to 16) -- the A fragments of vsp_conv2d_bf16dg, which multiplies them
+    by the image's style scale and rounds to bf16 itself."""
+    ng, T, cin, cout = wp.shape
+    if T != 9 or cout > 16 or cin > 64:
+        raise RuntimeError("bf16dg_weight: 3x3, at most 16 channels per group, at most 64 input channels")
+    nst = 1 if cin <= 32 else 2
+    Wz = wp.new_zeros(ng, 9, nst * 32, 16)
+    Wz[:, :, :cin, :cout] = wp
+    return Wz.view(ng, 9, nst, 4, 8, 16).permute(0, 2, 1, 3, 5, 4).contiguous().view(-1)
+
+
+def bf16dg_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0), in_shift=None):
+    """What vsp_conv2d_bf16dg serves (bf16 activations on top): the 2-4 dilation groups of a SMART branch launch with at most 16 channels
+    per group over at most 64 input channels."""
+    if (transposed or pc.kh != 3 or pc.kw != 3 or pc.stride != 1 or pc.cin % 8 or pc.cin > 64 or pc.cout_g > 16 or W % 8 or (OH, OW) != (H, W)
+            or tuple(out_stride) != (1, 1) or tuple(out_offset) != (0, 0) or pc.dil_by_input_quarter or pc.x_group_stride or in_shift is not None):
+        return False
+    return 1 <= pc.G <= 4 and all(pc.dil[g] in (1, 2, 4, 8) and pc.pad_y[g] == pc.dil[g] and pc.pad_x[g] == pc.dil[g] for g in range(pc.G))
+
+
+BF16_DG = os.environ.get("VSP_BF16_DG", "1") != "0"   # the dilation-group kernel on the launches it serves (G > 1)
 BF16_RV = os.environ.get("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
 
 
@@ -451,6 +482,20 @@ def _bf16rv_call(p, pc, keep, forced):
         p.w, p.tile_hint = w0, h0
         return False
     check(rc, "conv2d_bf16rv")
+    keep.append(bw)
+    return True
+
+
+def _bf16dg_call(p, pc, keep, forced):
+    """One launch of vsp_conv2d_bf16dg; False = the entry does not serve it (alignment): the caller goes on to the other bf16 kernels."""
+    bw = pc.bf16dg_weight()
+    w0, h0 = p.w, p.tile_hint
+    p.w, p.tile_hint = bw.data_ptr(), 0
+    rc = lib.vsp_conv2d_bf16dg(C.byref(p), _stream())
+    if rc == -3 and not forced:
+        p.w, p.tile_hint = w0, h0
+        return False
+    check(rc, "conv2d_bf16dg")
     keep.append(bw)
     return True
 
@@ -573,8 +618,11 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     x3 = bf16 == "x3" or (bf16 is None and BF16_CONV == "x3")
     rv = None          # the row-vector-K kernel (vsp_conv2d_bf16rv): "rv" forces it, None = where it is eligible and measured faster
+    dg = None          # the dilation-group kernel (vsp_conv2d_bf16dg): "dg" forces it, None = the dilation-group launches it serves
     if bf16 == "rv":
         bf16, rv = True, True
+    if bf16 == "dg":
+        bf16, dg = True, True
     if bf16 is None:
         bf16 = bool(BF16_CONV) and bf_ok and not winograd and bf16_profitable(pc, H, W, OH, OW, transposed)
         if x3 and bf16:  # split precision: doubled LDS images -- the layers where it beats the tuned fp32 kernels (tools/conv_breakdown.py)
@@ -584,6 +632,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         raise RuntimeError("conv2d: this layer is not eligible for the bf16 kernel (see bf16_eligible)")
     if rv and not bf16rv_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset):
         raise RuntimeError("conv2d: this layer is not eligible for the row-vector bf16 kernel (see bf16rv_eligible)")
+    if dg and not bf16dg_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
+        raise RuntimeError("conv2d: this layer is not eligible for the dilation-group bf16 kernel (see bf16dg_eligible)")
+    rv = rv or dg   # (the same activation-type requirement below)
     if rv and not (x.dtype == BF or (ACT_BF16 and out is None)) or (rv and out is not None and out.dtype != BF):
         raise RuntimeError("conv2d: bf16='rv' names the row-vector kernel, which reads and writes bf16 activations: pass a bf16 input "
                            "(and output) or switch ACT_BF16 on")
@@ -666,7 +717,10 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             check(lib.vsp_conv2d_f32(C.byref(p), _stream()), "conv2d")
         else:
             check(rc, "conv2d_bf16x3")
-    elif bf16 and (rv or (rv is None and BF16_RV and tile_hint == 0 and not BF16_FORCE)) and io_bf and bf16rv_eligible(
+    elif bf16 and io_bf and (dg or (dg is None and BF16_DG and pc.G > 1 and tile_hint == 0 and not BF16_FORCE and rv is None)) and bf16dg_eligible(
+            pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift) and _bf16dg_call(p, pc, keep, dg):
+        ran_rv = "dg"
+    elif bf16 and not dg and (rv or (rv is None and BF16_RV and tile_hint == 0 and not BF16_FORCE)) and io_bf and bf16rv_eligible(
             pc, H, W, OH, OW, transposed, out_stride, out_offset) and (rv or bf16rv_profitable(pc, H, W)) and _bf16rv_call(p, pc, keep, rv):
         ran_rv = True
     elif bf16:
@@ -710,7 +764,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         n_out_el = B * pc.cout * ((2 * H + 1) * (2 * W + 1) if transposed else OH * OW)
         nbytes = (x.numel() + n_out_el * (1 + (res1 is not None) + (res2 is not None))) * es + pc.cout * Cin * pc.kh * pc.kw * (2 if bf16 else 4) + (
             B * OH * OW * 4 if noise is not None else 0)
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else ("bf16rv" if ran_rv else "bf16")) if bf16 else (("wino4" if (winograd == 4 and winograd is not True) else "wino") if winograd else ("tconv" if transposed else "direct")), key), nbytes)
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else (("bf16dg" if ran_rv == "dg" else "bf16rv") if ran_rv else "bf16")) if bf16 else (("wino4" if (winograd == 4 and winograd is not True) else "wino") if winograd else ("tconv" if transposed else "direct")), key), nbytes)
     return out
 
 
