@@ -27,6 +27,18 @@ def _side_stream():
     return torch.cuda.Stream(priority=pr) if pr else torch.cuda.Stream()
 
 
+def _tensors(obj):
+    """every tensor inside nested tuples / lists / dicts"""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors(v)
+    elif isinstance(obj, (tuple, list)):
+        for v in obj:
+            yield from _tensors(v)
+
+
 def shard_range(n, rank, world):
     """Contiguous split of n items: rank r owns [lo, hi); sizes differ by at most one (ragged batches allowed)."""
     base, rem = divmod(n, world)
@@ -126,6 +138,15 @@ class RestorationPipeline:
     def decode(self, low_imgs, low_latent, pre, z=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None,
                image_index0=0):
         """Stages C + D: the StyleGAN2 prior and the restoration network (the compute-bound 97 % of the FLOPs)."""
+        noise, gen_noise, enc_noise, dec_noise, inject_index = self._decode_noise(low_imgs, z, gen_noise, enc_noise, dec_noise,
+                                                                                   inject_index, image_index0)
+        sample, feats = self.prior(pre, gen_noise)
+        restored = self.restore(low_imgs, feats, pre, noise, inject_index, enc_noise, dec_noise)
+        return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
+
+    def _decode_noise(self, low_imgs, z=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None, image_index0=0):
+        """The draws of stages C + D (keyed mode: one fill for all of them): (mixing noise list, prior noise, encoder noise, decoder
+        noise, inject_index)."""
         B = low_imgs.shape[0]
         if self.noise_seed is not None and (z is None or gen_noise is None or enc_noise is None or dec_noise is None):
             kz, kg, ke, kd = self.draw_decode_noise(B, image_index0, low_imgs.device)
@@ -136,16 +157,33 @@ class RestorationPipeline:
             gen_noise = kg if gen_noise is None else gen_noise
             enc_noise, dec_noise = (ke if enc_noise is None else enc_noise), (kd if dec_noise is None else dec_noise)
         noise = z if z is not None else mixing_noise(B, self.generator.style_dim, self.mixing, low_imgs.device)
+        return noise, gen_noise, enc_noise, dec_noise, inject_index
+
+    def _act_mode(self):
+        from . import hip_ops
+        return bool(self.act_bf16 and hip_ops.BF16_CONV is True)
+
+    @torch.no_grad()
+    def prior(self, pre, gen_noise=None):
+        """Stage C alone (restoration_test.py:130): (style sample or None, the prior's feature pyramid)."""
         from . import hip_ops
         prev = hip_ops.ACT_BF16
-        hip_ops.ACT_BF16 = bool(self.act_bf16 and hip_ops.BF16_CONV is True)
+        hip_ops.ACT_BF16 = self._act_mode()
         try:
-            sample, feats = self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
-            restored = self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise,
-                                      dec_noise=dec_noise)
+            return self.psp.get_stylegan_feats(pre, noise=gen_noise, with_sample=self.with_sample)
         finally:
             hip_ops.ACT_BF16 = prev
-        return {"restored": restored, "style_sample": sample, "latent": low_latent, "pre_latent": pre}
+
+    @torch.no_grad()
+    def restore(self, low_imgs, feats, pre, noise, inject_index=None, enc_noise=None, dec_noise=None):
+        """Stage D alone (restoration_test.py:131)."""
+        from . import hip_ops
+        prev = hip_ops.ACT_BF16
+        hip_ops.ACT_BF16 = self._act_mode()
+        try:
+            return self.generator(low_imgs, feats, pre, noise, inject_index=inject_index, enc_noise=enc_noise, dec_noise=dec_noise)
+        finally:
+            hip_ops.ACT_BF16 = prev
 
     @torch.no_grad()
     def __call__(self, low_imgs, z=None, x_T=None, gen_noise=None, enc_noise=None, dec_noise=None, inject_index=None,
@@ -168,6 +206,8 @@ class RestorationPipeline:
         if not hasattr(self, "_side"):
             self._side = _side_stream()
         side = self._side
+        import os
+        split = os.environ.get("VSP_OVERLAP_SPLIT", "ab") == "abc"   # experiment: stage C of the next batch on the side stream too
 
         counter = [0]
 
@@ -175,13 +215,18 @@ class RestorationPipeline:
             batch, idx0 = item if isinstance(item, (tuple, list)) else (item, counter[0])
             counter[0] = idx0 + batch.shape[0]
             side.wait_stream(main)  # the batch (and everything enqueued before) is visible to the side stream
+            extra = None
             with torch.cuda.stream(side):
                 lat, pre = self.encode(batch, image_index0=idx0)
+                if split:
+                    nz = self._decode_noise(batch, image_index0=idx0)
+                    sample, feats = self.prior(pre, nz[1])
+                    extra = (nz, sample, feats)
                 ev = torch.cuda.Event()
                 ev.record(side)
-            for t in (lat, pre):
+            for t in _tensors((lat, pre, extra)):
                 t.record_stream(main)  # allocated on the side stream's pool, consumed on the main stream
-            return batch, lat, pre, ev, idx0
+            return batch, lat, pre, ev, idx0, extra
 
         it = iter(batches)
         try:
@@ -193,9 +238,14 @@ class RestorationPipeline:
                 nxt = start(next(it))  # enqueue A + B of the next batch BEFORE C + D of this one
             except StopIteration:
                 nxt = None
-            batch, lat, pre, ev, idx0 = cur
+            batch, lat, pre, ev, idx0, extra = cur
             main.wait_event(ev)
-            yield self.decode(batch, lat, pre, image_index0=idx0)
+            if extra is None:
+                yield self.decode(batch, lat, pre, image_index0=idx0)
+            else:
+                (noise, _g, enc_noise, dec_noise, inject_index), sample, feats = extra
+                restored = self.restore(batch, feats, pre, noise, inject_index, enc_noise, dec_noise)
+                yield {"restored": restored, "style_sample": sample, "latent": lat, "pre_latent": pre}
             cur = nxt
 
 
