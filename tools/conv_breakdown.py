@@ -29,6 +29,6 @@ print("# effective = algorithmic 2*Cin*9 FLOP per output / time; executed = what
 for k in sorted(a32, key=lambda k: -a32[k][1]):
     n, ms, fl, kinds = a32[k]; n2, ms2, fl2, kinds2 = a16[k]
     tot32 += ms; tot16 += ms2
-    ex = fl * (16.0 / 36.0 if kinds == {"wino"} else (0.25 if kinds == {"wino4"} else 1.0))
+    ex = fl * (16.0 / 36.0 if kinds == {"wino"} else (0.25 if kinds <= {"wino4", "wino4f"} else 1.0))
     print(f"{k} | {n} | {ms:.2f} ({fl/ms/1e9:.0f} / {ex/ms/1e9:.0f}) {','.join(sorted(kinds))} | {ms2:.2f} ({fl2/ms2/1e9:.0f}) {','.join(sorted(kinds2))}")
 print(f"total fp32 {tot32:.2f} ms, bf16 config {tot16:.2f} ms")

@@ -406,6 +406,45 @@ extern "C" int vsp_conv2d_winograd4_f32(const vsp_conv_params* pp, float* work, 
   return vsp::check_launch("conv2d_winograd4");
 }
 
+extern "C" size_t vsp_winograd4f_weight_floats(int cin, int cout) { return vspconv::wino4f_weight_floats(cin, cout); }
+
+extern "C" int vsp_winograd4f_weight_f32(float* U, const float* wp, int cin, int cout, vsp_stream_t stream) {
+  VSP_REQUIRE(U && wp && cin >= 1 && cout >= 1, "winograd4f_weight: bad arguments");
+  if (int rc = vspconv::wino4f_weight_launch(U, wp, cin, cout, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("winograd4f_weight");
+}
+
+extern "C" int vsp_conv2d_winograd4f_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
+  VSP_REQUIRE(pp != nullptr, "conv2d_winograd4f: null params");
+  const vsp_conv_params& p = *pp;
+  VSP_REQUIRE(!p.transposed && p.G == 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 && p.dil[0] == 1 &&
+                  p.pad_y[0] == 1 && p.pad_x[0] == 1,
+              "conv2d_winograd4f: one group, 3x3, stride 1, dilation 1, padding 1");
+  VSP_REQUIRE(p.io_bf16 == 0 && p.dil_by_input_quarter == 0 && p.in_shift == nullptr, "conv2d_winograd4f: fp32, no affine input shift");
+  VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.OH == p.H && p.OW == p.W, "conv2d_winograd4f: dense same-size output");
+  VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd4f: weights must be 16-byte aligned");
+  int x_ch = 0;
+  bool empty = false;
+  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  if (empty) return VSP_OK;
+  ConvK q{};
+  if (int rc = fill_convk(p, x_ch, q)) return rc;
+  {
+    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    q.dbg = dbg;
+    const float* kc = device_consts();
+    q.wtp = p.in_scale ? p.in_scale : kc;
+    q.wt_cs = p.in_scale ? 1 : 0;
+    q.wt_bs = p.in_scale ? p.in_scale_bstride : 0;
+    q.wshp = kc + 1;
+    q.wsh_cs = 0;
+  }
+  if (!vspconv::wino4f_eligible(q))
+    return vsp::fail(VSP_ENOTSUP, "conv2d_winograd4f: needs Cin %% 8 == 0 (<= 256), H, W %% 4 == 0, W >= 16, dense 16-byte aligned input / output / noise / residual planes < 2 GiB per image");
+  if (int rc = vspconv::wino4f_launch(q, vsp::as_stream(stream))) return rc;
+  return vsp::check_launch("conv2d_winograd4f");
+}
+
 static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool split, int rv = 0);   // rv: 1 = conv_bf16_rv.hip, 2 = conv_bf16_dg.hip
 extern "C" int vsp_conv2d_bf16(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, false); }
 extern "C" int vsp_conv2d_bf16x3(const vsp_conv_params* pp, vsp_stream_t stream) { return conv2d_bf16_impl(pp, stream, true); }

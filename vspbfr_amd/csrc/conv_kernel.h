@@ -635,6 +635,11 @@ size_t wino4_weight_floats(int cin, int cout);
 size_t wino4_work_floats(int B, int cin, int H, int W);
 int wino4_weight_launch(float* U, const float* wp, int cin, int cout, hipStream_t stream);
 int wino4_launch(ConvK q, float* V, const float* scale, int scale_bs, hipStream_t stream);
+// conv_wino4f.hip: Winograd F(4x4,3x3) fused in registers (shallow wide layers)
+bool wino4f_eligible(const ConvK& q);
+size_t wino4f_weight_floats(int cin, int cout);
+int wino4f_weight_launch(float* U, const float* wp, int cin, int cout, hipStream_t stream);
+int wino4f_launch(ConvK q, hipStream_t stream);
 int wino_chunk();           // input channels per chunk the transformed-weight layout is built for
 int wino_mbw(int cout_g);   // 16-channel blocks per workgroup (fragment layout) for a layer with cout_g channels per group
 

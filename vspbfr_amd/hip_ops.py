@@ -43,7 +43,7 @@ class ConvProfiler:
     def executed_flops(self):
         """FLOPs the matrix pipe actually EXECUTED: a Winograd F(2x2,3x3) launch runs 16 multiplies per 2x2 output tile where the
         direct form (the algorithmic count of `summary`) has 36; every other kernel executes its algorithmic count."""
-        f = {"wino": 16.0 / 36.0, "wino4": 36.0 / 144.0}   # F(4x4,3x3): 36 multiplies per 4x4 tile against 144
+        f = {"wino": 16.0 / 36.0, "wino4": 36.0 / 144.0, "wino4f": 36.0 / 144.0}   # F(4x4,3x3): 36 multiplies per 4x4 tile against 144
         return sum(r[0] * (f.get(r[3][7], 1.0) if len(r[3]) > 7 else 1.0) for r in self.records)
 
     def by_kind(self):
@@ -87,7 +87,8 @@ def _config_ids():
 CONFIG_IDS = _config_ids()
 TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_IDS}
 # shapes where a Winograd kernel won: True = F(2x2,3x3) (vsp_conv2d_winograd_f32), 4 = F(4x4,3x3) (vsp_conv2d_winograd4_f32, deep layers)
-WINO = {k: (4 if v == "winograd4" else True) for k, v in _load_tune_table().items() if v in ("winograd", "winograd4")}
+#   5 = F(4x4,3x3) fused in registers (vsp_conv2d_winograd4f_f32, shallow wide layers)
+WINO = {k: ({"winograd4": 4, "winograd4f": 5}.get(v, True)) for k, v in _load_tune_table().items() if v in ("winograd", "winograd4", "winograd4f")}
 
 
 def _load_bf16_tune(name="conv_tune_bf16.json"):
@@ -290,7 +291,7 @@ class PackedConv:
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
-                 "_wino", "_wino4", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg")
+                 "_wino", "_wino4", "_wino4f", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -305,6 +306,7 @@ class PackedConv:
         self.pad_x = rep(pad_y if pad_x is None else pad_x, 0)
         self._wino = None
         self._wino4 = None
+        self._wino4f = None
         self._bf16 = None
         self._bf16x3 = None
         self._bf16rv = None
@@ -328,6 +330,13 @@ class PackedConv:
             with torch.no_grad():
                 self._wino4 = winograd4_weight(self.w)
         return self._wino4
+
+    def winograd4f_weight(self):
+        """U = G g G^T of F(4x4,3x3) in the order of the fused kernel vsp_conv2d_winograd4f_f32, built on first use."""
+        if self._wino4f is None:
+            with torch.no_grad():
+                self._wino4f = winograd4f_weight(self.w)
+        return self._wino4f
 
     def bf16_weight(self):
         """The weight rounded to bf16 in the LDS-image order of vsp_conv2d_bf16, built on first use."""
@@ -580,6 +589,23 @@ def winograd4_weight(wp):
     return U
 
 
+def winograd4f_weight(wp):
+    """packed weights (1, 9, Cin, Cout) -> U = G g G^T of F(4x4,3x3) in the order of vsp_conv2d_winograd4f_f32
+    ([co / 32][ci / 4][position pair][lane][4], include/vspbfr_hip.h)."""
+    wp = _req(wp, "packed weight")
+    ng, taps, cin, cout = wp.shape
+    if ng != 1 or taps != 9:
+        raise RuntimeError("winograd4f_weight: one group of 3x3 taps")
+    U = torch.empty(lib.vsp_winograd4f_weight_floats(cin, cout), device=wp.device, dtype=torch.float32)
+    check(lib.vsp_winograd4f_weight_f32(_ptr(U), _ptr(wp), cin, cout, _stream()), "winograd4f_weight")
+    return U
+
+
+def winograd4f_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0), in_shift=None):
+    """fused F(4x4,3x3): the layer class of the pair, Cin a multiple of 8 up to 256, rows of at least 16 pixels"""
+    return winograd4_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift) and pc.cin % 8 == 0 and pc.cin <= 256 and W >= 16
+
+
 def winograd4_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0), in_shift=None):
     """F(4x4,3x3) pair of kernels: one group, 3x3 / stride 1 / dilation 1 / padding 1, no affine shift, whole 4x4 tiles"""
     return (winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset) and pc.G == 1 and pc.dil[0] == 1 and in_shift is None
@@ -688,6 +714,8 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         raise RuntimeError("conv2d: this layer is not eligible for the Winograd kernel (3x3, stride 1, dilation 1, pad 1, G = 1)")
     if winograd == 4 and winograd is not True and not winograd4_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
         winograd = True     # (the deep-layer form does not serve this call's operands: F(2x2,3x3))
+    if winograd == 5 and not winograd4f_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
+        winograd = True
     if RECORDER is not None:
         RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))
     p.tile_hint = tile_hint
@@ -740,7 +768,16 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
     elif winograd:
         rc = -3
-        if winograd == 4 and winograd is not True:
+        if winograd == 5:
+            u4 = pc.winograd4f_weight()
+            keep.append(u4)
+            p.w = u4.data_ptr()
+            rc = lib.vsp_conv2d_winograd4f_f32(C.byref(p), _stream())
+            if rc not in (0, -3):
+                check(rc, "conv2d_winograd4f")
+            if rc == -3:   # VSP_ENOTSUP: alignment of an operand plane -> F(2x2,3x3)
+                winograd = True
+        elif winograd == 4 and winograd is not True:
             u4 = pc.winograd4_weight()
             nfl = lib.vsp_conv2d_winograd4_work_floats(C.byref(p))
             work = torch.empty(nfl, device=x.device, dtype=torch.float32)   # V = B^T d B in fragment order (2.25 x the input)
@@ -764,7 +801,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         n_out_el = B * pc.cout * ((2 * H + 1) * (2 * W + 1) if transposed else OH * OW)
         nbytes = (x.numel() + n_out_el * (1 + (res1 is not None) + (res2 is not None))) * es + pc.cout * Cin * pc.kh * pc.kw * (2 if bf16 else 4) + (
             B * OH * OW * 4 if noise is not None else 0)
-        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else (("bf16dg" if ran_rv == "dg" else "bf16rv") if ran_rv else "bf16")) if bf16 else (("wino4" if (winograd == 4 and winograd is not True) else "wino") if winograd else ("tconv" if transposed else "direct")), key), nbytes)
+        prof.end(start, 2.0 * B * pc.cout * (H * W if transposed else OH * OW) * Cin * pc.kh * pc.kw, (Cin, pc.cout, OH, OW, pc.kh, pc.stride, pc.G, ("bf16x3" if x3 else (("bf16dg" if ran_rv == "dg" else "bf16rv") if ran_rv else "bf16")) if bf16 else (("wino4f" if winograd == 5 else ("wino4" if (winograd == 4 and winograd is not True) else "wino")) if winograd else ("tconv" if transposed else "direct")), key), nbytes)
     return out
 
 
