@@ -18,6 +18,11 @@ __global__ __launch_bounds__(256, 1) void cluster_kernel(unsigned long long* out
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = f32x2{a + i, b + i};
   f32x2 cs = {c0, c0};
+  __shared__ f32x4 lbuf[256];
+  lbuf[threadIdx.x] = f32x4{1.f, 2.f, 3.f, 4.f};
+  const unsigned ldsaddr = threadIdx.x * 16;
+  const f32x4* gptr = reinterpret_cast<const f32x4*>(sink) + 4 + threadIdx.x;
+  f32x4 ld[4] = {};
   __syncthreads();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -34,15 +39,26 @@ __global__ __launch_bounds__(256, 1) void cluster_kernel(unsigned long long* out
         if (KIND == 7) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(cs));
         if (KIND == 8) asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x[0]) : "v"(y[0]));
         if (KIND == 9) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(cs));
+        if (KIND == 15) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[0][0]) : "v"(cs[0]));                  // one dependent chain
+        if (KIND == 16) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(v[0]) : "v"(cs));
+        if (KIND == 17) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(v[k % 2]) : "v"(cs));                   // two interleaved chains
+        if (KIND == 18) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(v[k % 4]) : "v"(cs));                   // four
+        if (KIND == 10) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[k % 4]) : "v"(ldsaddr));
+        if (KIND == 11) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[k % 4]) : "v"(gptr));
+        if (KIND == 12) asm volatile("ds_write_b128 %0, %1" :: "v"(ldsaddr), "v"(ld[0]));
+        if (KIND == 13) asm volatile("ds_read_b32 %0, %1" : "=v"(ld[k % 4][0]) : "v"(ldsaddr));
+        if (KIND == 14) asm volatile("global_load_dword %0, %1, off" : "=v"(ld[k % 4][0]) : "v"(gptr));
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)");   // (memory fillers are never waited for inside the loop: issue cost only)
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
+  for (int i = 0; i < 4; ++i) s += ld[i][0] + ld[i][3];
   if (s == 12345.678f) sink[0] = s;
   if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) out[threadIdx.x >> 6] = t1 - t0;
 }
@@ -110,7 +126,7 @@ void run(const char* name, unsigned long long* d_out, float* d_sink) {
 
 int main() {
   unsigned long long* d_out; float* d_sink;
-  hipMalloc(&d_out, 64); hipMalloc(&d_sink, 64);
+  hipMalloc(&d_out, 64); hipMalloc(&d_sink, 1 << 16); hipMemset(d_sink, 0, 1 << 16);
 #define ROW(KIND, NAME) run<0, KIND>(NAME, d_out, d_sink); run<1, KIND>(NAME, d_out, d_sink); run<2, KIND>(NAME, d_out, d_sink); run<3, KIND>(NAME, d_out, d_sink); run<4, KIND>(NAME, d_out, d_sink); run<6, KIND>(NAME, d_out, d_sink);
   ROW(0, "v_fma_f32 (VOP3)")
   ROW(1, "v_fmac_f32_e32 (VOP2)")
@@ -124,5 +140,14 @@ int main() {
   ROWC(7, "v_pk_mul_f32")
   ROWC(9, "v_pk_add_f32")
   ROWC(8, "v_mov_b32_dpp")
+  runc<2, 15, 8>("dependent v_fma_f32", d_out, d_sink); runc<2, 16, 8>("dependent v_pk_fma_f32", d_out, d_sink);
+  runc<2, 17, 8>("v_pk_fma_f32, 2 chains", d_out, d_sink); runc<2, 18, 8>("v_pk_fma_f32, 4 chains", d_out, d_sink);
+  runc<2, 6, 8>("v_pk_fma_f32 independent", d_out, d_sink);
+#define ROWM(KIND, NAME) runc<1, KIND, 1>(NAME, d_out, d_sink); runc<1, KIND, 4>(NAME, d_out, d_sink); runc<1, KIND, 16>(NAME, d_out, d_sink);
+  ROWM(10, "ds_read_b128")
+  ROWM(13, "ds_read_b32")
+  ROWM(12, "ds_write_b128")
+  ROWM(11, "global_load_dwordx4")
+  ROWM(14, "global_load_dword")
   return 0;
 }

@@ -708,6 +708,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         if tile_hint < 0:
             tile_hint = 0
     wino_ok = winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
+    named_fused = winograd == 5       # the caller asked for the fused F(4x4) kernel by name: no silent fall-back (tests, tuners)
     if winograd is None:
         winograd = wino_ok and tile_hint == 0 and WINO.get(key, WINO.get("8" + key[key.index(","):], False))
     elif winograd and not wino_ok:
@@ -715,6 +716,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
     if winograd == 4 and winograd is not True and not winograd4_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
         winograd = True     # (the deep-layer form does not serve this call's operands: F(2x2,3x3))
     if winograd == 5 and not winograd4f_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
+        if named_fused:
+            raise RuntimeError("conv2d: this launch is not eligible for the fused F(4x4,3x3) kernel (one group, 3x3 / stride 1 / dilation 1 / "
+                               "padding 1, no affine shift, Cin % 8 == 0 up to 256, H, W % 4 == 0, W >= 16)")
         winograd = True
     if RECORDER is not None:
         RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))
@@ -773,7 +777,7 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             keep.append(u4)
             p.w = u4.data_ptr()
             rc = lib.vsp_conv2d_winograd4f_f32(C.byref(p), _stream())
-            if rc not in (0, -3):
+            if rc not in (0, -3) or (rc == -3 and named_fused):
                 check(rc, "conv2d_winograd4f")
             if rc == -3:   # VSP_ENOTSUP: alignment of an operand plane -> F(2x2,3x3)
                 winograd = True
