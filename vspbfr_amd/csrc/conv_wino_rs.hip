@@ -258,7 +258,12 @@ __global__ __launch_bounds__(RS_NTHR, 2) void conv_wino_rs_kernel(const ConvK p,
         // once per unit).  The pipeline drains at the end of a stage: the next stage's slot is only readable behind the barrier.
         const int sl = s & 1;
         f32x2r wa[2][2], wb[2][2];
-        float vc[4] = {1.f, 1.f, 1.f, 1.f}, vn[4] = {1.f, 1.f, 1.f, 1.f}, w[4] = {1.f, 2.f, 3.f, 4.f};
+        // The fragment arithmetic as PACKED fp32 (round 5, tools/ubench/mfma_valu_gap.hip: fp32 MFMAs and fp32 VALU share the SIMD's FMA
+        // lanes -- a vector instruction beside a v_mfma_f32_16x16x4_f32 costs its full 5-6 cycles of matrix time, packed or not): the two
+        // row combinations of a window quad are one v_pk_fma_f32 each, (V0, V1) = (W0 - W2, W1 + W2) and (V2, V3) = (W2 - W1, W1 - W3) one
+        // v_pk_add_f32 each with half selection / negation -- four vector instructions per unit of four MFMAs where there were eight.
+        f32x2r vcA = {1.f, 1.f}, vcB = {1.f, 1.f}, vnA = {1.f, 1.f}, vnB = {1.f, 1.f}, w01 = {1.f, 2.f}, w23 = {3.f, 4.f};
+        const f32x2r sgn2 = {sgn, sgn};
         if (ab & 2) {
 #pragma unroll
           for (int a = 0; a < 2; ++a)
@@ -274,35 +279,35 @@ __global__ __launch_bounds__(RS_NTHR, 2) void conv_wino_rs_kernel(const ConvK p,
           wb[buf][0] = *(lds_win_t)(winB + off);
           wb[buf][1] = *(lds_win_t)(winB + off + 2);
         };
-        auto rows01 = [&](int q) { if (ab & 2) return; const int buf = q & 1; w[0] = fmaf(wb[buf][0].x, sgn, wa[buf][0].x); w[1] = fmaf(wb[buf][0].y, sgn, wa[buf][0].y); };
-        auto rows23 = [&](int q) { if (ab & 2) return; const int buf = q & 1; w[2] = fmaf(wb[buf][1].x, sgn, wa[buf][1].x); w[3] = fmaf(wb[buf][1].y, sgn, wa[buf][1].y); };
+        auto rows01 = [&](int q) { if (ab & 2) return; const int buf = q & 1; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(w01) : "v"(wb[buf][0]), "v"(sgn2), "v"(wa[buf][0])); };
+        auto rows23 = [&](int q) { if (ab & 2) return; const int buf = q & 1; asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(w23) : "v"(wb[buf][1]), "v"(sgn2), "v"(wa[buf][1])); };
+        auto cols01 = [&](f32x2r& v) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v) : "v"(w01), "v"(w23)); };                      // (W0 - W2, W1 + W2)
+        auto cols23 = [&](f32x2r& v) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v) : "v"(w23), "v"(w01)); };       // (W2 - W1, W1 - W3)
         RS_STAMP(4 * s + 0);
         read_win(0);
         read_win(1);
         __builtin_amdgcn_sched_barrier(0);
         rows01(0); rows23(0);
-        vc[0] = w[0] - w[2]; vc[1] = w[1] + w[2]; vc[2] = w[2] - w[1]; vc[3] = w[1] - w[3];
+        cols01(vcA); cols23(vcB);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int ks = q >> 2, nb = q & 3;
           const int k = 2 * s + ks;
           const bool nxt = q < 7;
-          if (!(ab & 1)) acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0][k], vc[0], acc[0][nb], 0, 0, 0);
-          if (nxt) rows01(q + 1);
+          const float vc0 = vcA.x, vc1 = vcA.y, vc2 = vcB.x, vc3 = vcB.y;
+          // (the four vector instructions in ONE run behind the second MFMA: a lone vector instruction between two MFMAs costs 13 cycles,
+          //  one inside a run 5.5 -- tools/ubench/mfma_valu_gap.hip)
+          if (!(ab & 1)) acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0][k], vc0, acc[0][nb], 0, 0, 0);
+          if (!(ab & 1)) acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1][k], vc1, acc[1][nb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (!(ab & 1)) acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1][k], vc[1], acc[1][nb], 0, 0, 0);
-          if (nxt) rows23(q + 1);
+          if (nxt) { rows01(q + 1); rows23(q + 1); cols01(vnA); cols23(vnB); }
           __builtin_amdgcn_sched_barrier(0);
           if (q + 2 < 8) read_win(q + 2);   // (the buffer of unit q: its rows were combined one unit ago)
-          if (!(ab & 1)) acc[2][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2][k], vc[2], acc[2][nb], 0, 0, 0);
-          if (nxt) { vn[0] = w[0] - w[2]; vn[1] = w[1] + w[2]; }
+          if (!(ab & 1)) acc[2][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[2][k], vc2, acc[2][nb], 0, 0, 0);
+          if (!(ab & 1)) acc[3][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3][k], vc3, acc[3][nb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (!(ab & 1)) acc[3][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[3][k], vc[3], acc[3][nb], 0, 0, 0);
-          if (nxt) { vn[2] = w[2] - w[1]; vn[3] = w[1] - w[3]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vc[e] = vn[e];
+          vcA = vnA; vcB = vnB;
           // Staging rides on the units: units 4..7 commit one load slot each to the other ring slot and re-issue it for the stage after
           // next (the last two stages load the NEXT item's first stages; none: padding marker, zeros) -- a slot's registers are in flight
           // for a whole stage.
