@@ -607,7 +607,8 @@ def test_config_c3_full_size():
     """BASELINE.json configs[2] exactly: batch 16, 512^2, DDIM S = 25 on T = 50, bf16 kernels.  The fp32 HIP run of the same
     step is the yardstick: (a) its DDIM chain against the oracle's sampler on the same codes; (b) the bf16 configuration's
     restored batch against it -- bf16 operands (2^-8 relative per product) cannot meet the 1e-3 parity bound, the bound here is
-    rms <= 3 % / max <= 25 % of the image's std, and <= 2 LSB on average after the save_image quantiser."""
+    rms <= 2 % / max <= 15 % of the image's std (measured over three rounds: 1.0-1.2 % / 10-12 %), and <= 2 LSB on average after the
+    save_image quantiser."""
     from oracle import device_rng as R
     from vspbfr_amd import hip_ops as H
     from vspbfr_amd.ddim import DDIMSampler
@@ -654,7 +655,7 @@ def test_config_c3_full_size():
     print("C3:", rep)
     assert e_chain < 3e-4
     assert rep["bf16_restored_rms"] < 2.0 * rep["fp32_activations_restored_rms"] + 1e-3   # storing activations in bf16 adds little
-    assert rep["bf16_restored_rms"] < 0.03 * std and rep["bf16_restored_max"] < 0.25 * std and rep["lsb_mean"] < 2.0
+    assert rep["bf16_restored_rms"] < 0.02 * std and rep["bf16_restored_max"] < 0.15 * std and rep["lsb_mean"] < 2.0
 
 
 # ---------------------------------------------------------------------------------------- training row
