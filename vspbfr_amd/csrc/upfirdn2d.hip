@@ -268,6 +268,168 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// bf16 planes, 4 x 4 taps, up = down = 1 (round 5): the blur as a COLUMN STRIP walk without LDS.  The tile kernel above spends ~49 vector
+// instructions per output on bf16 planes (PMC: 394 per wave of 8 outputs per lane: unpacking, LDS staging, border shifts, address
+// arithmetic around the 16 FMAs) and holds 2.2-2.9 TB/s: it is bound by its instruction count, not by HBM.  Here a lane owns 8 output
+// columns and walks RC output rows: every input row is fetched ONCE per lane as 24 bytes straight from global memory (neighbouring lanes
+// overlap by 3 pixels: L1 / L2), converted once (12 shifts / ands), kept with its three predecessors in registers (a rotating window of
+// four rows, the loop unrolled by four so that the rotation is a renaming), and feeds 128 FMAs per output row; the epilogue operands and
+// the store are 16-byte accesses.  ~24 vector instructions per output, no barrier.  Zero padding: rows outside the plane read through an
+// out-of-range buffer offset; columns outside a row (the lanes at a row's ends only) are cleared by six per-lane masks on the packed words.
+// EN / ACT: epilogue present / with activation -- compile-time: a uniform `if` in the row loop is a control-flow join, and hipcc waits for
+// every load in flight at a join (the two rows the walk keeps ahead).  Planes 1 .. major - 1 only: the first rows of plane 0 start at a
+// NEGATIVE offset (left padding before the tensor's first byte), which no range check expresses -- plane 0 goes to the tile kernel.
+#ifndef VSP_STRIP_OCC
+#define VSP_STRIP_OCC 3
+#endif
+#ifndef VSP_STRIP_RC
+#define VSP_STRIP_RC 32
+#endif
+template <int RC, bool EN, bool ACT>
+__global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp::bf16_t* __restrict__ out, const vsp::bf16_t* __restrict__ x, const float* __restrict__ kern,
+                                                             int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int strips_x,
+                                                             int chunks_y, int total, int x_bytes, int out_bytes, Epi epi) {
+  static_assert(RC % 4 == 0, "the row loop is unrolled by the four window slots");
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int sx = gid % strips_x;
+  const int t = gid / strips_x;
+  const int cy = t % chunks_y, plane = 1 + t / chunks_y;
+  const int ox = 8 * sx, oy0 = cy * RC;
+  const int ix0 = ox - pad_x0;
+  float taps[4][4];   // flipped: a true convolution
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) taps[ky][kx] = kern[(3 - ky) * 4 + (3 - kx)];
+  unsigned cmask[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int a = ix0 + 2 * k;
+    cmask[k] = ((a >= 0 && a < in_w) ? 0xffffu : 0u) | ((a + 1 >= 0 && a + 1 < in_w) ? 0xffff0000u : 0u);
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<vsp::bf16_t*>(x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
+  const int c = plane % epi.channels, b = plane / epi.channels;
+  float pscale = 1.f, nw = 0.f, ab = 0.f;
+  if (EN) {
+    if (epi.plane_scale) pscale = epi.plane_scale[plane];
+    if (epi.noise) nw = epi.noise_w[0];
+    if (ACT && epi.act_bias) ab = epi.act_bias[c];
+  }
+  const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.noise ? epi.noise : kern), 0,
+                                                                       epi.noise ? (int)((int64_t)(out_bytes / 2 / epi.channels) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(epi.res1 ? epi.res1 : (const void*)kern), 0, epi.res1 ? out_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(epi.res2 ? epi.res2 : (const void*)kern), 0, epi.res2 ? out_bytes : 0, 0x00020000);
+  typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+  // input row r of the chunk (image row oy0 - pad_y0 + r): six packed words, in flight until `unpack`
+  u32x4s qa[2];
+  u32x2s qb[2];
+  const int row_b = in_w * 2;
+  const int voff0 = (int)(((int64_t)plane * in_h + (oy0 - pad_y0)) * in_w + ix0) * 2;     // may be negative at the first plane's first rows: out of range, zeros
+  auto fetch = [&](int r, int slot) {
+    const int iy = oy0 - pad_y0 + r;
+    const int vo = (iy >= 0 && iy < in_h) ? voff0 + r * row_b : 0x7ffffff0;
+    qa[slot] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+    qb[slot] = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, 16, 0));
+  };
+  float win[4][12];   // the last four input rows, twelve columns (eleven used)
+  auto unpack = [&](int slot, float (&w)[12]) {
+    const unsigned d[6] = {qa[slot][0] & cmask[0], qa[slot][1] & cmask[1], qa[slot][2] & cmask[2], qa[slot][3] & cmask[3], qb[slot][0] & cmask[4],
+                           qb[slot][1] & cmask[5]};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      w[2 * k] = vsp::bf16_lo(d[k]);
+      w[2 * k + 1] = vsp::bf16_hi(d[k]);
+    }
+  };
+  const int orow0 = (int)(((int64_t)plane * out_h + oy0) * out_w + ox);     // element index of the chunk's first output
+  const int nrow0 = (int)(((int64_t)b * out_h + oy0) * out_w + ox);
+  auto emit = [&](int ro, const float (&w0)[12], const float (&w1)[12], const float (&w2)[12], const float (&w3)[12]) {   // output row ro of the chunk
+    const int oy = oy0 + ro;
+    const bool ok = oy < out_h;
+    f32x4u nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = nz0;
+    u32x4s r1 = {0u, 0u, 0u, 0u}, r2 = r1;
+    if (EN) {
+      const int no = ok ? (nrow0 + ro * out_w) * 4 : 0x7ffffff0;
+      nz0 = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(nrs, no, 0, 0));
+      nz1 = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(nrs, no, 16, 0));
+      const int eo = ok ? (orow0 + ro * out_w) * 2 : 0x7ffffff0;
+      r1 = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(r1rs, eo, 0, 0));
+      r2 = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(r2rs, eo, 0, 0));
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[0][kx], w0[j + kx], acc[j]);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[1][kx], w1[j + kx], acc[j]);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[2][kx], w2[j + kx], acc[j]);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[3][kx], w3[j + kx], acc[j]);
+    if (EN) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = fmaf(j < 4 ? nz0[j & 3] : nz1[j & 3], nw, acc[j] * pscale);
+        const unsigned w1r = r1[j >> 1], w2r = r2[j >> 1];
+        const float r1f = (j & 1) ? vsp::bf16_hi(w1r) : vsp::bf16_lo(w1r), r2f = (j & 1) ? vsp::bf16_hi(w2r) : vsp::bf16_lo(w2r);
+        if (ACT) {
+          a += ab;
+          a = (a > 0.f ? a : a * epi.slope) * epi.gain;
+        }
+        {
+          // (the tile kernel adds the residual to the ROUNDED product: hipcc contracts `x * gain + res1` to one fused multiply-add in the
+          //  vectorised form of this loop but not in the tile kernel's scalar form -- the two then differ in the last bit of one output
+          //  in 20 000; contraction off for the two additions)
+#pragma clang fp contract(off)
+          a = a + r1f;
+        }
+        a += r2f;
+        acc[j] = a;
+      }
+    }
+    const u32x4s o = {vsp::bf16_pack(acc[0], acc[1]), vsp::bf16_pack(acc[2], acc[3]), vsp::bf16_pack(acc[4], acc[5]), vsp::bf16_pack(acc[6], acc[7])};
+    __builtin_amdgcn_raw_buffer_store_b128(o, ors, ok ? (orow0 + ro * out_w) * 2 : 0x7ffffff0, 0, 0);
+  };
+  // rows 0..2 fill the window; from then on: row r + 2 in flight, row r + 1 ... hmm: two rows ahead
+  fetch(0, 0);
+  fetch(1, 1);
+  unpack(0, win[0]);
+  fetch(2, 0);
+  unpack(1, win[1]);
+  fetch(3, 1);
+  unpack(0, win[2]);
+  fetch(4, 0);
+#pragma unroll 1
+  for (int r0 = 0; r0 < RC; r0 += 4) {
+    // input rows r0 + 3 .. r0 + 6 complete output rows r0 .. r0 + 3; packed slots alternate: row r lives in slot r & 1
+    unpack(1, win[3]);                 // input row r0 + 3
+    fetch(r0 + 5, 1);
+    emit(r0 + 0, win[0], win[1], win[2], win[3]);
+    unpack(0, win[0]);                 // input row r0 + 4
+    fetch(r0 + 6, 0);
+    emit(r0 + 1, win[1], win[2], win[3], win[0]);
+    unpack(1, win[1]);                 // input row r0 + 5
+    fetch(r0 + 7, 1);
+    emit(r0 + 2, win[2], win[3], win[0], win[1]);
+    unpack(0, win[2]);                 // input row r0 + 6
+    fetch(r0 + 8, 0);
+    emit(r0 + 3, win[3], win[0], win[1], win[2]);
+  }
+}
+
 __global__ __launch_bounds__(256) void fir_generic_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                            const float* __restrict__ kern, int major, int in_h,
                                                            int in_w, int minor, int kh, int kw, int up_x, int up_y,
@@ -346,6 +508,35 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
   }
   hipStream_t s = vsp::as_stream(stream);
   const bool tile_ok = (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && out_w >= 16);
+  if constexpr (BF) {
+    // the strip walk (no LDS, ~24 vector instructions per output): 4 x 4 taps on planes whose rows are whole 16-byte output segments
+    static const int strip_env = getenv("VSP_FIR_STRIP") ? atoi(getenv("VSP_FIR_STRIP")) : 1;
+    const int64_t xb = (int64_t)major * in_h * in_w * 2, ob = (int64_t)major * out_h * out_w * 2;
+    if (strip_env && tile_ok && kh == 4 && kw == 4 && out_w % 8 == 0 && out_h >= 4 && xb < 0x7ffffff0ll && ob < 0x7ffffff0ll &&
+        (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!e.res1 || (reinterpret_cast<uintptr_t>(e.res1) & 15) == 0) &&
+        (!e.res2 || (reinterpret_cast<uintptr_t>(e.res2) & 15) == 0) && (!e.noise || (reinterpret_cast<uintptr_t>(e.noise) & 15) == 0)) {
+      constexpr int RC = VSP_STRIP_RC;
+      const int strips_x = out_w / 8, chunks_y = (out_h + RC - 1) / RC;
+      const int64_t total_t = (int64_t)(major - 1) * chunks_y * strips_x;
+      if (total_t < ((int64_t)1 << 31)) {
+        if (total_t > 0) {
+          const unsigned gridn = (unsigned)((total_t + 255) / 256);
+#define VSP_STRIP_LAUNCH(EN_, ACT_)                                                                                                         \
+  fir_strip_bf16_kernel<RC, EN_, ACT_><<<gridn, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, strips_x, chunks_y, \
+                                                             (int)total_t, (int)xb, (int)ob, e)
+          if (!e.enabled) VSP_STRIP_LAUNCH(false, false);
+          else if (e.act) VSP_STRIP_LAUNCH(true, true);
+          else VSP_STRIP_LAUNCH(true, false);
+#undef VSP_STRIP_LAUNCH
+        }
+        // plane 0 (see the kernel's header): the tile kernel on one plane
+        const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;
+        const int blocks0 = tiles_x * tiles_y;
+        fir_tile_kernel<4, 4, T, 1><<<(unsigned)blocks0, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, blocks0, e);
+        return vsp::check_launch("upfirdn2d(strip)");
+      }
+    }
+  }
   if (tile_ok && ((kh == 4 && kw == 4) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2))) {
     const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
