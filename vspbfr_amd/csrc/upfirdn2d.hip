@@ -508,6 +508,8 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
   }
   hipStream_t s = vsp::as_stream(stream);
   const bool tile_ok = (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && out_w >= 16);
+  // (fp32 planes stay on the tile kernel: the same strip walk measured 4.6 against 4.2 TB/s on 32 channels at 1024^2 but 3.4-4.0 against
+  //  4.1-4.6 everywhere else -- 151 registers, three waves per SIMD, twice the bytes per lane in flight; default bench 195.6 against 195.1)
   if constexpr (BF) {
     // the strip walk (no LDS, ~24 vector instructions per output): 4 x 4 taps on planes whose rows are whole 16-byte output segments
     static const int strip_env = getenv("VSP_FIR_STRIP") ? atoi(getenv("VSP_FIR_STRIP")) : 1;
