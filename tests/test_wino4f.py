@@ -139,3 +139,32 @@ def test_winograd4f_weight_layout(H):
         co, ci, pos = 32 * half + 16 * (e & 1) + (lane & 15), 4 * ks + (lane >> 4), 2 * pp + (e >> 1)
         want = ref[co, ci, pos].item() if co < Cout else 0.0
         assert abs(U[half, ks, pp, lane, e].item() - want) <= 1e-6 * (1 + abs(want)), (half, ks, pp, lane, e)
+
+
+def test_dilation_groups_first_group_on_fused_kernel(H):
+    """Tuned-table value "winograd+f4f0": group 0 (dilation 1) of a SMART dilation-group launch on the fused F(4x4) kernel, groups 1..3 on the
+    F(2x2) kernels, against float64 F.conv2d(dilation = d) -- and the launch really splits (two records in the profiler)."""
+    g_ = torch.Generator().manual_seed(11)
+    B, Cin, Cg, S = 8, 128, 32, 256
+    x = torch.randn(B, Cin, S, S, generator=g_)
+    ws = [torch.randn(Cg, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9) for _ in range(4)]
+    s_in, demod = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, 4 * Cg, generator=g_) + 0.5
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
+    key = H.conv_key(B, Cin, S, S, pc, S, S)
+    assert key in H.SPLIT_G0, key
+    prof = H.ConvProfiler()
+    H.PROFILER = prof
+    try:
+        y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod))
+    finally:
+        H.PROFILER = None
+    kinds = sorted(r[3][7] for r in prof.records)
+    assert kinds == ["wino", "wino4f"], kinds
+    for b in (0, B - 1):
+        xd = (x[b:b + 1] * s_in[b].view(1, -1, 1, 1)).double()
+        ref = torch.cat([F.conv2d(xd, w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1) * demod[b].double().view(1, -1, 1, 1)
+        close64(y[b:b + 1], ref, TOL, f"image {b}")
+    # a per-channel operand the split does not carry: one launch on the F(2x2) kernels, same numbers
+    y1 = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bias2=dev(torch.zeros(4 * Cg)), act2=0)
+    close64(y1[:1], y[:1], 2 * TOL, "split vs one launch")

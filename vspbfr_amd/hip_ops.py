@@ -88,7 +88,11 @@ CONFIG_IDS = _config_ids()
 TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_IDS}
 # shapes where a Winograd kernel won: True = F(2x2,3x3) (vsp_conv2d_winograd_f32), 4 = F(4x4,3x3) (vsp_conv2d_winograd4_f32, deep layers)
 #   5 = F(4x4,3x3) fused in registers (vsp_conv2d_winograd4f_f32, shallow wide layers)
-WINO = {k: ({"winograd4": 4, "winograd4f": 5}.get(v, True)) for k, v in _load_tune_table().items() if v in ("winograd", "winograd4", "winograd4f")}
+#   "winograd+f4f0": a dilation-group launch whose first group (dilation 1: a plain convolution) runs on the fused F(4x4) kernel and the
+#   other groups on the F(2x2) kernels (two launches, round 5)
+WINO = {k: ({"winograd4": 4, "winograd4f": 5}.get(v, True)) for k, v in _load_tune_table().items()
+        if v in ("winograd", "winograd4", "winograd4f", "winograd+f4f0")}
+SPLIT_G0 = {k for k, v in _load_tune_table().items() if v == "winograd+f4f0"} if os.environ.get("VSP_SPLIT_G0", "1") != "0" else set()
 
 
 def _load_bf16_tune(name="conv_tune_bf16.json"):
@@ -291,7 +295,7 @@ class PackedConv:
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
-                 "_wino", "_wino4", "_wino4f", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg")
+                 "_wino", "_wino4", "_wino4f", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg", "_split0")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -311,6 +315,15 @@ class PackedConv:
         self._bf16x3 = None
         self._bf16rv = None
         self._bf16dg = None
+        self._split0 = None
+
+    def split_first_group(self):
+        """(group 0 as a one-group layer, the remaining groups) of a shared-input dilation-group layer: views of the packed weight."""
+        if self._split0 is None:
+            g = self.G
+            self._split0 = (PackedConv(self.w[:1], 1, self.cout_g, self.cin, self.kh, self.kw, self.stride, self.dil[:1], self.pad_y[:1], self.pad_x[:1]),
+                            PackedConv(self.w[1:], g - 1, self.cout_g, self.cin, self.kh, self.kw, self.stride, self.dil[1:g], self.pad_y[1:g], self.pad_x[1:g]))
+        return self._split0
 
     @property
     def cout(self):
@@ -641,6 +654,23 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         if pref == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
             pref = TUNE.get("8" + key[key.index(","):], 0)
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
+    if (key in SPLIT_G0 and winograd is None and bf16 is None and not BF16_CONV and tile_hint <= 0 and pc.G >= 2 and pc.dil[0] == 1
+            and pc.x_group_stride == 0 and not pc.dil_by_input_quarter and not transposed and in_shift is None and x.dtype == torch.float32
+            and all(v is None for v in (ch_scale, ch_bias, bias1, bias2, prelu, noise, res1, res2)) and not act1 and not act2
+            and out_stride == (1, 1) and out_offset == (0, 0)):
+        # group 0 (dilation 1) is a plain convolution over the shared input: the fused F(4x4) kernel; the other groups keep the F(2x2)
+        # kernels (tools/bench_group_split.py: 128 -> 4 x 32 at 256^2 1096 -> 913 us, 256 -> 4 x 64 at 128^2 836 -> 712, same box)
+        pc0, pcr = pc.split_first_group()
+        if winograd4f_eligible(pc0, H, W, OH, OW):
+            if out is None:
+                out = torch.empty(B, pc.cout, OH, OW, device=x.device, dtype=torch.float32)
+            cg = pc.cout_g
+            os0 = out_scale[:, :cg].contiguous() if out_scale is not None else None
+            osr = out_scale[:, cg:].contiguous() if out_scale is not None else None
+            conv2d_packed(x, pc0, out=out, y_coff=y_coff, in_scale=in_scale, in_scale_per_sample=in_scale_per_sample, out_scale=os0, n_out=n_out, winograd=5)
+            conv2d_packed(x, pcr, out=out, y_coff=y_coff + cg, in_scale=in_scale, in_scale_per_sample=in_scale_per_sample, out_scale=osr, n_out=n_out,
+                          winograd=True)
+            return out
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     x3 = bf16 == "x3" or (bf16 is None and BF16_CONV == "x3")
     rv = None          # the row-vector-K kernel (vsp_conv2d_bf16rv): "rv" forces it, None = where it is eligible and measured faster
