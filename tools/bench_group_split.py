@@ -12,7 +12,7 @@ def t(f, n=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1000
 B = 8
-for cin, cg, hw in [(64, 16, 512), (128, 32, 256), (256, 64, 128)]:
+for cin, cg, hw in [(64, 16, 512), (128, 32, 256), (256, 64, 128), (512, 128, 64), (512, 128, 32)]:
     g_ = torch.Generator().manual_seed(1)
     x = torch.randn(B, cin, hw, hw, generator=g_).cuda()
     ws = [torch.randn(cg, cin, 3, 3, generator=g_) / math.sqrt(cin * 9) for _ in range(4)]
@@ -26,11 +26,12 @@ for cin, cg, hw in [(64, 16, 512), (128, 32, 256), (256, 64, 128)]:
     out = torch.empty(B, 4 * cg, hw, hw, device="cuda")
     def one():
         return H.conv2d_packed(x, pc4, out=out, in_scale=s_in, out_scale=demod, act2=1, bias2=bias)
+    w0 = 5 if cin <= 256 else 4       # (the fused kernel serves up to 256 input channels: the F(4x4) pair beyond)
     def split():
-        H.conv2d_packed(x, pc0, out=out, y_coff=0, in_scale=s_in, out_scale=demod[:, :cg].contiguous(), act2=1, bias2=bias[:cg].contiguous(), winograd=5)
+        H.conv2d_packed(x, pc0, out=out, y_coff=0, in_scale=s_in, out_scale=demod[:, :cg].contiguous(), act2=1, bias2=bias[:cg].contiguous(), winograd=w0)
         H.conv2d_packed(x, pc3, out=out, y_coff=cg, in_scale=s_in, out_scale=demod[:, cg:].contiguous(), act2=1, bias2=bias[cg:].contiguous(), winograd=True)
     y1 = one().clone(); split(); d = (out - y1).abs().max().item()
     us1, us2 = t(one), t(split)
-    us0 = t(lambda: H.conv2d_packed(x, pc0, out=out, y_coff=0, in_scale=s_in, winograd=5))
+    us0 = t(lambda: H.conv2d_packed(x, pc0, out=out, y_coff=0, in_scale=s_in, winograd=w0))
     us3 = t(lambda: H.conv2d_packed(x, pc3, out=out, y_coff=cg, in_scale=s_in, winograd=True))
     print(f"{cin} -> 4 x {cg} at {hw}^2: one launch {us1:.0f} us | split {us2:.0f} us (F4f group 0: {us0:.0f}, three dilated groups: {us3:.0f}) | max diff {d:.1e}", flush=True)
