@@ -141,9 +141,10 @@ def test_winograd4f_weight_layout(H):
         assert abs(U[half, ks, pp, lane, e].item() - want) <= 1e-6 * (1 + abs(want)), (half, ks, pp, lane, e)
 
 
-def test_dilation_groups_first_group_on_fused_kernel(H):
-    """Tuned-table value "winograd+f4f0": group 0 (dilation 1) of a SMART dilation-group launch on the fused F(4x4) kernel, groups 1..3 on the
-    F(2x2) kernels, against float64 F.conv2d(dilation = d) -- and the launch really splits (two records in the profiler)."""
+def test_dilation_groups_on_fused_kernel(H):
+    """Tuned-table value "winograd4f+groups": every group (dilation 1, 2, 4, 8) of a SMART dilation-group launch as its own launch of the fused
+    F(4x4) kernel -- the dilated ones through its LDS window loader --, against float64 F.conv2d(dilation = d); the launch really splits
+    (four records in the profiler)."""
     g_ = torch.Generator().manual_seed(11)
     B, Cin, Cg, S = 8, 128, 32, 256
     x = torch.randn(B, Cin, S, S, generator=g_)
@@ -152,7 +153,7 @@ def test_dilation_groups_first_group_on_fused_kernel(H):
     wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
     pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
     key = H.conv_key(B, Cin, S, S, pc, S, S)
-    assert key in H.SPLIT_G0, key
+    assert key in H.SPLIT_ALL, key
     prof = H.ConvProfiler()
     H.PROFILER = prof
     try:
@@ -160,7 +161,7 @@ def test_dilation_groups_first_group_on_fused_kernel(H):
     finally:
         H.PROFILER = None
     kinds = sorted(r[3][7] for r in prof.records)
-    assert kinds == ["wino", "wino4f"], kinds
+    assert kinds == ["wino4f"] * 4, kinds
     for b in (0, B - 1):
         xd = (x[b:b + 1] * s_in[b].view(1, -1, 1, 1)).double()
         ref = torch.cat([F.conv2d(xd, w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1) * demod[b].double().view(1, -1, 1, 1)
@@ -168,3 +169,28 @@ def test_dilation_groups_first_group_on_fused_kernel(H):
     # a per-channel operand the split does not carry: one launch on the F(2x2) kernels, same numbers
     y1 = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bias2=dev(torch.zeros(4 * Cg)), act2=0)
     close64(y1[:1], y[:1], 2 * TOL, "split vs one launch")
+
+
+@pytest.mark.parametrize("d", [2, 4, 8])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 64), (3, 64, 48, 32, 96), (2, 24, 40, 160, 64), (1, 256, 16, 64, 128), (1, 16, 32, 40, 72)])
+def test_conv2d_winograd4f_dilated(H, d, shape):
+    """The fused F(4x4) kernel on dilated layers (polyphase tiles, LDS window loader): every epilogue operand, maps narrower / shorter than a
+    workgroup region, channel counts off the 32-channel half, against float64 F.conv2d; bit-identical across launches (hand-counted waits)."""
+    B, Cin, Cout, Hh, Ww = shape
+    if Hh % (4 * d) or Ww % (4 * d):
+        pytest.skip("not whole tiles at this dilation")
+    g_ = torch.Generator().manual_seed(100 * d + Cin)
+    x = torch.randn(B, Cin, Hh, Ww, generator=g_)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9)
+    s_in, demod = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, Cout, generator=g_) + 0.5
+    bias, res, nz = torch.randn(Cout, generator=g_), torch.randn(B, Cout, Hh, Ww, generator=g_), torch.randn(B, 1, Hh, Ww, generator=g_)
+    pc = H.PackedConv(H.pack_weight(dev(w)), 1, Cout, Cin, 3, 3, 1, (d,), (d,))
+    kw = dict(in_scale=dev(s_in), out_scale=dev(demod), act2=1, bias2=dev(bias), res1=dev(res), noise=dev(nz), noise_w=dev(torch.tensor([0.3])))
+    y = H.conv2d_packed(dev(x), pc, winograd=5, **kw)
+    ref = F.conv2d(x.double() * s_in.double()[:, :, None, None], w.double(), padding=d, dilation=d) * demod.double()[:, :, None, None]
+    ref = F.leaky_relu(ref + 0.3 * nz.double() + bias.double()[None, :, None, None], 0.2) * math.sqrt(2.0) + res.double()
+    close64(y, ref, TOL, f"d = {d}")
+    for _ in range(5):
+        assert torch.equal(H.conv2d_packed(dev(x), pc, winograd=5, **kw), y)
+    y2 = H.conv2d_packed(dev(x), pc, winograd=5, in_scale=dev(s_in))          # no residual / second activation: the other template instance
+    close64(y2, F.conv2d(x.double() * s_in.double()[:, :, None, None], w.double(), padding=d, dilation=d), TOL, f"plain d = {d}")

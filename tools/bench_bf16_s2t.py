@@ -25,8 +25,11 @@ for (Cin, Cout, S, pad, G) in [(512, 5632, 64, 1, 1), (64, 128, 513, 0, 1), (128
     fl = 2.0 * B * (cg * G if G > 1 else Cout) * Cin * 9 * oh * ow
     uf = t(lambda: H.conv2d_packed(x, pc))
     out = [f"{Cin}->{Cout} G{G} @{S}->{oh}: fp32 {uf:.0f} us {fl/uf/1e6:.0f} TF |"]
-    for v in ((0, 6, 7) if os.environ.get("X3") else (0, 4, 6)):
-        ub = t(lambda: H.conv2d_packed(x, pc, bf16="x3" if os.environ.get("X3") else True, tile_hint=v))
+    for v in ((0, 6, 7) if os.environ.get("X3") else (0, 4, 6, 2, 3)):
+        try:
+            ub = t(lambda: H.conv2d_packed(x, pc, bf16="x3" if os.environ.get("X3") else True, tile_hint=v))
+        except Exception as e:
+            out.append(f" v{v} n/a |"); continue
         out.append(f" v{v} {ub:.0f} us {fl/ub/1e6:.0f} TF x{uf/ub:.2f} |")
     print("".join(out), flush=True)
 print("transposed:")

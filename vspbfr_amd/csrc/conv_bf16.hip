@@ -720,7 +720,7 @@ int launch_shape(const ConvK& q, hipStream_t stream) {
 
 // mode: 0 = stride-1 conv, 1 = stride-2 conv, 2 = stride-2 transposed conv.
 // variant: 0 = automatic; stride 1: 1 = 32 ch x 256 px, 2 = 64 x 256, 3 = 128 x 128, 4 = 64 x 128;
-//          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions,
+//          6 = 128 ch x 64 px, 7 = 32 ch x 128 px;  stride 2: 3 = 128 ch x 128 px, 4 = 64 ch x 128 px, 6 = 128 ch x 64 px;  transposed: 4 = 64 ch x 128 positions, 5 = 32 ch x 128 positions,
 //          8 = 32 ch x 256 positions
 // split = 1: the bf16x3 form (stride-1 / stride-2 modes): variants 1 = 32 ch x 256 px, 4 = 64 ch x 128 px, 7 = 32 ch x 128 px
 int bf16_launch_split(const ConvK& q, int mode, int variant, hipStream_t stream) {
@@ -760,8 +760,10 @@ int bf16_launch(const ConvK& q, int mode, int variant, hipStream_t stream) {
     }
   }
   if (mode == M_S2) {
-    if (variant == 0) variant = (q.cout_g >= 128 && (int64_t)q.OH * q.OW <= 16 * 16) ? 6 : 4;
+    // 128 ch x 128 px for the wide heads (512 -> 5632 at 32^2: 939 -> 865 us, 512 -> 2048 at 16^2: 116 -> 90 us at B = 8; tools/bench_bf16_s2t.py)
+    if (variant == 0) variant = q.cout_g >= 2048 ? 3 : (q.cout_g >= 128 && (int64_t)q.OH * q.OW <= 16 * 16) ? 6 : 4;
     switch (variant) {
+      case 3: return launch_shape<2, 2, 2, 2, M_S2>(q, stream);
       case 4: return launch_shape<2, 1, 1, 4, M_S2>(q, stream);
       case 6: return launch_shape<2, 1, 2, 2, M_S2>(q, stream);
       default: return vsp::fail(VSP_EINVAL, "conv2d_bf16: unknown stride-2 variant %d", variant);

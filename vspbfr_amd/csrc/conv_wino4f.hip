@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void wino4f_weight_kernel(float* __restrict__ 
 // LDS hand-over barrier: the LDS queue drained, NOT the vector-memory queue (__syncthreads waits for every window load in flight)
 #define F4_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// ---- LDS window loader (template D >= 1; D = 0 is the register loader above).  The window stream of a workgroup goes global -> LDS by
+// LDS-DMA (buffer_load_dwordx4 ... lds: no register, no vector instruction -- beside fp32 MFMAs every vector instruction costs pipe time)
+// and the lanes read their 6 x 6 window from there (LDS reads are free beside the MFMAs).  That also opens the DILATED layers: with
+// dilation D the convolution is D x D independent dense convolutions on the polyphase sub-images, a lane's tile = 4 x 4 outputs D apart,
+// its window = 6 x 6 inputs D apart -- strided in HBM (4-byte loads cost twice the vector-memory time of 16-byte ones and the kernel
+// would be bound there), but any stride is one ds_read_b32 in LDS.  A workgroup item is still a 16-row x 64-column output region of
+// one image: its D^2 phases hold (16 / D / 4) x (64 / D / 4) tiles each, 64 in all = 4 waves x 16 lanes.
+//   region in LDS per k-step (4 channels): [channel][row -D .. 16 + D)[column -HQ .. 64 + HQ)  (HQ = max(4, D): whole 16-byte quads),
+//   written in that linear order by NI DMA instructions per wave (lane l of instruction n of wave w = quad (4 n + w) 64 + l; quads outside
+//   the image or the region have an out-of-range offset: the DMA writes zeros there -- tools/ubench/lds_dma_oob.hip -- the padding for free).
+//   Three slots: window ks + 4 is requested behind MFMA 53 of k-step ks, awaited (counted vmcnt) before the barrier of k-step ks + 1, read
+//   after MFMA 35 of k-step ks + 2.  (Dilation 8, two slots: requested behind the barrier of k-step ks instead -- into the slot read in that k-step.)
+template <int D>
+struct F4G {
+  static constexpr int DD = D == 0 ? 1 : D;
+  static constexpr int HQ = DD < 4 ? 4 : DD;
+  static constexpr int RH = DD == 8 ? 32 : 16, RW = DD == 8 ? 32 : 64;   // the item's output region (dilation 8: a tile spans 32 rows; 64 phases x one tile)
+  static constexpr int NR = RH + 2 * DD, RWP = RW + 2 * HQ, NQ = RWP / 4;
+  static constexpr int PLANE = (NR * RWP + 15) / 16 * 16 + (DD == 8 ? 8 : 4);   // floats per channel; the four channels of a k-step start 4 (8) banks apart
+  static constexpr int PLANEQ = PLANE / 4;
+  static constexpr int NI = (4 * PLANEQ + 255) / 256;          // DMA instructions per wave and k-step
+  static constexpr int SLOT = NI * 256 * 4;                     // floats of one window slot
+  static constexpr int WS = DD == 8 ? 2 : 3;                    // window slots (dilation 8: 40 KB each -- two, and the item's third window is awaited in the prologue)
+  static constexpr int LDS = D == 0 ? F4_LDS : F4_LDS + WS * SLOT;
+};
+// one DMA instruction: 64 lanes x 16 bytes from (descriptor, lane byte offset voff + scalar offset soff) to LDS byte address ldsb + 16 lane.
+// hipcc does not see it (it would order every LDS read of the k-step behind a DMA it knows of): its completion is counted by hand below.
+#define F4_DMA(voff, rsrc, soff, ldsb)                                                                                              \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"   \
+               : "=&s"(m0keep) : "v"(voff), "s"(rsrc), "s"(ldsb), "s"(soff) : "memory")
+
 #ifdef VSP_F4_TRACE   // tuning only: shader-clock stamps of one workgroup's waves inside its third item (tools/build_abl.sh conv_wino4f.hip VSP_F4_TRACE f4trace)
 __device__ unsigned long long f4_trace_buf[4 * 64];
 // (stamps are kept in scalar registers and written once at the end of the item: a store behind a branch per stamp is a join, and a join
@@ -121,11 +152,14 @@ constexpr int f4ab = 0;
 
 // RES: residual operands present; ACT1: first activation present (compile-time: a branch in the epilogue is a join, and hipcc waits for
 // every store in flight at a join -- the first build spent 43 % of its time there)
-template <bool RES, bool ACT1>
+template <bool RES, bool ACT1, int D>
 __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, const F4Plan pl) {
+  using GE = F4G<D>;
+  constexpr int DD = GE::DD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem + F4_RING * F4_SLABL;
   float* Et = Sc + F4_MAXC;
+  float* Wr = Et + 32 * 4;               // (D >= 1) window ring: three slots of GE::SLOT floats
   typedef __attribute__((address_space(3))) float lds_f;
   typedef __attribute__((address_space(3))) f32x4f lds_f4;
   const int tid = threadIdx.x;
@@ -161,9 +195,11 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
     t /= pl.nbx;
     const int byg = t % pl.nbyg;
     const int b = t / pl.nbyg;
-    const int y0 = 4 * (4 * byg + wave), x0 = 64 * bx;
-    const bool wave_ok = y0 < p.H;
-    const int xq = x0 + 4 * lr;
+    // the lane's tile: phase (py, px) of the region, tile (ty, tx) inside the phase -- first output (y0, xq), outputs DD apart
+    const int ry = GE::RH * byg, x0 = GE::RW * bx;
+    const int y0 = DD == 8 ? ry + 2 * wave + (lr >> 3) : ry + (wave & (DD - 1)) + 4 * DD * (wave / DD);
+    const bool wave_ok = DD == 8 ? ry < p.H : y0 < p.H;       // (dilation 8: H is a multiple of the 32-row region; otherwise y0 is the wave's)
+    const int xq = DD == 8 ? x0 + (lr & 7) : x0 + (lr & (DD - 1)) + 4 * DD * (lr / DD);
     const float* xb = p.x + (int64_t)b * p.x_ch * chw;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, p.Cin * chw * 4, 0x00020000);
     // Window loads: one aligned 16-byte quad per row (window columns 1..4 = the tile's own pixels) + one 4-byte load per row that only
@@ -183,6 +219,55 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
 
     f32x4f Rq[6];          // window rows: columns 1..4
     float Rh[6];           //              the N-block's outer column (lanes 0 / 15 of a 16-lane row)
+    f32x2f Rhp[6];         // (D == 1)     columns (0, 5)
+    f32x2f Wp[6][3];       // (D >= 2)     column pairs (1, 2), (3, 4), (0, 5)
+    // ---- LDS loader: the lane's DMA source offsets (constant over the k-steps), its window base in a slot, the descriptor in scalar registers
+    int dmo[GE::NI];
+    const lds_f* Wl = nullptr;
+    u32x4f xdesc = {0u, 0u, 0u, 0u};
+    unsigned wr_base = 0;
+    if constexpr (D >= 1) {
+#pragma unroll
+      for (int n = 0; n < GE::NI; ++n) {
+        const int L = (4 * n + wave) * 64 + lane_i;
+        const int ch = L / GE::PLANEQ, rem = L - ch * GE::PLANEQ, row = rem / GE::NQ, cq = rem - row * GE::NQ;
+        const int gy = ry - DD + row, gx = x0 - GE::HQ + 4 * cq;
+        const bool ok = ch < 4 && row < GE::NR && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        dmo[n] = ok ? (ch * chw + gy * p.W + gx) * 4 : F4_OOB;
+      }
+      Wl = (const lds_f*)Wr + kq * GE::PLANE + (y0 - ry) * GE::RWP + (xq - x0) + GE::HQ - DD;
+      const uint64_t xa = reinterpret_cast<uint64_t>(xb);
+      xdesc = u32x4f{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(xa >> 32) & 0xffffu)),
+                     (unsigned)__builtin_amdgcn_readfirstlane(p.Cin * chw * 4), 0x00020000u};
+      wr_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_f*)Wr);
+    }
+    auto dma_w = [&](int ksw) {       // window ksw -> ring slot ksw % WS (k-steps past the end re-request the last one)
+      const int so = __builtin_amdgcn_readfirstlane(min(ksw, nks - 1) * 16 * chw);
+      const unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(wr_base + ((ksw % GE::WS) * GE::SLOT + wave * 256) * 4));
+      static_for<0, GE::NI>([&](auto Nc) {
+        constexpr int n = decltype(Nc)::value;
+        const int vo = dmo[n], so_l = so;
+        const u32x4f rd = xdesc;
+        const unsigned lbn = lb + n * 4096;
+        unsigned m0keep;
+        F4_DMA(vo, rd, so_l, lbn);
+      });
+    };
+    auto read_w = [&](int ksw) {      // the lane's window of k-step ksw from its slot
+      const lds_f* s = Wl + (ksw % GE::WS) * GE::SLOT;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if constexpr (D == 1) {
+          Rq[i] = *reinterpret_cast<const lds_f4*>(s + i * GE::RWP + 1);
+          Rhp[i] = f32x2f{s[i * GE::RWP], s[i * GE::RWP + 5]};
+        } else {
+          const lds_f* r = s + i * DD * GE::RWP;
+          Wp[i][0] = f32x2f{r[DD], r[2 * DD]};
+          Wp[i][1] = f32x2f{r[3 * DD], r[4 * DD]};
+          Wp[i][2] = f32x2f{r[0], r[5 * DD]};
+        }
+      }
+    };
     auto load_w = [&](int so_k) {
       Rq[0] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, vq0, so_k, 0));
       Rh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vh0, so_k, 0));
@@ -204,9 +289,11 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const f32x4f q = Rq[i];
-        if constexpr (X == 0) w[i] = f32x2f{q[0], q[1]};
-        if constexpr (X == 1) w[i] = f32x2f{q[2], q[3]};
-        if constexpr (X == 2) {
+        if constexpr (D >= 2) w[i] = Wp[i][X];
+        if constexpr (D <= 1 && X == 0) w[i] = f32x2f{q[0], q[1]};
+        if constexpr (D <= 1 && X == 1) w[i] = f32x2f{q[2], q[3]};
+        if constexpr (D == 1 && X == 2) w[i] = Rhp[i];
+        if constexpr (D == 0 && X == 2) {
           const float hh = Rh[i];
           int lo = __builtin_bit_cast(int, hh), hi = lo;
           const float qwf = q[3], qxf = q[0];      // (hipcc: a bit_cast of a vector ELEMENT expression reads element 0 -- scalars first)
@@ -300,7 +387,13 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
 
     // ---- prologue: window 0 -> Ta, window 1 in flight, U(0) in slot 0, U(1) in the staging registers
     F4_STAMP(1);
-    load_w(0);
+    if constexpr (D >= 1) {
+      dma_w(0);
+      dma_w(1);
+      if constexpr (GE::WS == 3) dma_w(2);
+    } else {
+      load_w(0);
+    }
     u_load(0);
     {
       const float sc = ((lds_f*)Sc)[kq];
@@ -310,10 +403,24 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
       for (int r = 0; r < 5; ++r) dst[F4_THR * r] = ust[r];
     }
     u_load(nks > 1 ? 1 : 0);
+    if constexpr (D >= 1) {
+      // (the staging of U(0) above waited for its loads: the DMA requests are older, hence landed; the barrier publishes all three windows)
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      F4_BARRIER();
+      read_w(0);
+    }
     static_for<0, 3>([&](auto Xc) { rowpass(Xc); });
-    load_w((f4ab & 1) ? 0 : __builtin_amdgcn_readfirstlane((nks > 1 ? 1 : 0) * 16 * chw));
+    if constexpr (D >= 1) read_w(1);
+    else load_w((f4ab & 1) ? 0 : __builtin_amdgcn_readfirstlane((nks > 1 ? 1 : 0) * 16 * chw));
     static_for<0, 6>([&](auto Ic) { colpass(Ic, Ta); });
     F4_BARRIER();
+    if constexpr (D >= 1 && GE::WS == 3) dma_w(3);      // (slot 0: every wave has read window 0)
+    if constexpr (D >= 1 && GE::WS == 2) {              // (both slots are free now: window 2 is read in the first k-step -- awaited here)
+      dma_w(2);
+      dma_w(3);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "i"(GE::NI) : "memory");
+      F4_BARRIER();
+    }
     {
       const lds_f4* Us = Ul4 + lane;
       uf[0] = Us[0];
@@ -368,7 +475,10 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
               colpass(std::integral_constant<int, 2 * (run - 3) + 1>{}, Vn);
             }
           }
-          if constexpr (run == 2) load_w(so_r);                                       // window ks + 2 (the row passes are through with the registers)
+          if constexpr (run == 2) {                                                   // window ks + 2 (the row passes are through with the registers)
+            if constexpr (D >= 1) read_w(ks + 2);
+            else load_w(so_r);
+          }
           if constexpr (!(f4ab & 2)) {
             if constexpr (run == 0) sc = ((lds_f*)Sc)[4 * k1 + kq];
             if constexpr (run == 1) { u_scale(std::integral_constant<int, 0>{}, sc); u_scale(std::integral_constant<int, 1>{}, sc); }
@@ -384,7 +494,13 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
             ust[c] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(urs, ci < F4_SLAB / 4 ? ci * 16 : F4_OOB, so_u, 0));
           }
         }
-        if constexpr (sl == 56 && !(f4ab & 32)) F4_BARRIER();
+        if constexpr (D >= 1 && GE::WS == 3 && sl == 53) dma_w(ks + 4);
+        if constexpr (sl == 56 && !(f4ab & 32)) {
+          // (in flight, oldest first: window ks + 3, the five U chunks of this k-step, [three slots: window ks + 4] -- the first must have landed)
+          if constexpr (D >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(GE::WS == 3 ? 5 + GE::NI : 5) : "memory");
+          F4_BARRIER();
+        }
+        if constexpr (D >= 1 && GE::WS == 2 && sl == 57) dma_w(ks + 4);
         __builtin_amdgcn_sched_barrier(0);
       });
     };
@@ -404,7 +520,7 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int lr_e = lane_e & 15, kq_e = lane_e >> 4;
-    const int xq_e = x0 + 4 * lr_e;
+    const int xq_e = DD == 8 ? x0 + (lr_e & 7) : x0 + (lr_e & (DD - 1)) + 4 * DD * (lr_e / DD);
     if (wave_ok && xq_e < p.W && !(f4ab & 16)) {
       const int ybytes = Cout * y_plane * 4;
       const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + ((int64_t)b * p.y_ch + p.y_coff) * y_plane, 0, ybytes, 0x00020000);
@@ -414,11 +530,24 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
           const_cast<float*>(p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * y_plane * p.r2s), 0, p.r2s ? ybytes : 16, 0x00020000);
       const __amdgpu_buffer_rsrc_t nzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nzp + (int64_t)b * p.OH * p.OW * p.nzs), 0,
                                                                             p.nzs ? p.OH * p.OW * 4 : 16, 0x00020000);
-      const int pix = (y0 * p.y_w + xq_e) * 4;      // byte offset of the tile's first output inside a channel plane (y_w == OW)
+      const int y0_e = DD == 8 ? ry + 2 * wave + (lr_e >> 3) : y0;
+      const int pix = (y0_e * p.y_w + xq_e) * 4;      // byte offset of the tile's first output inside a channel plane (y_w == OW)
       F4_STAMP(40);
+      // a tile row = four outputs DD apart: one 16-byte access at dilation 1, four 4-byte ones otherwise (`mul`: 0 / 1, the operand's stride)
+      auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, int off, int mul) -> f32x4f {
+        if constexpr (DD == 1) {
+          return __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off * mul, 0, 0));
+        } else {
+          f32x4f v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (off + e * DD * 4) * mul, 0, 0));
+          return v;
+        }
+      };
+      const int rowb_y = DD * p.y_w * 4;       // bytes between two output rows of a tile
       f32x4f nz[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) nz[i] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(nzrs, (pix + i * p.OW * 4) * p.nzs, 0, 0)) * nw;
+      for (int i = 0; i < 4; ++i) nz[i] = ld4(nzrs, pix + i * rowb_y, p.nzs) * nw;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -433,9 +562,9 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
           if (RES) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int ro = cbase + pix + i * p.y_w * 4;
-              rs1[i] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(r1rs, ro * p.r1s, 0, 0));
-              rs2[i] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(r2rs, ro * p.r2s, 0, 0));
+              const int ro = cbase + pix + i * rowb_y;
+              rs1[i] = ld4(r1rs, ro, p.r1s);
+              rs2[i] = ld4(r2rs, ro, p.r2s);
             }
           }
           float z[4][6];
@@ -460,7 +589,7 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
               v += nz[i][e] + et[2];
               o4[e] = v * (v > 0.f ? p.g2 : et[3] * p.g2);
             }
-            const int ro = cbase + pix + i * p.y_w * 4;
+            const int ro = cbase + pix + i * rowb_y;
             if (RES) {
               // (an absent residual is a stride-0 pointer at ONE constant zero: the 16-byte load reads its neighbours too, the factor drops them)
               o4 += rs1[i] * (float)p.r1s;
@@ -468,8 +597,14 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
             }
             if constexpr ((f4ab & 64) != 0) {      // (tuning: keep the arithmetic alive without the store)
               asm volatile("" :: "v"(o4));
-            } else {
+            } else if constexpr (DD == 1) {
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4f, o4), yrs, ro, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float oe = o4[e];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), yrs, ro + e * DD * 4, 0, 0);
+              }
             }
           }
           F4_STAMP(41 + 4 * cb + r);
@@ -488,8 +623,9 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
 
 // layers the fused F(4x4) form serves: one group, dilation 1, style scale only (no affine shift), whole 4 x 4 tiles, 16-byte rows, dense output
 bool wino4f_eligible(const ConvK& q) {
-  if (q.G != 1 || q.dil[0] != 1 || q.Cin % 8 != 0 || q.Cin > F4_MAXC) return false;
-  if (q.H % 4 != 0 || q.W % 4 != 0 || q.W < 16 || q.H < 4) return false;
+  const int d = q.dil[0];
+  if (q.G != 1 || (d != 1 && d != 2 && d != 4 && d != 8) || q.pady[0] != d || q.padx[0] != d || q.Cin % 8 != 0 || q.Cin > F4_MAXC) return false;
+  if (q.H % (4 * d) != 0 || q.W % (4 * d) != 0 || q.W < 16 || q.H < 4) return false;   // whole 4 x 4 tiles in every polyphase sub-image
   if (q.y_w != q.OW || q.y_h != q.OH) return false;
   if (q.wshp != nullptr && q.wsh_cs != 0) return false;
   if (reinterpret_cast<uintptr_t>(q.x) & 15) return false;
@@ -518,8 +654,8 @@ int wino4f_launch(ConvK q, hipStream_t stream) {
   F4Plan pl;
   pl.nks = q.Cin / 4;
   pl.nco2 = (q.cout_g + 31) / 32;
-  pl.nbx = (q.W + 63) / 64;
-  pl.nbyg = (q.H + 15) / 16;
+  pl.nbx = q.dil[0] == 8 ? (q.W + 31) / 32 : (q.W + 63) / 64;
+  pl.nbyg = q.dil[0] == 8 ? (q.H + 31) / 32 : (q.H + 15) / 16;
   const int64_t items = (int64_t)q.B * pl.nbyg * pl.nbx * pl.nco2;
   if (items > 0x7fffffff) return vsp::fail(VSP_EINVAL, "conv2d_winograd4f: too many tiles");
   pl.items = (int)items;
@@ -527,19 +663,36 @@ int wino4f_launch(ConvK q, hipStream_t stream) {
   int nwg = wgs_env > 0 ? (wgs_env + 7) / 8 * 8 : vsp::kNumCU;
   pl.J = (pl.items + nwg - 1) / nwg;
   pl.nwg = nwg;
-  const size_t lds = (size_t)F4_LDS * sizeof(float);
   const bool res = q.r1s || q.r2s, act1 = !(q.s1 == 1.f && q.g1 == 1.f);
-#define F4_LAUNCH(RES_, ACT_)                                                                                                     \
+  // loader: dilation 1 = window loads into registers (D = 0) unless VSP_WINO4F_LDS=1 asks for the LDS loader (D = 1); dilation 2 / 4 / 8 = LDS loader
+  static const int lds_env = getenv("VSP_WINO4F_LDS") ? atoi(getenv("VSP_WINO4F_LDS")) : 0;
+  const int dsel = q.dil[0] == 1 ? (lds_env ? 1 : 0) : q.dil[0];
+#define F4_LAUNCH(RES_, ACT_, D_)                                                                                                 \
   do {                                                                                                                            \
+    const size_t lds = (size_t)F4G<D_>::LDS * sizeof(float);                                                                      \
     static vsp::LdsAttrOnce attr;                                                                                                 \
-    if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino4f_kernel<RES_, ACT_>), (int)lds, "conv2d_winograd4f")) return rc; \
-    conv_wino4f_kernel<RES_, ACT_><<<nwg, F4_THR, lds, stream>>>(q, pl);                                                        \
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino4f_kernel<RES_, ACT_, D_>), (int)lds, "conv2d_winograd4f")) return rc; \
+    conv_wino4f_kernel<RES_, ACT_, D_><<<nwg, F4_THR, lds, stream>>>(q, pl);                                                      \
   } while (0)
-  if (res) {
-    if (act1) F4_LAUNCH(true, true); else F4_LAUNCH(true, false);
-  } else {
-    if (act1) F4_LAUNCH(false, true); else F4_LAUNCH(false, false);
+#define F4_LAUNCH_D(D_)                                                                                                           \
+  do {                                                                                                                            \
+    if (res) {                                                                                                                    \
+      if (act1) F4_LAUNCH(true, true, D_); else F4_LAUNCH(true, false, D_);                                                       \
+    } else {                                                                                                                      \
+      if (act1) F4_LAUNCH(false, true, D_); else F4_LAUNCH(false, false, D_);                                                     \
+    }                                                                                                                             \
+  } while (0)
+  switch (dsel) {
+    case 0: F4_LAUNCH_D(0); break;
+    case 1: F4_LAUNCH_D(1); break;
+#ifndef VSP_F4_NODIL
+    case 2: F4_LAUNCH_D(2); break;
+    case 4: F4_LAUNCH_D(4); break;
+    case 8: F4_LAUNCH_D(8); break;
+#endif
+    default: return vsp::fail(VSP_ENOTSUP, "conv2d_winograd4f: dilation %d", q.dil[0]);
   }
+#undef F4_LAUNCH_D
 #undef F4_LAUNCH
 #ifdef VSP_F4_TRACE
   {
