@@ -142,9 +142,9 @@ def test_winograd4f_weight_layout(H):
 
 
 def test_dilation_groups_on_fused_kernel(H):
-    """Tuned-table value "winograd4f+groups": every group (dilation 1, 2, 4, 8) of a SMART dilation-group launch as its own launch of the fused
-    F(4x4) kernel -- the dilated ones through its LDS window loader --, against float64 F.conv2d(dilation = d); the launch really splits
-    (four records in the profiler)."""
+    """A SMART dilation-group launch (dilation 1, 2, 4, 8 over one shared input) on the fused F(4x4) kernel: ONE launch, a partition of
+    workgroups per group, the dilated groups through the LDS window loader -- against float64 F.conv2d(dilation = d), picked by the tuned
+    table, with and without per-channel epilogue operands (their channel index runs over all four groups)."""
     g_ = torch.Generator().manual_seed(11)
     B, Cin, Cg, S = 8, 128, 32, 256
     x = torch.randn(B, Cin, S, S, generator=g_)
@@ -153,7 +153,7 @@ def test_dilation_groups_on_fused_kernel(H):
     wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
     pc = H.PackedConv(wp, 4, Cg, Cin, 3, 3, 1, (1, 2, 4, 8), (1, 2, 4, 8))
     key = H.conv_key(B, Cin, S, S, pc, S, S)
-    assert key in H.SPLIT_ALL, key
+    assert H.WINO.get(key) == 5, key
     prof = H.ConvProfiler()
     H.PROFILER = prof
     try:
@@ -161,14 +161,37 @@ def test_dilation_groups_on_fused_kernel(H):
     finally:
         H.PROFILER = None
     kinds = sorted(r[3][7] for r in prof.records)
-    assert kinds == ["wino4f"] * 4, kinds
+    assert kinds == ["wino4f"], kinds
     for b in (0, B - 1):
         xd = (x[b:b + 1] * s_in[b].view(1, -1, 1, 1)).double()
         ref = torch.cat([F.conv2d(xd, w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1) * demod[b].double().view(1, -1, 1, 1)
         close64(y[b:b + 1], ref, TOL, f"image {b}")
-    # a per-channel operand the split does not carry: one launch on the F(2x2) kernels, same numbers
-    y1 = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), bias2=dev(torch.zeros(4 * Cg)), act2=0)
-    close64(y1[:1], y[:1], 2 * TOL, "split vs one launch")
+    # per-channel operands, a residual and noise; against the F(2x2) kernels on the same launch
+    bias, res, nz = torch.randn(4 * Cg, generator=g_), torch.randn(B, 4 * Cg, S, S, generator=g_), torch.randn(B, 1, S, S, generator=g_)
+    kw = dict(in_scale=dev(s_in), out_scale=dev(demod), bias2=dev(bias), act2=1, res1=dev(res), noise=dev(nz), noise_w=dev(torch.tensor([0.3])))
+    y1 = H.conv2d_packed(dev(x), pc, winograd=5, **kw)
+    b = B - 1
+    xd = (x[b:b + 1] * s_in[b].view(1, -1, 1, 1)).double()
+    ref = torch.cat([F.conv2d(xd, w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (1, 2, 4, 8))], dim=1) * demod[b].double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref + 0.3 * nz[b:b + 1].double() + bias.double().view(1, -1, 1, 1), 0.2) * math.sqrt(2.0) + res[b:b + 1].double()
+    close64(y1[b:b + 1], ref, TOL, "group launch with epilogue operands")
+    close64(H.conv2d_packed(dev(x), pc, winograd=True, **kw), y1, 2 * TOL, "fused vs F(2x2) kernels")
+
+
+def test_dilation_groups_512_channels_on_fused_kernel(H):
+    """512 -> 4 x 128 at 64^2 (the deepest SMART launch the fused kernel takes: 128 k-steps, scale table of 512 channels), three groups."""
+    g_ = torch.Generator().manual_seed(12)
+    B, Cin, Cg, S = 2, 512, 128, 64
+    x = torch.randn(B, Cin, S, S, generator=g_)
+    ws = [torch.randn(Cg, Cin, 3, 3, generator=g_) / math.sqrt(Cin * 9) for _ in range(3)]
+    s_in, demod = torch.rand(B, Cin, generator=g_) + 0.5, torch.rand(B, 3 * Cg, generator=g_) + 0.5
+    wp = torch.stack([H.pack_weight(dev(w_))[0] for w_ in ws]).contiguous()
+    pc = H.PackedConv(wp, 3, Cg, Cin, 3, 3, 1, (4, 1, 8), (4, 1, 8))
+    y = H.conv2d_packed(dev(x), pc, in_scale=dev(s_in), out_scale=dev(demod), winograd=5)
+    for b in range(B):
+        xd = (x[b:b + 1] * s_in[b].view(1, -1, 1, 1)).double()
+        ref = torch.cat([F.conv2d(xd, w_.double(), padding=d, dilation=d) for w_, d in zip(ws, (4, 1, 8))], dim=1) * demod[b].double().view(1, -1, 1, 1)
+        close64(y[b:b + 1], ref, 2 * TOL, f"image {b}")
 
 
 @pytest.mark.parametrize("d", [2, 4, 8])

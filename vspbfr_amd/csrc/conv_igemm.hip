@@ -417,9 +417,11 @@ extern "C" int vsp_winograd4f_weight_f32(float* U, const float* wp, int cin, int
 extern "C" int vsp_conv2d_winograd4f_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   VSP_REQUIRE(pp != nullptr, "conv2d_winograd4f: null params");
   const vsp_conv_params& p = *pp;
-  VSP_REQUIRE(!p.transposed && p.G == 1 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1 &&
-                  (p.dil[0] == 1 || p.dil[0] == 2 || p.dil[0] == 4 || p.dil[0] == 8) && p.pad_y[0] == p.dil[0] && p.pad_x[0] == p.dil[0],
-              "conv2d_winograd4f: one group, 3x3, stride 1, dilation 1 / 2 / 4 / 8, padding = dilation");
+  VSP_REQUIRE(!p.transposed && p.G >= 1 && p.G <= 4 && p.KH == 3 && p.KW == 3 && p.stride_y == 1 && p.stride_x == 1,
+              "conv2d_winograd4f: 3x3, stride 1, one group or up to four dilation groups over one shared input");
+  for (int g = 0; g < p.G; ++g)
+    VSP_REQUIRE((p.dil[g] == 1 || p.dil[g] == 2 || p.dil[g] == 4 || p.dil[g] == 8) && p.pad_y[g] == p.dil[g] && p.pad_x[g] == p.dil[g],
+                "conv2d_winograd4f: dilation 1 / 2 / 4 / 8, padding = dilation");
   VSP_REQUIRE(p.io_bf16 == 0 && p.dil_by_input_quarter == 0 && p.in_shift == nullptr, "conv2d_winograd4f: fp32, no affine input shift");
   VSP_REQUIRE(p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.OH == p.H && p.OW == p.W, "conv2d_winograd4f: dense same-size output");
   VSP_REQUIRE(vsp::aligned16(p.w), "conv2d_winograd4f: weights must be 16-byte aligned");
@@ -440,7 +442,7 @@ extern "C" int vsp_conv2d_winograd4f_f32(const vsp_conv_params* pp, vsp_stream_t
     q.wsh_cs = 0;
   }
   if (!vspconv::wino4f_eligible(q))
-    return vsp::fail(VSP_ENOTSUP, "conv2d_winograd4f: needs Cin %% 8 == 0 (<= 256), H, W %% 4 == 0, W >= 16, dense 16-byte aligned input / output / noise / residual planes < 2 GiB per image");
+    return vsp::fail(VSP_ENOTSUP, "conv2d_winograd4f: needs Cin %% 8 == 0 (<= 512), H, W %% (4 x dilation) == 0, W >= 16, groups over one shared input, dense 16-byte aligned input / output / noise / residual planes < 2 GiB per image");
   if (int rc = vspconv::wino4f_launch(q, vsp::as_stream(stream))) return rc;
   return vsp::check_launch("conv2d_winograd4f");
 }

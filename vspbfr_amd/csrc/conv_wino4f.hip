@@ -38,12 +38,15 @@ constexpr int F4_THR = 256;
 constexpr int F4_SLAB = 18 * 64 * 4;          // floats of one (half, k-step) slab in HBM
 constexpr int F4_SLABL = 5 * F4_THR * 4;      // floats of one LDS ring slot: five 16-byte chunks per thread (the last half-round lands in the slot's tail)
 constexpr int F4_RING = 3;
-constexpr int F4_MAXC = 256;                  // input channels of the scale table
+constexpr int F4_MAXC = 512;                  // input channels of the scale table
 constexpr int F4_LDS = F4_RING * F4_SLABL + F4_MAXC + 32 * 4;
 constexpr int F4_OOB = 0x7ffffff0;
 
 struct F4Plan {
-  int nwg, items, J, nbx, nbyg, nco2, nks;
+  int nwg, items, J, nbx, nbyg, nco2, nks;      // nwg: workgroups that share these items (the launch, or one group's partition of it)
+};
+struct F4PlanG {
+  F4Plan g[4];
 };
 
 // ------------------------------------------------------------------------------------------------------------ weights: U = G g G^T
@@ -152,11 +155,12 @@ constexpr int f4ab = 0;
 
 // RES: residual operands present; ACT1: first activation present (compile-time: a branch in the epilogue is a join, and hipcc waits for
 // every store in flight at a join -- the first build spent 43 % of its time there)
+// g: the workgroup's index among the pl.nwg that share the plan's items; grp: the dilation group (channels grp * cout_g ... of every per-channel
+// operand, of y and of the residuals; weight slabs of that group) -- 0 for a one-group layer
 template <bool RES, bool ACT1, int D>
-__global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, const F4Plan pl) {
+__device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float* smem, const int g, const int grp) {
   using GE = F4G<D>;
   constexpr int DD = GE::DD;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem + F4_RING * F4_SLABL;
   float* Et = Sc + F4_MAXC;
   float* Wr = Et + 32 * 4;               // (D >= 1) window ring: three slots of GE::SLOT floats
@@ -167,13 +171,12 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chw = p.H * p.W;
   const int nks = pl.nks;
-  const int Cout = p.cout_g;
+  const int Cout = p.cout_g, cgo = grp * p.cout_g, Ctot = p.G * p.cout_g;
   const int y_plane = p.y_h * p.y_w;
   const float nw = p.nwp[0];
-  const int g = blockIdx.x;
   const int slot = (g & 7) * (pl.nwg >> 3) + (g >> 3);      // workgroups of one XCD (g % 8) walk neighbouring items
   const int it0 = slot * pl.J, it1 = min(pl.items, it0 + pl.J);
-  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, pl.nco2 * nks * F4_SLAB * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w) + (int64_t)grp * pl.nco2 * nks * F4_SLAB, 0, pl.nco2 * nks * F4_SLAB * 4, 0x00020000);
   lds_f4* const Ul4 = (lds_f4*)(lds_f*)smem;
   // constant pairs of B^T (conv_wino4.hip header): C1 = (-b2, -a2), C2 = (-(a2 + b2), a2 b2), C3 = (a, b)
   const f32x2f C1 = {-FB2, -FA2}, C2 = {-FSUM2, FA2B2}, C3 = {FA, FB};
@@ -347,12 +350,12 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
 
     // ---- per-item tables: style scale per input channel, epilogue operands of this half's 32 output channels
     __syncthreads();   // (the previous item's epilogue read Et)
-    if (tid < p.Cin) Sc[tid] = p.wtp[(int64_t)b * p.wt_bs + (int64_t)tid * p.wt_cs];
+    for (int c = tid; c < p.Cin; c += F4_THR) Sc[c] = p.wtp[(int64_t)b * p.wt_bs + (int64_t)c * p.wt_cs];
     if (tid >= 64 && tid < 96) {
       const int j = tid - 64;
       const int cgi = 32 * half + j;
-      const int cg = cgi < Cout ? cgi : Cout - 1;
-      const float os = p.osp[((int64_t)b * Cout + cg) * p.oss], cs = p.csp[cg * p.css];
+      const int cg = cgo + (cgi < Cout ? cgi : Cout - 1);
+      const float os = p.osp[((int64_t)b * Ctot + cg) * p.oss], cs = p.csp[cg * p.css];
       *reinterpret_cast<f32x4f*>(Et + 4 * j) = f32x4f{os * cs, p.cbp[cg * p.cbs] + p.b1p[cg * p.b1s], p.b2p[cg * p.b2s], p.s2p[cg * p.s2s]};
     }
     __syncthreads();
@@ -523,11 +526,11 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
     const int xq_e = DD == 8 ? x0 + (lr_e & 7) : x0 + (lr_e & (DD - 1)) + 4 * DD * (lr_e / DD);
     if (wave_ok && xq_e < p.W && !(f4ab & 16)) {
       const int ybytes = Cout * y_plane * 4;
-      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + ((int64_t)b * p.y_ch + p.y_coff) * y_plane, 0, ybytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + ((int64_t)b * p.y_ch + p.y_coff + cgo) * y_plane, 0, ybytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t r1rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.r1p + ((int64_t)b * p.res_ch + p.res_coff) * y_plane * p.r1s), 0, p.r1s ? ybytes : 16, 0x00020000);
+          const_cast<float*>(p.r1p + ((int64_t)b * p.res_ch + p.res_coff + cgo) * y_plane * p.r1s), 0, p.r1s ? ybytes : 16, 0x00020000);
       const __amdgpu_buffer_rsrc_t r2rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<float*>(p.r2p + ((int64_t)b * p.res_ch + p.res_coff) * y_plane * p.r2s), 0, p.r2s ? ybytes : 16, 0x00020000);
+          const_cast<float*>(p.r2p + ((int64_t)b * p.res_ch + p.res_coff + cgo) * y_plane * p.r2s), 0, p.r2s ? ybytes : 16, 0x00020000);
       const __amdgpu_buffer_rsrc_t nzrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.nzp + (int64_t)b * p.OH * p.OW * p.nzs), 0,
                                                                             p.nzs ? p.OH * p.OW * 4 : 16, 0x00020000);
       const int y0_e = DD == 8 ? ry + 2 * wave + (lr_e >> 3) : y0;
@@ -619,13 +622,37 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, c
   }
 }
 
+template <bool RES, bool ACT1, int D>
+__global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_kernel(const ConvK p, const F4Plan pl) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f4_body<RES, ACT1, D>(p, pl, smem, blockIdx.x, 0);
+}
+
+// Up to four dilation groups over ONE shared input (SMART branches, dilation 1 / 2 / 4 / 8) in one launch: the grid is cut into one partition
+// of workgroups per group, each running the body of its group's dilation on its group's items (four launches of 128 items each leave half the
+// chip idle on 512 -> 4 x 128 at 64^2; together they fill it).
+template <bool RES, bool ACT1>
+__global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_groups_kernel(const ConvK p, const F4PlanG pg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nwgp = pg.g[0].nwg;
+  const int grp = blockIdx.x / nwgp, g = blockIdx.x - grp * nwgp;
+  const int d = p.dil[grp];
+  if (d == 1) f4_body<RES, ACT1, 0>(p, pg.g[grp], smem, g, grp);
+  else if (d == 2) f4_body<RES, ACT1, 2>(p, pg.g[grp], smem, g, grp);
+  else if (d == 4) f4_body<RES, ACT1, 4>(p, pg.g[grp], smem, g, grp);
+  else f4_body<RES, ACT1, 8>(p, pg.g[grp], smem, g, grp);
+}
+
 }  // namespace
 
 // layers the fused F(4x4) form serves: one group, dilation 1, style scale only (no affine shift), whole 4 x 4 tiles, 16-byte rows, dense output
 bool wino4f_eligible(const ConvK& q) {
-  const int d = q.dil[0];
-  if (q.G != 1 || (d != 1 && d != 2 && d != 4 && d != 8) || q.pady[0] != d || q.padx[0] != d || q.Cin % 8 != 0 || q.Cin > F4_MAXC) return false;
-  if (q.H % (4 * d) != 0 || q.W % (4 * d) != 0 || q.W < 16 || q.H < 4) return false;   // whole 4 x 4 tiles in every polyphase sub-image
+  if (q.G < 1 || q.G > 4 || (q.G > 1 && q.x_gs != 0) || q.Cin % 8 != 0 || q.Cin > F4_MAXC || q.W < 16 || q.H < 4) return false;
+  for (int g = 0; g < q.G; ++g) {
+    const int d = q.dil[g];
+    if ((d != 1 && d != 2 && d != 4 && d != 8) || q.pady[g] != d || q.padx[g] != d) return false;
+    if (q.H % (4 * d) != 0 || q.W % (4 * d) != 0) return false;   // whole 4 x 4 tiles in every polyphase sub-image
+  }
   if (q.y_w != q.OW || q.y_h != q.OH) return false;
   if (q.wshp != nullptr && q.wsh_cs != 0) return false;
   if (reinterpret_cast<uintptr_t>(q.x) & 15) return false;
@@ -634,6 +661,7 @@ bool wino4f_eligible(const ConvK& q) {
       (q.nzs && (reinterpret_cast<uintptr_t>(q.nzp) & 15)))
     return false;
   if ((int64_t)q.Cin * q.H * q.W * 4 >= 0x7fffff00ll || (int64_t)q.cout_g * q.y_h * q.y_w * 4 >= 0x7fffff00ll) return false;
+  if ((int64_t)q.G * ((q.cout_g + 31) / 32) * (q.Cin / 4) * F4_SLAB * 4 >= 0x7fffff00ll) return false;
   return true;
 }
 
@@ -650,20 +678,47 @@ int wino4f_weight_launch(float* U, const float* wp, int cin, int cout, hipStream
 }
 
 // q.w = U4F (wino4f_weight_launch)
-int wino4f_launch(ConvK q, hipStream_t stream) {
-  F4Plan pl;
-  pl.nks = q.Cin / 4;
-  pl.nco2 = (q.cout_g + 31) / 32;
-  pl.nbx = q.dil[0] == 8 ? (q.W + 31) / 32 : (q.W + 63) / 64;
-  pl.nbyg = q.dil[0] == 8 ? (q.H + 31) / 32 : (q.H + 15) / 16;
-  const int64_t items = (int64_t)q.B * pl.nbyg * pl.nbx * pl.nco2;
+static int f4_plan(const ConvK& q, int d, int nwg, F4Plan* pl) {
+  pl->nks = q.Cin / 4;
+  pl->nco2 = (q.cout_g + 31) / 32;
+  pl->nbx = d == 8 ? (q.W + 31) / 32 : (q.W + 63) / 64;
+  pl->nbyg = d == 8 ? (q.H + 31) / 32 : (q.H + 15) / 16;
+  const int64_t items = (int64_t)q.B * pl->nbyg * pl->nbx * pl->nco2;
   if (items > 0x7fffffff) return vsp::fail(VSP_EINVAL, "conv2d_winograd4f: too many tiles");
-  pl.items = (int)items;
+  pl->items = (int)items;
+  pl->J = (pl->items + nwg - 1) / nwg;
+  pl->nwg = nwg;
+  return VSP_OK;
+}
+
+int wino4f_launch(ConvK q, hipStream_t stream) {
   static const int wgs_env = getenv("VSP_WINO4F_WGS") ? atoi(getenv("VSP_WINO4F_WGS")) : 0;
   int nwg = wgs_env > 0 ? (wgs_env + 7) / 8 * 8 : vsp::kNumCU;
-  pl.J = (pl.items + nwg - 1) / nwg;
-  pl.nwg = nwg;
   const bool res = q.r1s || q.r2s, act1 = !(q.s1 == 1.f && q.g1 == 1.f);
+  if (q.G > 1) {   // dilation groups: one partition of workgroups per group (a multiple of 8: the XCD walk of the body)
+    F4PlanG pg;
+    const int nwgp = nwg / q.G / 8 * 8;
+    if (nwgp < 8) return vsp::fail(VSP_EINVAL, "conv2d_winograd4f: too few workgroups for %d groups", q.G);
+    for (int g = 0; g < 4; ++g)
+      if (int rc = f4_plan(q, q.dil[g < q.G ? g : 0], nwgp, &pg.g[g])) return rc;
+    const size_t lds = (size_t)F4G<4>::LDS * sizeof(float);       // (the largest of the four bodies)
+    static_assert(F4G<4>::LDS >= F4G<8>::LDS && F4G<4>::LDS >= F4G<2>::LDS && F4G<4>::LDS >= F4G<0>::LDS, "LDS of the group launch");
+#define F4_LAUNCH_G(RES_, ACT_)                                                                                                   \
+  do {                                                                                                                            \
+    static vsp::LdsAttrOnce attr;                                                                                                 \
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_wino4f_groups_kernel<RES_, ACT_>), (int)lds, "conv2d_winograd4f")) return rc; \
+    conv_wino4f_groups_kernel<RES_, ACT_><<<nwgp * q.G, F4_THR, lds, stream>>>(q, pg);                                            \
+  } while (0)
+    if (res) {
+      if (act1) F4_LAUNCH_G(true, true); else F4_LAUNCH_G(true, false);
+    } else {
+      if (act1) F4_LAUNCH_G(false, true); else F4_LAUNCH_G(false, false);
+    }
+#undef F4_LAUNCH_G
+    return VSP_OK;
+  }
+  F4Plan pl;
+  if (int rc = f4_plan(q, q.dil[0], nwg, &pl)) return rc;
   // loader: dilation 1 = window loads into registers (D = 0) unless VSP_WINO4F_LDS=1 asks for the LDS loader (D = 1); dilation 2 / 4 / 8 = LDS loader
   static const int lds_env = getenv("VSP_WINO4F_LDS") ? atoi(getenv("VSP_WINO4F_LDS")) : 0;
   const int dsel = q.dil[0] == 1 ? (lds_env ? 1 : 0) : q.dil[0];

@@ -88,14 +88,10 @@ CONFIG_IDS = _config_ids()
 TUNE = {k: CONFIG_IDS[v] for k, v in _load_tune_table().items() if v in CONFIG_IDS}
 # shapes where a Winograd kernel won: True = F(2x2,3x3) (vsp_conv2d_winograd_f32), 4 = F(4x4,3x3) (vsp_conv2d_winograd4_f32, deep layers)
 #   5 = F(4x4,3x3) fused in registers (vsp_conv2d_winograd4f_f32, shallow wide layers)
-#   "winograd+f4f0": a dilation-group launch whose first group (dilation 1: a plain convolution) runs on the fused F(4x4) kernel and the
-#   other groups on the F(2x2) kernels (two launches, round 5)
-#   "winograd4f+groups": EVERY group of a dilation-group launch as its own launch of the fused F(4x4) kernel (dilated groups: its LDS window
-#   loader on the polyphase sub-images; groups it cannot serve stay on the F(2x2) kernels)
+#   (also the SMART dilation-group launches of 128 / 256 channels: one launch, a partition of workgroups per group, dilated groups through the
+#   kernel's LDS window loader)
 WINO = {k: ({"winograd4": 4, "winograd4f": 5}.get(v, True)) for k, v in _load_tune_table().items()
-        if v in ("winograd", "winograd4", "winograd4f", "winograd+f4f0", "winograd4f+groups")}
-SPLIT_G0 = {k for k, v in _load_tune_table().items() if v == "winograd+f4f0"} if os.environ.get("VSP_SPLIT_G0", "1") != "0" else set()
-SPLIT_ALL = {k for k, v in _load_tune_table().items() if v == "winograd4f+groups"} if os.environ.get("VSP_SPLIT_GROUPS", "1") != "0" else set()
+        if v in ("winograd", "winograd4", "winograd4f")}
 
 
 def _load_bf16_tune(name="conv_tune_bf16.json"):
@@ -298,7 +294,7 @@ class PackedConv:
     Built once per device on first use (pack_weight below; cached on the owning module)."""
 
     __slots__ = ("w", "G", "cout_g", "cin", "kh", "kw", "stride", "dil", "pad_y", "pad_x", "x_group_stride", "dil_by_input_quarter",
-                 "_wino", "_wino4", "_wino4f", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg", "_split0", "_splitg")
+                 "_wino", "_wino4", "_wino4f", "_bf16", "_bf16x3", "_bf16rv", "_bf16dg")
 
     def __init__(self, w, G, cout_g, cin, kh, kw, stride=1, dil=(1,), pad_y=(0,), pad_x=None, x_group_stride=0, dil_by_input_quarter=False):
         self.w, self.G, self.cout_g, self.cin, self.kh, self.kw = w, G, cout_g, cin, kh, kw
@@ -318,23 +314,6 @@ class PackedConv:
         self._bf16x3 = None
         self._bf16rv = None
         self._bf16dg = None
-        self._split0 = None
-        self._splitg = None
-
-    def split_first_group(self):
-        """(group 0 as a one-group layer, the remaining groups) of a shared-input dilation-group layer: views of the packed weight."""
-        if self._split0 is None:
-            g = self.G
-            self._split0 = (PackedConv(self.w[:1], 1, self.cout_g, self.cin, self.kh, self.kw, self.stride, self.dil[:1], self.pad_y[:1], self.pad_x[:1]),
-                            PackedConv(self.w[1:], g - 1, self.cout_g, self.cin, self.kh, self.kw, self.stride, self.dil[1:g], self.pad_y[1:g], self.pad_x[1:g]))
-        return self._split0
-
-    def split_groups(self):
-        """every group of a shared-input dilation-group layer as a one-group layer (views of the packed weight)"""
-        if self._splitg is None:
-            self._splitg = tuple(PackedConv(self.w[g:g + 1], 1, self.cout_g, self.cin, self.kh, self.kw, self.stride, self.dil[g:g + 1],
-                                            self.pad_y[g:g + 1], self.pad_x[g:g + 1]) for g in range(self.G))
-        return self._splitg
 
     @property
     def cout(self):
@@ -614,23 +593,25 @@ def winograd4_weight(wp):
 
 
 def winograd4f_weight(wp):
-    """packed weights (1, 9, Cin, Cout) -> U = G g G^T of F(4x4,3x3) in the order of vsp_conv2d_winograd4f_f32
-    ([co / 32][ci / 4][position pair][lane][4], include/vspbfr_hip.h)."""
+    """packed weights (G, 9, Cin, cout_g) -> U = G g G^T of F(4x4,3x3) in the order of vsp_conv2d_winograd4f_f32
+    ([group][co / 32][ci / 4][position pair][lane][4], include/vspbfr_hip.h)."""
     wp = _req(wp, "packed weight")
     ng, taps, cin, cout = wp.shape
-    if ng != 1 or taps != 9:
-        raise RuntimeError("winograd4f_weight: one group of 3x3 taps")
-    U = torch.empty(lib.vsp_winograd4f_weight_floats(cin, cout), device=wp.device, dtype=torch.float32)
-    check(lib.vsp_winograd4f_weight_f32(_ptr(U), _ptr(wp), cin, cout, _stream()), "winograd4f_weight")
+    if taps != 9:
+        raise RuntimeError("winograd4f_weight: 3x3 taps")
+    n = lib.vsp_winograd4f_weight_floats(cin, cout)
+    U = torch.empty(ng * n, device=wp.device, dtype=torch.float32)
+    for g in range(ng):
+        check(lib.vsp_winograd4f_weight_f32(_ptr(U[g * n:]), _ptr(wp[g]), cin, cout, _stream()), "winograd4f_weight")
     return U
 
 
 def winograd4f_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0), in_shift=None):
-    """fused F(4x4,3x3): one group, 3x3 / stride 1 / padding = dilation in (1, 2, 4, 8) -- dilated layers run on their polyphase sub-images:
-    whole 4x4 tiles in each (H, W multiples of 4 x dilation) --, no affine shift, Cin a multiple of 8 up to 256, rows of at least 16 pixels"""
-    d = pc.dil[0]
-    return (winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset) and pc.G == 1 and d in (1, 2, 4, 8) and in_shift is None
-            and pc.cin % 8 == 0 and pc.cin <= 256 and H % (4 * d) == 0 and W % (4 * d) == 0 and W >= 16)
+    """fused F(4x4,3x3): one group or up to four dilation groups over one shared input, 3x3 / stride 1 / padding = dilation in (1, 2, 4, 8)
+    -- dilated groups run on their polyphase sub-images: whole 4x4 tiles in each (H, W multiples of 4 x dilation) --, no affine shift, Cin a
+    multiple of 8 up to 512, rows of at least 16 pixels"""
+    return (winograd_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset) and in_shift is None
+            and pc.cin % 8 == 0 and pc.cin <= 512 and W >= 16 and all(H % (4 * pc.dil[g]) == 0 and W % (4 * pc.dil[g]) == 0 for g in range(pc.G)))
 
 
 def winograd4_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_offset=(0, 0), in_shift=None):
@@ -668,36 +649,6 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         if pref == 0 and B != 8:  # the table was measured at batch 8; large layers keep their tile at other batches
             pref = TUNE.get("8" + key[key.index(","):], 0)
         tile_hint = -pref  # negative = preference: falls back to the cost model when it cannot serve this call's operands
-    splittable = (winograd is None and bf16 is None and not BF16_CONV and tile_hint <= 0 and pc.G >= 2
-                  and pc.x_group_stride == 0 and not pc.dil_by_input_quarter and not transposed and in_shift is None and x.dtype == torch.float32
-                  and all(v is None for v in (ch_scale, ch_bias, bias1, bias2, prelu, noise, res1, res2)) and not act1 and not act2
-                  and out_stride == (1, 1) and out_offset == (0, 0))
-    if key in SPLIT_ALL and splittable:
-        # every group is a one-group (dilated) convolution over the shared input: four launches of the fused F(4x4) kernel
-        # (tools/bench_wino4f_dil.py: 128 -> 32 at 256^2 155 / 179 / 181 / 190 us at dilation 1 / 2 / 4 / 8 against 250 / 313 / 307 / 319 on the
-        # F(2x2) kernels; the one-launch F(2x2) form of the four groups: 1096 us)
-        if out is None:
-            out = torch.empty(B, pc.cout, OH, OW, device=x.device, dtype=torch.float32)
-        cg = pc.cout_g
-        for g, pcg in enumerate(pc.split_groups()):
-            osg = out_scale[:, g * cg:(g + 1) * cg].contiguous() if out_scale is not None else None
-            conv2d_packed(x, pcg, out=out, y_coff=y_coff + g * cg, in_scale=in_scale, in_scale_per_sample=in_scale_per_sample, out_scale=osg, n_out=n_out,
-                          winograd=5 if winograd4f_eligible(pcg, H, W, OH, OW) else True)
-        return out
-    if key in SPLIT_G0 and splittable and pc.dil[0] == 1:
-        # group 0 (dilation 1) is a plain convolution over the shared input: the fused F(4x4) kernel; the other groups keep the F(2x2)
-        # kernels (tools/bench_group_split.py: 128 -> 4 x 32 at 256^2 1096 -> 913 us, 256 -> 4 x 64 at 128^2 836 -> 712, same box)
-        pc0, pcr = pc.split_first_group()
-        if winograd4f_eligible(pc0, H, W, OH, OW):
-            if out is None:
-                out = torch.empty(B, pc.cout, OH, OW, device=x.device, dtype=torch.float32)
-            cg = pc.cout_g
-            os0 = out_scale[:, :cg].contiguous() if out_scale is not None else None
-            osr = out_scale[:, cg:].contiguous() if out_scale is not None else None
-            conv2d_packed(x, pc0, out=out, y_coff=y_coff, in_scale=in_scale, in_scale_per_sample=in_scale_per_sample, out_scale=os0, n_out=n_out, winograd=5)
-            conv2d_packed(x, pcr, out=out, y_coff=y_coff + cg, in_scale=in_scale, in_scale_per_sample=in_scale_per_sample, out_scale=osr, n_out=n_out,
-                          winograd=True)
-            return out
     bf_ok = bf16_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset)
     x3 = bf16 == "x3" or (bf16 is None and BF16_CONV == "x3")
     rv = None          # the row-vector-K kernel (vsp_conv2d_bf16rv): "rv" forces it, None = where it is eligible and measured faster
