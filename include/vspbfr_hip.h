@@ -206,12 +206,18 @@ int vsp_conv2d_winograd_mbw(int cout_g);
  *         = U[position 3*wave + q][ci = 4*chunk + (lane >> 4)][co = 64*tile + 16*mb + (lane & 15)],   U = G g G^T
  * (one wave-wide 16-byte load = 1 KiB of consecutive memory). */
 int vsp_conv2d_winograd4_f32(const vsp_conv_params* p, float* work, size_t work_floats, vsp_stream_t stream);
-/* Winograd F(4x4,3x3), FUSED form for the shallow wide layers (round 5, conv_wino4f.hip): the same layer class as vsp_conv2d_winograd4_f32
- * (one group, 3x3, stride 1, dilation 1, padding 1, fp32, style scale `in_scale` but no `in_shift`, dense same-size output) without a work
- * buffer -- the input transform runs in registers in the MFMA's fragment layout, the transformed input never exists in memory.  Serves
- * Cin % 8 == 0 (<= 256), H % 4 == 0, W % 4 == 0 (>= 16); made for 32 / 64-channel layers on maps >= 128^2 (reference
- * e4e/models/stylegan2/model.py:268-276, models/RestoreNet.py:421-555), where the two-kernel form's V round trip costs more than it saves.
- * `w` = vsp_winograd4f_weight_f32's output: U = G g G^T (the same 36 values per (ci, co) as vsp_winograd4_weight_f32) in the order
+/* Winograd F(4x4,3x3), FUSED form (round 5, conv_wino4f.hip): the layer class of vsp_conv2d_winograd4_f32 (3x3, stride 1, fp32, style scale
+ * `in_scale` but no `in_shift`, dense same-size output) without a work buffer -- the input transform runs in registers in the MFMA's
+ * fragment layout, the transformed input never exists in memory.  Serves Cin % 8 == 0 (<= 512), W >= 16 and
+ *   - one group with padding = dilation in {1, 2, 4, 8}, H and W multiples of 4 x dilation: dilation 1 = the 32 / 64-channel layers on maps
+ *     >= 128^2 (reference e4e/models/stylegan2/model.py:268-276, models/RestoreNet.py:421-555), where the two-kernel form's V round trip
+ *     costs more than it saves; a dilated layer runs on its polyphase sub-images (tiles of 4 x 4 outputs `dilation` apart, windows read
+ *     from an LDS-staged region);
+ *   - G = 2..4 dilation groups over ONE shared input (x_group_stride = 0; the SMART branches models/RestoreNet.py:179-244), each group's
+ *     geometry as above, in one launch: group g writes channels y_coff + g * cout_g ..., and every per-channel operand (out_scale, ch_scale,
+ *     biases, prelu) and the residuals are indexed g * cout_g + channel -- the convention of vsp_conv2d_f32 for G > 1.
+ * `w` = vsp_winograd4f_weight_f32's output, per group and the groups one after the other: U = G g G^T (the same 36 values per (ci, co) as
+ * vsp_winograd4_weight_f32) in the order
  * [co / 32][ci / 4][position pair 18][lane 64][4]: lane = 16 (ci % 4) + (co % 16), element e = position 2 pp + (e >> 1), co block (e & 1).
  * VSP_ENOTSUP for a launch it does not serve (the caller falls back to vsp_conv2d_winograd_f32). */
 size_t vsp_winograd4f_weight_floats(int cin, int cout);
