@@ -430,7 +430,7 @@ def main():
         PEAK = {"f32": PEAK_FP32_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.conv_dtype]  # bf16x3: three MFMAs per product
         KERNEL_NOTE = ("conv family: conv_pipe_kernel (direct, double-buffered pipeline: stride-2 / transposed) + "
                        "conv_igemm_kernel / conv_smallmap_kernel (direct, small maps and 1x1) + conv_wino_ro_kernel / conv_wino_rod_kernel / "
-                       "conv_wino_rs_kernel / conv_wino_kernel (Winograd F(2x2,3x3): row-owner, dilation groups, register-resident U) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers); "
+                       "conv_wino_rs_kernel / conv_wino_kernel (Winograd F(2x2,3x3): row-owner, dilation groups, register-resident U) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers) + conv_wino4f_kernel / conv_wino4f_groups_kernel (Winograd F(4x4,3x3) fused in registers: shallow wide layers, dilation groups of 128 - 512 channels); "
                        "achieved / frac = FLOPs the matrix pipe EXECUTED / kernel time (F(2x2) launches run 16/36, F(4x4) launches 36/144 of their "
                        "direct-form count); algorithmic_tflops / algorithmic_frac = direct-form FLOPs / time, an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
             "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + conv_bf16_rv_kernel "
