@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void wino4f_weight_kernel(float* __restrict__ 
 //   written in that linear order by NI DMA instructions per wave (lane l of instruction n of wave w = quad (4 n + w) 64 + l; quads outside
 //   the image or the region have an out-of-range offset: the DMA writes zeros there -- tools/ubench/lds_dma_oob.hip -- the padding for free).
 //   Three slots: window ks + 4 is requested behind MFMA 53 of k-step ks, awaited (counted vmcnt) before the barrier of k-step ks + 1, read
-//   after MFMA 35 of k-step ks + 2.  (Dilation 8, two slots: requested behind the barrier of k-step ks instead -- into the slot read in that k-step.)
+//   behind MFMAs 37 .. 55 of k-step ks + 2, a row at a time.  (Dilation 8, two slots: requested behind the barrier of k-step ks instead -- into the slot read in that k-step.)
 template <int D>
 struct F4G {
   static constexpr int DD = D == 0 ? 1 : D;
@@ -222,8 +222,7 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
 
     f32x4f Rq[6];          // window rows: columns 1..4
     float Rh[6];           //              the N-block's outer column (lanes 0 / 15 of a 16-lane row)
-    f32x2f Rhp[6];         // (D == 1)     columns (0, 5)
-    f32x2f Wp[6][3];       // (D >= 2)     column pairs (1, 2), (3, 4), (0, 5)
+    f32x2f Wp[6][3];       // (D >= 1)     column pairs (0, 1), (2, 3), (4, 5)
     // ---- LDS loader: the lane's DMA source offsets (constant over the k-steps), its window base in a slot, the descriptor in scalar registers
     int dmo[GE::NI];
     const lds_f* Wl = nullptr;
@@ -256,21 +255,16 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
         F4_DMA(vo, rd, so_l, lbn);
       });
     };
-    auto read_w = [&](int ksw) {      // the lane's window of k-step ksw from its slot
+    auto read_row = [&](int ksw, auto Ic) {      // row i of the lane's window of k-step ksw from its slot
+      constexpr int i = decltype(Ic)::value;
       const lds_f* s = Wl + (ksw % GE::WS) * GE::SLOT;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if constexpr (D == 1) {
-          Rq[i] = *reinterpret_cast<const lds_f4*>(s + i * GE::RWP + 1);
-          Rhp[i] = f32x2f{s[i * GE::RWP], s[i * GE::RWP + 5]};
-        } else {
-          const lds_f* r = s + i * DD * GE::RWP;
-          Wp[i][0] = f32x2f{r[DD], r[2 * DD]};
-          Wp[i][1] = f32x2f{r[3 * DD], r[4 * DD]};
-          Wp[i][2] = f32x2f{r[0], r[5 * DD]};
-        }
-      }
+      // (column pairs (0, 1), (2, 3), (4, 5): what hipcc's ds_read2_b32 merging yields anyway -- and the column pass below is six packed FMAs on them)
+      const lds_f* r = s + i * DD * GE::RWP;
+      Wp[i][0] = f32x2f{r[0], r[DD]};
+      Wp[i][1] = f32x2f{r[2 * DD], r[3 * DD]};
+      Wp[i][2] = f32x2f{r[4 * DD], r[5 * DD]};
     };
+    auto read_w = [&](int ksw) { static_for<0, 6>([&](auto Ic) { read_row(ksw, Ic); }); };
     auto load_w = [&](int so_k) {
       Rq[0] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(xrs, vq0, so_k, 0));
       Rh[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vh0, so_k, 0));
@@ -292,10 +286,9 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const f32x4f q = Rq[i];
-        if constexpr (D >= 2) w[i] = Wp[i][X];
-        if constexpr (D <= 1 && X == 0) w[i] = f32x2f{q[0], q[1]};
-        if constexpr (D <= 1 && X == 1) w[i] = f32x2f{q[2], q[3]};
-        if constexpr (D == 1 && X == 2) w[i] = Rhp[i];
+        if constexpr (D >= 1) w[i] = Wp[i][X];
+        if constexpr (D == 0 && X == 0) w[i] = f32x2f{q[0], q[1]};
+        if constexpr (D == 0 && X == 1) w[i] = f32x2f{q[2], q[3]};
         if constexpr (D == 0 && X == 2) {
           const float hh = Rh[i];
           int lo = __builtin_bit_cast(int, hh), hi = lo;
@@ -328,9 +321,23 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
       constexpr int i = decltype(Ic)::value;
       const f32x2f c1 = C1, c3 = C3;
       const float fs = -FSUM2, fab = FA2B2;
+      f32x2f e12, o12, v12, v34;
+      if constexpr (D >= 1) {
+        // LDS loader: the pairs are (d0, d1), (d2, d3), (d4, d5) -- (V0, V5) = a2b2 (d0, d1) - (a2 + b2) (d2, d3) + (d4, d5) is two packed FMAs as well
+        const f32x2f c2 = C2;
+        const f32x2f P01 = Xt[0][i], P23 = Xt[1][i], P45 = Xt[2][i];
+        f32x2f n05, v05;
+        F4_PK(n05, c2, P23, P45, F4_SEL_AX);
+        F4_PK(e12, c1, P23, P45, " op_sel:[0,0,0] op_sel_hi:[1,0,0]");         // (-b2, -a2) d2 + d4
+        F4_PK(o12, c1, P01, P23, " op_sel:[0,1,1] op_sel_hi:[1,1,1]");         // (-b2, -a2) d1 + d3
+        F4_PK(v05, c2, P01, n05, F4_SEL_AY);
+        F4_PK(v12, c3, o12, e12, " op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_hi:[1,0,0]");
+        F4_PK(v34, c3, o12, e12, " op_sel:[1,1,1] op_sel_hi:[1,1,1] neg_hi:[1,0,0]");
+        T[i][0] = v05; T[i][1] = v12; T[i][2] = v34;
+        return;
+      }
       const f32x2f A = Xt[0][i], B = Xt[1][i], H = Xt[2][i];
       const float d0 = H[0], d1 = A[0], d2 = A[1], d3 = B[0], d4 = B[1], d5 = H[1];
-      f32x2f e12, o12, v12, v34;
       float n0, n5, v0, v5;
       F4_PK(e12, c1, A, B, " op_sel:[0,1,1] op_sel_hi:[1,1,1]");          // (-b2, -a2) d2 + d4
       F4_PK(o12, c1, A, B, " op_sel:[0,0,0] op_sel_hi:[1,0,0]");          // (-b2, -a2) d1 + d3
@@ -478,10 +485,7 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
               colpass(std::integral_constant<int, 2 * (run - 3) + 1>{}, Vn);
             }
           }
-          if constexpr (run == 2) {                                                   // window ks + 2 (the row passes are through with the registers)
-            if constexpr (D >= 1) read_w(ks + 2);
-            else load_w(so_r);
-          }
+          if constexpr (run == 2 && D == 0) load_w(so_r);                             // window ks + 2 (the row passes are through with the registers)
           if constexpr (!(f4ab & 2)) {
             if constexpr (run == 0) sc = ((lds_f*)Sc)[4 * k1 + kq];
             if constexpr (run == 1) { u_scale(std::integral_constant<int, 0>{}, sc); u_scale(std::integral_constant<int, 1>{}, sc); }
@@ -497,6 +501,10 @@ __device__ __forceinline__ void f4_body(const ConvK& p, const F4Plan& pl, float*
             ust[c] = __builtin_bit_cast(f32x4f, __builtin_amdgcn_raw_buffer_load_b128(urs, ci < F4_SLAB / 4 ? ci * 16 : F4_OOB, so_u, 0));
           }
         }
+        // (LDS loader) window ks + 2, one row at a time: LDS returns in order -- a U fragment read behind a burst of 36 reads from four waves
+        // at once waits for all of them; all rows before the barrier (two-slot ring: the request behind it overwrites this slot)
+        if constexpr (D >= 1 && (sl == 37 || sl == 41 || sl == 45 || sl == 49 || sl == 53 || sl == 55))
+          read_row(ks + 2, std::integral_constant<int, sl == 55 ? 5 : (sl - 37) / 4>{});
         if constexpr (D >= 1 && GE::WS == 3 && sl == 53) dma_w(ks + 4);
         if constexpr (sl == 56 && !(f4ab & 32)) {
           // (in flight, oldest first: window ks + 3, the five U chunks of this k-step, [three slots: window ks + 4] -- the first must have landed)
