@@ -255,7 +255,7 @@ def conv_traffic(B, args):
         tag = "c3_bf16act"
     elif args.conv_dtype == "bf16" and not args.act_bf16 and B == 8 and args.timesteps == 50 and args.sampler == "ddpm":
         tag = "b8_bf16"
-    for name in ({"c2_f32": ["r04_conv_traffic_pmc_c2_f32.json", "r03_conv_traffic_pmc_c2_f32.json", "r02_conv_traffic_pmc_c2_f32.json", "r01_conv_traffic_pmc.json"], "c3_bf16act": ["r04_conv_traffic_pmc_c3_bf16act.json", "r02_conv_traffic_pmc_c3_bf16act.json"],
+    for name in ({"c2_f32": ["r05_conv_traffic_pmc_c2_f32.json", "r04_conv_traffic_pmc_c2_f32.json", "r03_conv_traffic_pmc_c2_f32.json", "r02_conv_traffic_pmc_c2_f32.json", "r01_conv_traffic_pmc.json"], "c3_bf16act": ["r05_conv_traffic_pmc_c3_bf16act.json", "r04_conv_traffic_pmc_c3_bf16act.json", "r02_conv_traffic_pmc_c3_bf16act.json"],
                   "b8_bf16": ["r01_conv_traffic_pmc_bf16.json"]}.get(tag, [])):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):

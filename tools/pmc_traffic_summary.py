@@ -27,8 +27,9 @@ cal = {
 }
 bf = load(f"{out}/fetch/f_counter_collection.csv", "FETCH_SIZE")
 bw = load(f"{out}/write/w_counter_collection.csv", "WRITE_SIZE")
-FAMILIES = {"wino_f2": ("conv_wino_kernel", "conv_wino_ro_kernel"), "wino_f4": ("wino4_gemm_kernel", "wino4_input_kernel"),
-            "pipe": ("conv_pipe",), "igemm": ("conv_igemm",), "smallmap": ("conv_smallmap",), "bf16": ("conv_bf16_kernel",), "bf16_rv": ("conv_bf16_rv_kernel",)}
+FAMILIES = {"wino_f2": ("conv_wino_kernel", "conv_wino_ro_kernel", "conv_wino_rod_kernel", "conv_wino_rs_kernel"), "wino_f4": ("wino4_gemm_kernel", "wino4_input_kernel"),
+            "wino_f4_fused": ("conv_wino4f_kernel", "conv_wino4f_groups_kernel"),
+            "pipe": ("conv_pipe",), "igemm": ("conv_igemm",), "smallmap": ("conv_smallmap",), "bf16": ("conv_bf16_kernel",), "bf16_rv": ("conv_bf16_rv_kernel",), "bf16_dg": ("conv_bf16_dg_kernel",)}
 ALL = tuple(t for ts in FAMILIES.values() for t in ts)
 conv_f = [v for k, vs in bf.items() if any(t in k for t in ALL) for v in vs]
 conv_w = [v for k, vs in bw.items() if any(t in k for t in ALL) for v in vs]
@@ -48,7 +49,7 @@ for fam, keys in FAMILIES.items():
 res = {"calibration_true_over_reported": cal, "conv_launches_per_step": launches, "per_family": split,
        "conv_fetch_bytes_per_step": fetch_bytes, "conv_write_bytes_per_step": write_bytes,
        "conv_hbm_bytes_per_launch": (fetch_bytes + write_bytes) / max(launches, 1),
-       "note": "FETCH_SIZE/WRITE_SIZE (KiB) of all conv_igemm_kernel / conv_pipe_kernel / conv_smallmap_kernel / conv_wino(_ro)_kernel / wino4_input + wino4_gemm / conv_bf16_kernel / conv_bf16_rv_kernel dispatches of one bench step, each corrected by the factor "
+       "note": "FETCH_SIZE/WRITE_SIZE (KiB) of all conv_igemm_kernel / conv_pipe_kernel / conv_smallmap_kernel / conv_wino(_ro|_rod|_rs)_kernel / wino4_input + wino4_gemm / conv_wino4f(_groups)_kernel / conv_bf16_kernel / conv_bf16_rv_kernel / conv_bf16_dg_kernel dispatches of one bench step, each corrected by the factor "
                "measured on fba_scalar_kernel (4-byte accesses, 1.07 GB known traffic); separate PMC passes"}
 json.dump(res, open(f"{out}/conv_traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
