@@ -1789,3 +1789,15 @@ def test_smart_tail_backward(H, shape):
     close(gb1, db1.float(), 1e-4, 1e-4, "d bias1")
     close(gb2, db2.float(), 1e-4, 1e-4, "d bias2")
     close(gnw, dnw.float(), 1e-4, 1e-4, "d noise weight")
+
+
+@pytest.mark.gpu
+def test_bf16_pair_staging_bit_identical():
+    """bf16-activation conv kernel: pixel-pair staging tasks (one aligned 4-byte load for two neighbouring pixels) against the one-pixel tasks
+    (VSP_BF16_PAIR=0) -- bit-identical over stride-1 (plain, dilation groups, ragged maps), stride-2 (padding 0 / 1) and transposed launches
+    and their tile variants.  The switch is read once per process: tools/ab_bf16_pair.py runs both settings as child processes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ab_bf16_pair.py")], env=dict(os.environ, QUICK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count("bit-identical") >= 15, r.stdout[-3000:]

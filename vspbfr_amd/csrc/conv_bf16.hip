@@ -60,10 +60,15 @@ enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 // IOB: the activations are bf16 IN HBM (x, y and the two residuals; 2 B per element instead of 4: the bf16-activation
 // configuration, hip_ops.ACT_BF16): the patch is fetched as 16-bit loads (same instruction count, half the bytes: the 512^2 and
 // 256^2 layers are bound by what the fabric delivers), the epilogue reads / writes four bf16 per 8-byte access.
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false>
+// PAIR (bf16 activations, even W): a staging task is TWO neighbouring pixels (an aligned 4-byte load) instead of one 2-byte load.  A wave
+// load instruction costs the CU's vector-memory path 32 cycles whatever its width (tools/ubench/mfma_valu_gap.hip): with one bf16 element per
+// lane the staging of the whole chip is capped at 256 CUs x 4 B/clk = 2.1 TB/s -- which is what every layer of this kernel ran at (512 -> 512 at
+// 64^2, B = 16: 700 MB staged in 343 us) -- with the matrix pipe a third busy.
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false>
 __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   static_assert(!(SPLIT && IOB), "the split-precision form keeps fp32 activations");
+  static_assert(!PAIR || IOB, "pixel-pair staging is the bf16-activation form");
   using AT = typename std::conditional<IOB, vsp::bf16_t, float>::type;  // activation element in HBM
   constexpr unsigned ES = sizeof(AT);
   constexpr int NPART = SPLIT ? 2 : 1;
@@ -184,7 +189,43 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   const int NTASK = S2 ? (2 * PR - 1) * RC : PR * pitch;
   unsigned poff[PT];  // BYTE offset inside a channel plane, unsigned 32-bit: the loads take the scalar-base + lane-offset form
   int pdst[PT];
+  int pdst1[PAIR ? PT : 1];   // (PAIR) LDS slot of the task's second pixel
   unsigned pin = 0, pwr = 0;  // bit e: position inside the image / position exists in the plane
+  unsigned pwr1 = 0;          // (PAIR) second pixel exists in the plane
+  if constexpr (PAIR) {
+    // tasks = pixel PAIRS at even image columns (W is even: a pair lies wholly inside or wholly outside a row, its load is 4-byte aligned).
+    // Patch column 0 is image column x_first; when that is odd it is the SECOND pixel of its pair (s0 = 1).
+    const int x_first = S2 ? 2 * ox0 - p.padx[0] : ox0 - d;
+    const int s0 = x_first & 1;
+    const int NCOL = S2 ? 2 * PC - 1 : PC, NROW = S2 ? 2 * PR - 1 : PR;
+    const int NPC = (NCOL + s0 + 1) >> 1;
+    const int NT2 = NROW * NPC;
+#pragma unroll
+    for (int e = 0; e < PT; ++e) {
+      const int idx = pbase + 128 * e;
+      const int r = idx / NPC, c0 = 2 * (idx - r * NPC) - s0;
+      int iy;
+      bool row_in;
+      if constexpr (S2) {
+        iy = 2 * oy0 - p.pady[0] + r;
+        row_in = iy >= 0 && iy < p.H;
+      } else {
+        const int sy = oy0 - 1 + r;
+        iy = sy * d + ry;
+        row_in = sy >= 0 && iy < p.H;
+      }
+      const int ix = x_first + c0;
+      const bool task = idx < NT2;
+      const bool in = task && row_in && ix >= 0 && ix < p.W;
+      auto slot = [&](int c) { return S2 ? ((r & 1) * 2 + (c & 1)) * PLANE + (r >> 1) * pitch + (c >> 1) : r * pitch + c; };
+      pdst[e] = slot(c0);
+      pdst1[e] = slot(c0 + 1);
+      poff[e] = in ? (unsigned)(iy * p.W + ix) * ES : 0u;
+      pin |= in ? (1u << e) : 0u;
+      pwr |= (task && c0 >= 0) ? (1u << e) : 0u;
+      pwr1 |= (task && c0 + 1 < NCOL) ? (1u << e) : 0u;
+    }
+  } else {
 #pragma unroll
   for (int e = 0; e < PT; ++e) {
     const int idx = pbase + 128 * e;
@@ -209,6 +250,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     pin |= in ? (1u << e) : 0u;
     pwr |= wr ? (1u << e) : 0u;
   }
+  }
   const AT* xb = reinterpret_cast<const AT*>(p.x) + ((int64_t)b * p.x_ch + (int64_t)g * p.x_gs) * chw;
   // Two register sets: chunk k lives in set k & 1.  Its loads are issued TWO intervals before its MFMAs (top of interval
   // k - 2), its conversion + LDS write is spread over the tap loop of interval k - 1 (VALU work in the shadow of the MFMAs).
@@ -230,7 +272,9 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
       for (int e = 0; e < PT; ++e) {  // (tasks past the plane read element 0 and are never written)
-        if constexpr (IOB)  // the raw 16 bits (sign-extended by the load); widened to fp32 when the value is committed
+        if constexpr (PAIR)  // two neighbouring pixels: one aligned 4-byte load
+          pr[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)poff[e], soff, 0));
+        else if constexpr (IOB)  // the raw 16 bits (sign-extended by the load); widened to fp32 when the value is committed
           pr[e][j] = __builtin_bit_cast(float, (int)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (int)poff[e], soff, 0));
         else
           pr[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)poff[e], soff, 0));
@@ -257,6 +301,23 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     return c * BCK + 8 * oct < p.Cin;
   };
   auto commit_one = [&](u32x4* Pdst, const float (&pr)[PT][8], const float (&sc)[8], const float (&sh)[8], bool oct_ok, int e) {
+    if constexpr (PAIR) {
+      const bool in = ((pin >> e) & 1u) && oct_ok;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (!(((h ? pwr1 : pwr) >> e) & 1u)) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned w2 = __builtin_bit_cast(unsigned, pr[e][j]);
+          const float xv = __builtin_bit_cast(float, h ? (w2 & 0xffff0000u) : (w2 << 16));
+          v[j] = in ? fmaf(xv, sc[j], sh[j]) : 0.f;
+        }
+        Pdst[oct * NPL * PLANE + (h ? pdst1[e] : pdst[e])] =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      }
+      return;
+    }
     if (!((pwr >> e) & 1u)) return;
     const bool in = ((pin >> e) & 1u) && oct_ok;
     float v[8];
@@ -602,6 +663,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
 
 struct BfGeom {
   int twl, pitch, plane, pt, tab;
+  int pt2;      // staging tasks per thread when a task is a pixel pair (PAIR)
   size_t lds;
 };
 
@@ -637,6 +699,7 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
     npl = 4;
   }
   r.pt = (ntask + 127) / 128;
+  r.pt2 = ((mode == M_S2 ? (2 * PR - 1) * PC : PR * ((PC + 2) / 2)) + 127) / 128;   // (rows x pairs per row, the odd first column included)
   r.lds = ((size_t)2 * 9 * 2 * co_t + (size_t)2 * 2 * npl * r.plane) * 16 * npart;
   const size_t epi = (size_t)erows * npix * sizeof(float);  // epilogue transpose buffer
   if (epi > r.lds) r.lds = epi;
@@ -645,14 +708,24 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
   return r;
 }
 
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false>
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   if constexpr (!SPLIT && !IOB) {
-    if (q.io_bf16) return launch_bf<MB, NB, WM, WN, PT, MODE, false, true>(q, gm, stream);
+    if (q.io_bf16) {
+      // bf16 activations: pixel-pair staging wherever rows are 4-byte multiples (env VSP_BF16_PAIR=0: the one-pixel tasks, for A/B runs)
+      static const bool pair_env = !(getenv("VSP_BF16_PAIR") && atoi(getenv("VSP_BF16_PAIR")) == 0);
+      if (pair_env && (q.W & 1) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 3) == 0) {
+        if (gm.pt2 <= 1) return launch_bf<MB, NB, WM, WN, 1, MODE, false, true, true>(q, gm, stream);
+        if (gm.pt2 <= 2) return launch_bf<MB, NB, WM, WN, 2, MODE, false, true, true>(q, gm, stream);
+        if (gm.pt2 <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE, false, true, true>(q, gm, stream);
+        if (gm.pt2 <= 5 && PT >= 5) return launch_bf<MB, NB, WM, WN, 5, MODE, false, true, true>(q, gm, stream);
+      }
+      return launch_bf<MB, NB, WM, WN, PT, MODE, false, true>(q, gm, stream);
+    }
   }
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
   static vsp::LdsAttrOnce attr;   // per device
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB>), 150 * 1024, "conv2d_bf16")) return rc;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR>), 150 * 1024, "conv2d_bf16")) return rc;
   q.tw_log2 = gm.twl;
   q.bf_pitch = gm.pitch;
   q.bf_plane = gm.plane;
@@ -693,7 +766,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
     }
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB><<<grid, BNT, gm.lds, stream>>>(q);
+  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR><<<grid, BNT, gm.lds, stream>>>(q);
   return VSP_OK;
 }
 
