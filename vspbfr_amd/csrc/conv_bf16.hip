@@ -358,30 +358,6 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
         __builtin_amdgcn_global_load_lds(src + row * co_pad + co0 + co, Wdst + i * 64, 16, 0, 0);
     }
   };
-#ifndef VSP_BF16_EARLY_DMA
-#define VSP_BF16_EARLY_DMA 1
-#endif
-  // The same DMA hidden from hipcc (inline asm, M0 saved / set / restored in the statement).  With a DMA it knows of in flight hipcc waits
-  // vmcnt(0) at the first use of ANY loaded register, which forced the request of chunk c + 1 behind the last commit of interval c -- its
-  // round trip then sat in front of the interval's closing barrier, once per chunk (512 -> 512 at 64^2: 6.6k cycles per chunk for 2.3k cycles of
-  // MFMAs).  Hidden, it is requested at the TOP of the interval (the slab it overwrites was released by the previous barrier) and has the
-  // whole interval to land; the explicit vmcnt(0) in front of the closing barrier covers it.
-  auto issue_w_early = [&](u32x4* Wdst, int c) {
-    const u32x4* src = wsrc + (int64_t)c * (NPART * T * 2) * co_pad;
-#pragma unroll
-    for (int k = 0; k < (NDMA + 3) / 4; ++k) {
-      const int i = wave + 4 * k;
-      const int L = i * 64 + lane;
-      const int row = L / CO_T, co = L - row * CO_T;
-      if (i < NDMA && co0 + co < co_pad) {
-        const u32x4* gsrc = src + row * co_pad + co0 + co;
-        const unsigned ldst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) u32x4*)(Wdst + i * 64));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
-      }
-    }
-  };
-  constexpr bool EARLY = DEEP && !COMMIT_FIRST && bool(VSP_BF16_EARLY_DMA);
 
   // ---- fragments
   int pixpos[NB];
@@ -418,9 +394,6 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
       if (c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
       if (c + 2 < nchunk) issue_p(prLoad, c + 2);
     } else if constexpr (DEEP) {
-      if constexpr (EARLY) {
-        if (c + 1 < nchunk) issue_w_early(Wl + nxt * WSLAB, c + 1);
-      }
       if (c + 2 < nchunk) issue_p(prLoad, c + 2);
     } else {
       if (c + 1 < nchunk) {
@@ -462,7 +435,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           }
         if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
-          if (!EARLY && tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
+          if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
         }
       }
     } else {
@@ -497,7 +470,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
           }
         if constexpr (DEEP && !COMMIT_FIRST) {
           if (tap < PT) commit_one(Pn, prCommit, sc, sh, oct_ok, tap);
-          if (!EARLY && tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
+          if (tap == DMA_TAP && c + 1 < nchunk) issue_w(Wl + nxt * WSLAB, c + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -508,7 +481,6 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
         for (int e = 0; e < PT; ++e) commit_one(Pn, prCommit, sc, sh, oct_ok, e);
       }
     }
-    if constexpr (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the hidden weight DMA of this interval)
     __syncthreads();
   };
   // Epilogue operands of the tile's channels: ONE table in LDS (scale = out_scale x ch_scale, bias = ch_bias + bias1, bias2, slope2),
