@@ -311,10 +311,11 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
         for (int j = 0; j < 8; ++j) {
           const unsigned w2 = __builtin_bit_cast(unsigned, pr[e][j]);
           const float xv = __builtin_bit_cast(float, h ? (w2 & 0xffff0000u) : (w2 << 16));
-          v[j] = in ? fmaf(xv, sc[j], sh[j]) : 0.f;
+          v[j] = fmaf(xv, sc[j], sh[j]);
         }
-        Pdst[oct * NPL * PLANE + (h ? pdst1[e] : pdst[e])] =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        // (the padding select on the four packed words instead of the eight values: a pixel outside the image loaded element 0 of its plane)
+        const u32x4 pk = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        Pdst[oct * NPL * PLANE + (h ? pdst1[e] : pdst[e])] = in ? pk : u32x4{0u, 0u, 0u, 0u};
       }
       return;
     }
