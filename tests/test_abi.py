@@ -109,3 +109,34 @@ def test_operand_device_refusal_logic():
     assert not hasattr(H.conv_key, "__wrapped_op__")
     with pytest.raises(RuntimeError, match="different devices"):
         H.fused_bias_act(a, m, torch.zeros(0), 3, 0, 0.2, 1.0)
+
+
+def test_tuned_table_winograd_entries_name_eligible_layers():
+    """Every shape key of vspbfr_amd/conv_tune.json that names a Winograd kernel describes a layer that kernel's eligibility rule accepts
+    (a key the rule refuses would silently fall back at run time and the table's measurement would no longer describe what runs): the
+    fused F(4x4) kernel incl. its dilation-group launches (G = 4, dilations 1 / 2 / 4 / 8 over one shared input), the F(4x4) pair, F(2x2)."""
+    import json
+
+    from vspbfr_amd import hip_ops as H
+    table = json.load(open(os.path.join(ROOT, "vspbfr_amd", "conv_tune.json")))
+    seen = {"winograd": 0, "winograd4": 0, "winograd4f": 0}
+    for key, val in table.items():
+        if val not in seen:
+            continue
+        parts = key.split(",")
+        B, Cin, Hh, Ww, G, cg, kh, kw, stride, d0, OH, OW = (int(v) for v in parts[:12])
+        flags = parts[12:]
+        assert not any(f.startswith("g") or f in ("q", "t") for f in flags), key     # grouped-input / gradient / transposed layers have no Winograd form
+        dil = (1, 2, 4, 8)[:G] if G > 1 else (d0,)
+        pc = H.PackedConv(None, G, cg, Cin, kh, kw, stride, dil, dil)
+        shift = object() if "s" in flags else None
+        if val == "winograd4f":
+            ok = H.winograd4f_eligible(pc, Hh, Ww, OH, OW, in_shift=shift)
+        elif val == "winograd4":
+            ok = H.winograd4_eligible(pc, Hh, Ww, OH, OW, in_shift=shift)
+        else:
+            ok = H.winograd_eligible(pc, Hh, Ww, OH, OW)
+        assert ok, (key, val)
+        seen[val] += 1
+    assert seen["winograd4f"] >= 20 and seen["winograd4"] >= 3 and seen["winograd"] >= 10, seen
+    assert sum(1 for k, v in table.items() if v == "winograd4f" and k.split(",")[4] == "4") >= 8      # the dilation-group launches of DESIGN 6.6
