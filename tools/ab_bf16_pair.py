@@ -49,14 +49,17 @@ if len(sys.argv) > 1:
     child(sys.argv[1])
 else:
     import torch
-    for tag, env in (("pair", "1"), ("one", "0")):
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), tag], env=dict(os.environ, VSP_BF16_PAIR=env))
+    # AB_LIBS=<a.so>,<b.so>: the same comparison between two builds of the library instead of the two staging forms
+    libs = os.environ.get("AB_LIBS", "").split(",") if os.environ.get("AB_LIBS") else None
+    for k, (tag, env) in enumerate((("pair", "1"), ("one", "0"))):
+        e = dict(os.environ, VSP_BF16_PAIR=env) if libs is None else dict(os.environ, VSPBFR_HIP_LIB=libs[k])
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), tag], env=e)
     a, b = torch.load("/tmp/ab_bf16_pair_pair.pt"), torch.load("/tmp/ab_bf16_pair_one.pt")
     bad = 0
     for k, (ya, yb) in enumerate(zip(a["outs"], b["outs"])):
         same = torch.equal(ya, yb)
         bad += not same
         case = (CASES + BIG)[k]
-        extra = f" | pair {a['times'][k]:.0f} us, one-pixel tasks {b['times'][k]:.0f} us" if k >= len(CASES) else ""
+        extra = f" | {'first library' if libs else 'pair'} {a['times'][k]:.0f} us, {'second library' if libs else 'one-pixel tasks'} {b['times'][k]:.0f} us" if k >= len(CASES) else ""
         print(f"{case}: {'bit-identical' if same else 'DIFFERENT max ' + str((ya - yb).abs().max().item())}{extra}", flush=True)
     sys.exit(1 if bad else 0)
