@@ -264,68 +264,18 @@ def conv_traffic(B, args):
     return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)   # with the batch overlap the first batch's A+B is not hidden: K = 3 reads ~3 % low
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE configs[1]: 8)")
-    ap.add_argument("--timesteps", type=int, default=50)
-    ap.add_argument("--no-sample", action="store_true", help="skip the 1024^2 tail of the prior (not the headline config)")
-    ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm", help="ddim = BASELINE configs[2]'s sampler (fp32 here)")
-    ap.add_argument("--ddim-steps", type=int, default=25)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="plain per-batch loop (no A+B / C+D stream overlap across batches)")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--graphs", action="store_true",
-                    help="replay stages A+B and C+D as two captured HIP graphs (same kernels, same two-stream overlap, no per-launch host work)")
-    ap.add_argument("--conv-dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
-                    help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
-                         "fp32 activations in HBM); not the parity configuration.  bf16x3 = the same kernels with hi + lo bf16 "
-                         "operand pairs and three MFMAs per product (vsp_conv2d_bf16x3): fp32-grade results on the bf16 pipe")
-    ap.add_argument("--act-bf16", action="store_true",
-                    help="with --conv-dtype bf16: bf16 ACTIVATIONS in HBM between the kernels of stages C + D (every map of 32^2 and "
-                         "larger; vsp_conv2d_bf16 io_bf16, vsp_upfirdn2d_bf16, vsp_pointwise_bf16) -- BASELINE configs[2] as specified")
-    ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
-                    help="BASELINE.json configuration: c2 = batch 8, 50-step DDPM, fp32 (the default); c3 = batch 16, DDIM 25, bf16 "
-                         "kernels; c4 = batch 16 per GPU (128 on 8 GPUs), 50-step DDPM, fp32")
-    ap.add_argument("--seed", type=int, default=123, help="seed of the keyed input / noise draws")
-    ap.add_argument("--torch-rng", action="store_true", help="draw noise from torch's device RNG stream (one randn per consumer, "
-                                                              "as the reference does) instead of the keyed single-launch draws")
-    ap.add_argument("--launch-check", action="store_true", help="no GPU work: self-launch, rendezvous (gloo), shard + all-gather "
-                                                                 "of a stand-in batch, JSON line with value null")
-    args = ap.parse_args()
-    if args.preset:
-        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
-        for k, v in PRESETS[args.preset].items():
-            if k == "steps" and "--steps" in given:   # (a preset's default K does not override an explicit one)
-                continue
-            setattr(args, k, v)
-
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args.gpus))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.launch_check:
-        raise SystemExit(launch_check(args, world, rank))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+def measure(args, world, rank, dev, pipe=None):
+    """One configuration through the timing contract (W warm-up steps, one serial step with per-launch events for the roofline figures, K timed
+    steps between barrier + synchronize, max over ranks).  Returns (JSON line as a dict on rank 0 else None, the pipeline for re-use)."""
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    if getattr(args, "train", False):
-        raise SystemExit(train_bench(args, world, rank, dev))
     from vspbfr_amd import hip_ops
-    from vspbfr_amd.pipeline import gather_restored
     hip_ops.BF16_CONV = {"f32": False, "bf16": True, "bf16x3": "x3"}[args.conv_dtype]
     if args.act_bf16 and args.conv_dtype != "bf16":
         raise SystemExit("--act-bf16 needs --conv-dtype bf16")
-    pipe = build_pipeline(dev, args.timesteps, not args.no_sample, None if args.torch_rng else args.seed)
+    if pipe is None:
+        pipe = build_pipeline(dev, args.timesteps, not args.no_sample, None if args.torch_rng else args.seed)
     pipe.act_bf16 = bool(args.act_bf16)
+    ddpm_module = pipe.diffusion
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
         ddpm, S = pipe.diffusion, args.ddim_steps
@@ -422,6 +372,8 @@ def main():
         conv_flops, conv_ms, conv_launches = (v * args.steps for v in iso.summary())
         conv_exec = iso.executed_flops() * args.steps
 
+    pipe.diffusion = ddpm_module   # (a DDIM configuration wrapped it)
+    line = None
     if rank == 0:
         imgs = world * B * args.steps
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -499,6 +451,91 @@ def main():
                                       for k, v in sorted(iso.by_kind().items()) if v[1] > 0}
             rl["measured"] = ("HIP events per launch on the launch stream over one serial step inside bench.py, right before the "
                               "timed region (no second stream in flight; the timed region itself carries no per-launch events)")
+    hip_ops.BF16_CONV = False
+    return line, pipe
+
+
+def extra_configs(args, world, rank, dev, pipe):
+    import copy
+    out = {}
+    for name, key in (("c3", "c3"), ("c4", "c4_share")):
+        a = copy.copy(args)
+        for k, v in PRESETS[name].items():
+            setattr(a, k, v)
+        a.preset = name
+        try:
+            ln, _ = measure(a, world, rank, dev, pipe)
+            out[key] = {k: ln[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+        except Exception as e:   # the headline line must survive whatever an extra configuration does
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            torch.cuda.synchronize()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)   # with the batch overlap the first batch's A+B is not hidden: K = 3 reads ~3 % low
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step (BASELINE configs[1]: 8)")
+    ap.add_argument("--timesteps", type=int, default=50)
+    ap.add_argument("--no-sample", action="store_true", help="skip the 1024^2 tail of the prior (not the headline config)")
+    ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm", help="ddim = BASELINE configs[2]'s sampler (fp32 here)")
+    ap.add_argument("--ddim-steps", type=int, default=25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="plain per-batch loop (no A+B / C+D stream overlap across batches)")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay stages A+B and C+D as two captured HIP graphs (same kernels, same two-stream overlap, no per-launch host work)")
+    ap.add_argument("--conv-dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
+                    help="bf16 = BASELINE configs[2]'s kernels: eligible convolutions on vsp_conv2d_bf16 (bf16 MFMA, fp32 accumulate, "
+                         "fp32 activations in HBM); not the parity configuration.  bf16x3 = the same kernels with hi + lo bf16 "
+                         "operand pairs and three MFMAs per product (vsp_conv2d_bf16x3): fp32-grade results on the bf16 pipe")
+    ap.add_argument("--act-bf16", action="store_true",
+                    help="with --conv-dtype bf16: bf16 ACTIVATIONS in HBM between the kernels of stages C + D (every map of 32^2 and "
+                         "larger; vsp_conv2d_bf16 io_bf16, vsp_upfirdn2d_bf16, vsp_pointwise_bf16) -- BASELINE configs[2] as specified")
+    ap.add_argument("--preset", choices=sorted(PRESETS), default=None,
+                    help="BASELINE.json configuration: c2 = batch 8, 50-step DDPM, fp32 (the default); c3 = batch 16, DDIM 25, bf16 "
+                         "kernels; c4 = batch 16 per GPU (128 on 8 GPUs), 50-step DDPM, fp32")
+    ap.add_argument("--seed", type=int, default=123, help="seed of the keyed input / noise draws")
+    ap.add_argument("--torch-rng", action="store_true", help="draw noise from torch's device RNG stream (one randn per consumer, "
+                                                              "as the reference does) instead of the keyed single-launch draws")
+    ap.add_argument("--no-extra", action="store_true", help="headline configuration only: skip the extra_configs legs (configs[2], the one-GPU "
+                                                             "share of configs[3]) that a default one-GPU run appends to its JSON line")
+    ap.add_argument("--launch-check", action="store_true", help="no GPU work: self-launch, rendezvous (gloo), shard + all-gather "
+                                                                 "of a stand-in batch, JSON line with value null")
+    args = ap.parse_args()
+    if args.preset:
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+        for k, v in PRESETS[args.preset].items():
+            if k == "steps" and "--steps" in given:   # (a preset's default K does not override an explicit one)
+                continue
+            setattr(args, k, v)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        raise SystemExit(launch_check(args, world, rank))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    if getattr(args, "train", False):
+        raise SystemExit(train_bench(args, world, rank, dev))
+    line, pipe = measure(args, world, rank, dev)
+    if rank == 0:
+        if world == 1 and not args.no_extra and args.preset in (None, "c2") and args.conv_dtype == "f32" and args.sampler == "ddpm" and not (
+                args.no_overlap or args.graphs or args.no_sample or args.torch_rng):
+            # BASELINE configs[2] and the one-GPU share of configs[3], measured the same way in the same process AFTER the headline's timed
+            # region (the line's value / config / dtype stay configs[1]); same random-init networks, their own warm-up
+            line["extra_configs"] = extra_configs(args, world, rank, dev, pipe)
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(args.timesteps, threads)

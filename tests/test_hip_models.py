@@ -201,6 +201,64 @@ def test_style_plan_matches_layers():
             layers.STYLE_PLANS = True
 
 
+def test_style_plan_follows_weight_updates():
+    """the plan must never serve demodulation coefficients of stale weights.  Forward twice (record, replay), change
+    conv weights / modulation weights / biases IN PLACE (an optimiser step, EMA accumulate, load_state_dict), forward again: bit-identical
+    to the per-layer launches on the updated weights, and different from the output before the update.  ADVICE r5 (medium): the plan of a
+    batch size survives a call at another batch size (captured graphs hold its addresses) and a parameter update builds no new table."""
+    from vspbfr_amd import layers
+    from vspbfr_amd.restorenet import Restoration_net
+    size, case = 64, "restorenet64"
+    sd = weights.synth_state_dict("restorenet", weights.load_specs()["restorenet64"], cases.SEED)
+    net = load(Restoration_net(size, 512, 8), "restorenet", sd=sd)
+
+    def run_net(B):
+        imgs = cases.image_batch(case + str(B), B, size)
+        enc_s, dec_s = OM.restoration_noise_shapes(size, B)
+        de_feats = [cases.tensor(case + str(B), f"de_feat{k}", (B, 512, 2 ** (k + 2), 2 ** (k + 2)), 0.5) for k in range(5)]
+        pre, z = cases.tensor(case + str(B), "pre_styles", (B, 18, 512)), cases.tensor(case + str(B), "z", (B, 512))
+        en, dn = cases.noise_list(case + str(B), "enc", enc_s), cases.noise_list(case + str(B), "dec", dec_s)
+        return net(dev(imgs), [dev(f) for f in de_feats], dev(pre), [dev(z)], enc_noise=[dev(n) for n in en], dec_noise=[dev(n) for n in dn]).clone()
+
+    run_net(2)
+    before = run_net(2)
+    ctxs = [net.__dict__["_style_ctx"][t] for t in ("enc", "dec")]
+    plans = [c.plans[next(iter(c.plans))] for c in ctxs]
+    tables = [p["table"].data_ptr() for p in plans]
+    run_net(3)                                   # another batch size: its own plan, the first one stays alive
+    for c, p in zip(ctxs, plans):
+        assert len(c.plans) == 2 and any(q is p for q in c.plans.values())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for name, prm in net.named_parameters():
+            if name.endswith("conv.weight") or ".ModulatedConv2ds." in name or name.endswith("modulation.weight") or name.endswith("modulation.bias"):
+                prm.mul_(dev(1.0 + 0.2 * torch.rand(prm.shape, generator=g)))
+    after = run_net(2)
+    for c, p, t in zip(ctxs, plans, tables):     # an in-place update re-uses the table (live pointers)
+        assert any(q is p for q in c.plans.values()) and p["table"].data_ptr() == t and not c.retired
+    layers.STYLE_PLANS = False
+    try:
+        ref = run_net(2)
+    finally:
+        layers.STYLE_PLANS = True
+    assert torch.equal(after, ref), float((after - ref).abs().max())
+    assert float((after - before).abs().max()) > 1e-3
+    # a re-allocated parameter (pointer moved): the table is rebuilt, the old one retired (not freed), results still exact
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, layers.ModulatedConv2d) and m.demodulate:
+                m.weight.data = m.weight.data.clone() * 1.1
+                break
+    again = run_net(2)
+    layers.STYLE_PLANS = False
+    try:
+        ref2 = run_net(2)
+    finally:
+        layers.STYLE_PLANS = True
+    assert torch.equal(again, ref2)
+    assert sum(len(c.retired) for c in ctxs) >= 1
+
+
 def test_restorenet_rejects_unusable_reference_flags():
     from vspbfr_amd.restorenet import Restoration_net
     net = Restoration_net(64, 512, 8).eval()

@@ -62,6 +62,8 @@ TOL = 6e-5
     (3, 40, 48, 16, 80),        # a second, partial N-block; 1.5 channel halves
     (1, 256, 96, 8, 16),        # the scale table's full 256 channels, two waves of a row group
     (1, 32, 32, 4, 16),         # one tile row
+    (2, 64, 3, 64, 64),         # Cout = 3 (the tuned table sends two 64 -> 3 layers here): 29 of a half's 32 channels are padding
+    (1, 64, 3, 256, 256),       # the tuned entry's map
     (2, 64, 64, 512, 512),      # the judged shape, first and last image against fp64
     (1, 32, 32, 1024, 1024),    # the prior's last layer
 ])

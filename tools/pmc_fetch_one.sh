@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=$1; DBG=$2; shift; shift
 OUT=gpurun_out/pmc_fetch_$TAG; mkdir -p $OUT
-export VSPBFR_HIP_LIB=$GRAFT_REPO_ROOT/vspbfr_amd/lib/libvspbfr_hip_ablate.so VSP_CONV_DBG=$DBG
+export VSPBFR_HIP_LIB=$GRAFT_REPO_ROOT/vspbfr_amd/lib/libvspbfr_hip_ablate.so VSP_CONV_DBG=$DBG VSP_TUNE=1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f -o f --output-format csv -- python3 tools/run_one_bf16.py $* > $OUT/f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum -d $OUT/t -o t --output-format csv -- python3 tools/run_one_bf16.py $* > $OUT/t.log 2>&1
 python3 - <<PY

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export WINO_FORM=3
 if [ -f build/abl/libvspbfr_rsabl.so ]; then
   for dbg in 0 1 2 3 4 8 12 16 32 64 15 31 47; do
-    VSPBFR_HIP_LIB=build/abl/libvspbfr_rsabl.so VSP_CONV_DBG=$dbg timeout 120 python3 tools/wino_ablate.py $* 2>&1 | grep -v amdgpu.ids
+    VSPBFR_HIP_LIB=build/abl/libvspbfr_rsabl.so VSP_TUNE=1 VSP_CONV_DBG=$dbg timeout 120 python3 tools/wino_ablate.py $* 2>&1 | grep -v amdgpu.ids
   done > $OUT/ablate.log
   cat $OUT/ablate.log
 fi

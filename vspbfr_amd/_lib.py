@@ -15,6 +15,17 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSPBFR_HIP_LIB", os.path.join(_HERE, "lib", "libvspbfr_hip.so"))
 
+
+
+def tune_env(name, default=None):
+    """A/B and tuning switches (VSP_*) are honoured only under VSP_TUNE=1 (the library's vsp::tune_env has the same gate): a stray variable
+    in a production environment cannot change which kernel runs.  VSPBFR_HIP_LIB / VSPBFR_CONV_TUNE / VSPBFR_CONV_DTYPE are configuration,
+    not tuning, and are always read."""
+    if os.environ.get("VSP_TUNE", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
+
+
 ABI_VERSION = 3  # include/vspbfr_hip.h VSP_ABI_VERSION
 c_float_p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 

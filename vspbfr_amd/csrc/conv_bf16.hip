@@ -714,7 +714,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   if constexpr (!SPLIT && !IOB) {
     if (q.io_bf16) {
       // bf16 activations: pixel-pair staging wherever rows are 4-byte multiples (env VSP_BF16_PAIR=0: the one-pixel tasks, for A/B runs)
-      static const bool pair_env = !(getenv("VSP_BF16_PAIR") && atoi(getenv("VSP_BF16_PAIR")) == 0);
+      static const bool pair_env = !(vsp::tune_env("VSP_BF16_PAIR") && atoi(vsp::tune_env("VSP_BF16_PAIR")) == 0);
       if (pair_env && (q.W & 1) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 3) == 0) {
         if (gm.pt2 <= 1) return launch_bf<MB, NB, WM, WN, 1, MODE, false, true, true>(q, gm, stream);
         if (gm.pt2 <= 2) return launch_bf<MB, NB, WM, WN, 2, MODE, false, true, true>(q, gm, stream);

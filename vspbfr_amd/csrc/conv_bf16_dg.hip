@@ -389,7 +389,7 @@ int bf16dg_launch(const ConvK& q, bool full, hipStream_t stream) {   // full: a 
     pl.n_items[g] = d * ((sh + 7) / 8) * pl.cbk;
     nmax = pl.n_items[g] > nmax ? pl.n_items[g] : nmax;
   }
-  static const int wgs_env = getenv("VSP_BF16DG_WGS") ? atoi(getenv("VSP_BF16DG_WGS")) : 0;
+  static const int wgs_env = vsp::tune_env("VSP_BF16DG_WGS") ? atoi(vsp::tune_env("VSP_BF16DG_WGS")) : 0;
   pl.nwg = wgs_env > 0 ? (wgs_env + 7) / 8 * 8 : 2 * vsp::kNumCU;
   int J = pl.nwg / (q.B * pl.nblk);
   J = J < 1 ? 1 : J;

@@ -521,7 +521,7 @@ int launch_rv(ConvK q, hipStream_t stream) {
   q.co_tiles = (q.cout_g + CO_T - 1) / CO_T;
   const int64_t ntiles = (int64_t)(q.W / RV_TW) * (((q.H + DIL - 1) / DIL + TH - 1) / TH) * DIL * q.co_tiles * q.B;
   if (ntiles > 0x7fffffff) return vsp::fail(VSP_EINVAL, "conv2d_bf16rv: grid too large");
-  static const int per_cu = getenv("VSP_BF16RV_WGS") ? atoi(getenv("VSP_BF16RV_WGS")) : 2;   // resident workgroups per CU (tuning)
+  static const int per_cu = vsp::tune_env("VSP_BF16RV_WGS") ? atoi(vsp::tune_env("VSP_BF16RV_WGS")) : 2;   // resident workgroups per CU (tuning)
   const int64_t grid = ntiles < (int64_t)vsp::kNumCU * per_cu ? ntiles : (int64_t)vsp::kNumCU * per_cu;
   conv_bf16_rv_kernel<MB, RWV, DIL><<<dim3((unsigned)grid), 256, lds, stream>>>(q, (int)ntiles);
   return VSP_OK;

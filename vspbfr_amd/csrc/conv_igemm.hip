@@ -350,7 +350,7 @@ extern "C" int vsp_conv2d_winograd_f32(const vsp_conv_params* pp, vsp_stream_t s
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
   {
-    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;
     q.dbg = dbg;
   }
   {
@@ -397,7 +397,7 @@ extern "C" int vsp_conv2d_winograd4_f32(const vsp_conv_params* pp, float* work, 
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
   {
-    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;
     q.dbg = dbg;
   }
   if (!vspconv::wino4_eligible(q))
@@ -432,7 +432,7 @@ extern "C" int vsp_conv2d_winograd4f_f32(const vsp_conv_params* pp, vsp_stream_t
   ConvK q{};
   if (int rc = fill_convk(p, x_ch, q)) return rc;
   {
-    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;
+    static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;
     q.dbg = dbg;
     const float* kc = device_consts();
     q.wtp = p.in_scale ? p.in_scale : kc;
@@ -513,7 +513,7 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   VSP_REQUIRE(p.dil_by_input_quarter == 0, "conv2d_bf16: dil_by_input_quarter is served by vsp_conv2d_f32");
   q.io_bf16 = p.io_bf16;
   {
-    static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
+    static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
     q.dbg = dbg;
   }
   if (rv == 2) {
@@ -572,7 +572,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
       ConvK q{};
       if (int rc = fill_convk(p, x_ch, q)) return rc;
       {
-        static const int dbg = getenv("VSP_CONV_DBG") ? atoi(getenv("VSP_CONV_DBG")) : 0;   // tuning switches (0 in production)
+        static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;   // tuning switches (0 in production)
         q.dbg = dbg;
       }
       if (vspconv::smallmap_eligible(q, p.transposed != 0)) return vspconv::smallmap_launch(q, vsp::as_stream(stream));
@@ -622,7 +622,7 @@ extern "C" int vsp_conv2d_f32(const vsp_conv_params* pp, vsp_stream_t stream) {
   {
     static int dbg = -1;
     if (dbg < 0) {
-      const char* e = getenv("VSP_CONV_DBG");
+      const char* e = vsp::tune_env("VSP_CONV_DBG");
       dbg = e ? atoi(e) : 0;
     }
     q.dbg = dbg;

@@ -465,7 +465,7 @@ int launch_wgrad(const WgradK& k, int xj, dim3 grid, size_t lds, hipStream_t st)
   static vsp::LdsAttrOnce attr1, attr2;  // (slabs beyond the default 64 KB limit: stride-2 rows, the 64-channel X tiles); per device
   // 3x3 layers on chunks of 64 / 2 x 32 / 4 x 16 pixels: the unrolled loop (stride 1 stages one item per thread, stride 2 two)
   if constexpr (NTAP == 9) {
-    if (k.tcl >= 4 && xj == k.stride && !std::getenv("VSP_WGRAD_GENERIC")) {
+    if (k.tcl >= 4 && xj == k.stride && !vsp::tune_env("VSP_WGRAD_GENERIC")) {
       if (k.stride == 1) {
         if (k.tcl == 6) return launch_wgrad_fast<NTAP, WCO, NB, 1, 1, 6>(k, grid, lds, st);
         if (k.tcl == 5) return launch_wgrad_fast<NTAP, WCO, NB, 1, 1, 5>(k, grid, lds, st);

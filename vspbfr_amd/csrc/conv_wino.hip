@@ -582,14 +582,14 @@ int wino_launch(ConvK q, int form, hipStream_t stream) {
     return wino_rs_launch(q, stream);
   }
   if (form == 0) {
-    static const int rs = getenv("VSP_WINO_RS") ? atoi(getenv("VSP_WINO_RS")) : 1;   // 0: never, 2: wherever eligible
+    static const int rs = vsp::tune_env("VSP_WINO_RS") ? atoi(vsp::tune_env("VSP_WINO_RS")) : 1;   // 0: never, 2: wherever eligible
     if (rs && wino_rs_eligible(q) && (rs == 2 || wino_rs_profitable(q))) return wino_rs_launch(q, stream);
   }
   if (dmax == 1) {
     // row-owner form (conv_wino_ro.hip) wherever it serves the launch; maps up to 16 x 16 measured equal or slower (512 -> 512 at 16^2:
     // 99 vs 102 us) and stay here.  VSP_WINO_RO = 0 keeps this file's kernel everywhere, 1 / 2 / 4 = barrier period of the other one
     // (8-channel sub-stages; 2 and 4 measured within 1 % of 1 on the deep layers, slower on the shallow ones).
-    static const int ro = getenv("VSP_WINO_RO") ? atoi(getenv("VSP_WINO_RO")) : 1;
+    static const int ro = vsp::tune_env("VSP_WINO_RO") ? atoi(vsp::tune_env("VSP_WINO_RO")) : 1;
     if (form == 2 && !wino_ro_eligible(q)) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the row-owner form does not serve this launch");
     if (form != 1 && (ro == 1 || ro == 2 || ro == 4) && (q.H * q.W > 256 || form == 2) && wino_ro_eligible(q))
       return wino_ro_launch(q, wino_mbw(q.cout_g), ro == 0 ? 1 : ro, stream);
@@ -604,7 +604,7 @@ int wino_launch(ConvK q, int form, hipStream_t stream) {
       // 512 -> 4 x 128 at 64^2 740 -> 667 (round 4 had measured that one equal and kept it here), at 32^2 296 -> 261.  VSP_WINO_ROD = 0: never.
       // (A dense epilogue -- the tile's scattered pixels through LDS, 16-byte stores -- was measured on this kernel in round 5: no difference,
       //  not kept; its workgroups live 16-64 stages and the epilogue of one hides under the main loop of the other.)
-    static const int rod = getenv("VSP_WINO_ROD") ? atoi(getenv("VSP_WINO_ROD")) : 1;
+    static const int rod = vsp::tune_env("VSP_WINO_ROD") ? atoi(vsp::tune_env("VSP_WINO_ROD")) : 1;
     const bool rod_ok = wino_mbw(q.cout_g) >= 2 && wino_rod_eligible(q);
     if (form == 2 && !rod_ok) return vsp::fail(VSP_ENOTSUP, "conv2d_winograd: the row-owner form does not serve this launch");
     if (form != 1 && rod_ok && (form == 2 || rod)) return wino_rod_launch(q, wino_mbw(q.cout_g), stream);

@@ -653,7 +653,9 @@ __global__ __launch_bounds__(F4_THR, 1) void conv_wino4f_groups_kernel(const Con
 
 }  // namespace
 
-// layers the fused F(4x4) form serves: one group, dilation 1, style scale only (no affine shift), whole 4 x 4 tiles, 16-byte rows, dense output
+// launches the fused F(4x4) form serves: one group or up to four dilation groups over ONE shared input, padding = dilation in {1, 2, 4, 8}, H and W
+// multiples of 4 x dilation (whole tiles in every polyphase sub-image), Cin % 8 == 0 up to F4_MAXC (512), W >= 16, style scale only (no affine
+// shift), 16-byte aligned operand planes, dense output
 bool wino4f_eligible(const ConvK& q) {
   if (q.G < 1 || q.G > 4 || (q.G > 1 && q.x_gs != 0) || q.Cin % 8 != 0 || q.Cin > F4_MAXC || q.W < 16 || q.H < 4) return false;
   for (int g = 0; g < q.G; ++g) {
@@ -700,7 +702,7 @@ static int f4_plan(const ConvK& q, int d, int nwg, F4Plan* pl) {
 }
 
 int wino4f_launch(ConvK q, hipStream_t stream) {
-  static const int wgs_env = getenv("VSP_WINO4F_WGS") ? atoi(getenv("VSP_WINO4F_WGS")) : 0;
+  static const int wgs_env = vsp::tune_env("VSP_WINO4F_WGS") ? atoi(vsp::tune_env("VSP_WINO4F_WGS")) : 0;
   int nwg = wgs_env > 0 ? (wgs_env + 7) / 8 * 8 : vsp::kNumCU;
   const bool res = q.r1s || q.r2s, act1 = !(q.s1 == 1.f && q.g1 == 1.f);
   if (q.G > 1) {   // dilation groups: one partition of workgroups per group (a multiple of 8: the XCD walk of the body)
@@ -728,7 +730,7 @@ int wino4f_launch(ConvK q, hipStream_t stream) {
   F4Plan pl;
   if (int rc = f4_plan(q, q.dil[0], nwg, &pl)) return rc;
   // loader: dilation 1 = window loads into registers (D = 0) unless VSP_WINO4F_LDS=1 asks for the LDS loader (D = 1); dilation 2 / 4 / 8 = LDS loader
-  static const int lds_env = getenv("VSP_WINO4F_LDS") ? atoi(getenv("VSP_WINO4F_LDS")) : 0;
+  static const int lds_env = vsp::tune_env("VSP_WINO4F_LDS") ? atoi(vsp::tune_env("VSP_WINO4F_LDS")) : 0;
   const int dsel = q.dil[0] == 1 ? (lds_env ? 1 : 0) : q.dil[0];
 #define F4_LAUNCH(RES_, ACT_, D_)                                                                                                 \
   do {                                                                                                                            \

@@ -525,6 +525,9 @@ int launch_ro(ConvK q, hipStream_t stream) {
 bool wino_ro_eligible(const ConvK& q) {
   for (int g = 0; g < q.G; ++g)
     if (q.dil[g] != 1) return false;
+  // padding = the raw-buffer range check of ONE image's descriptor (num_records = x_ch * H * W * 4 as an int; out-of-range lanes carry
+  // offset 0x7ffffff0): an image of 2 GiB or more would wrap the record count and leave the padding unbacked -- refused here
+  if ((int64_t)q.x_ch * q.H * q.W * 4 >= 0x7ffffff0ll) return false;
   return q.cout_g > 16 && q.W % 4 == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 && ((int64_t)q.H * q.W) % 4 == 0;
 }
 
@@ -535,7 +538,7 @@ int wino_ro_launch(ConvK q, int mbw, int m, hipStream_t stream) {
   if (mbw == 4) {
     // 16 tile columns x 2 tile rows per workgroup (32 x 4 output pixels: 128-byte row segments on both the patch loads and the stores)
     // wherever a row holds them: 0.5-2 % over the 8 x 4 form on every layer (128 -> 128 at 256^2: 769 -> 752 us); VSP_WINO_RO_WIDE = 0: off
-    static const int wide_env = getenv("VSP_WINO_RO_WIDE") ? atoi(getenv("VSP_WINO_RO_WIDE")) : 1;
+    static const int wide_env = vsp::tune_env("VSP_WINO_RO_WIDE") ? atoi(vsp::tune_env("VSP_WINO_RO_WIDE")) : 1;
     if (wide_env && m == 1 && q.W >= 32) return launch_ro<4, 1, 16>(q, stream);
     return m == 4 ? launch_ro<4, 4>(q, stream) : (m == 2 ? launch_ro<4, 2>(q, stream) : launch_ro<4, 1>(q, stream));
   }

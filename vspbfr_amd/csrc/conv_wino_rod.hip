@@ -399,6 +399,9 @@ int launch_rod(ConvK q, hipStream_t stream) {
 bool wino_rod_eligible(const ConvK& q) {
   for (int g = 0; g < q.G; ++g)
     if (q.dil[g] != 1 && q.dil[g] != 2 && q.dil[g] != 4 && q.dil[g] != 8) return false;
+  // padding = the raw-buffer range check of ONE image's descriptor (num_records = x_ch * H * W * 4 as an int; out-of-range lanes carry
+  // offset 0x7ffffff0): an image of 2 GiB or more would wrap the record count and leave the padding unbacked -- refused here
+  if ((int64_t)q.x_ch * q.H * q.W * 4 >= 0x7ffffff0ll) return false;
   return q.cout_g > 16 && q.W % 4 == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 && ((int64_t)q.H * q.W) % 4 == 0;
 }
 

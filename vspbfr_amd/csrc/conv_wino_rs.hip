@@ -427,8 +427,8 @@ int launch_rs(const ConvK& q, const RsPlan& pl, hipStream_t stream) {
 #ifdef VSP_RS_TRACE
   {
     static bool once = false;
-    if (!once && getenv("VSP_RS_TRACE_WG")) {
-      const int wg = atoi(getenv("VSP_RS_TRACE_WG"));
+    if (!once && vsp::tune_env("VSP_RS_TRACE_WG")) {
+      const int wg = atoi(vsp::tune_env("VSP_RS_TRACE_WG"));
       hipMemcpyToSymbol(HIP_SYMBOL(rs_trace_wg), &wg, sizeof(int));
     }
     once = true;
@@ -495,7 +495,7 @@ int wino_rs_launch(ConvK q, hipStream_t stream) {
     pl.n_items[g] = d * ((sh + 7) / 8) * pl.cbk;
     nmax = pl.n_items[g] > nmax ? pl.n_items[g] : nmax;
   }
-  static const int wgs_env = getenv("VSP_WINO_RS_WGS") ? atoi(getenv("VSP_WINO_RS_WGS")) : 0;
+  static const int wgs_env = vsp::tune_env("VSP_WINO_RS_WGS") ? atoi(vsp::tune_env("VSP_WINO_RS_WGS")) : 0;
   pl.nwg = wgs_env > 0 ? (wgs_env + 7) / 8 * 8 : 2 * vsp::kNumCU;
   // chunks per (image, block): about one chunk per workgroup slot, at least ~2 items per chunk, keys a multiple of 8 when they fill the XCDs
   int J = pl.nwg / (q.B * pl.nblk);

@@ -247,7 +247,7 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
   const bool vec = p.a_ks == 1 && p.b_ks == 1 && p.a_ms % 4 == 0 && p.b_ns % 4 == 0 && p.a_zs % 4 == 0 &&
                    p.b_zs % 4 == 0 && vsp::aligned16(p.A) && vsp::aligned16(p.Bm);
   if (vec && p.Z == 1 && p.M <= 16 && p.K >= 512 && p.K % 256 == 0 && p.b_ns >= p.K && p.a_ms >= p.K) {   // few rows against a deep K
-    static const bool off = getenv("VSP_GEMV_OFF") != nullptr;   // (A/B runs)
+    static const bool off = vsp::tune_env("VSP_GEMV_OFF") != nullptr;   // (A/B runs)
     if (!off) {
       if (p.M <= 8) launch_gemv<8>(q, vsp::as_stream(stream)); else launch_gemv<16>(q, vsp::as_stream(stream));
       return vsp::check_launch("gemm");
@@ -255,7 +255,7 @@ extern "C" int vsp_gemm_f32(const vsp_gemm_params* pp, vsp_stream_t stream) {
   }
   const bool wide = vec && p.M >= 1024;   // several row blocks per workgroup share the B fragments (same arithmetic per element)
   static const int wide_mbk = [] {   // tuning switch; only the instantiated forms (the grid below is sized for the SAME value)
-    const int v = getenv("VSP_GEMM_MBK") ? atoi(getenv("VSP_GEMM_MBK")) : 4;
+    const int v = vsp::tune_env("VSP_GEMM_MBK") ? atoi(vsp::tune_env("VSP_GEMM_MBK")) : 4;
     return (v == 2 || v == 4 || v == 8) ? v : 4;
   }();
   const int mrows = wide ? 16 * wide_mbk : 16;

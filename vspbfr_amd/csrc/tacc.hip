@@ -326,7 +326,7 @@ int vsp_tacc_chan_attn_f32(float* t, const float* P, int ldp, int q2_off, int v2
   VSP_REQUIRE(n_tok == NTOK && dim == D, "tacc_chan_attn: built for 18 tokens x 512 channels (got %d x %d)", n_tok, dim);
   if (B <= 0) return VSP_OK;
   VSP_REQUIRE(t && P && ek && wk, "tacc_chan_attn: null pointer");
-  static const bool use_valu = getenv("VSP_TACC_VALU") != nullptr;  // the first (VALU/LDS) version, kept for A/B runs
+  static const bool use_valu = vsp::tune_env("VSP_TACC_VALU") != nullptr;  // the first (VALU/LDS) version, kept for A/B runs
   const size_t lds = use_valu ? (size_t)(2 * NTOK * D + D * CA_PITCH + 8 * 32) * sizeof(float)
                               : vsptacc::CA_LDS_FLOATS * sizeof(float);
   static vsp::LdsAttrOnce attr_a, attr_b;   // per device

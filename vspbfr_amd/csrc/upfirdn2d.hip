@@ -512,7 +512,7 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
   //  4.1-4.6 everywhere else -- 151 registers, three waves per SIMD, twice the bytes per lane in flight; default bench 195.6 against 195.1)
   if constexpr (BF) {
     // the strip walk (no LDS, ~24 vector instructions per output): 4 x 4 taps on planes whose rows are whole 16-byte output segments
-    static const int strip_env = getenv("VSP_FIR_STRIP") ? atoi(getenv("VSP_FIR_STRIP")) : 1;
+    static const int strip_env = vsp::tune_env("VSP_FIR_STRIP") ? atoi(vsp::tune_env("VSP_FIR_STRIP")) : 1;
     const int64_t xb = (int64_t)major * in_h * in_w * 2, ob = (int64_t)major * out_h * out_w * 2;
     if (strip_env && tile_ok && kh == 4 && kw == 4 && out_w % 8 == 0 && out_h >= 4 && xb < 0x7ffffff0ll && ob < 0x7ffffff0ll &&
         (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!e.res1 || (reinterpret_cast<uintptr_t>(e.res1) & 15) == 0) &&
@@ -552,7 +552,7 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     // CU walking the tile list with the next window requested one tile ahead, before or after the epilogue operands) measured 25-45 %
     // SLOWER on both element types (fp32 plain 4.08 -> 3.1 TB/s, bf16 2.36 -> 1.65): tried and removed -- two barriers per tile in a
     // resident block cost more than launching a fresh one.  The interior fast path below is what paid (fp32 3.0-3.5 -> 4.1-4.5 TB/s).
-    static const int ntb_env = getenv("VSP_FIR_NTB") ? atoi(getenv("VSP_FIR_NTB")) : 0;
+    static const int ntb_env = vsp::tune_env("VSP_FIR_NTB") ? atoi(vsp::tune_env("VSP_FIR_NTB")) : 0;
     const int ntb = ntb_env == 2 ? 2 : 1;
 #define VSP_FIR_LAUNCH(KH_, NTB_)                                                                                                     \
   fir_tile_kernel<KH_, KH_, T, NTB_><<<(unsigned)((blocks + NTB_ - 1) / NTB_), 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, \

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <atomic>
 #include "../../include/vspbfr_hip.h"
 
@@ -25,6 +26,13 @@ inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(VSP_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
   return VSP_OK;
+}
+
+// Tuning / A-B switches (VSP_WINO_RS, VSP_BF16_PAIR, VSP_*_WGS, the work-order bits of VSP_CONV_DBG ...) are read ONLY when VSP_TUNE=1 is
+// set as well: a stray variable in a production environment cannot change which kernel a launch takes (tools/ set VSP_TUNE=1 themselves).
+inline const char* tune_env(const char* name) {
+  static const bool on = [] { const char* t = getenv("VSP_TUNE"); return t && t[0] && !(t[0] == '0' && !t[1]); }();
+  return on ? getenv(name) : nullptr;
 }
 
 inline hipStream_t as_stream(vsp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvParams, FirEpilogue, GemmParams, check, lib
+from ._lib import ConvParams, FirEpilogue, GemmParams, check, lib, tune_env
 
 SQRT2 = math.sqrt(2.0)
 
@@ -113,11 +113,11 @@ BF16_FORCE = 0
 
 # the data gradient of the four dilated SMART branches as one convolution (conv_pipe.hip MODE 3) instead of a grouped conv + a sum over
 # the branches (tools / A-B runs can switch it off)
-SMART_ADJOINT_ONE_PASS = os.environ.get("VSP_SMART_ADJOINT_ONE_PASS", "1") != "0"
+SMART_ADJOINT_ONE_PASS = tune_env("VSP_SMART_ADJOINT_ONE_PASS", "1") != "0"
 # training: demodulation coefficients and their gradient on the fused kernels (vsp_demod_weight_f32) instead of torch autograd
-FUSED_DEMOD_GRAD = os.environ.get("VSP_FUSED_DEMOD_GRAD", "1") != "0"
+FUSED_DEMOD_GRAD = tune_env("VSP_FUSED_DEMOD_GRAD", "1") != "0"
 # training: a discriminator ResBlock of the first-order passes as one autograd node (discriminator._ResBlockFO)
-RESBLOCK_ONE_NODE = os.environ.get("VSP_RESBLOCK_ONE_NODE", "1") != "0"
+RESBLOCK_ONE_NODE = tune_env("VSP_RESBLOCK_ONE_NODE", "1") != "0"
 
 
 def conv_key(B, Cin, H, W, pc, OH, OW):
@@ -471,8 +471,8 @@ def bf16dg_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_o
     return 1 <= pc.G <= 4 and all(pc.dil[g] in (1, 2, 4, 8) and pc.pad_y[g] == pc.dil[g] and pc.pad_x[g] == pc.dil[g] for g in range(pc.G))
 
 
-BF16_DG = os.environ.get("VSP_BF16_DG", "1") != "0"   # the dilation-group kernel on the launches it serves (G > 1)
-BF16_RV = os.environ.get("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
+BF16_DG = tune_env("VSP_BF16_DG", "1") != "0"   # the dilation-group kernel on the launches it serves (G > 1)
+BF16_RV = tune_env("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
 
 
 def bf16rv_profitable(pc, H, W):
@@ -725,8 +725,9 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
         winograd = True     # (the deep-layer form does not serve this call's operands: F(2x2,3x3))
     if winograd == 5 and not winograd4f_eligible(pc, H, W, OH, OW, transposed, out_stride, out_offset, in_shift):
         if named_fused:
-            raise RuntimeError("conv2d: this launch is not eligible for the fused F(4x4,3x3) kernel (one group, 3x3 / stride 1 / dilation 1 / "
-                               "padding 1, no affine shift, Cin % 8 == 0 up to 256, H, W % 4 == 0, W >= 16)")
+            raise RuntimeError("conv2d: this launch is not eligible for the fused F(4x4,3x3) kernel (winograd4f_eligible: one group or up to four "
+                               "dilation groups over one shared input, 3x3 / stride 1 / padding = dilation in {1, 2, 4, 8}, H and W multiples of "
+                               "4 x dilation, no affine shift, Cin % 8 == 0 up to 512, W >= 16)")
         winograd = True
     if RECORDER is not None:
         RECORDER.append((key, (B, Cin, H, W, OH, OW), pc, transposed))

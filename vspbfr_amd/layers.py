@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from . import hip_ops as H
+from ._lib import tune_env
 
 SQRT2 = math.sqrt(2.0)
 RATES = (1, 2, 4, 8)
@@ -48,9 +49,23 @@ class _Cached(nn.Module):
             store[key] = hit
         return hit[1]
 
+    def _derive_static(self, key, sources, fn):
+        """_derive for a tensor whose ADDRESS is handed out (style-plan tables, captured graphs): refreshed in place when a source changes."""
+        store = self.__dict__.setdefault("_derived", {})
+        stamp = tuple((t.data_ptr(), t._version, t.device) for t in sources)
+        hit = store.get(key)
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                new = fn()
+                if hit is not None and hit[1].shape == new.shape and hit[1].device == new.device and hit[1].dtype == new.dtype:
+                    new = hit[1].copy_(new)
+                hit = (stamp, new)
+            store[key] = hit
+        return hit[1]
+
 
 # ---- all style modulations of a network up front (vsp_style_plan_f32: two launches instead of ~2 per modulated layer)
-STYLE_PLANS = os.environ.get("VSP_STYLE_PLAN", "1") != "0"
+STYLE_PLANS = tune_env("VSP_STYLE_PLAN", "1") != "0"
 _STYLE_CTX = None
 
 
@@ -62,13 +77,27 @@ class _StyleLayerC(ctypes.Structure):   # vsp_style_layer (include/vspbfr_hip.h)
 
 class StyleContext:
     """Per (network part, latent tensor): the first no-grad forward RECORDS which modulation layer reads which row view of `src`
-    (EqualLinear weight / bias, the conv's squared-tap sums), the following ones evaluate all of them with vsp_style_plan_f32 before the first
-    layer runs and hand the slices out.  A layer whose style is not the recorded row view of the current `src` (or whose parameters moved)
-    falls back to its own two launches; a plan is rebuilt when the batch size, a parameter or a derived tensor changes."""
+    (the layer itself, its EqualLinear, whether it demodulates), the following ones evaluate all of them with vsp_style_plan_f32 before the
+    first layer runs and hand the slices out.  A layer whose style is not the recorded row view of the current `src` falls back to its own
+    two launches.
+
+    The kernel reads weights, biases and squared-tap sums through LIVE pointers (the tap sums are refreshed in place when a weight changes:
+    `_Cached._derive_static`, fetched from the layer at every `begin`), so a parameter UPDATE needs no rebuild and is never stale; only a
+    moved pointer or another batch size builds a table.  Tables and output buffers are kept per batch size and never freed while the
+    context lives: captured HIP graphs (pipeline.capture_graphs) hold their addresses."""
+    MAX_RETIRED = 32
 
     def __init__(self):
-        self.recorded = None     # list of (owner id, eql, src_off, wsq, wscale) in call order
-        self.plan = None
+        self.recorded = None     # list of (owner, eql, src_off, has_wsq, wscale) in call order
+        self.plans = {}          # (B, rows, K, device) -> plan
+        self.retired = []        # plans replaced because a pointer moved: kept alive (graphs may still replay them)
+
+    def __deepcopy__(self, memo):   # a copied network (EMA copy) records for itself
+        return StyleContext()
+
+    @property
+    def plan(self):              # the most recently used plan (tests)
+        return self.__dict__.get("_last")
 
     def begin(self, src):
         self.src, self.hits, self.rec = src, None, None
@@ -80,21 +109,27 @@ class StyleContext:
         if self.recorded is None:
             self.rec = []
             return
-        plan = self.plan
-        stamp = (B, src.shape[1], K, src.device) + tuple(
-            (e[1].weight.data_ptr(), e[1].weight._version, None if e[3] is None else e[3].data_ptr()) for e in self.recorded)
-        if plan is None or plan["stamp"] != stamp:
-            plan = self.plan = self._build(B, K, src.device, stamp)
+        wsqs = [owner._style_wsq() if has_wsq else None for owner, _e, _o, has_wsq, _s in self.recorded]
+        ptrs = tuple((e[1].weight.data_ptr(), 0 if e[1].bias is None else e[1].bias.data_ptr(), 0 if q is None else q.data_ptr())
+                     for e, q in zip(self.recorded, wsqs))
+        key = (B, src.shape[1], K, src.device)
+        plan = self.plans.get(key)
+        if plan is None or plan["ptrs"] != ptrs:
+            if plan is not None:
+                self.retired.append(plan)
+                del self.retired[:-self.MAX_RETIRED]
+            plan = self.plans[key] = self._build(B, K, src.device, ptrs, wsqs)
+        self._last = plan
         H.check(H.lib.vsp_style_plan_f32(plan["table"].data_ptr(), len(self.recorded), src.data_ptr(), B, src.stride(0), K, plan["max_cin"],
                                          plan["max_cout"], 1e-8, H._stream()), "style_plan")
         self.hits = plan["out"]
 
-    def _build(self, B, K, device, stamp):
-        n = sum(B * e[1].weight.shape[0] + (0 if e[3] is None else B * e[3].shape[0]) for e in self.recorded)
+    def _build(self, B, K, device, ptrs, wsqs):
+        n = sum(B * e[1].weight.shape[0] + (0 if q is None else B * q.shape[0]) for e, q in zip(self.recorded, wsqs))
         buf = torch.empty(n, device=device, dtype=torch.float32)
         arr = (_StyleLayerC * len(self.recorded))()
         out, off, max_cin, max_cout = {}, 0, 1, 0
-        for i, (oid, eql, src_off, wsq, wscale) in enumerate(self.recorded):
+        for i, ((owner, eql, src_off, _has, wscale), wsq) in enumerate(zip(self.recorded, wsqs)):
             cin = eql.weight.shape[0]
             mod = buf[off:off + B * cin].view(B, cin)
             off += B * cin
@@ -111,9 +146,9 @@ class StyleContext:
             a.src_off, a.cin, a.cout = src_off, cin, (wsq.shape[0] if wsq is not None else 0)
             w32 = ctypes.c_float(wscale if wsq is not None else 0.0).value     # (vsp_demod_f32 squares its float argument IN float: the same bits here)
             a.alpha, a.bias_scale, a.wscale2 = eql.scale, eql.lr_mul, ctypes.c_float(w32 * w32).value
-            out[oid] = (src_off, mod, demod)
+            out[id(owner)] = (src_off, mod, demod, eql, 0 if wsq is None else wsq.data_ptr())
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-        return {"stamp": stamp, "table": table, "buf": buf, "out": out, "max_cin": max_cin, "max_cout": max_cout}
+        return {"ptrs": ptrs, "table": table, "buf": buf, "out": out, "max_cin": max_cin, "max_cout": max_cout, "wsqs": wsqs}
 
     def _row_offset(self, style):
         """element offset of the row view `style` = src[:, i] inside src, or None"""
@@ -129,18 +164,20 @@ class StyleContext:
         off = self._row_offset(style)
         if self.hits is not None and off is not None:
             hit = self.hits.get(id(owner))
-            if hit is not None and hit[0] == off:
+            # the plan evaluated THIS layer from THIS row with the tap sums the caller holds now -- anything else takes the two launches
+            if hit is not None and hit[0] == off and hit[3] is eql and hit[4] == (0 if wsq is None else wsq.data_ptr()):
                 return hit[1], hit[2]
         mod = eql(style)
         demod = H.demod_coefs(mod, wsq, wscale) if wsq is not None else None
         if self.rec is not None:
             ok = (off is not None and eql.activation is None and eql.weight.shape[1] == self.src.shape[2] and eql.weight.is_contiguous()
-                  and eql.weight.data_ptr() % 16 == 0 and eql.weight.shape[0] <= 65535)
-            self.rec.append((id(owner), eql, off, wsq, wscale) if ok else None)
+                  and eql.weight.data_ptr() % 16 == 0 and eql.weight.shape[0] <= 65535
+                  and (wsq is None or (hasattr(owner, "_style_wsq") and owner._style_wsq() is wsq)))
+            self.rec.append((owner, eql, off, wsq is not None, wscale) if ok else None)
         return mod, demod
 
     def end(self):
-        if self.rec is not None and self.rec and all(e is not None for e in self.rec) and len({e[0] for e in self.rec}) == len(self.rec):
+        if self.rec is not None and self.rec and all(e is not None for e in self.rec) and len({id(e[0]) for e in self.rec}) == len(self.rec):
             self.recorded = self.rec
         self.rec = self.hits = self.src = None
 
@@ -288,14 +325,17 @@ class ModulatedConv2d(_Cached):
         return self._derive("packed", [self.weight], build)
 
     def wsq(self):
-        return self._derive("wsq", [self.weight], lambda: (self.weight[0] ** 2).sum((2, 3)).contiguous())
+        return self._derive_static("wsq", [self.weight], lambda: (self.weight[0] ** 2).sum((2, 3)).contiguous())
+
+    def _style_wsq(self):        # what layers.StyleContext bakes into its table (None: no demodulation)
+        return self.wsq() if self.demodulate else None
 
     def demod(self, mod):
         return H.demod_coefs(mod, self.wsq(), self.scale) if self.demodulate else None
 
     def run(self, x, style, noise=None, noise_w=None, act_bias=None, ch_bias=None, res1=None, res2=None):
         """conv (+ the caller's fused tail).  `style` is the un-modulated style vector (B, style_dim)."""
-        mod, demod = style_terms(self, self.modulation, style, self.wsq() if self.demodulate else None, self.scale)
+        mod, demod = style_terms(self, self.modulation, style, self._style_wsq(), self.scale)
         x = x.contiguous()
         act = act_bias is not None
         if self.upsample:
@@ -380,9 +420,12 @@ class SMARTLayer(_Cached):
             scale = self.ModulatedConv2ds[0].scale
             wp = H.pack_weight_stack([w[0] for w in ws], scale=scale)
             pc = H.PackedConv(wp, len(RATES), self.out_channel // len(RATES), self.in_channel, 3, 3, 1, RATES, RATES)
-            wsq = torch.cat([(w[0] ** 2).sum((2, 3)) for w in ws], 0).contiguous()
-            return pc, wsq
+            return pc
         return self._derive("branches", ws, build)
+
+    def _style_wsq(self):        # squared-tap sums of the four branches, (out_channel, in_channel); address stable (layers.StyleContext)
+        ws = [m.weight for m in self.ModulatedConv2ds]
+        return self._derive_static("branch_wsq", ws, lambda: torch.cat([(w[0] ** 2).sum((2, 3)) for w in ws], 0).contiguous())
 
     def _fusion_pack(self):
         conv = self.fusion[0]
@@ -391,8 +434,8 @@ class SMARTLayer(_Cached):
 
     def forward(self, x, style, noise=None):
         x = x.contiguous()
-        pc, wsq = self._branch_pack()
-        mod, demod = style_terms(self, self.modulation, style, wsq, self.ModulatedConv2ds[0].scale)
+        pc = self._branch_pack()
+        mod, demod = style_terms(self, self.modulation, style, self._style_wsq(), self.ModulatedConv2ds[0].scale)
         mid = H.conv2d_packed(x, pc, in_scale=mod, out_scale=demod)
         nz = self.noise.draw(noise, (x.shape[0], 1, x.shape[2], x.shape[3]), x.device)
         return H.conv2d_packed(mid, self._fusion_pack(), act1=True, bias1=self.fusion[1].bias, noise=nz,

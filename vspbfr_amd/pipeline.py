@@ -12,6 +12,7 @@ torch.distributed backend "nccl"); there is no collective inside the path.
 """
 import torch
 
+from ._lib import tune_env
 from .diffusion import Code_diffuser, My_DDPM
 from .e4e import E4e_embedding
 from .restorenet import Restoration_net, mixing_noise
@@ -23,7 +24,7 @@ def _side_stream():
     trailing into the next batch (round 5, same box, --steps 20: 190.0 / 190.6 img/s against 188.8 / 189.2 at the default
     priority).  VSP_SIDE_PRIORITY = 0 restores the default."""
     import os
-    pr = int(os.environ.get("VSP_SIDE_PRIORITY", "-1"))
+    pr = int(tune_env("VSP_SIDE_PRIORITY", "-1"))
     return torch.cuda.Stream(priority=pr) if pr else torch.cuda.Stream()
 
 
@@ -207,7 +208,7 @@ class RestorationPipeline:
             self._side = _side_stream()
         side = self._side
         import os
-        split = os.environ.get("VSP_OVERLAP_SPLIT", "ab") == "abc"   # experiment: stage C of the next batch on the side stream too
+        split = tune_env("VSP_OVERLAP_SPLIT", "ab") == "abc"   # experiment: stage C of the next batch on the side stream too
 
         counter = [0]
 

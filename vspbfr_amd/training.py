@@ -288,7 +288,7 @@ class _SmartBranches(Function):
             demod = torch.cat(parts, 1)
         demod = demod.contiguous()
         ctx.n_w = len(weights)
-        pc, _ = layer._branch_pack()
+        pc = layer._branch_pack()
         y = H.conv2d_packed(x, pc, in_scale=s, out_scale=demod)
         ctx.layer = layer
         ctx.save_for_backward(x, s, demod, y, *wsqs, *(weights if wsqs else ()))
