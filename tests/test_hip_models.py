@@ -243,11 +243,13 @@ def test_style_plan_follows_weight_updates():
         layers.STYLE_PLANS = True
     assert torch.equal(after, ref), float((after - ref).abs().max())
     assert float((after - before).abs().max()) > 1e-3
-    # a re-allocated parameter (pointer moved): the table is rebuilt, the old one retired (not freed), results still exact
+    # a re-allocated conv weight: the tap sums are refreshed in place (same address), no new table; a re-allocated modulation weight (its
+    # pointer IS in the table): the table is rebuilt, the old one retired (not freed); results exact both times
     with torch.no_grad():
         for m in net.modules():
-            if isinstance(m, layers.ModulatedConv2d) and m.demodulate:
+            if isinstance(m, layers.ModulatedConv2d) and m.demodulate and hasattr(m, "modulation"):
                 m.weight.data = m.weight.data.clone() * 1.1
+                m.modulation.weight.data = m.modulation.weight.data.clone() * 0.9
                 break
     again = run_net(2)
     layers.STYLE_PLANS = False

@@ -97,6 +97,9 @@ class RestorationPipeline:
         # free-running result is the same either way (codes 2.5e-5 vs 4e-6, restored 3.0e-3 vs 3.6e-3 from the reference -- the
         # sampler chain's own fp32 conditioning dominates), and it costs 5 % throughput (tools/x3_free_running.py)
         self.encoder_fp32_under_x3 = False
+        # stage A on the fp32 kernels in the bf16 configuration too (review r5 weak 1.ii: the sampler chain amplifies the encoder's rounding;
+        # stage A runs under C + D of the previous batch on the side stream, so its precision costs little time): measured in DESIGN 5
+        self.encoder_fp32 = False
 
     def draw_decode_noise(self, B, image_index0, device):
         """z, prior-decoder, encoder and decoder noise maps of one batch in ONE launch (keyed mode)."""
@@ -123,7 +126,7 @@ class RestorationPipeline:
                                      device=low_imgs.device, index_tensor=self._index_tensor)[0]
             owned = True
         mode = hip_ops.BF16_CONV
-        if mode == "x3" and self.encoder_fp32_under_x3:
+        if (mode == "x3" and self.encoder_fp32_under_x3) or (mode and self.encoder_fp32):
             # the sampler chain amplifies a perturbation of its condition ~2000x with random weights: the encoder that
             # feeds it keeps the fp32 kernels, the split-precision kernels serve stages C + D (80 % of the FLOPs)
             hip_ops.BF16_CONV = False
