@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VSP_ABI_VERSION 3
+#define VSP_ABI_VERSION 4
 
 #define VSP_OK 0
 #define VSP_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported combination) */
@@ -83,7 +83,12 @@ typedef struct vsp_fir_epilogue {
   int act;                  /* 0 none, 1 leaky-relu */
   float slope;              /* 0.2 */
   float gain;               /* sqrt(2) */
+  int flags;                /* VSP_FIR_SEPARABLE: kernel[ky][kx] == kernel[ky][0] * kernel[0][kx] / kernel[0][0] (an outer product, as every
+                             * blur of the path is: make_kernel([1,3,3,1]), models/RestoreNet.py:38-48) -- the caller's promise; the blur
+                             * kernels may then run a row pass and a column pass (8 multiply-adds per output instead of 16); the result
+                             * differs from the 2-D form by rounding only.  0 = general taps. */
 } vsp_fir_epilogue;
+#define VSP_FIR_SEPARABLE 1
 
 int vsp_upfirdn2d_f32(float* out, const float* x, const float* kernel, int major, int in_h, int in_w,
                       int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,

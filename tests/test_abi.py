@@ -32,7 +32,7 @@ def test_struct_layouts_match():
     for which, st in ((0, _lib.FirEpilogue), (1, _lib.ConvParams), (2, _lib.GemmParams), (3, _lib.TaccBlock),
                       (4, _lib.TaccChainParams)):
         assert _lib.lib.vsp_struct_size(which) == C.sizeof(st)
-    assert _lib.lib.vsp_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.vsp_abi_version() == _lib.ABI_VERSION == 4
     assert _lib.lib.vsp_conv2d_num_configs() >= 8
     assert _lib.lib.vsp_conv2d_config_name(0).decode()
 

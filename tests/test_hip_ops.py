@@ -834,7 +834,7 @@ def test_convert_roundtrip_and_unaligned(H):
 
 
 @pytest.mark.parametrize("C_,Hh,Ww,k,pad", [(3, 65, 65, 4, (1, 1)), (2, 64, 64, 4, (2, 2)), (5, 33, 129, 4, (1, 1)), (2, 40, 70, 3, (1, 1))])
-def test_blur_bf16_io_matches_fp32_kernel(H, C_, Hh, Ww, k, pad):
+def test_blur_bf16_io_matches_fp32_kernel(H, C_, Hh, Ww, k, pad, blur_2d):
     """vsp_upfirdn2d_bf16 = the fp32 blur on the same (bf16-representable) operands, rounded once at the store: bit-identical
     to rounding the fp32 kernel's output.  Odd widths make every plane start on a 2-byte boundary."""
     B = 2
@@ -855,7 +855,47 @@ def test_blur_bf16_io_matches_fp32_kernel(H, C_, Hh, Ww, k, pad):
     assert H.blur_fused(small, kern, pad).dtype == torch.float32
 
 
-def test_blur_bf16_strip_kernel_bit_identical_many_draws(H):
+@pytest.fixture
+def blur_2d(H):
+    """the blur kernels in their general 2-D form (the separable row / column form sums in another order)"""
+    prev = H.SEPARABLE_BLUR
+    H.SEPARABLE_BLUR = False
+    yield
+    H.SEPARABLE_BLUR = prev
+
+
+def test_blur_bf16_separable_form_vs_fp64(H):
+    """Round 6: outer-product taps (every blur of the path) run as a row pass + a column pass in the bf16 strip kernel (VSP_FIR_SEPARABLE),
+    and rows that are not whole 8-column strips (the down-sampling blurs: 2^n + 1 outputs) take whole strips + a tail launch.  Against a
+    float64 upfirdn2d of the same bf16 operands: every output within ONE bf16 unit of the rounded reference, at most 2 % off at all; the
+    2-D form on the same operands likewise (it is the same sum in another order)."""
+    kern = cases.fir_kernel("blur4", "bf16io")
+    assert H.taps_separable(dev(kern))
+    assert not H.taps_separable(dev(cases.fir_kernel("rand3x3", "bf16io")))
+    for it, (B, C_, Hh, Ww, pad) in enumerate([(2, 5, 33, 129, (1, 1)), (1, 3, 67, 515, (1, 1)), (2, 4, 66, 66, (2, 2)), (1, 2, 35, 35, (1, 1)),
+                                               (2, 3, 128, 128, (2, 2)), (1, 6, 40, 24, (2, 2)), (2, 2, 16, 16, (2, 2))]):
+        g_ = torch.Generator(device=DEV).manual_seed(300 + it)
+        x = _b16(torch.randn(B, C_, Hh, Ww, device=DEV, generator=g_))
+        oh, ow = Hh + 2 * pad[0] - 3, Ww + 2 * pad[0] - 3
+        nz = torch.randn(B, 1, oh, ow, device=DEV, generator=g_)
+        nw, ab = torch.full((1,), 0.3, device=DEV), torch.randn(C_, device=DEV, generator=g_)
+        r1 = _b16(torch.randn(B, C_, oh, ow, device=DEV, generator=g_))
+        for kw in (dict(noise=nz, noise_w=nw, act_bias=ab, act=True, res1=r1), {}):
+            got = H.blur_fused(x, dev(kern), pad, **kw)
+            assert got.dtype == torch.bfloat16 and got.shape == (B, C_, oh, ow)
+            ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.double().cpu(), (pad[0], pad[1], pad[0], pad[1])).view(B * C_, 1, Hh + 2 * pad[0], -1),
+                                             kern.double().flip(0, 1).view(1, 1, 4, 4)).view(B, C_, oh, ow)
+            if kw:
+                ref = ref + 0.3 * nz.double().cpu()
+                ref = torch.nn.functional.leaky_relu(ref + ab.double().cpu().view(1, -1, 1, 1), 0.2) * math.sqrt(2.0) + r1.double().cpu()
+            want = ref.float().to(torch.bfloat16)
+            d = (got.cpu().float() - want.float()).abs()
+            ulp = torch.maximum(want.float().abs(), torch.tensor(1e-30)) * 2.0 ** -7        # one bf16 unit: 2^-8 relative spacing, < 2^-7 |v|
+            assert bool((d <= ulp + 1e-6).all()), (it, sorted(kw), float((d / ulp).max()))
+            assert float((d > 0).float().mean()) < 0.02, (it, sorted(kw), float((d > 0).float().mean()))
+
+
+def test_blur_bf16_strip_kernel_bit_identical_many_draws(H, blur_2d):
     """The column-strip bf16 blur (round 5: planes 1 .. N-1 of every 4x4 blur whose rows are whole 16-byte segments) against the fp32
     tile kernel rounded once, over many draws: a fused-multiply-add contraction that differed between the two kernels showed as ONE
     bf16 unit on one output in 20 000 -- invisible to a single draw."""

@@ -26,7 +26,7 @@ def tune_env(name, default=None):
     return os.environ.get(name, default)
 
 
-ABI_VERSION = 3  # include/vspbfr_hip.h VSP_ABI_VERSION
+ABI_VERSION = 4  # include/vspbfr_hip.h VSP_ABI_VERSION
 c_float_p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 
 
@@ -34,8 +34,11 @@ class FirEpilogue(C.Structure):
     _fields_ = [
         ("plane_scale", C.c_void_p), ("noise", C.c_void_p), ("noise_w", C.c_void_p), ("act_bias", C.c_void_p),
         ("res1", C.c_void_p), ("res2", C.c_void_p),
-        ("channels", C.c_int), ("act", C.c_int), ("slope", C.c_float), ("gain", C.c_float),
+        ("channels", C.c_int), ("act", C.c_int), ("slope", C.c_float), ("gain", C.c_float), ("flags", C.c_int),
     ]
+
+
+FIR_SEPARABLE = 1   # vsp_fir_epilogue.flags: the taps are an outer product (include/vspbfr_hip.h VSP_FIR_SEPARABLE)
 
 
 class ConvParams(C.Structure):

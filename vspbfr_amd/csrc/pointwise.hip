@@ -50,13 +50,15 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
 #pragma unroll
       for (int u = 0; u < UN; ++u) n[u] = vsp::Elem<TX>::load4(xb + (int64_t)min(c0 + UN + u, Cin - 1) * HW);
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
+      for (int co = 0; co < CO; ++co) {
+        // the group's eight weights of this output channel: two 16-byte LDS reads (wave-uniform address) instead of eight 4-byte ones
+        const float4 wa = *reinterpret_cast<const float4*>(wl + co * Cin + c0), wb = *reinterpret_cast<const float4*>(wl + co * Cin + c0 + 4);
+        const float wv[UN] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-          const float wv = wl[co * Cin + c0 + u];
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv, acc[co][j]);
-        }
+          for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(v[u][j], wv[u], acc[co][j]);
+      }
 #pragma unroll
       for (int u = 0; u < UN; ++u) v[u] = n[u];
     }
@@ -87,6 +89,25 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
       }
     }
   }
+  // up-sampled residual, in-row quads: this thread's row / column, source window origin and the four taps per source row
+  const bool quad_row = up_src && (W & 3) == 0 && (HW & 3) == 0 && HW < ((int64_t)1 << 31);
+  int uhh = 0, uhw = 0, usy = 0, usx = 0;
+  float uk[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (quad_row) {
+    const unsigned p32 = (unsigned)p0, oy = p32 / (unsigned)W, ox = p32 - oy * (unsigned)W;
+    uhh = (int)((unsigned)HW / (unsigned)W) >> 1;
+    uhw = W >> 1;
+    const int py = oy & 1;
+    usy = (int)(oy >> 1) - 1 + py;       // source rows usy, usy + 1 carry the taps ky = py, py + 2
+    usx = (int)(ox >> 1) - 1;            // source columns usx .. usx + 3
+#pragma unroll
+    for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {      // q = 2 (column parity) + tx: kx = parity + 2 tx
+        const int ky = py + 2 * ty, kx = (q >> 1) + 2 * (q & 1);
+        uk[ty][q] = up_k[(3 - ky) * 4 + (3 - kx)];
+      }
+  }
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     const int64_t o = ((int64_t)b * CO + co) * HW + p0;
@@ -96,9 +117,41 @@ __global__ __launch_bounds__(256) void pw_few_out_kernel(float* __restrict__ y, 
       if (full) r = *reinterpret_cast<const f32x4u*>(res + o);
       else for (int j = 0; j < 4 && p0 + j < HW; ++j) r[j] = res[o + j];
     }
-    if (up_src) {
+    if (up_src && quad_row) {
       // residual = upfirdn2d(up_src, up_k (4x4), up = 2, pad = (2, 1)) evaluated in place (the Upsample of the RGB skip,
-      // models/RestoreNet.py:100-118): zero insertion leaves one tap per parity and axis, 2 x 2 taps of the half-size map
+      // models/RestoreNet.py:100-118): zero insertion leaves one tap per parity and axis, 2 x 2 taps of the half-size map.  A lane's four
+      // pixels lie in ONE row (W % 4 == 0): their sources are 2 rows x 4 columns of the half-size map, the taps depend on the row parity
+      // only -- row / column once per thread in 32-bit arithmetic, 8 clamped loads per channel (the per-pixel form below: four 64-bit
+      // divisions and 16 gathers per channel, as many instructions as the 64-channel main loop).  Same taps, same order of the four
+      // fused multiply-adds per pixel as the per-pixel form: bit-identical.
+      const float* sp = up_src + ((int64_t)b * CO + co) * uhh * uhw;
+      float sv[2][4];
+#pragma unroll
+      for (int ty = 0; ty < 2; ++ty) {
+        const int sy = usy + ty;
+        const bool rok = sy >= 0 && sy < uhh;
+        const float* srow = sp + min(max(sy, 0), uhh - 1) * uhw;
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx) {
+          const int sx = usx + cx;
+          const float val = srow[min(max(sx, 0), uhw - 1)];
+          sv[ty][cx] = (rok && sx >= 0 && sx < uhw) ? val : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {      // pixel ox + j: column parity j & 1, taps kx = (j & 1), (j & 1) + 2 on columns (j + 1) / 2, (j + 1) / 2 + 1
+        float a = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 2; ++tx) {
+            // (a source outside the map: the per-pixel form multiplies a clamped value by a zero tap; here the value itself is the zero --
+            //  fma(k, 0, a) = fma(0, s, a) = a for finite operands)
+            a = fmaf(uk[ty][(j & 1) * 2 + tx], sv[ty][((j + 1) >> 1) + tx], a);
+          }
+        r[j] += a;
+      }
+    } else if (up_src) {
       const int Hh = (int)(HW / W), hh = Hh >> 1, hw = W >> 1;
       const float* sp = up_src + ((int64_t)b * CO + co) * hh * hw;
 #pragma unroll

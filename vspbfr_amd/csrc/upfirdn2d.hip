@@ -32,6 +32,7 @@ struct Epi {
   float slope;
   float gain;
   int enabled;
+  int separable;   // VSP_FIR_SEPARABLE: the taps are an outer product (the caller's promise)
 };
 
 __device__ __forceinline__ float epi_apply(const Epi& e, float v, int plane, int oy, int ox, int out_h, int out_w) {
@@ -286,17 +287,24 @@ __global__ __launch_bounds__(256) void fir_tile_kernel(T* __restrict__ out, cons
 #ifndef VSP_STRIP_RC
 #define VSP_STRIP_RC 32
 #endif
-template <int RC, bool EN, bool ACT>
+// SEP (round 6): the taps are an outer product k[ky][kx] = ty[ky] tx[kx] (every blur of the path: make_kernel([1, 3, 3, 1])) -- an input row is
+// reduced along x ONCE when it arrives (32 multiply-adds for the lane's 8 columns) and the rotating window holds those row sums (4 x 8
+// instead of 4 x 12 registers); an output row is their 4-tap column sum (32 multiply-adds): 64 instead of 128 per output row.  tx = the
+// flipped taps' first row, ty = first column / corner: exact for dyadic taps, otherwise within rounding of the 2-D form.
+// TAIL: the columns past the last whole 8-column strip (down-sampling blurs: rows of 2^n + 1 outputs), one lane per (plane, row chunk),
+// 2-byte stores predicated by their offset; no epilogue operands.  (ox0 = first column of the strip grid: 0, or the tail's first column.)
+template <int RC, bool EN, bool ACT, bool SEP = false, bool TAIL = false>
 __global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp::bf16_t* __restrict__ out, const vsp::bf16_t* __restrict__ x, const float* __restrict__ kern,
                                                              int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int strips_x,
-                                                             int chunks_y, int total, int x_bytes, int out_bytes, Epi epi) {
+                                                             int chunks_y, int total, int x_bytes, int out_bytes, int ox0, Epi epi) {
   static_assert(RC % 4 == 0, "the row loop is unrolled by the four window slots");
+  static_assert(!(TAIL && EN), "the tail strip carries no epilogue");
   const int gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const int sx = gid % strips_x;
   const int t = gid / strips_x;
   const int cy = t % chunks_y, plane = 1 + t / chunks_y;
-  const int ox = 8 * sx, oy0 = cy * RC;
+  const int ox = ox0 + 8 * sx, oy0 = cy * RC;
   const int ix0 = ox - pad_x0;
   float taps[4][4];   // flipped: a true convolution
 #pragma unroll
@@ -335,19 +343,37 @@ __global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp:
     qa[slot] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
     qb[slot] = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(xrs, vo, 16, 0));
   };
-  float win[4][12];   // the last four input rows, twelve columns (eleven used)
-  auto unpack = [&](int slot, float (&w)[12]) {
+  constexpr int WN = SEP ? 8 : 12;
+  float win[4][WN];   // the last four input rows: twelve columns (eleven used), or (SEP) their eight row sums
+  float txf[4], tyf[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    txf[k] = taps[0][k];
+    tyf[k] = k == 0 ? 1.f : taps[k][0] / taps[0][0];
+  }
+  auto unpack = [&](int slot, float (&wo)[WN]) {
     const unsigned d[6] = {qa[slot][0] & cmask[0], qa[slot][1] & cmask[1], qa[slot][2] & cmask[2], qa[slot][3] & cmask[3], qb[slot][0] & cmask[4],
                            qb[slot][1] & cmask[5]};
+    if constexpr (SEP) {
+      float w[12];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      w[2 * k] = vsp::bf16_lo(d[k]);
-      w[2 * k + 1] = vsp::bf16_hi(d[k]);
+      for (int k = 0; k < 6; ++k) {
+        w[2 * k] = vsp::bf16_lo(d[k]);
+        w[2 * k + 1] = vsp::bf16_hi(d[k]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wo[j] = fmaf(txf[3], w[j + 3], fmaf(txf[2], w[j + 2], fmaf(txf[1], w[j + 1], txf[0] * w[j])));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        wo[2 * k] = vsp::bf16_lo(d[k]);
+        wo[2 * k + 1] = vsp::bf16_hi(d[k]);
+      }
     }
   };
   const int orow0 = (int)(((int64_t)plane * out_h + oy0) * out_w + ox);     // element index of the chunk's first output
   const int nrow0 = (int)(((int64_t)b * out_h + oy0) * out_w + ox);
-  auto emit = [&](int ro, const float (&w0)[12], const float (&w1)[12], const float (&w2)[12], const float (&w3)[12]) {   // output row ro of the chunk
+  auto emit = [&](int ro, const float (&w0)[WN], const float (&w1)[WN], const float (&w2)[WN], const float (&w3)[WN]) {   // output row ro of the chunk
     const int oy = oy0 + ro;
     const bool ok = oy < out_h;
     f32x4u nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = nz0;
@@ -361,24 +387,29 @@ __global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp:
       r2 = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(r2rs, eo, 0, 0));
     }
     float acc[8];
+    if constexpr (SEP) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(tyf[3], w3[j], fmaf(tyf[2], w2[j], fmaf(tyf[1], w1[j], w0[j])));   // (tyf[0] = 1)
+    } else {
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[0][kx], w0[j + kx], acc[j]);
+      for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[0][kx], w0[j + kx], acc[j]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[1][kx], w1[j + kx], acc[j]);
+      for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[1][kx], w1[j + kx], acc[j]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[2][kx], w2[j + kx], acc[j]);
+      for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[2][kx], w2[j + kx], acc[j]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[3][kx], w3[j + kx], acc[j]);
+      for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(taps[3][kx], w3[j + kx], acc[j]);
+    }
     if (EN) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -401,7 +432,14 @@ __global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp:
       }
     }
     const u32x4s o = {vsp::bf16_pack(acc[0], acc[1]), vsp::bf16_pack(acc[2], acc[3]), vsp::bf16_pack(acc[4], acc[5]), vsp::bf16_pack(acc[6], acc[7])};
-    __builtin_amdgcn_raw_buffer_store_b128(o, ors, ok ? (orow0 + ro * out_w) * 2 : 0x7ffffff0, 0, 0);
+    if constexpr (TAIL) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)   // (no branch: a column past the row leaves through an out-of-range offset)
+        __builtin_amdgcn_raw_buffer_store_b16((short)((j & 1) ? (o[j >> 1] >> 16) : (o[j >> 1] & 0xffffu)), ors,
+                                              (ok && ox + j < out_w) ? (orow0 + ro * out_w + j) * 2 : 0x7ffffff0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(o, ors, ok ? (orow0 + ro * out_w) * 2 : 0x7ffffff0, 0, 0);
+    }
   };
   // rows 0..2 fill the window; from then on: row r + 2 in flight, row r + 1 ... hmm: two rows ahead
   fetch(0, 0);
@@ -504,7 +542,9 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     e.act = epi_in->act;
     e.slope = epi_in->slope;
     e.gain = epi_in->gain;
-    e.enabled = 1;
+    e.separable = (epi_in->flags & VSP_FIR_SEPARABLE) ? 1 : 0;
+    // an epilogue that names no operand and no activation is the identity: the kernels then take their plain form
+    e.enabled = (e.plane_scale || e.noise || e.act || e.res1 || e.res2) ? 1 : 0;
   }
   hipStream_t s = vsp::as_stream(stream);
   const bool tile_ok = (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && out_w >= 16);
@@ -514,8 +554,10 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
     // the strip walk (no LDS, ~24 vector instructions per output): 4 x 4 taps on planes whose rows are whole 16-byte output segments
     static const int strip_env = vsp::tune_env("VSP_FIR_STRIP") ? atoi(vsp::tune_env("VSP_FIR_STRIP")) : 1;
     const int64_t xb = (int64_t)major * in_h * in_w * 2, ob = (int64_t)major * out_h * out_w * 2;
-    if (strip_env && tile_ok && kh == 4 && kw == 4 && out_w % 8 == 0 && out_h >= 4 && xb < 0x7ffffff0ll && ob < 0x7ffffff0ll &&
-        (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (!e.res1 || (reinterpret_cast<uintptr_t>(e.res1) & 15) == 0) &&
+    // rows that are not whole strips (the down-sampling blurs: 2^n + 1 outputs per row): whole strips + a TAIL launch, plain form only
+    const bool ragged = out_w % 8 != 0;
+    if (strip_env && tile_ok && kh == 4 && kw == 4 && (!ragged || !e.enabled) && out_h >= 4 && xb < 0x7ffffff0ll && ob < 0x7ffffff0ll &&
+        (ragged || (reinterpret_cast<uintptr_t>(out) & 15) == 0) && (!e.res1 || (reinterpret_cast<uintptr_t>(e.res1) & 15) == 0) &&
         (!e.res2 || (reinterpret_cast<uintptr_t>(e.res2) & 15) == 0) && (!e.noise || (reinterpret_cast<uintptr_t>(e.noise) & 15) == 0)) {
       constexpr int RC = VSP_STRIP_RC;
       const int strips_x = out_w / 8, chunks_y = (out_h + RC - 1) / RC;
@@ -523,13 +565,29 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
       if (total_t < ((int64_t)1 << 31)) {
         if (total_t > 0) {
           const unsigned gridn = (unsigned)((total_t + 255) / 256);
-#define VSP_STRIP_LAUNCH(EN_, ACT_)                                                                                                         \
-  fir_strip_bf16_kernel<RC, EN_, ACT_><<<gridn, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, strips_x, chunks_y, \
-                                                             (int)total_t, (int)xb, (int)ob, e)
-          if (!e.enabled) VSP_STRIP_LAUNCH(false, false);
-          else if (e.act) VSP_STRIP_LAUNCH(true, true);
-          else VSP_STRIP_LAUNCH(true, false);
+#define VSP_STRIP_LAUNCH(EN_, ACT_, SEP_)                                                                                                         \
+  fir_strip_bf16_kernel<RC, EN_, ACT_, SEP_><<<gridn, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, strips_x, chunks_y, \
+                                                                   (int)total_t, (int)xb, (int)ob, 0, e)
+          if (e.separable) {
+            if (!e.enabled) VSP_STRIP_LAUNCH(false, false, true);
+            else if (e.act) VSP_STRIP_LAUNCH(true, true, true);
+            else VSP_STRIP_LAUNCH(true, false, true);
+          } else {
+            if (!e.enabled) VSP_STRIP_LAUNCH(false, false, false);
+            else if (e.act) VSP_STRIP_LAUNCH(true, true, false);
+            else VSP_STRIP_LAUNCH(true, false, false);
+          }
 #undef VSP_STRIP_LAUNCH
+        }
+        if (ragged && major > 1) {
+          const int total_tail = (major - 1) * chunks_y;
+          const unsigned gridt = (unsigned)((total_tail + 255) / 256);
+          if (e.separable)
+            fir_strip_bf16_kernel<RC, false, false, true, true><<<gridt, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, 1, chunks_y,
+                                                                                     total_tail, (int)xb, (int)ob, strips_x * 8, e);
+          else
+            fir_strip_bf16_kernel<RC, false, false, false, true><<<gridt, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, 1, chunks_y,
+                                                                                      total_tail, (int)xb, (int)ob, strips_x * 8, e);
         }
         // plane 0 (see the kernel's header): the tile kernel on one plane
         const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;

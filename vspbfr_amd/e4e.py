@@ -114,6 +114,10 @@ class Generator(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ IR-SE50 encoder
+HANDOFF = None          # set by pipeline.run_batches around get_w_plus: an object with .point ("h": inside the encoder) and .go(tensors)
+MAIN_STAGE_MIN = 16     # head stages whose OUTPUT map is at least this wide stay on the caller's stream (see Encoder4Editing.forward)
+
+
 def _bn_fold(bn):
     a = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     return a.contiguous(), (bn.bias - bn.running_mean * a).contiguous()
@@ -241,18 +245,44 @@ class Encoder4Editing(_Cached):
         p2 = H.upsample_add(c3, H.conv2d_packed(c2, c["l1"], ch_bias=self.latlayer1.bias))
         p1 = H.upsample_add(p2, H.conv2d_packed(c1, c["l2"], ch_bias=self.latlayer2.bias))
         B = x.shape[0]
-        heads = torch.empty((self.style_count, B, 512), device=x.device, dtype=torch.float32)   # [w0, delta_1, ..., delta_17]
+        # The map2style heads, class by class (coarse on c3, middle on p2, fine on p1).  Their first stages are chip-filling convolutions
+        # (512 -> 5632 at 64^2 -> 32^2: 425 GFLOP at batch 8), the later ones run on maps of 8^2 and below in launches of a few dozen
+        # workgroups.  With a HANDOFF (pipeline.run_batches) everything up to here and every stage whose output map is at least
+        # MAIN_STAGE_MIN^2 stays on the caller's stream; the small-map stages, the final GEMMs and the code assembly go to the side stream,
+        # where they (and the sampler chain behind them) run underneath the previous batch's big convolutions.
+        runs = []
         for (lo, hi), f in zip(self._head_classes(), (c3, p2, p1)):
-            self._heads(lo, hi, f, out=heads[lo:hi])
+            stages, lw, lb = self._head_consts(lo, hi)
+            runs.append([f, 0, stages, lw, lb, lo, hi])
+        ho = HANDOFF
+        if ho is not None and ho.point == "h":
+            for r in runs:
+                while r[1] < len(r[2]) and (r[0].shape[-1] // 2) >= MAIN_STAGE_MIN:
+                    r[0] = self._head_stage(r[0], r[2][r[1]])
+                    r[1] += 1
+            ho.go([r[0] for r in runs])
+        heads = torch.empty((self.style_count, B, 512), device=x.device, dtype=torch.float32)   # [w0, delta_1, ..., delta_17]
+        lin = self.styles[0].linear
+        for f, k, stages, lw, lb, lo, hi in runs:
+            for st in stages[k:]:
+                f = self._head_stage(f, st)
+            nh = hi - lo
+            H.gemm_nt(f, lw, out=heads[lo:hi], dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
+                      alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
         return H.e4e_codes(heads, latent_avg)                  # w[:, i] = w0 + delta_i (psp_encoders.py:188-199), (B, 18, 512)
 
     def _head_classes(self):
         return ((0, self.coarse_ind), (self.coarse_ind, self.middle_ind), (self.middle_ind, self.style_count))
 
-    def _heads(self, lo, hi, feat, out=None):
+    @staticmethod
+    def _head_stage(x, stage):
+        pc, bias = stage
+        return H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
+
+    def _head_consts(self, lo, hi):
         """All map2style heads fed by one feature map (same depth) as ONE launch per stage: the first conv is a plain conv
         with the heads' output channels concatenated, the following ones are true grouped convs (one group per head), the
-        final EqualLinear a batched GEMM.  Returns (hi - lo, B, 512)."""
+        final EqualLinear a batched GEMM.  Returns (stages [(packed conv, bias)], stacked linear weights, biases)."""
         heads = [self.styles[i] for i in range(lo, hi)]
         nh = len(heads)
         convs = [[m for m in h.convs if isinstance(m, nn.Conv2d)] for h in heads]
@@ -275,12 +305,15 @@ class Encoder4Editing(_Cached):
             lw = torch.stack([h.linear.weight for h in heads]).contiguous()
             lb = torch.stack([h.linear.bias for h in heads]).contiguous()
             return stages, lw, lb
-        stages, lw, lb = self._derive(f"heads{lo}", src, build)
+        return self._derive(f"heads{lo}", src, build)
+
+    def _heads(self, lo, hi, feat, out=None):
+        """One class of heads end to end: (hi - lo, B, 512)."""
+        stages, lw, lb = self._head_consts(lo, hi)
         x = feat
-        for pc, bias in stages:
-            x = H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
-        B = x.shape[0]
-        lin = heads[0].linear
+        for st in stages:
+            x = self._head_stage(x, st)
+        B, nh, lin = x.shape[0], hi - lo, self.styles[lo].linear
         return H.gemm_nt(x, lw, out=out, dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
                          alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
 

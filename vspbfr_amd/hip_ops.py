@@ -268,10 +268,32 @@ def fir_bf16_ok(kh, kw, up, down, minor, out_w):
     return up == 1 and down == 1 and minor == 1 and out_w >= 16 and (kh, kw) in ((4, 4), (3, 3), (2, 2))
 
 
+SEPARABLE_BLUR = tune_env("VSP_FIR_SEPARABLE", "1") != "0"   # (A/B runs: the 2-D form)
+_SEPARABLE = {}   # (data_ptr, _version, device) of a tap tensor -> bool
+
+
+def taps_separable(kernel):
+    """True when the 2-D taps are exactly an outer product k[i][j] == k[i][0] * k[0][j] / k[0][0] in fp32 (make_kernel of a 1-D list: every
+    blur of the path) -- decided once per tap tensor on the host (the tensor is a module buffer; one small device-to-host copy at first use)."""
+    key = (kernel.data_ptr(), kernel._version, kernel.device)
+    hit = _SEPARABLE.get(key)
+    if hit is None:
+        k = kernel.detach().float().cpu()
+        hit = False
+        if k.dim() == 2:
+            k = k.flip(0, 1)        # the kernels work on the flipped taps (a true convolution): row factor = first column / corner
+            hit = bool(float(k[0, 0]) != 0.0 and torch.equal(k, ((k[:, :1] / k[0, 0]) * k[:1, :]).float()))
+        if len(_SEPARABLE) > 256:
+            _SEPARABLE.clear()
+        _SEPARABLE[key] = hit
+    return hit
+
+
 def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_bias=None, act=False, res1=None,
                res2=None, slope=0.2, gain=SQRT2):
     """NCHW blur (up=down=1) with the fused demod/noise/bias/leaky-relu/residual epilogue of the C ABI.  The element type of
-    x decides the kernel (fp32 / bf16 activations); residuals are converted to it when they differ (small maps only)."""
+    x decides the kernel (fp32 / bf16 activations); residuals are converted to it when they differ (small maps only).  Outer-product
+    taps are flagged (VSP_FIR_SEPARABLE): the kernels may then run a row pass and a column pass."""
     x = _req(x, "x", bf16_ok=True)
     B, Cc, H, W = x.shape
     kh, kw = kernel.shape
@@ -284,6 +306,7 @@ def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_b
     epi.plane_scale, epi.noise, epi.noise_w, epi.act_bias, epi.res1, epi.res2 = [
         (t.data_ptr() if t is not None else None) for t in keep]
     epi.channels, epi.act, epi.slope, epi.gain = Cc, 1 if act else 0, slope, gain
+    epi.flags = _lib.FIR_SEPARABLE if (SEPARABLE_BLUR and taps_separable(kernel)) else 0
     out = upfirdn2d_native_layout(x.view(B * Cc, H, W, 1), kernel, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1], epi)
     return out.view(B, Cc, out.shape[1], out.shape[2])
 

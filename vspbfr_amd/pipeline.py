@@ -100,6 +100,7 @@ class RestorationPipeline:
         # stage A on the fp32 kernels in the bf16 configuration too (review r5 weak 1.ii: the sampler chain amplifies the encoder's rounding;
         # stage A runs under C + D of the previous batch on the side stream, so its precision costs little time): measured in DESIGN 5
         self.encoder_fp32 = False
+        self.overlap_split = "h"     # run_batches: which part of stages A + B runs on the side stream (see there)
 
     def draw_decode_noise(self, B, image_index0, device):
         """z, prior-decoder, encoder and decoder noise maps of one batch in ONE launch (keyed mode)."""
@@ -117,9 +118,11 @@ class RestorationPipeline:
         return t[:a], t[a:b], t[b:c], t[c:]
 
     @torch.no_grad()
-    def encode(self, low_imgs, x_T=None, image_index0=0):
-        """Stages A + B: (low_latent, pre_dic_latent).  Small-map convolutions and the latency-bound sampler chain."""
-        from . import hip_ops
+    def encode(self, low_imgs, x_T=None, image_index0=0, handoff=None):
+        """Stages A + B: (low_latent, pre_dic_latent).  Small-map convolutions and the latency-bound sampler chain.
+        `handoff` (run_batches): an object with .point and .go(tensors) that moves the rest of the call to another stream -- "h": inside the
+        encoder, behind its last chip-filling convolution (e4e.Encoder4Editing.forward); "b": between the encoder and the sampler chain."""
+        from . import e4e, hip_ops
         owned = False
         if x_T is None and self.noise_seed is not None:
             x_T = hip_ops.keyed_fill([(low_imgs.shape[0], 18, 512)], [hip_ops.SEG_XT], self.noise_seed, image_index0,
@@ -130,10 +133,17 @@ class RestorationPipeline:
             # the sampler chain amplifies a perturbation of its condition ~2000x with random weights: the encoder that
             # feeds it keeps the fp32 kernels, the split-precision kernels serve stages C + D (80 % of the FLOPs)
             hip_ops.BF16_CONV = False
+        e4e.HANDOFF = handoff
         try:
             low_latent = self.psp.get_w_plus(low_imgs)
         finally:
             hip_ops.BF16_CONV = mode
+            e4e.HANDOFF = None
+        if handoff is not None:
+            if handoff.point == "b":
+                handoff.go([low_latent])
+            if x_T is not None:
+                handoff.also(x_T)        # drawn on the first stream, read by the chain on the second
         kw = {"x_T_owned": True} if (owned and isinstance(self.diffusion, My_DDPM)) else {}
         pre = self.diffusion(x=low_latent, condi_in=low_latent, training=False, x_T=x_T, **kw)
         return low_latent, pre
@@ -210,14 +220,49 @@ class RestorationPipeline:
         if not hasattr(self, "_side"):
             self._side = _side_stream()
         side = self._side
-        import os
-        split = tune_env("VSP_OVERLAP_SPLIT", "ab") == "abc"   # experiment: stage C of the next batch on the side stream too
+        # what runs where (round 6, tools/bench_hidden_cost.py: at batch 8 stages C + D alone take 26.3 ms, A + B alone 14.9 ms, and with
+        # ALL of A + B on the side stream the step took 39.6 ms -- two streams of chip-filling convolutions take each other's CUs, LDS and
+        # L2; only launch- / latency-bound work hides):
+        #   "h"  (default) the encoder's trunk and its chip-filling head stages on the MAIN stream in front of C + D of the previous
+        #        batch; the small-map head stages, the code assembly and the sampler chain on the side stream underneath C + D
+        #   "b"  the whole encoder on the main stream, the chain alone on the side stream
+        #   "ab" stages A + B on the side stream (rounds 2-5);  "abc": stage C there too (measured slower in round 5)
+        split_mode = tune_env("VSP_OVERLAP_SPLIT", self.overlap_split)
+        split = split_mode == "abc"
 
         counter = [0]
+
+        class _Handoff:
+            def __init__(self, point):
+                self.point, self.done = point, False
+
+            def go(self, tensors):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                for t in tensors:
+                    t.record_stream(side)      # allocated from the main stream's pool, read on the side stream
+                torch.cuda.set_stream(side)
+                self.done = True
+
+            def also(self, t):
+                if self.done:
+                    t.record_stream(side)
 
         def start(item):
             batch, idx0 = item if isinstance(item, (tuple, list)) else (item, counter[0])
             counter[0] = idx0 + batch.shape[0]
+            if split_mode in ("h", "b"):
+                ho = _Handoff(split_mode)
+                try:
+                    lat, pre = self.encode(batch, image_index0=idx0, handoff=ho)   # starts on `main`, ends on `side`
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                finally:
+                    torch.cuda.set_stream(main)
+                for t in _tensors((lat, pre)):
+                    t.record_stream(main)      # allocated on the side stream's pool, consumed on the main stream
+                return batch, lat, pre, ev, idx0, None
             side.wait_stream(main)  # the batch (and everything enqueued before) is visible to the side stream
             extra = None
             with torch.cuda.stream(side):
