@@ -713,28 +713,39 @@ def test_config_c3_full_size():
     pipe.act_bf16 = True                                              # bf16 activations in HBM for stages C + D
     try:
         out = pipe(lq, image_index0=i0)
+        pipe.encoder_fp32 = True                                      # stage A on the fp32 kernels (review r5 weak 1.ii): what does the
+        out_encf32 = pipe(lq, image_index0=i0)                        # bf16 encoder cost in accuracy -- the chain amplifies its codes' error
+        pipe.encoder_fp32 = False
         pipe.act_bf16 = False
         out_f32act = pipe(lq, image_index0=i0)                        # same bf16 kernels, fp32 activations in HBM (round 1's form)
     finally:
         H.BF16_CONV = False
         pipe.act_bf16 = False
+        pipe.encoder_fp32 = False
     assert out["restored"].shape == (B, 3, 512, 512) and torch.isfinite(out["restored"]).all()
     assert out["restored"].dtype == torch.float32 and out["style_sample"].dtype == torch.float32
     d = (out["restored"] - ref["restored"]).float()
     d32 = (out_f32act["restored"] - ref["restored"]).float()
     std = float(ref["restored"].std())
     q = OM.save_image_quantize(out["restored"][:, :, ::4, ::4].cpu()).int() - OM.save_image_quantize(ref["restored"][:, :, ::4, ::4].cpu()).int()
+    de = (out_encf32["restored"] - ref["restored"]).float()
+    qe = OM.save_image_quantize(out_encf32["restored"][:, :, ::4, ::4].cpu()).int() - OM.save_image_quantize(ref["restored"][:, :, ::4, ::4].cpu()).int()
+    rep_enc = {"encoder_fp32_restored_rms": float(de.pow(2).mean().sqrt()), "encoder_fp32_restored_max": float(de.abs().max()),
+               "encoder_fp32_pre_latent_max": maxerr(out_encf32["pre_latent"], ref["pre_latent"]), "encoder_fp32_lsb_mean": float(qe.abs().float().mean()),
+               "encoder_fp32_lsb_max": int(qe.abs().max())}
     rep = {"ddim_chain_vs_oracle": e_chain, "restored_std": std, "bf16_restored_rms": float(d.pow(2).mean().sqrt()),
            "bf16_restored_max": float(d.abs().max()), "bf16_codes_max": maxerr(out["latent"], ref["latent"]),
            "bf16_pre_latent_max": maxerr(out["pre_latent"], ref["pre_latent"]), "lsb_mean": float(q.abs().float().mean()),
            "lsb_max": int(q.abs().max()), "fp32_activations_restored_rms": float(d32.pow(2).mean().sqrt()),
            "fp32_activations_restored_max": float(d32.abs().max())}
+    rep.update(rep_enc)
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/parity_c3_b16_ddim25_bf16.json", "w"), indent=1)
     print("C3:", rep)
     assert e_chain < 3e-4
+    assert rep["encoder_fp32_pre_latent_max"] == 0.0                  # stages A + B in fp32 are the fp32 run's
     assert rep["bf16_restored_rms"] < 2.0 * rep["fp32_activations_restored_rms"] + 1e-3   # storing activations in bf16 adds little
     assert rep["bf16_restored_rms"] < 0.02 * std and rep["bf16_restored_max"] < 0.15 * std and rep["lsb_mean"] < 2.0
 

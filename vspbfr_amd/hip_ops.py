@@ -269,24 +269,25 @@ def fir_bf16_ok(kh, kw, up, down, minor, out_w):
 
 
 SEPARABLE_BLUR = tune_env("VSP_FIR_SEPARABLE", "1") != "0"   # (A/B runs: the 2-D form)
-_SEPARABLE = {}   # (data_ptr, _version, device) of a tap tensor -> bool
 
 
 def taps_separable(kernel):
     """True when the 2-D taps are exactly an outer product k[i][j] == k[i][0] * k[0][j] / k[0][0] in fp32 (make_kernel of a 1-D list: every
-    blur of the path) -- decided once per tap tensor on the host (the tensor is a module buffer; one small device-to-host copy at first use)."""
-    key = (kernel.data_ptr(), kernel._version, kernel.device)
-    hit = _SEPARABLE.get(key)
-    if hit is None:
-        k = kernel.detach().float().cpu()
-        hit = False
-        if k.dim() == 2:
-            k = k.flip(0, 1)        # the kernels work on the flipped taps (a true convolution): row factor = first column / corner
-            hit = bool(float(k[0, 0]) != 0.0 and torch.equal(k, ((k[:, :1] / k[0, 0]) * k[:1, :]).float()))
-        if len(_SEPARABLE) > 256:
-            _SEPARABLE.clear()
-        _SEPARABLE[key] = hit
-    return hit
+    blur of the path) -- decided once per tap tensor on the host (one small device-to-host copy at first use); the answer rides on the
+    tensor OBJECT (a module buffer lives as long as its module; a temporary takes its answer with it -- an address is not an identity)."""
+    hit = getattr(kernel, "_vsp_separable", None)
+    if hit is not None and hit[0] == kernel._version:
+        return hit[1]
+    k = kernel.detach().float().cpu()
+    sep = False
+    if k.dim() == 2:
+        k = k.flip(0, 1)        # the kernels work on the flipped taps (a true convolution): row factor = first column / corner
+        sep = bool(float(k[0, 0]) != 0.0 and torch.equal(k, ((k[:, :1] / k[0, 0]) * k[:1, :]).float()))
+    try:
+        kernel._vsp_separable = (kernel._version, sep)
+    except (AttributeError, RuntimeError):
+        pass
+    return sep
 
 
 def blur_fused(x, kernel, pad, plane_scale=None, noise=None, noise_w=None, act_bias=None, act=False, res1=None,
