@@ -179,6 +179,11 @@ typedef struct vsp_conv_params {
    * and dil[q] / pad[q] belong to input-channel quarter q.  3x3, stride 1, Cin a multiple of 16; served by the pipelined kernels
    * only (VSP_ENOTSUP when no configuration fits). */
   int dil_by_input_quarter;
+  /* w_bstride != 0 (vsp_conv2d_bf16 with io_bf16 = 1 only; every other entry requires 0): PER-IMAGE weights -- image b reads the weight set at
+   * (char*)w + b * w_bstride (bytes, a multiple of 16), each in the layout of vsp_conv2d_bf16.  This is the reference's own "fused" modulated
+   * convolution (models/RestoreNet.py:381-416: weight * style per sample): vsp_modulate_weight_bf16 builds bf16(W * style[b]) once per layer and
+   * batch, in_scale / in_shift must then be NULL, and the kernel stages bf16 pixels into LDS with no arithmetic at all. */
+  int64_t w_bstride;
 } vsp_conv_params;
 
 int vsp_conv2d_f32(const vsp_conv_params* p, vsp_stream_t stream);
@@ -511,6 +516,15 @@ int vsp_convert_bf16_to_f32(float* out, const uint16_t* x, int64_t n, vsp_stream
 int vsp_upfirdn2d_bf16(uint16_t* out, const uint16_t* x, const float* kernel, int major, int in_h, int in_w, int minor,
                        int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
                        int pad_y1, const vsp_fir_epilogue* epilogue, vsp_stream_t stream);
+/* Per-image modulated weights for vsp_conv2d_bf16 (w_bstride): out[b] = bf16(wp * style[b][ci]) in the kernel's LDS-image order
+ * [group][chunk][tap][octet 2][co_pad][8] (ci = 16 chunk + 8 octet + j; Cin zero-padded to 16, cout_g to 32), wp = the packed fp32 weights
+ * [G][9][Cin][cout_g] of vsp_conv2d_f32, style = (B, Cin) rows `style_bstride` floats apart (shared by the groups of a dilation-group launch).
+ * One rounding per weight (the kernel's own path rounds W and x * style separately).  Returns the byte size of one image's set through
+ * vsp_modulate_weight_bf16_bytes.  Reference: models/RestoreNet.py:381-383 (weight = scale * weight * style), without the demodulation,
+ * which stays an fp32 (B, Cout) vector in the epilogue. */
+size_t vsp_modulate_weight_bf16_bytes(int G, int cin, int cout_g);
+int vsp_modulate_weight_bf16(uint16_t* out, const float* wp, const float* style, int B, int64_t style_bstride, int G, int cin, int cout_g,
+                             vsp_stream_t stream);
 int vsp_pointwise_bf16(void* y, const void* x, const float* w, const float* in_scale, const float* ch_bias,
                        const float* bias1, int act1, const float* bias2, int act2, const float* res, const float* up_src,
                        const float* up_kernel, int W, int B, int Cin, int Cout, int64_t HW, vsp_stream_t stream);

@@ -932,8 +932,125 @@ def test_pointwise_bf16_wide_side(H):
     assert got2.dtype == torch.bfloat16 and torch.equal(got2, _b16(ref2))
 
 
+@pytest.fixture
+def shared_weights(H):
+    """vsp_conv2d_bf16 with ONE weight set and the style scale applied to the staged pixels (round 6 moved modulated layers with bf16
+    activations to per-image weights, which round differently: test_conv2d_bf16_per_image_weights)"""
+    prev = H.BF16_MODW
+    H.BF16_MODW = False
+    yield
+    H.BF16_MODW = prev
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hh,Ww,G,mode", [
+    (2, 64, 64, 64, 64, 1, "s1"),        # plain stride 1
+    (3, 24, 40, 34, 48, 1, "s1"),        # Cin = 16 + 8 (the second octet of the last chunk is empty), ragged output channels and map
+    (2, 128, 32, 64, 64, 4, "s1"),       # four dilation groups over one shared input
+    (2, 512, 512, 16, 16, 1, "s1"),      # deep layer, many chunks
+    (2, 64, 128, 64, 64, 1, "s2"),       # stride 2 (parity planes), padding 0 after the blur in the path: tested with padding 1 and 0
+    (2, 32, 48, 30, 44, 1, "s2"),
+    (2, 128, 64, 32, 32, 1, "tc"),       # one-pass transposed
+    (1, 64, 32, 40, 64, 1, "tc"),
+])
+def test_conv2d_bf16_per_image_weights(H, B, Cin, Cout, Hh, Ww, G, mode):
+    """Round 6: a modulated layer with bf16 activations runs vsp_conv2d_bf16 on PER-IMAGE weights bf16(W * style[b]) (vsp_modulate_weight_bf16,
+    w_bstride; the reference's own fused form, models/RestoreNet.py:381-416) and its staging is a copy.  Against float64 F.conv2d /
+    F.conv_transpose2d on exactly those operands (bf16 pixels, bf16-rounded modulated weights; products exact, fp32 accumulation): within one
+    bf16 unit of the rounded reference everywhere.  Also: the weight image itself against a host restatement, bit for bit."""
+    g_ = torch.Generator(device=DEV).manual_seed(Cin * 3 + Hh)
+    x = _b16(torch.randn(B, Cin, Hh, Ww, device=DEV, generator=g_))
+    ws = [torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g_) / math.sqrt(Cin * 9) for _ in range(G)]
+    s_in = torch.rand(B, Cin, device=DEV, generator=g_) + 0.5
+    demod, bias = torch.rand(B, G * Cout, device=DEV, generator=g_) + 0.5, torch.randn(G * Cout, device=DEV, generator=g_)
+    dils = (1, 2, 4, 8)[:G] if G > 1 else (1,)
+    wp = torch.stack([H.pack_weight(w_)[0] for w_ in ws]).contiguous() if G > 1 else H.pack_weight(ws[0])
+    # the weight image: [b][group][chunk][tap][octet][co_pad][8]
+    pc0 = H.PackedConv(wp, G, Cout, Cin, 3, 3, 1, dils, dils)
+    img, nbytes = H.bf16_modulated_weight(pc0, s_in)
+    nch, co_pad = (Cin + 15) // 16, (Cout + 31) // 32 * 32
+    assert nbytes == G * nch * 9 * 2 * co_pad * 16 and img.shape == (B, nbytes // 2)
+    wz = torch.zeros(B, G, 9, nch * 16, co_pad, device=DEV)
+    wz[:, :, :, :Cin, :Cout] = wp[None] * s_in[:, None, None, :, None]
+    want = wz.view(B, G, 9, nch, 2, 8, co_pad).permute(0, 1, 3, 2, 4, 6, 5).to(torch.bfloat16).contiguous().view(B, -1)
+    assert torch.equal(img, want)
+
+    def wmod(b, g):   # bf16(W * s) as float64, (Cout, Cin, 3, 3)
+        return (ws[g] * s_in[b].view(1, -1, 1, 1)).to(torch.bfloat16).double().cpu()
+
+    def close(got, ref, what):
+        assert got.dtype == torch.bfloat16 and got.shape == ref.shape, (what, got.shape, ref.shape)
+        want_ = ref.float().to(torch.bfloat16).float()
+        err = (got.cpu().float() - want_).abs()
+        lim = ref.abs().float() * 2.0 ** -7 + 3e-5 * float(ref.abs().max())
+        assert bool((err <= lim).all()), (what, float((err / lim).max()))
+
+    xd = x.double().cpu()
+    if mode == "s1":
+        pc = pc0
+        kw = dict(in_scale=s_in, out_scale=demod, act2=1, bias2=bias)
+        prof = H.ConvProfiler()
+        H.PROFILER = prof
+        try:
+            got = H.conv2d_packed(x, pc, bf16=True, tile_hint=0, **kw) if G == 1 else None
+        finally:
+            H.PROFILER = None
+        if G > 1:
+            H.BF16_DG = False     # (keep the launch on vsp_conv2d_bf16: the dilation-group kernel has its own test)
+            try:
+                got = H.conv2d_packed(x, pc, bf16=True, **kw)
+            finally:
+                H.BF16_DG = True
+        ref = torch.stack([torch.cat([F.conv2d(xd[b:b + 1], wmod(b, g), padding=dils[g], dilation=dils[g]) for g in range(G)], 1)[0] for b in range(B)])
+        ref = F.leaky_relu(ref * demod.double().cpu()[:, :, None, None] + bias.double().cpu()[None, :, None, None], 0.2) * math.sqrt(2.0)
+        close(got, ref, "stride 1")
+    elif mode == "s2":
+        for pad in (1, 0):
+            pc = H.PackedConv(wp, 1, Cout, Cin, 3, 3, 2, (1,), (pad,))
+            got = H.conv2d_packed(x, pc, bf16=True, in_scale=s_in, out_scale=demod)
+            ref = torch.stack([F.conv2d(xd[b:b + 1], wmod(b, 0), stride=2, padding=pad)[0] for b in range(B)]) * demod.double().cpu()[:, :, None, None]
+            close(got, ref, f"stride 2 pad {pad}")
+    else:
+        pc = H.PackedConv(wp, 1, Cout, Cin, 3, 3, 1, (1,), (1,))
+        got = H.conv_transpose2d_s2_fused(x, pc, in_scale=s_in, out_scale=demod, bf16=True)
+        ref = torch.stack([F.conv_transpose2d(xd[b:b + 1], wmod(b, 0).transpose(0, 1), stride=2)[0] for b in range(B)]) * demod.double().cpu()[:, :, None, None]
+        close(got, ref, "transposed")
+    # the launch really took the per-image form: with it switched off the result differs somewhere (another rounding), and stays close
+    H.BF16_MODW = False
+    try:
+        if mode == "s1" and G == 1:
+            alt = H.conv2d_packed(x, pc, bf16=True, in_scale=s_in, out_scale=demod, act2=1, bias2=bias)
+            assert not torch.equal(alt, got)
+            assert float((alt.float() - got.float()).abs().max()) < 0.05 * float(got.float().abs().max())
+    finally:
+        H.BF16_MODW = True
+
+
+def test_conv2d_bf16_per_image_weights_refusals(H):
+    """w_bstride is served by vsp_conv2d_bf16 with bf16 activations only; every other entry refuses it (VSP_EINVAL), it does not ignore it."""
+    import ctypes as C
+    from vspbfr_amd import _lib
+    x = torch.randn(1, 16, 16, 16, device=DEV)
+    w = torch.randn(16, 16, 3, 3, device=DEV)
+    pc = H.PackedConv(H.pack_weight(w), 1, 16, 16, 3, 3, 1, (1,), (1,))
+    y = torch.empty(1, 16, 16, 16, device=DEV)
+    p = _lib.ConvParams()
+    p.x, p.w, p.y = x.data_ptr(), pc.w.data_ptr(), y.data_ptr()
+    p.B, p.Cin, p.H, p.W, p.G, p.cout_g, p.OH, p.OW, p.KH, p.KW = 1, 16, 16, 16, 1, 16, 16, 16, 3, 3
+    p.stride_y = p.stride_x = 1
+    p.dil[0] = p.pad_y[0] = p.pad_x[0] = 1
+    p.y_ch, p.y_h, p.y_w, p.osy, p.osx = 16, 16, 16, 1, 1
+    p.slope1 = p.slope2 = 0.2
+    p.gain1 = p.gain2 = 1.0
+    p.w_bstride = 4096
+    assert _lib.lib.vsp_conv2d_f32(C.byref(p), None) == -1          # VSP_EINVAL
+    assert _lib.lib.vsp_conv2d_bf16(C.byref(p), None) == -1         # fp32 activations
+    assert b"w_bstride" in _lib.lib.vsp_last_error() or b"per-image" in _lib.lib.vsp_last_error()
+    p.w_bstride = 0
+    assert _lib.lib.vsp_conv2d_f32(C.byref(p), None) == 0
+
+
 @pytest.mark.parametrize("B,Cin,Cout,Hh,Ww", [(2, 32, 64, 64, 64), (1, 64, 32, 33, 70), (2, 128, 128, 32, 32)])
-def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww):
+def test_conv2d_bf16_io(H, B, Cin, Cout, Hh, Ww, shared_weights):
     """io_bf16: the bf16 conv kernel with bf16 x / y / residuals equals the same kernel with fp32 I/O on the same
     (bf16-representable) operands, rounded once at the store -- stride 1 with the whole epilogue, the four dilation groups,
     stride 2 and the one-pass transposed form (whose (2H+1)^2 planes are only 2-byte aligned)."""

@@ -52,7 +52,7 @@ else:
     # AB_LIBS=<a.so>,<b.so>: the same comparison between two builds of the library instead of the two staging forms
     libs = os.environ.get("AB_LIBS", "").split(",") if os.environ.get("AB_LIBS") else None
     for k, (tag, env) in enumerate((("pair", "1"), ("one", "0"))):
-        e = dict(os.environ, VSP_TUNE="1", VSP_BF16_PAIR=env) if libs is None else dict(os.environ, VSPBFR_HIP_LIB=libs[k])
+        e = dict(os.environ, VSP_TUNE="1", VSP_BF16_MODW="0", VSP_BF16_PAIR=env) if libs is None else dict(os.environ, VSPBFR_HIP_LIB=libs[k])
         subprocess.check_call([sys.executable, os.path.abspath(__file__), tag], env=e)
     a, b = torch.load("/tmp/ab_bf16_pair_pair.pt"), torch.load("/tmp/ab_bf16_pair_one.pt")
     bad = 0

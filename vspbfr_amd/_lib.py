@@ -61,6 +61,7 @@ class ConvParams(C.Structure):
         ("tile_hint", C.c_int), ("x_ch", C.c_int), ("x_group_stride", C.c_int), ("transposed", C.c_int),
         ("io_bf16", C.c_int),
         ("dil_by_input_quarter", C.c_int),
+        ("w_bstride", C.c_int64),
     ]
 
 
@@ -168,13 +169,14 @@ SIGNATURES = {
     "vsp_conv2d_winograd4_f32": [_p, _p, C.c_size_t, _p],
     "vsp_winograd4f_weight_f32": [_p, _p, _i, _i, _p],
     "vsp_conv2d_winograd4f_f32": [_p, _p],
+    "vsp_modulate_weight_bf16": [_p, _p, _p, _i, _i64, _i, _i, _i, _p],
     "vsp_conv2d_winograd_chunk": [],
     "vsp_conv2d_winograd_mbw": [_i],
 }
 _CHARP = {"vsp_last_error": [], "vsp_conv2d_config_name": [_i]}
 _SIZET = {"vsp_tacc_chain_work_floats": [_i], "vsp_conv2d_wgrad_work_floats": [C.POINTER(ConvWgradParams)],
           "vsp_winograd_weight_floats": [_i, _i, _i], "vsp_winograd4_weight_floats": [_i, _i], "vsp_winograd4f_weight_floats": [_i, _i],
-          "vsp_conv2d_winograd4_work_floats": [_p]}
+          "vsp_conv2d_winograd4_work_floats": [_p], "vsp_modulate_weight_bf16_bytes": [_i, _i, _i]}
 
 
 def _load():

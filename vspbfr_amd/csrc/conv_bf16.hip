@@ -64,11 +64,18 @@ enum { M_CONV = 0, M_S2 = 1, M_TC = 2 };
 // load instruction costs the CU's vector-memory path 32 cycles whatever its width (tools/ubench/mfma_valu_gap.hip): with one bf16 element per
 // lane the staging of the whole chip is capped at 256 CUs x 4 B/clk = 2.1 TB/s -- which is what every layer of this kernel ran at (512 -> 512 at
 // 64^2, B = 16: 700 MB staged in 343 us) -- with the matrix pipe a third busy.
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false>
+// NOSC (round 6; bf16 activations, pair staging): the style lives in PER-IMAGE weights (p.w_bs; vsp_modulate_weight_bf16: bf16(W * style[b]), the
+// reference's own fused form), so a staged pixel is copied, not computed: the eight 4-byte loads of a pair task are interleaved into the two
+// pixels' channel octets by eight v_perm_b32 -- no widening, no multiply-add, no rounding, no scale loads (4.5 instead of ~28 vector
+// instructions per staged octet; PMC round 5: 4.9 vector + 3.7 scalar instructions per MFMA on 512 -> 512 at 64^2, the pipe 40 % busy).
+// Pixels outside the image come back as zeros from the buffer range check (the descriptor covers ONE image, the lane offset of an outside
+// pixel lies past it), so the commit has no padding select either.
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false, bool NOSC = false>
 __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 4 : 2) void conv_bf16_kernel(const ConvK p) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   static_assert(!(SPLIT && IOB), "the split-precision form keeps fp32 activations");
   static_assert(!PAIR || IOB, "pixel-pair staging is the bf16-activation form");
+  static_assert(!NOSC || PAIR, "the copy-only commit is a pair-staging form");
   using AT = typename std::conditional<IOB, vsp::bf16_t, float>::type;  // activation element in HBM
   constexpr unsigned ES = sizeof(AT);
   constexpr int NPART = SPLIT ? 2 : 1;
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
       auto slot = [&](int c) { return S2 ? ((r & 1) * 2 + (c & 1)) * PLANE + (r >> 1) * pitch + (c >> 1) : r * pitch + c; };
       pdst[e] = slot(c0);
       pdst1[e] = slot(c0 + 1);
-      poff[e] = in ? (unsigned)(iy * p.W + ix) * ES : 0u;
+      poff[e] = in ? (unsigned)(iy * p.W + ix) * ES : (NOSC ? 0x7ffffff0u : 0u);   // (NOSC: past the image's descriptor -> the load returns zeros)
       pin |= in ? (1u << e) : 0u;
       pwr |= (task && c0 >= 0) ? (1u << e) : 0u;
       pwr1 |= (task && c0 + 1 < NCOL) ? (1u << e) : 0u;
@@ -255,7 +262,8 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
   // Two register sets: chunk k lives in set k & 1.  Its loads are issued TWO intervals before its MFMAs (top of interval
   // k - 2), its conversion + LDS write is spread over the tap loop of interval k - 1 (VALU work in the shadow of the MFMAs).
   float pregA[PT][8], pregB[PT][8];
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<AT*>(xb), 0, 0x7fffffff, 0x00020000);
+  // (NOSC: the descriptor ends with this group's last channel plane -- the range check compares the lane offset with size - scalar offset)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<AT*>(xb), 0, NOSC ? p.Cin * chw * (int)ES : 0x7fffffff, 0x00020000);
   const float* iscp = p.in_scale + (int64_t)b * p.in_scale_bstride;
   const float* ishp = p.in_shift;
   // Cin is a multiple of 8 (host): a wave's channel octet is either wholly inside or wholly past Cin
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     }
   };
   auto load_scales = [&](int c, float (&sc)[8], float (&sh)[8]) -> bool {  // wave-uniform: scalar loads
+    if constexpr (NOSC) return c * BCK + 8 * oct < p.Cin;
     const int cib = min(c * BCK + 8 * oct, p.Cin - 8);
     // constant address space: a uniform load from it goes through the scalar cache (a plain global pointer does not, the
     // compiler cannot know that nothing stores to it).  Absent operands: a device constant through stride 0 (host).
@@ -301,6 +310,21 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
     return c * BCK + 8 * oct < p.Cin;
   };
   auto commit_one = [&](u32x4* Pdst, const float (&pr)[PT][8], const float (&sc)[8], const float (&sh)[8], bool oct_ok, int e) {
+    if constexpr (NOSC) {
+      constexpr unsigned LO = 0x05040100u, HI = 0x07060302u;   // v_perm_b32 selectors: the low / the high halves of (S1, S0)
+      u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = p0;
+      if (oct_ok) {   // (wave-uniform; an octet past Cin was never loaded: zeros)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned a = __builtin_bit_cast(unsigned, pr[e][2 * k]), bq_ = __builtin_bit_cast(unsigned, pr[e][2 * k + 1]);
+          p0[k] = __builtin_amdgcn_perm(bq_, a, LO);
+          p1[k] = __builtin_amdgcn_perm(bq_, a, HI);
+        }
+      }
+      if ((pwr >> e) & 1u) Pdst[oct * NPL * PLANE + pdst[e]] = p0;
+      if ((pwr1 >> e) & 1u) Pdst[oct * NPL * PLANE + pdst1[e]] = p1;
+      return;
+    }
     if constexpr (PAIR) {
       const bool in = ((pin >> e) & 1u) && oct_ok;
 #pragma unroll
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(BNT, (MB == 1 && MODE == 0 && PT <= 3 && !SPLIT) ? 
 
   // ---- weight slab by LDS-DMA: the chunk's [tap][octet] rows of this co tile, 64 rows (1 KiB) per wave instruction
   constexpr int NDMA = WSLAB / 64;
-  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)g * nchunk * (NPART * T * 2) * co_pad;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (int64_t)b * p.w_bs + (int64_t)g * nchunk * (NPART * T * 2) * co_pad;
   auto issue_w = [&](u32x4* Wdst, int c) {
 #ifdef VSP_BF16_ABLATE  // tuning only (VSP_CONV_DBG): 0x100000 no weight DMA after the prologue, 0x400000 every chunk re-reads chunk 0's slab
     if ((p.dbg & 0x100000) && c > 0) return;
@@ -709,9 +733,16 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
   return r;
 }
 
-template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false>
+template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false, bool NOSC = false>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   if constexpr (!SPLIT && !IOB) {
+    if (q.io_bf16 && q.w_bs != 0) {   // per-image weights: the copy-only pair staging (the entry checked even rows and the alignment of x)
+      if (gm.pt2 <= 1) return launch_bf<MB, NB, WM, WN, 1, MODE, false, true, true, true>(q, gm, stream);
+      if (gm.pt2 <= 2) return launch_bf<MB, NB, WM, WN, 2, MODE, false, true, true, true>(q, gm, stream);
+      if (gm.pt2 <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE, false, true, true, true>(q, gm, stream);
+      if (gm.pt2 <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE, false, true, true, true>(q, gm, stream);
+      return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: per-image weights: the patch plane of this tile needs more than five pair tasks per thread");
+    }
     if (q.io_bf16) {
       // bf16 activations: pixel-pair staging wherever rows are 4-byte multiples (env VSP_BF16_PAIR=0: the one-pixel tasks, for A/B runs)
       static const bool pair_env = !(vsp::tune_env("VSP_BF16_PAIR") && atoi(vsp::tune_env("VSP_BF16_PAIR")) == 0);
@@ -726,7 +757,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   }
   constexpr int CO_T = 32 * MB * WM, NPIX = 32 * NB * WN;
   static vsp::LdsAttrOnce attr;   // per device
-  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR>), 150 * 1024, "conv2d_bf16")) return rc;
+  if (int rc = attr.ensure(reinterpret_cast<const void*>(conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR, NOSC>), 150 * 1024, "conv2d_bf16")) return rc;
   q.tw_log2 = gm.twl;
   q.bf_pitch = gm.pitch;
   q.bf_plane = gm.plane;
@@ -767,7 +798,7 @@ int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
     }
   }
   dim3 grid((unsigned)blocks, (unsigned)(q.co_tiles * q.G), (unsigned)q.B);
-  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR><<<grid, BNT, gm.lds, stream>>>(q);
+  conv_bf16_kernel<MB, NB, WM, WN, PT, MODE, SPLIT, IOB, PAIR, NOSC><<<grid, BNT, gm.lds, stream>>>(q);
   return VSP_OK;
 }
 

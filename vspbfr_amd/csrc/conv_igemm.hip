@@ -230,13 +230,14 @@ static const float* slope_slot(const float* kc, float slope) {
 }  // namespace
 
 // Argument checks shared by vsp_conv2d_f32 and vsp_conv2d_winograd_f32; *empty = nothing to do.
-static int validate_conv(const vsp_conv_params& p, int* x_ch_out, bool* empty) {
+static int validate_conv(const vsp_conv_params& p, int* x_ch_out, bool* empty, bool allow_w_bstride = false) {
   *empty = false;
   VSP_REQUIRE(p.x && p.w && p.y, "conv2d: null tensor pointer");
   VSP_REQUIRE(p.B >= 0 && p.Cin >= 1 && p.H >= 1 && p.W >= 1, "conv2d: bad input dims B=%d Cin=%d H=%d W=%d", p.B,
               p.Cin, p.H, p.W);
   VSP_REQUIRE(p.G >= 1 && p.G <= 1024 && p.cout_g >= 1, "conv2d: bad group spec G=%d cout_g=%d", p.G, p.cout_g);
   VSP_REQUIRE(p.x_group_stride >= 0 && p.x_ch >= 0, "conv2d: negative x_ch / x_group_stride");
+  VSP_REQUIRE(p.w_bstride == 0 || allow_w_bstride, "conv2d: per-image weights (w_bstride) are served by vsp_conv2d_bf16 with io_bf16 = 1 only");
   const int x_ch = p.x_ch > 0 ? p.x_ch : p.Cin;
   VSP_REQUIRE((int64_t)(p.G - 1) * p.x_group_stride + p.Cin <= x_ch, "conv2d: group input channels exceed x_ch=%d", x_ch);
   VSP_REQUIRE(p.x_group_stride == 0 || !p.in_shift, "conv2d: an input shift is not supported with grouped input");
@@ -496,7 +497,14 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
               "conv2d_bf16: one input image must be smaller than 2 GiB (32-bit buffer offsets)");
   int x_ch = 0;
   bool empty = false;
-  if (int rc = validate_conv(p, &x_ch, &empty)) return rc;
+  const bool per_image_w = p.w_bstride != 0;
+  if (per_image_w) {
+    VSP_REQUIRE(!split && rv == 0 && p.io_bf16 == 1, "conv2d_bf16: per-image weights need the general bf16 kernel with bf16 activations");
+    VSP_REQUIRE(p.w_bstride > 0 && p.w_bstride % 16 == 0, "conv2d_bf16: w_bstride must be a positive multiple of 16 bytes");
+    VSP_REQUIRE(!p.in_scale && !p.in_shift, "conv2d_bf16: per-image weights carry the style: in_scale / in_shift must be NULL");
+    VSP_REQUIRE((p.W & 1) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 3) == 0, "conv2d_bf16: per-image weights need even rows (pixel-pair staging)");
+  }
+  if (int rc = validate_conv(p, &x_ch, &empty, true)) return rc;
   if (empty) return VSP_OK;
   VSP_REQUIRE((int64_t)p.G * p.cout_g <= 65535 && p.B <= 65535, "conv2d_bf16: grid too large");
   ConvK q{};
@@ -512,6 +520,7 @@ static int conv2d_bf16_impl(const vsp_conv_params* pp, vsp_stream_t stream, bool
   VSP_REQUIRE(p.io_bf16 == 0 || p.io_bf16 == 1, "conv2d_bf16: io_bf16 must be 0 or 1");
   VSP_REQUIRE(p.dil_by_input_quarter == 0, "conv2d_bf16: dil_by_input_quarter is served by vsp_conv2d_f32");
   q.io_bf16 = p.io_bf16;
+  q.w_bs = p.w_bstride / 16;
   {
     static const int dbg = vsp::tune_env("VSP_CONV_DBG") ? atoi(vsp::tune_env("VSP_CONV_DBG")) : 0;  // ablation builds only (VSP_BF16_ABLATE)
     q.dbg = dbg;

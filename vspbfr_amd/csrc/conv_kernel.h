@@ -69,6 +69,7 @@ struct ConvK {
   const float* wcp; int wc_cs, wc_bs;
   const float* wshp; int wsh_cs;
   int io_bf16;                                   // conv_bf16.hip: x, y, res1, res2 are bf16 in HBM
+  int64_t w_bs;                                  // conv_bf16.hip: 16-byte units between the per-image weight sets (0: one set); then no input scale
   int bf_tab;                                    // conv_bf16.hip: byte offset of the per-channel operand table in dynamic LDS
   int wg_cgs;                                    // conv_pipe.hip, wg_order 2: channel tiles per group (their weights fit half an XCD's L2)
   int rv_copad, rv_cbase, rv_ctot;               // conv_bf16_rv.hip: channel rows of a weight slab (cout_g rounded up to 32); first channel of the

@@ -107,6 +107,43 @@ __global__ __launch_bounds__(256) void winograd_weight_kernel(float* __restrict_
 
 }  // namespace
 
+namespace {
+// Per-image modulated weights of vsp_conv2d_bf16 (w_bstride): out[b][g][chunk][tap][octet][co][j] = bf16(wp[g][tap][16 chunk + 8 octet + j][co] *
+// style[b][ci]), zero past Cin / cout_g -- the LDS-image order of conv_bf16.hip, one 16-byte unit per thread (neighbouring threads = neighbouring
+// output channels: the eight strided reads of a thread coalesce across the wave).
+__global__ __launch_bounds__(256) void modulate_weight_bf16_kernel(uint4* __restrict__ out, const float* __restrict__ wp, const float* __restrict__ style,
+                                                                    int64_t style_bstride, int G, int cin, int cout_g, int nch, int co_pad, int units) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int b = blockIdx.y;
+  int r = u;
+  const int co = r % co_pad; r /= co_pad;
+  const int oct = r & 1; r >>= 1;
+  const int tap = r % 9; r /= 9;
+  const int chunk = r % nch;
+  const int g = r / nch;
+  const float* sp = style + (int64_t)b * style_bstride;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = 16 * chunk + 8 * oct + j;
+    const bool ok = ci < cin && co < cout_g;
+    const int cic = ok ? ci : 0, coc = ok ? co : 0;
+    const float w = wp[(((int64_t)g * 9 + tap) * cin + cic) * cout_g + coc];
+    v[j] = ok ? w * sp[cic] : 0.f;
+  }
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+  o.y = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, bf16x2));
+  o.z = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[4], v[5]}, bf16x2));
+  o.w = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[6], v[7]}, bf16x2));
+  out[(int64_t)b * units + u] = o;
+}
+
+}  // namespace
+
 extern "C" {
 
 int vsp_pack_weight_f32(float* wp, const float* w, int G, int cout_g, int cin, int KH, int KW, int adjoint, int flip, float scale,
@@ -145,6 +182,24 @@ int vsp_winograd_weight_f32(float* U, const float* wp, int G, int cin, int cout_
     default: return vsp::fail(VSP_EINVAL, "winograd_weight: unexpected block width");
   }
   return vsp::check_launch("winograd_weight");
+}
+
+size_t vsp_modulate_weight_bf16_bytes(int G, int cin, int cout_g) {
+  const int64_t nch = (cin + 15) / 16, co_pad = (cout_g + 31) / 32 * 32;
+  return (size_t)(G * nch * 9 * 2 * co_pad * 16);
+}
+
+int vsp_modulate_weight_bf16(uint16_t* out, const float* wp, const float* style, int B, int64_t style_bstride, int G, int cin, int cout_g,
+                             vsp_stream_t stream) {
+  VSP_REQUIRE(B >= 0 && G >= 1 && cin >= 1 && cout_g >= 1, "modulate_weight: bad dims");
+  if (B == 0) return VSP_OK;
+  VSP_REQUIRE(out && wp && style && vsp::aligned16(out), "modulate_weight: null / unaligned pointer");
+  const int nch = (cin + 15) / 16, co_pad = (cout_g + 31) / 32 * 32;
+  const int64_t units = (int64_t)G * nch * 9 * 2 * co_pad;   // 16-byte units per image
+  VSP_REQUIRE(units < ((int64_t)1 << 31) && B <= 65535, "modulate_weight: weight too large");
+  modulate_weight_bf16_kernel<<<dim3((unsigned)((units + 255) / 256), (unsigned)B), 256, 0, vsp::as_stream(stream)>>>(
+      reinterpret_cast<uint4*>(out), wp, style, style_bstride, G, cin, cout_g, nch, co_pad, (int)units);
+  return vsp::check_launch("modulate_weight");
 }
 
 }  // extern "C"

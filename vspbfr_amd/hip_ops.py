@@ -495,6 +495,21 @@ def bf16dg_eligible(pc, H, W, OH, OW, transposed=False, out_stride=(1, 1), out_o
     return 1 <= pc.G <= 4 and all(pc.dil[g] in (1, 2, 4, 8) and pc.pad_y[g] == pc.dil[g] and pc.pad_x[g] == pc.dil[g] for g in range(pc.G))
 
 
+BF16_MODW = tune_env("VSP_BF16_MODW", "1") != "0"   # per-image modulated weights (vsp_modulate_weight_bf16) on the modulated layers of vsp_conv2d_bf16
+
+
+def bf16_modulated_weight(pc, in_scale):
+    """(B sets of bf16(W * style[b]) in the LDS-image order of vsp_conv2d_bf16, byte stride between them): the reference's own fused
+    modulated convolution (models/RestoreNet.py:381-383) -- one small launch per layer and batch; the conv kernel then copies its pixels."""
+    in_scale = _req(in_scale, "in_scale")
+    B = in_scale.shape[0]
+    nbytes = lib.vsp_modulate_weight_bf16_bytes(pc.G, pc.cin, pc.cout_g)
+    out = torch.empty((B, nbytes // 2), device=in_scale.device, dtype=BF)
+    check(lib.vsp_modulate_weight_bf16(_ptr(out), _ptr(pc.w), _ptr(in_scale), B, in_scale.stride(0), pc.G, pc.cin, pc.cout_g, _stream()),
+          "modulate_weight")
+    return out, nbytes
+
+
 BF16_DG = tune_env("VSP_BF16_DG", "1") != "0"   # the dilation-group kernel on the launches it serves (G > 1)
 BF16_RV = tune_env("VSP_BF16_RV", "1") != "0"   # the row-vector-K kernel on the layers bf16rv_profitable names
 
@@ -789,20 +804,38 @@ def conv2d_packed(x, pc, out=None, out_hw=None, y_coff=0, out_stride=(1, 1), out
             pc, H, W, OH, OW, transposed, out_stride, out_offset) and (rv or bf16rv_profitable(pc, H, W)) and _bf16rv_call(p, pc, keep, rv):
         ran_rv = True
     elif bf16:
-        bw = pc.bf16_weight()
+        modw = (BF16_MODW and io_bf and in_scale is not None and in_scale_per_sample and in_shift is None and pc.x_group_stride == 0
+                and W % 2 == 0 and in_scale.dim() == 2 and in_scale.shape == (B, Cin) and x.data_ptr() % 4 == 0)
+        if modw:
+            # the style goes into per-image weights (the reference's fused form): the kernel's staging becomes a copy (conv_bf16.hip NOSC)
+            bw, wbytes = bf16_modulated_weight(pc, in_scale)
+            p.in_scale, p.in_scale_bstride, p.w_bstride = None, 0, wbytes
+        else:
+            bw = pc.bf16_weight()
         keep.append(bw)
         p.w = bw.data_ptr()
+
+        def launch_bf16(strict=True):
+            rc = lib.vsp_conv2d_bf16(C.byref(p), _stream())
+            if rc == -3 and p.w_bstride:   # VSP_ENOTSUP: this tile's patch plane is too large for the copy-only staging -> shared weights + style scale
+                b2 = pc.bf16_weight()
+                keep.append(b2)
+                p.w, p.w_bstride, p.in_scale, p.in_scale_bstride = b2.data_ptr(), 0, in_scale.data_ptr(), Cin
+                rc = lib.vsp_conv2d_bf16(C.byref(p), _stream())
+            if strict:
+                check(rc, "conv2d_bf16")
+            return rc
         if tile_hint == 0:
             p.tile_hint = BF16_TUNE.get(key, BF16_TUNE.get("8" + key[key.index(","):], 0))
             if BF16_FORCE:
                 p.tile_hint = BF16_FORCE
-                if lib.vsp_conv2d_bf16(C.byref(p), _stream()) != 0:  # the forced variant does not serve this launch
+                if launch_bf16(strict=False) != 0:  # the forced variant does not serve this launch
                     p.tile_hint = 0
-                    check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+                    launch_bf16()
             else:
-                check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+                launch_bf16()
         else:
-            check(lib.vsp_conv2d_bf16(C.byref(p), _stream()), "conv2d_bf16")
+            launch_bf16()
     elif winograd:
         rc = -3
         if winograd == 5:
