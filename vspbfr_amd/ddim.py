@@ -50,6 +50,14 @@ class DDIMSampler(object):
         setattr(self, name, attr)
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        # The schedule depends on (S, discretisation, eta) and the model's betas only.  `sample` asks for it on every batch, as the reference
+        # does; rebuilding it costs a DEVICE-TO-HOST copy of alphas_cumprod -- a host synchronisation on the stream that runs the chain, which
+        # in the two-stream batch loop stalls the host until the previous batch's convolutions have drained and leaves the main stream idle
+        # for ~3 ms per step while the host catches up (tools/overlap_timeline.py, round 6: configs[2] 33.3 -> 30 ms per step).  Built once.
+        ac_t = self.model.alphas_cumprod
+        key = (int(ddim_num_steps), ddim_discretize, float(ddim_eta), self.ddpm_num_timesteps, ac_t.data_ptr(), ac_t._version, str(self.device))
+        if getattr(self, "_schedule_key", None) == key:
+            return
         self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps, verbose)
         if self.ddim_timesteps.max() >= self.ddpm_num_timesteps:
             raise ValueError("DDIM needs S < T: with S == T the reference indexes alphas_cumprod out of range "
@@ -65,6 +73,7 @@ class DDIMSampler(object):
         at, ap, som, st = f32(a), f32(a_prev), f32(np.sqrt(1. - a)), f32(sig)
         self.register_buffer("coef_x", ap.sqrt() / at.sqrt())
         self.register_buffer("coef_e", (1. - ap - st ** 2).sqrt() - ap.sqrt() * som / at.sqrt())
+        self._schedule_key = key
 
     @torch.no_grad()
     def sample(self, S, batch_size, shape, conditioning=None, eta=0., x_T=None, temperature=1., verbose=True, **kwargs):
