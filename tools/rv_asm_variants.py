@@ -1,0 +1,57 @@
+"""Variants of the SLP-vectorised device assembly of conv_bf16_rv.hip for the bisection of the packed-fp32 miscompare (tools/rv_asm_build.py).
+Only the packed multiply-adds of the AFFINE COMMIT path are touched -- the two forms the commit compiles to:
+   hi : v_pk_fma_f32 v[D:D+1], v[A:A+1], v[S:S+1], v[H:H+1] op_sel_hi:[1,0,0]     (scale = low half of S, shift = low half of H, both lanes)
+   sel: v_pk_fma_f32 v[D:D+1], v[A:A+1], v[S:S+1], v[H:H+1] op_sel:[0,1,1]        (scale / shift = the HIGH halves)
+usage: rv_asm_variants.py <slp.s> <outdir>   -> writes <outdir>/<variant>.s, prints the variant names"""
+import re
+import sys
+
+src = open(sys.argv[1]).read().split("\n")
+out = sys.argv[2]
+PAT = re.compile(r"^\tv_pk_fma_f32 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], v\[(\d+):(\d+)\] (op_sel_hi:\[1,0,0\]|op_sel:\[0,1,1\])\s*$")
+
+
+def scalar(m):
+    d, _, a, _, s, _, h, _, form = m.groups()
+    d, a, s, h = int(d), int(a), int(s), int(h)
+    if form.startswith("op_sel_hi"):
+        lo = f"\tv_fma_f32 v{d}, v{a}, v{s}, v{h}"
+        hi = f"\tv_fma_f32 v{d + 1}, v{a + 1}, v{s}, v{h}"
+        # a destination that is also the scale / shift register of the OTHER lane's instruction goes last
+        return [hi, lo] if d in (s, h) else [lo, hi]
+    lo = f"\tv_fma_f32 v{d}, v{a}, v{s + 1}, v{h + 1}"
+    hi = f"\tv_fma_f32 v{d + 1}, v{a + 1}, v{s + 1}, v{h + 1}"
+    return [lo, hi] if d + 1 in (s + 1, h + 1) else [hi, lo] if d in (s + 1, h + 1) else [lo, hi]
+
+
+def variant(name, fn):
+    res, n = [], 0
+    for i, line in enumerate(src):
+        m = PAT.match(line)
+        if m:
+            new = fn(m, line, i)
+            n += new != [line]
+            res += new
+        else:
+            res.append(line)
+    open(f"{out}/{name}.s", "w").write("\n".join(res))
+    print(name, n)
+
+
+def prev_writes_high_of_S(i, m):
+    """the instruction(s) right before write the HIGH register of the scale pair (the 'dead half' the compiler re-uses as a temporary)"""
+    s = int(m.group(5))
+    for j in range(i - 1, max(i - 4, 0), -1):
+        if re.match(rf"^\tv_cvt_pk_bf16_f32 v{s + 1},", src[j]):
+            return True
+    return False
+
+
+variant("B_all_scalar", lambda m, l, i: scalar(m))
+variant("B1_hi_scalar", lambda m, l, i: scalar(m) if m.group(9).startswith("op_sel_hi") else [l])
+variant("B2_sel_scalar", lambda m, l, i: scalar(m) if m.group(9).startswith("op_sel:") else [l])
+variant("B3_dst_is_src_scalar", lambda m, l, i: scalar(m) if m.group(1) == m.group(5) else [l])
+variant("B4_after_deadhalf_write_scalar", lambda m, l, i: scalar(m) if prev_writes_high_of_S(i, m) else [l])
+variant("B5_all_but_deadhalf_scalar", lambda m, l, i: [l] if (prev_writes_high_of_S(i, m) or m.group(1) == m.group(5)) else scalar(m))
+variant("C_nop_before", lambda m, l, i: ["\ts_nop 7", l])
+variant("D_nop_after", lambda m, l, i: [l, "\ts_nop 7"])
