@@ -49,6 +49,34 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
       } else if (MODE == 1) {
         asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 7\n\tv_pk_fma_f32 %0, %2, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
                      : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
+      } else if (MODE == 7 || MODE == 8) {
+        // Round 6: the form the assembly-level bisection names (tools/rv_asm_variants.py: scalarising ONLY the `op_sel:[0,1,1]` multiply-adds of
+        // the SLP build makes the kernel exact): scale and shift are the HIGH halves of two register pairs, selected for BOTH lanes.
+        // MODE 7: the pairs straight from LDS; MODE 8: the kernel's sequence -- source 0 produced by a shift / and pair right in front, two
+        // packed operations back to back on the same scale / shift pairs.
+        asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
+        f32x2 sp = {-7.25f, t[0]}, hp = {11.5f, t[1]};      // {junk, scale}, {junk, shift}
+        f32x2 r2, r3;
+        if (MODE == 7) {
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=&v"(r2) : "v"(accp), "v"(sp), "v"(hp));
+        } else {
+          unsigned w0 = (__builtin_bit_cast(unsigned, acc0) >> 16) | (__builtin_bit_cast(unsigned, acc1) & 0xffff0000u);
+          float o0, o1, o2, o3;
+          asm volatile("v_lshlrev_b32 v60, 16, %4\n\tv_and_b32 v61, 0xffff0000, %4\n\tv_lshlrev_b32 v62, 16, %4\n\tv_and_b32 v63, 0xffff0000, %4\n\t"
+                       "v_pk_fma_f32 v[60:61], v[60:61], %5, %6 op_sel:[0,1,1]\n\tv_pk_fma_f32 v[62:63], v[62:63], %5, %6 op_sel:[0,1,1]\n\t"
+                       "s_nop 4\n\tv_mov_b32 %0, v60\n\tv_mov_b32 %1, v61\n\tv_mov_b32 %2, v62\n\tv_mov_b32 %3, v63"
+                       : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(w0), "v"(sp), "v"(hp) : "v60", "v61", "v62", "v63");
+          r2 = f32x2{o0, o1};
+          r3 = f32x2{o2, o3};
+          // expected for MODE 8: bf16-truncated operands
+          const float q0 = __builtin_bit_cast(float, w0 << 16), q1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
+          const float y0 = fmaf(q0, tab_a(it, e), tab_b(it, e)), y1 = fmaf(q1, tab_a(it, e), tab_b(it, e));
+          const float g0_ = r2[0], g1_ = r2[1], g2_ = r3[0], g3_ = r3[1];
+          const bool ok8 = __builtin_bit_cast(unsigned, g0_) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, g1_) == __builtin_bit_cast(unsigned, y1) &&
+                           __builtin_bit_cast(unsigned, g2_) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, g3_) == __builtin_bit_cast(unsigned, y1);
+          r2 = ok8 ? f32x2{fmaf(acc0, tab_a(it, e), tab_b(it, e)), fmaf(acc1, tab_a(it, e), tab_b(it, e))} : f32x2{g0_, g1_};
+        }
+        res = r2;
       } else if (MODE >= 3 && MODE <= 6) {
         // The sequence of the SLP build (commit_one, second slot): pk_fma -> v_cvt_pk_bf16_f32 writing the DEAD high register of the next
         // packed op's source pair (op_sel_hi never selects it) -> pk_fma reading that pair.  Fixed registers: v[60:61] = {scale, dead},
@@ -114,9 +142,9 @@ int main(int argc, char** argv) {
   hipMemset(gsrc, 0, 64 * 256 * 16);
   const size_t lds = per_cu == 2 ? 1024 + 32768 + 4096 : 100 * 1024;   // one workgroup per CU: a request no second one fits beside
   const int grid = 256 * per_cu;
-  for (int mode = 0; mode < 7; ++mode) {
+  for (int mode = 0; mode < 9; ++mode) {
     hipMemset(bad, 0, 8); hipMemset(first, 0, 4 * 64);
-    auto fn = mode == 0 ? repro<0> : (mode == 1 ? repro<1> : (mode == 2 ? repro<2> : (mode == 3 ? repro<3> : (mode == 4 ? repro<4> : (mode == 5 ? repro<5> : repro<6>)))));
+    auto fn = mode == 0 ? repro<0> : (mode == 1 ? repro<1> : (mode == 2 ? repro<2> : (mode == 3 ? repro<3> : (mode == 4 ? repro<4> : (mode == 5 ? repro<5> : (mode == 6 ? repro<6> : (mode == 7 ? repro<7> : repro<8>)))))));
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, 0, bad, first, iters, gsrc);
     hipError_t e = hipDeviceSynchronize();
@@ -124,7 +152,7 @@ int main(int argc, char** argv) {
     hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(hf, first, 4 * 64, hipMemcpyDeviceToHost);
     const double total = (double)grid * 256 * iters * 16;
     printf("mode %d (%s), %d workgroup(s) per CU: %u mismatches of %.3g (%s)\n", mode,
-           mode == 0 ? "v_pk_fma_f32 op_sel behind the wait" : (mode == 1 ? "v_pk_fma_f32 behind s_nop 7" : (mode == 2 ? "v_fma_f32 x 2" : (mode == 3 ? "pk_fma, cvt into the dead high half of the pair, pk_fma" : (mode == 4 ? "the same with s_nop 1 before the second pk_fma" : (mode == 5 ? "mode 3 with four MFMAs in flight" : "mode 4 with four MFMAs in flight"))))), per_cu, hb[0], total,
+           mode == 0 ? "v_pk_fma_f32 op_sel behind the wait" : (mode == 1 ? "v_pk_fma_f32 behind s_nop 7" : (mode == 2 ? "v_fma_f32 x 2" : (mode == 3 ? "pk_fma, cvt into the dead high half of the pair, pk_fma" : (mode == 4 ? "the same with s_nop 1 before the second pk_fma" : (mode == 5 ? "mode 3 with four MFMAs in flight" : (mode == 6 ? "mode 4 with four MFMAs in flight" : (mode == 7 ? "v_pk_fma_f32 op_sel:[0,1,1] (scale / shift = HIGH halves)" : "shift / and -> two v_pk_fma_f32 op_sel:[0,1,1] back to back"))))))), per_cu, hb[0], total,
            hipGetErrorString(e));
     for (unsigned i = 0; i < (hf[1] < 8 ? hf[1] : 8); ++i)
       printf("   lane %u iter %u: lo got %08x want %08x, hi got %08x want %08x\n", hf[8 + i * 6], hf[8 + i * 6 + 1], hf[8 + i * 6 + 2], hf[8 + i * 6 + 3],

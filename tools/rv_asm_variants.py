@@ -55,3 +55,18 @@ variant("B4_after_deadhalf_write_scalar", lambda m, l, i: scalar(m) if prev_writ
 variant("B5_all_but_deadhalf_scalar", lambda m, l, i: [l] if (prev_writes_high_of_S(i, m) or m.group(1) == m.group(5)) else scalar(m))
 variant("C_nop_before", lambda m, l, i: ["\ts_nop 7", l])
 variant("D_nop_after", lambda m, l, i: [l, "\ts_nop 7"])
+
+
+# ---- second round: only the `op_sel:[0,1,1]` form (the first round: scalarising these 104 instructions alone makes the kernel exact)
+def good_form_after_moves(m, l):
+    """the same arithmetic in the form the first round found innocent: the wanted (high) halves copied into the low registers of the SAME
+    aligned pairs first (gfx950 wants 64-bit aligned tuples, so the pairs cannot be re-based), then `op_sel_hi:[1,0,0]`.  The low halves
+    (channel 0's scale / shift) are dead by then: the first commit serves channel 0 before channel 1 and the loop re-reads its scales."""
+    d, d1, a, a1, s, s1, h, h1, _ = m.groups()
+    return [f"\tv_mov_b32_e32 v{s}, v{s1}", f"\tv_mov_b32_e32 v{h}, v{h1}",
+            f"\tv_pk_fma_f32 v[{d}:{d1}], v[{a}:{a1}], v[{s}:{s1}], v[{h}:{h1}] op_sel_hi:[1,0,0]"]
+
+
+SEL = lambda m: m.group(9).startswith("op_sel:")   # noqa: E731
+variant("G6_sel_as_good_form_after_moves", lambda m, l, i: good_form_after_moves(m, l) if SEL(m) else [l])
+variant("G5_sel_nop_both_sides", lambda m, l, i: ["\ts_nop 7", l, "\ts_nop 7"] if SEL(m) else [l])
