@@ -70,3 +70,26 @@ def good_form_after_moves(m, l):
 SEL = lambda m: m.group(9).startswith("op_sel:")   # noqa: E731
 variant("G6_sel_as_good_form_after_moves", lambda m, l, i: good_form_after_moves(m, l) if SEL(m) else [l])
 variant("G5_sel_nop_both_sides", lambda m, l, i: ["\ts_nop 7", l, "\ts_nop 7"] if SEL(m) else [l])
+
+
+# ---- third round: which of the `op_sel:[0,1,1]` instructions?  They come in runs of four per commit slot (two back-to-back pairs); a kernel's
+# first commit has two such slots per site: the first under the full exec mask, the second under a partial one (lanes 0 .. 35).
+_sel_idx = {}
+
+
+def nth_sel(i):
+    """running index of the op_sel:[0,1,1] instruction at source line i (over the whole file)"""
+    if not _sel_idx:
+        n = 0
+        for j, line in enumerate(src):
+            m = PAT.match(line)
+            if m and SEL(m):
+                _sel_idx[j] = n
+                n += 1
+    return _sel_idx[i]
+
+
+variant("H1_first_slot_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 8 < 4 else [l])
+variant("H2_second_slot_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 8 >= 4 else [l])
+variant("H3_first_of_pair_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 2 == 0 else [l])
+variant("H4_second_of_pair_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 2 == 1 else [l])
