@@ -49,6 +49,35 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
       } else if (MODE == 1) {
         asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 7\n\tv_pk_fma_f32 %0, %2, %1, %1 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
                      : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
+      } else if (MODE == 9) {
+        // The failing slot of the kernel with ITS register numbers (round 6, bisection round 3: only the first `op_sel:[0,1,1]` slot of a commit
+        // site fails): v[2:3] = {scale0, scale1}, v[8:9] = {shift0, shift1}, data in v[4:7] / v[14:15], in place, the conversions and the
+        // lane reads of the kernel in between.
+        asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
+        const unsigned w0 = (__builtin_bit_cast(unsigned, acc0) >> 16) | (__builtin_bit_cast(unsigned, acc1) & 0xffff0000u);
+        float o0, o1, o2, o3;
+        float s1_ = t[0], h1_ = t[1];
+        asm volatile("v_mov_b32 v2, 0x40e00000\n\tv_mov_b32 v3, %5\n\tv_mov_b32 v8, 0xc1200000\n\tv_mov_b32 v9, %6\n\t"
+                     "v_mov_b32 v12, 0\n\ts_nop 4\n\t"
+                     "v_lshlrev_b32 v4, 16, %4\n\tv_and_b32 v5, 0xffff0000, %4\n\tv_lshlrev_b32 v6, 16, %4\n\tv_and_b32 v7, 0xffff0000, %4\n\t"
+                     "v_pk_fma_f32 v[4:5], v[4:5], v[2:3], v[8:9] op_sel:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[6:7], v[6:7], v[2:3], v[8:9] op_sel:[0,1,1]\n\t"
+                     "v_cvt_pk_bf16_f32 v10, v4, v5\n\t"
+                     "v_readlane_b32 s34, v12, 45\n\t"
+                     "v_cvt_pk_bf16_f32 v11, v6, v7\n\t"
+                     "v_lshlrev_b32 v6, 16, %4\n\tv_and_b32 v7, 0xffff0000, %4\n\tv_lshlrev_b32 v14, 16, %4\n\tv_and_b32 v15, 0xffff0000, %4\n\t"
+                     "v_cmp_eq_u32 vcc, 0, v12\n\t"
+                     "v_readlane_b32 s35, v12, 46\n\t"
+                     "v_pk_fma_f32 v[6:7], v[6:7], v[2:3], v[8:9] op_sel:[0,1,1]\n\t"
+                     "v_pk_fma_f32 v[14:15], v[14:15], v[2:3], v[8:9] op_sel:[0,1,1]\n\t"
+                     "s_nop 4\n\tv_mov_b32 %0, v4\n\tv_mov_b32 %1, v5\n\tv_mov_b32 %2, v14\n\tv_mov_b32 %3, v15"
+                     : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(w0), "v"(s1_), "v"(h1_)
+                     : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v14", "v15", "s34", "s35", "vcc");
+        const float q0 = __builtin_bit_cast(float, w0 << 16), q1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float y0 = fmaf(q0, tab_a(it, e), tab_b(it, e)), y1 = fmaf(q1, tab_a(it, e), tab_b(it, e));
+        const bool ok9 = __builtin_bit_cast(unsigned, o0) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, o1) == __builtin_bit_cast(unsigned, y1) &&
+                         __builtin_bit_cast(unsigned, o2) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, o3) == __builtin_bit_cast(unsigned, y1);
+        res = ok9 ? f32x2{fmaf(acc0, tab_a(it, e), tab_b(it, e)), fmaf(acc1, tab_a(it, e), tab_b(it, e))} : f32x2{o0, o1};
       } else if (MODE == 7 || MODE == 8) {
         // Round 6: the form the assembly-level bisection names (tools/rv_asm_variants.py: scalarising ONLY the `op_sel:[0,1,1]` multiply-adds of
         // the SLP build makes the kernel exact): scale and shift are the HIGH halves of two register pairs, selected for BOTH lanes.
@@ -142,9 +171,9 @@ int main(int argc, char** argv) {
   hipMemset(gsrc, 0, 64 * 256 * 16);
   const size_t lds = per_cu == 2 ? 1024 + 32768 + 4096 : 100 * 1024;   // one workgroup per CU: a request no second one fits beside
   const int grid = 256 * per_cu;
-  for (int mode = 0; mode < 9; ++mode) {
+  for (int mode = 0; mode < 10; ++mode) {
     hipMemset(bad, 0, 8); hipMemset(first, 0, 4 * 64);
-    auto fn = mode == 0 ? repro<0> : (mode == 1 ? repro<1> : (mode == 2 ? repro<2> : (mode == 3 ? repro<3> : (mode == 4 ? repro<4> : (mode == 5 ? repro<5> : (mode == 6 ? repro<6> : (mode == 7 ? repro<7> : repro<8>)))))));
+    auto fn = mode == 0 ? repro<0> : (mode == 1 ? repro<1> : (mode == 2 ? repro<2> : (mode == 3 ? repro<3> : (mode == 4 ? repro<4> : (mode == 5 ? repro<5> : (mode == 6 ? repro<6> : (mode == 7 ? repro<7> : (mode == 8 ? repro<8> : repro<9>))))))));
     hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, 0, bad, first, iters, gsrc);
     hipError_t e = hipDeviceSynchronize();
@@ -152,7 +181,7 @@ int main(int argc, char** argv) {
     hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(hf, first, 4 * 64, hipMemcpyDeviceToHost);
     const double total = (double)grid * 256 * iters * 16;
     printf("mode %d (%s), %d workgroup(s) per CU: %u mismatches of %.3g (%s)\n", mode,
-           mode == 0 ? "v_pk_fma_f32 op_sel behind the wait" : (mode == 1 ? "v_pk_fma_f32 behind s_nop 7" : (mode == 2 ? "v_fma_f32 x 2" : (mode == 3 ? "pk_fma, cvt into the dead high half of the pair, pk_fma" : (mode == 4 ? "the same with s_nop 1 before the second pk_fma" : (mode == 5 ? "mode 3 with four MFMAs in flight" : (mode == 6 ? "mode 4 with four MFMAs in flight" : (mode == 7 ? "v_pk_fma_f32 op_sel:[0,1,1] (scale / shift = HIGH halves)" : "shift / and -> two v_pk_fma_f32 op_sel:[0,1,1] back to back"))))))), per_cu, hb[0], total,
+           mode == 0 ? "v_pk_fma_f32 op_sel behind the wait" : (mode == 1 ? "v_pk_fma_f32 behind s_nop 7" : (mode == 2 ? "v_fma_f32 x 2" : (mode == 3 ? "pk_fma, cvt into the dead high half of the pair, pk_fma" : (mode == 4 ? "the same with s_nop 1 before the second pk_fma" : (mode == 5 ? "mode 3 with four MFMAs in flight" : (mode == 6 ? "mode 4 with four MFMAs in flight" : (mode == 7 ? "v_pk_fma_f32 op_sel:[0,1,1] (scale / shift = HIGH halves)" : (mode == 8 ? "shift / and -> two v_pk_fma_f32 op_sel:[0,1,1] back to back" : "the failing commit slot with the kernel's register numbers")))))))), per_cu, hb[0], total,
            hipGetErrorString(e));
     for (unsigned i = 0; i < (hf[1] < 8 ? hf[1] : 8); ++i)
       printf("   lane %u iter %u: lo got %08x want %08x, hi got %08x want %08x\n", hf[8 + i * 6], hf[8 + i * 6 + 1], hf[8 + i * 6 + 2], hf[8 + i * 6 + 3],

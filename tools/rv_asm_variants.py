@@ -93,3 +93,13 @@ variant("H1_first_slot_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(
 variant("H2_second_slot_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 8 >= 4 else [l])
 variant("H3_first_of_pair_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 2 == 0 else [l])
 variant("H4_second_of_pair_scalar", lambda m, l, i: scalar(m) if SEL(m) and nth_sel(i) % 2 == 1 else [l])
+
+
+# ---- fourth round: the first slot's instructions kept, a LONG quiet period in front of the slot (everything in flight drained)
+def drained(m, l, i):
+    if SEL(m) and nth_sel(i) % 8 == 0:
+        return ["\ts_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)"] + ["\ts_nop 7"] * 16 + [l]
+    return [l]
+
+
+variant("I1_first_slot_behind_drain", drained)
