@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
         asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
         const unsigned w0 = (__builtin_bit_cast(unsigned, acc0) >> 16) | (__builtin_bit_cast(unsigned, acc1) & 0xffff0000u);
         float o0, o1, o2, o3;
-        float s1_ = t[0], h1_ = t[1];
-        asm volatile("v_mov_b32 v2, 0x40e00000\n\tv_mov_b32 v3, %5\n\tv_mov_b32 v8, 0xc1200000\n\tv_mov_b32 v9, %6\n\t"
+        float s1_ = t[0] + 0.5f * (float)wave, h1_ = t[1] + 0.25f * (float)wave;   // per-wave operands, as in the kernel
+        asm volatile("v_sub_f32 v2, 0x40e00000, %5\n\tv_mov_b32 v3, %5\n\tv_sub_f32 v8, 0xc1200000, %6\n\tv_mov_b32 v9, %6\n\t"
                      "v_mov_b32 v12, 0\n\ts_nop 4\n\t"
                      "v_lshlrev_b32 v4, 16, %4\n\tv_and_b32 v5, 0xffff0000, %4\n\tv_lshlrev_b32 v6, 16, %4\n\tv_and_b32 v7, 0xffff0000, %4\n\t"
                      "v_pk_fma_f32 v[4:5], v[4:5], v[2:3], v[8:9] op_sel:[0,1,1]\n\t"
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
                      : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3) : "v"(w0), "v"(s1_), "v"(h1_)
                      : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v14", "v15", "s34", "s35", "vcc");
         const float q0 = __builtin_bit_cast(float, w0 << 16), q1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
-        const float y0 = fmaf(q0, tab_a(it, e), tab_b(it, e)), y1 = fmaf(q1, tab_a(it, e), tab_b(it, e));
+        const float y0 = fmaf(q0, s1_, h1_), y1 = fmaf(q1, s1_, h1_);
         const bool ok9 = __builtin_bit_cast(unsigned, o0) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, o1) == __builtin_bit_cast(unsigned, y1) &&
                          __builtin_bit_cast(unsigned, o2) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, o3) == __builtin_bit_cast(unsigned, y1);
         res = ok9 ? f32x2{fmaf(acc0, tab_a(it, e), tab_b(it, e)), fmaf(acc1, tab_a(it, e), tab_b(it, e))} : f32x2{o0, o1};
@@ -84,10 +84,16 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
         // MODE 7: the pairs straight from LDS; MODE 8: the kernel's sequence -- source 0 produced by a shift / and pair right in front, two
         // packed operations back to back on the same scale / shift pairs.
         asm volatile("ds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(res), "=&v"(t) : "v"(accp), "v"(addr) : "memory");
-        f32x2 sp = {-7.25f, t[0]}, hp = {11.5f, t[1]};      // {junk, scale}, {junk, shift}
+        // (scale / shift differ from wave to wave -- in the kernel every wave stages its own two channels: a value picked up from another wave's
+        //  operand read would go unnoticed with wave-uniform operands)
+        const float sW = t[0] + 0.5f * (float)wave, hW = t[1] + 0.25f * (float)wave;
+        f32x2 sp = {-7.25f - (float)wave, sW}, hp = {11.5f + (float)wave, hW};      // {junk, scale}, {junk, shift}
         f32x2 r2, r3;
         if (MODE == 7) {
           asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=&v"(r2) : "v"(accp), "v"(sp), "v"(hp));
+          const float z0 = fmaf(acc0, sW, hW), z1 = fmaf(acc1, sW, hW), u0 = r2[0], u1 = r2[1];
+          const bool ok7 = __builtin_bit_cast(unsigned, u0) == __builtin_bit_cast(unsigned, z0) && __builtin_bit_cast(unsigned, u1) == __builtin_bit_cast(unsigned, z1);
+          r2 = ok7 ? f32x2{fmaf(acc0, tab_a(it, e), tab_b(it, e)), fmaf(acc1, tab_a(it, e), tab_b(it, e))} : f32x2{u0 + 1.f, u1};
         } else {
           unsigned w0 = (__builtin_bit_cast(unsigned, acc0) >> 16) | (__builtin_bit_cast(unsigned, acc1) & 0xffff0000u);
           float o0, o1, o2, o3;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void repro(unsigned* bad, unsigned* first, 
           r3 = f32x2{o2, o3};
           // expected for MODE 8: bf16-truncated operands
           const float q0 = __builtin_bit_cast(float, w0 << 16), q1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
-          const float y0 = fmaf(q0, tab_a(it, e), tab_b(it, e)), y1 = fmaf(q1, tab_a(it, e), tab_b(it, e));
+          const float y0 = fmaf(q0, sW, hW), y1 = fmaf(q1, sW, hW);
           const float g0_ = r2[0], g1_ = r2[1], g2_ = r3[0], g3_ = r3[1];
           const bool ok8 = __builtin_bit_cast(unsigned, g0_) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, g1_) == __builtin_bit_cast(unsigned, y1) &&
                            __builtin_bit_cast(unsigned, g2_) == __builtin_bit_cast(unsigned, y0) && __builtin_bit_cast(unsigned, g3_) == __builtin_bit_cast(unsigned, y1);
