@@ -115,7 +115,7 @@ class Generator(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ IR-SE50 encoder
 HANDOFF = None          # set by pipeline.run_batches around get_w_plus: an object with .point ("h": inside the encoder) and .go(tensors)
-MAIN_STAGE_MIN = 16     # (8 / 32 / 4 measured the same within run-to-run noise: 205.3 - 206.2 img/s) head stages whose OUTPUT map is at least this wide stay on the caller's stream (see Encoder4Editing.forward)
+MAIN_STAGE_MIN = 16     # head stages whose OUTPUT map is at least this wide stay on the caller's stream (see Encoder4Editing.forward)
 
 
 def _bn_fold(bn):
