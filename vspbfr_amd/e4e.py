@@ -115,6 +115,7 @@ class Generator(nn.Module):
 
 # ------------------------------------------------------------------------------------------------ IR-SE50 encoder
 HANDOFF = None          # set by pipeline.run_batches around get_w_plus: an object with .point ("h": inside the encoder) and .go(tensors)
+HEADS_BF16_ACT = H.tune_env("VSP_HEADS_BF16_ACT", "1") != "0"   # bf16 configuration: head-stage outputs as bf16 in HBM (Encoder4Editing._head_stage)
 MAIN_STAGE_MIN = 16     # head stages whose OUTPUT map is at least this wide stay on the caller's stream (see Encoder4Editing.forward)
 
 
@@ -266,6 +267,7 @@ class Encoder4Editing(_Cached):
         for f, k, stages, lw, lb, lo, hi in runs:
             for st in stages[k:]:
                 f = self._head_stage(f, st)
+            f = H.to_f32(f)
             nh = hi - lo
             H.gemm_nt(f, lw, out=heads[lo:hi], dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
                       alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
@@ -276,7 +278,17 @@ class Encoder4Editing(_Cached):
 
     @staticmethod
     def _head_stage(x, stage):
+        """One stage of a head class.  In the bf16-kernel configuration (hip_ops.BF16_CONV is True) the stage outputs travel as bf16 -- the next
+        stage's kernel rounds its input to bf16 while staging anyway, so the values are the same; the 512 -> 5632 stem then writes half the bytes
+        and the grouped second stage stages pixel pairs (round 6; small maps fall back to the fp32 kernels, which convert)."""
         pc, bias = stage
+        if HEADS_BF16_ACT and H.BF16_CONV is True and x.shape[-1] >= 32:
+            prev = H.ACT_BF16
+            H.ACT_BF16 = True
+            try:
+                return H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
+            finally:
+                H.ACT_BF16 = prev
         return H.conv2d_packed(x, pc, ch_bias=bias, act2=1, slope2=0.01, gain2=1.0)
 
     def _head_consts(self, lo, hi):
@@ -313,6 +325,7 @@ class Encoder4Editing(_Cached):
         x = feat
         for st in stages:
             x = self._head_stage(x, st)
+        x = H.to_f32(x)
         B, nh, lin = x.shape[0], hi - lo, self.styles[lo].linear
         return H.gemm_nt(x, lw, out=out, dims=(nh, B, 512, 512), a_strides=(512, nh * 512, 1), b_strides=(512 * 512, 512, 1),
                          alpha=lin.scale, bias=lb, bias_scale=lin.lr_mul, bias_zs=512)
