@@ -255,7 +255,7 @@ def conv_traffic(B, args):
         tag = "c3_bf16act"
     elif args.conv_dtype == "bf16" and not args.act_bf16 and B == 8 and args.timesteps == 50 and args.sampler == "ddpm":
         tag = "b8_bf16"
-    for name in ({"c2_f32": ["r05_conv_traffic_pmc_c2_f32.json", "r04_conv_traffic_pmc_c2_f32.json", "r03_conv_traffic_pmc_c2_f32.json", "r02_conv_traffic_pmc_c2_f32.json", "r01_conv_traffic_pmc.json"], "c3_bf16act": ["r05_conv_traffic_pmc_c3_bf16act.json", "r04_conv_traffic_pmc_c3_bf16act.json", "r02_conv_traffic_pmc_c3_bf16act.json"],
+    for name in ({"c2_f32": ["r06_conv_traffic_pmc_c2_f32.json", "r05_conv_traffic_pmc_c2_f32.json", "r04_conv_traffic_pmc_c2_f32.json", "r03_conv_traffic_pmc_c2_f32.json", "r02_conv_traffic_pmc_c2_f32.json", "r01_conv_traffic_pmc.json"], "c3_bf16act": ["r06_conv_traffic_pmc_c3_bf16act.json", "r05_conv_traffic_pmc_c3_bf16act.json", "r04_conv_traffic_pmc_c3_bf16act.json", "r02_conv_traffic_pmc_c3_bf16act.json"],
                   "b8_bf16": ["r01_conv_traffic_pmc_bf16.json"]}.get(tag, [])):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -385,7 +385,7 @@ def measure(args, world, rank, dev, pipe=None):
                        "conv_wino_rs_kernel / conv_wino_kernel (Winograd F(2x2,3x3): row-owner, dilation groups, register-resident U) + wino4_input_kernel / wino4_gemm_kernel (Winograd F(4x4,3x3), deep layers) + conv_wino4f_kernel / conv_wino4f_groups_kernel (Winograd F(4x4,3x3) fused in registers: shallow wide layers, dilation groups of 128 - 512 channels); "
                        "achieved / frac = FLOPs the matrix pipe EXECUTED / kernel time (F(2x2) launches run 16/36, F(4x4) launches 36/144 of their "
                        "direct-form count); algorithmic_tflops / algorithmic_frac = direct-form FLOPs / time, an effective rate on the Winograd layers") if args.conv_dtype == "f32" else (
-            "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers) + conv_bf16_rv_kernel "
+            "conv family: conv_bf16_kernel (bf16 MFMA 32x32x16, fp32 accumulate: stride-1 / stride-2 / transposed 3x3 layers; modulated layers on per-image weights bf16(W * style), copy-only staging) + conv_bf16_dg_kernel (64 -> 4 x 16 dilation groups) + conv_bf16_rv_kernel "
             "(row-vector K: plain stride-1 layers with <= 256 channels on maps >= 128^2, bf16 activations) + the fp32 "
             "conv_igemm_kernel on small maps and 1x1 layers; achieved = algorithmic FLOPs / time against the dense bf16 MFMA peak; with "
             "fp32 activations in HBM the 512^2 / 256^2 layers are fabric-bound (DESIGN 9)")
