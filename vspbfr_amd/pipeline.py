@@ -298,6 +298,10 @@ class RestorationPipeline:
                     t.record_stream(side)      # allocated from the main stream's pool, read on the side stream
                 torch.cuda.set_stream(side)
                 self.done = True
+                if gates is not None and armed[0]:
+                    # armed HERE, behind this batch's own trunk (whose "trunk" phase belongs to the PREVIOUS batch's last segment):
+                    # consumed by the chain call that follows on the side stream
+                    hip_ops.CHAIN_GATES = gates.arm()
 
             def also(self, t):
                 if self.done:
@@ -309,8 +313,6 @@ class RestorationPipeline:
             if split_mode in ("h", "b"):
                 ho = _Handoff(split_mode)
                 try:
-                    if gates is not None and armed[0]:
-                        hip_ops.CHAIN_GATES = gates.arm()      # (consumed by the chain call inside encode, on the side stream)
                     lat, pre = self.encode(batch, image_index0=idx0, handoff=ho)   # starts on `main`, ends on `side`
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream())
