@@ -44,16 +44,6 @@ int vsp_device_count(void);
  * another language check its own struct layout when it loads the library. */
 int vsp_struct_size(int which);
 
-/* Stream-ordered flag (round 6; plumbing of the two-stream batch loop, vspbfr_amd/pipeline.py): a signal word that a stream-ordered write
- * on one stream sets and a stream-ordered wait on another stream waits for (*sig >= value).  Unlike an event, a wait may be enqueued before
- * the write that satisfies it: the sampler chain of batch i+1 is enqueued first and released, segment by segment, when the main stream
- * reaches the small-map phases of batch i (hipStreamWaitValue32 / hipStreamWriteValue32 on hipMallocSignalMemory).  Values must only grow.
- * VSP_ENOTSUP when the device cannot wait on memory values. */
-int vsp_signal_alloc(void** sig);
-int vsp_signal_free(void* sig);
-int vsp_stream_wait_geq32(void* sig, uint32_t value, vsp_stream_t stream);
-int vsp_stream_write32(void* sig, uint32_t value, vsp_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------------
  * fused bias + activation  -- replaces `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)`
  * (reference op/fused_bias_act.cpp:18-31, kernel op/fused_bias_act_kernel.cu:19-65).

@@ -105,8 +105,6 @@ SIGNATURES = {
     "vsp_abi_version": [],
     "vsp_device_count": [],
     "vsp_struct_size": [_i],
-    "vsp_signal_alloc": [C.POINTER(C.c_void_p)], "vsp_signal_free": [_p],
-    "vsp_stream_wait_geq32": [_p, C.c_uint32, _p], "vsp_stream_write32": [_p, C.c_uint32, _p],
     "vsp_fused_bias_act_f32": [_p, _p, _p, _p, _i64, _i, _i, _i, _i, _f, _f, _p],
     "vsp_upfirdn2d_f32": [_p, _p, _p] + [_i] * 14 + [C.POINTER(FirEpilogue), _p],
     "vsp_conv2d_f32": [C.POINTER(ConvParams), _p],

@@ -38,38 +38,4 @@ int vsp_struct_size(int which) {
   }
 }
 
-/* Stream-ordered flags (round 6): one 64-bit signal word that one stream writes and another waits on -- the pipeline's way of letting the
- * sampler chain of the NEXT batch (side stream) run only underneath the phases of the main stream that leave the chip idle.  A wait may be
- * enqueued BEFORE the write that satisfies it is enqueued (an event cannot do that). */
-int vsp_signal_alloc(void** sig) {
-  VSP_REQUIRE(sig != nullptr, "signal_alloc: null pointer");
-  int dev = 0, can = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !can)
-    return vsp::fail(VSP_ENOTSUP, "signal_alloc: this device does not support hipStreamWaitValue32");
-  hipError_t e = hipExtMallocWithFlags(sig, 8, hipMallocSignalMemory);
-  if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "signal_alloc: %s", hipGetErrorString(e));
-  e = hipMemset(*sig, 0, 8);
-  if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "signal_alloc: memset: %s", hipGetErrorString(e));
-  return VSP_OK;
-}
-
-int vsp_signal_free(void* sig) {
-  if (sig && hipFree(sig) != hipSuccess) return vsp::fail(VSP_ELAUNCH, "signal_free failed");
-  return VSP_OK;
-}
-
-int vsp_stream_wait_geq32(void* sig, uint32_t value, vsp_stream_t stream) {
-  VSP_REQUIRE(sig != nullptr, "stream_wait_geq32: null signal");
-  hipError_t e = hipStreamWaitValue32(vsp::as_stream(stream), sig, value, hipStreamWaitValueGte, 0xffffffffu);
-  if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "hipStreamWaitValue32: %s", hipGetErrorString(e));
-  return VSP_OK;
-}
-
-int vsp_stream_write32(void* sig, uint32_t value, vsp_stream_t stream) {
-  VSP_REQUIRE(sig != nullptr, "stream_write32: null signal");
-  hipError_t e = hipStreamWriteValue32(vsp::as_stream(stream), sig, value, 0);
-  if (e != hipSuccess) return vsp::fail(VSP_ELAUNCH, "hipStreamWriteValue32: %s", hipGetErrorString(e));
-  return VSP_OK;
-}
-
 }  // extern "C"

@@ -94,7 +94,6 @@ class Generator(nn.Module):
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
         B = latent.shape[0]
-        H.phase("prior")    # the prior's 4^2 ... 32^2 levels: small launches (pipeline.run_batches lets the next batch's chain start underneath)
         with style_context(self, "gen", latent):   # (every layer's modulation / demodulation vector in two launches, layers.StyleContext)
             out = self.conv1(self.input(B), latent[:, 0], noise[0])
             skip = self.to_rgb1(out, latent[:, 1])
@@ -240,8 +239,6 @@ class Encoder4Editing(_Cached):
         x = H.conv2d_packed(x.contiguous(), c["in"], ch_scale=c["bn"][0], ch_bias=c["bn"][1], act2=2, prelu=il[2].weight)
         taps = {}
         for i, unit in enumerate(self.body):
-            if i == 7:
-                H.phase("trunk")    # the 256-channel units at 32^2 and the 512-channel ones at 16^2: 64 - 128 workgroups per launch
             x = unit(x)
             if i in (6, 20, 23):
                 taps[i] = x

@@ -1318,65 +1318,7 @@ def pointwise(x, w, in_scale=None, ch_bias=None, bias1=None, bias2=None, res=Non
     return y
 
 
-# ---- phases of the main stream / gated chain segments (pipeline.run_batches)
-PHASE_HOOK = None     # callable(name): the model code reports where the main stream is ("prior", "enc32", "trunk")
-CHAIN_GATES = None    # list of (fraction of the chain's steps, callable that enqueues a wait on the current stream) for the NEXT tacc_chain call
-
-
-def phase(name):
-    hook = PHASE_HOOK
-    if hook is not None:
-        hook(name)
-
-
-class StreamSignal:
-    """A stream-ordered flag (vsp_signal_alloc): `wait_geq(v)` enqueues a wait for *sig >= v on the current stream, `write(v)` a write on the
-    current stream; a wait may be enqueued before its write."""
-
-    def __init__(self):
-        h = C.c_void_p()
-        check(lib.vsp_signal_alloc(C.byref(h)), "signal_alloc")
-        self.h = h
-
-    def wait_geq(self, v):
-        check(lib.vsp_stream_wait_geq32(self.h, int(v), _stream()), "stream_wait_geq32")
-
-    def write(self, v):
-        check(lib.vsp_stream_write32(self.h, int(v), _stream()), "stream_write32")
-
-    def __del__(self):
-        try:
-            if self.h:
-                lib.vsp_signal_free(self.h)
-        except Exception:
-            pass
-
-
 def tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None):
-    gates = globals().get("CHAIN_GATES")
-    if gates:
-        # segments of the chain behind stream-ordered gates: x is the only state between steps, so consecutive calls are the same computation
-        globals()["CHAIN_GATES"] = None
-        steps = [int(s) for s in steps]
-        n, done = len(steps), 0
-        cuts = []
-        acc = 0.0
-        for frac, _w in gates:
-            acc += frac
-            cuts.append(min(n, max(done, int(round(acc * n)))))
-            done = cuts[-1]
-        cuts[-1] = n
-        lo = 0
-        for (frac, wait), hi in zip(gates, cuts):
-            wait()
-            if hi > lo:
-                _tacc_chain(x, blocks, steps[lo:hi], None if coef_idx is None else list(coef_idx)[lo:hi], c1, c2, t_div, head_steps)
-            lo = hi
-        return x
-    return _tacc_chain(x, blocks, steps, coef_idx, c1, c2, t_div, head_steps)
-
-
-def _tacc_chain(x, blocks, steps, coef_idx=None, c1=None, c2=None, t_div=1.0, head_steps=None):
     """Run the whole sampler chain in place on x (B,18,512): for each t in `steps` (host ints, execution order) x <- c1[k] *
     denoiser(x, t) + c2[k] * x with k = coef_idx[s] (default t); c1 = c2 = None: x <- denoiser(x, t).  `blocks`: one dict per
     TACC block with device tensors wcat, eQ, ek, wq, wk, gamma, beta (gamma/beta: (head_steps, B, 18, 512))."""

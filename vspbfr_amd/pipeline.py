@@ -28,42 +28,6 @@ def _side_stream():
     return torch.cuda.Stream(priority=pr) if pr else torch.cuda.Stream()
 
 
-class _ChainGates:
-    """Tickets of the gated chain segments (run_batches).  arm(): three waits (prior, enc32, trunk) with fresh, growing ticket numbers, returned
-    as hip_ops.CHAIN_GATES entries; hit(name): the main stream reached that phase -> a stream-ordered write of the ticket (never a smaller
-    value than one already written); release_all(): write the highest ticket handed out."""
-    NAMES = ("prior", "enc32", "trunk")
-
-    def __init__(self, fractions):
-        from . import hip_ops
-        self.sig = hip_ops.StreamSignal()
-        self.fractions = tuple(fractions)
-        self.ticket, self.written, self.pending = 0, 0, {}
-
-    def arm(self):
-        out = []
-        for name, frac in zip(self.NAMES, self.fractions):
-            self.ticket += 1
-            t = self.ticket
-            self.pending[name] = t
-            out.append((frac, lambda t=t: self.sig.wait_geq(t)))
-        return out
-
-    def _write(self, t):
-        if t > self.written:
-            self.sig.write(t)
-            self.written = t
-
-    def hit(self, name):
-        t = self.pending.pop(name, None)
-        if t is not None:
-            self._write(t)
-
-    def release_all(self):
-        self.pending.clear()
-        self._write(self.ticket)
-
-
 def _tensors(obj):
     """every tensor inside nested tuples / lists / dicts"""
     if torch.is_tensor(obj):
@@ -137,8 +101,6 @@ class RestorationPipeline:
         # stage A runs under C + D of the previous batch on the side stream, so its precision costs little time): measured in DESIGN 5
         self.encoder_fp32 = False
         self.overlap_split = "h"     # run_batches: which part of stages A + B runs on the side stream (see there)
-        self.gate_chain = tune_env("VSP_GATE_CHAIN", "1") != "0"   # run_batches: the next batch's chain in gated segments under the small-map phases
-        self.chain_gate_fractions = tuple(float(v) for v in tune_env("VSP_GATE_FRACTIONS", "0.2,0.5,0.3").split(","))   # prior / enc32 / trunk
 
     def draw_decode_noise(self, B, image_index0, device):
         """z, prior-decoder, encoder and decoder noise maps of one batch in ONE launch (keyed mode)."""
@@ -254,7 +216,6 @@ class RestorationPipeline:
         are small-map / latency-bound work that leaves most CUs idle; overlapped with the big convolutions of the previous
         batch they cost almost nothing.  Yields the same dicts as __call__, in order.  An item is a device batch or a pair
         (batch, image_index0) (keyed mode: GLOBAL index of its first image; plain batches count up from 0)."""
-        from . import hip_ops
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
             self._side = _side_stream()
@@ -270,21 +231,6 @@ class RestorationPipeline:
         split = split_mode == "abc"
 
         counter = [0]
-        # The chain of the NEXT batch in gated segments: a `tacc_*` launch puts a workgroup on every CU and displaces a conv
-        # workgroup there -- underneath the big convolutions the chain cost C + D 3 ms.  It is enqueued as three segments behind stream-ordered
-        # flags (hip_ops.StreamSignal: a wait may be enqueued before its write) that the MAIN stream sets when it reaches its small-map
-        # phases: the prior's 4^2 - 32^2 levels, Restoration_net's encoder tail + decoder head (32^2 ... 4^2 ... 32^2), and the 256 / 512-channel
-        # units of the NEXT encoder trunk.  Flag values only grow; every armed gate is released when the loop ends, however it ends.
-        gate_on = self.gate_chain and split_mode in ("h", "b")
-        gates = self.__dict__.get("_gates") if gate_on else None
-        if gate_on and gates is None:
-            try:
-                gates = self._gates = _ChainGates(self.chain_gate_fractions)
-            except RuntimeError:      # the device cannot wait on memory values: the ungated loop
-                gates = None
-        prev_hook = hip_ops.PHASE_HOOK
-        if gates is not None:
-            hip_ops.PHASE_HOOK = gates.hit
 
         class _Handoff:
             def __init__(self, point):
@@ -298,10 +244,6 @@ class RestorationPipeline:
                     t.record_stream(side)      # allocated from the main stream's pool, read on the side stream
                 torch.cuda.set_stream(side)
                 self.done = True
-                if gates is not None and armed[0]:
-                    # armed HERE, behind this batch's own trunk (whose "trunk" phase belongs to the PREVIOUS batch's last segment):
-                    # consumed by the chain call that follows on the side stream
-                    hip_ops.CHAIN_GATES = gates.arm()
 
             def also(self, t):
                 if self.done:
@@ -318,8 +260,6 @@ class RestorationPipeline:
                     ev.record(torch.cuda.current_stream())
                 finally:
                     torch.cuda.set_stream(main)
-                    hip_ops.CHAIN_GATES = None
-                armed[0] = True                # from the second batch on there is a C + D of the previous batch to hide under
                 for t in _tensors((lat, pre)):
                     t.record_stream(main)      # allocated on the side stream's pool, consumed on the main stream
                 return batch, lat, pre, ev, idx0, None
@@ -337,38 +277,25 @@ class RestorationPipeline:
                 t.record_stream(main)  # allocated on the side stream's pool, consumed on the main stream
             return batch, lat, pre, ev, idx0, extra
 
-        armed = [False]
         it = iter(batches)
         try:
+            cur = start(next(it))
+        except StopIteration:
+            return
+        while cur is not None:
             try:
-                cur = start(next(it))
+                nxt = start(next(it))  # enqueue A + B of the next batch BEFORE C + D of this one
             except StopIteration:
-                return
-            while cur is not None:
-                try:
-                    nxt = start(next(it))  # enqueue A + B of the next batch BEFORE C + D of this one
-                except StopIteration:
-                    nxt = None
-                    if gates is not None:
-                        gates.release_all()    # no further encoder trunk will come: what is still armed runs now
-                batch, lat, pre, ev, idx0, extra = cur
-                main.wait_event(ev)
-                if extra is None:
-                    out = self.decode(batch, lat, pre, image_index0=idx0)
-                else:
-                    (noise, _g, enc_noise, dec_noise, inject_index), sample, feats = extra
-                    restored = self.restore(batch, feats, pre, noise, inject_index, enc_noise, dec_noise)
-                    out = {"restored": restored, "style_sample": sample, "latent": lat, "pre_latent": pre}
-                if gates is not None and nxt is None:
-                    gates.release_all()
-                yield out
-                cur = nxt
-        finally:
-            hip_ops.PHASE_HOOK = prev_hook
-            hip_ops.CHAIN_GATES = None
-            if gates is not None:
-                with torch.cuda.stream(main):
-                    gates.release_all()        # (generator closed early / an exception: never leave the side stream waiting)
+                nxt = None
+            batch, lat, pre, ev, idx0, extra = cur
+            main.wait_event(ev)
+            if extra is None:
+                yield self.decode(batch, lat, pre, image_index0=idx0)
+            else:
+                (noise, _g, enc_noise, dec_noise, inject_index), sample, feats = extra
+                restored = self.restore(batch, feats, pre, noise, inject_index, enc_noise, dec_noise)
+                yield {"restored": restored, "style_sample": sample, "latent": lat, "pre_latent": pre}
+            cur = nxt
 
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -100,8 +100,6 @@ class Restoration_net(nn.Module):
         feats = []
         with style_context(self, "enc", latent_cp):   # every modulation / demodulation vector of the encoder in two launches (layers.StyleContext)
             for ii in range(0, len(self.encoder_convs), 2):
-                if out.shape[-1] <= 32:
-                    H.phase("enc32")    # from here to the decoder's 32^2 level the launches leave most of the chip idle (pipeline.run_batches)
                 sty = latent_cp[:, ii]
                 out = self.encoder_convs[ii](out, sty, enc_noise[ii])
                 feats.append(out)
