@@ -49,7 +49,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PJ_KW = 8;                  // waves splitting K
 constexpr int PJ_NS = D / 16 / PJ_KW;     // 16-wide k-steps per wave
-constexpr int PJ_NJ = 8;                  // 16-column blocks per workgroup: the PixelNorm VALU work is redone per workgroup
+constexpr int PJ_NJ = 4;                  // 16-column blocks per workgroup: the PixelNorm VALU work is redone per workgroup
                                           // of a sample, so wider tiles (fewer workgroups per sample) cut it
 
 __global__ __launch_bounds__(64 * PJ_KW) void tacc_proj_kernel(float* __restrict__ P, const float* __restrict__ y,
@@ -149,11 +149,10 @@ __global__ __launch_bounds__(64 * vsptacc::CA_NW) void tacc_attn_kernel(float* _
                                                         const float* __restrict__ P, int ldp, const float* __restrict__ ek,
                                                         const float* __restrict__ wk, const float* __restrict__ eQ,
                                                         const float* __restrict__ wq, float tf, int B) {
-  constexpr int WPS = 16 / vsptacc::CA_NCB;   // channel-attention workgroups per sample
-  const int nca = WPS * B;
+  const int nca = 16 * B;
   if ((int)blockIdx.x < nca) {
     vsptacc::chan_attn_mfma_body(tout, P, ldp, 2 * D, 3 * D, ek, wk, 1, tf, 0.044194173824159216f /* 1/sqrt(512) */,
-                                 ((int)blockIdx.x % WPS) * vsptacc::CA_NCB, (int)blockIdx.x / WPS, vsptacc::CA_NCB);
+                                 blockIdx.x & 15, blockIdx.x >> 4);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -320,7 +319,7 @@ int vsp_tacc_chain_f32(const vsp_tacc_chain_params* pp, vsp_stream_t stream) {
       const vsp_tacc_block& k = p.blocks[bi];
       const bool last = bi == p.n_blocks - 1;
       tacc_proj_kernel<<<(4 * D / (16 * PJ_NJ)) * p.B, 64 * PJ_KW, pj_lds, st>>>(P, cur, k.wcat, 4 * D, k.wcat_frag);
-      tacc_attn_kernel<<<(16 / vsptacc::CA_NCB) * p.B + (M + vsptacc::CA_NW - 1) / vsptacc::CA_NW, 64 * vsptacc::CA_NW, lds, st>>>(tb, hb, P, 4 * D, k.ek, k.wk, k.eQ, k.wq, tf, p.B);
+      tacc_attn_kernel<<<16 * p.B + (M + vsptacc::CA_NW - 1) / vsptacc::CA_NW, 64 * vsptacc::CA_NW, lds, st>>>(tb, hb, P, 4 * D, k.ek, k.wk, k.eQ, k.wq, tf, p.B);
       float* out = last ? p.x : yb[bi & 1];
       const size_t hoff = (size_t)step * M * D;
       tacc_post_kernel<<<row_blocks, 256, 0, st>>>(out, hb, tb, k.gamma + hoff, k.beta + hoff,

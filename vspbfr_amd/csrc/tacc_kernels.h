@@ -20,7 +20,6 @@ constexpr int D = 512;
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int CA_KP = D + 16;  // k2 pitch: k-slot groups land on different bank halves
 constexpr int CA_VP = D + 1;   // v2 pitch: 16 token rows hit 16 different banks
-constexpr int CA_NCB = 2;      // 32-column blocks per workgroup in the sampler chain's launch (tacc_chain.hip)
 constexpr int CA_NW = 8;       // waves per workgroup (each owns 512 / CA_NW rows of the attention matrix)
 constexpr size_t CA_LDS_FLOATS = 20 * CA_KP + NTOK * CA_VP + 2 * CA_NW * 32 + (CA_NW - 1) * 4 * 4 * 64;
 
@@ -28,7 +27,7 @@ constexpr size_t CA_LDS_FLOATS = 20 * CA_KP + NTOK * CA_VP + 2 * CA_NW * 32 + (C
 __device__ __forceinline__ void chan_attn_mfma_body(float* __restrict__ tout, const float* __restrict__ P, int ldp,
                                                     int q2_off, int v2_off, const float* __restrict__ ek,
                                                     const float* __restrict__ wk, int wk_stride, float tf, float scale,
-                                                    const int cb0, const int b, const int ncb = 1) {
+                                                    const int cb, const int b) {
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   constexpr int NW = CA_NW, NT = 64 * NW;
   constexpr int MT = D / 16 / NW;  // 16-row tiles per wave
@@ -41,6 +40,14 @@ __device__ __forceinline__ void chan_attn_mfma_body(float* __restrict__ tout, co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
 
+  float qb[5][2];
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int tok = 4 * s + kq;
+      qb[s][nt] = tok < NTOK ? P[((int64_t)b * NTOK + tok) * ldp + q2_off + cb * 32 + nt * 16 + lr] * scale : 0.f;
+    }
   if (wk_stride == 1) {  // contiguous condition column (the sampler passes it that way): 16-byte staging loads
     // every global load of a thread is issued before the first LDS write: one L2 round trip for the whole staging
     constexpr int TR = NT / 128;               // token rows covered per pass
@@ -82,19 +89,6 @@ __device__ __forceinline__ void chan_attn_mfma_body(float* __restrict__ tout, co
     }
   }
   __syncthreads();
-
-  // `ncb` consecutive 32-column blocks per workgroup (round 6): the staged k2 / v2 of the sample serve all of them -- half (a quarter) of
-  // the workgroups per launch and of the staging traffic; the arithmetic of a column block is unchanged
-  for (int cbi = 0; cbi < ncb; ++cbi) {
-  const int cb = cb0 + cbi;
-  float qb[5][2];
-#pragma unroll
-  for (int s = 0; s < 5; ++s)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int tok = 4 * s + kq;
-      qb[s][nt] = tok < NTOK ? P[((int64_t)b * NTOK + tok) * ldp + q2_off + cb * 32 + nt * 16 + lr] * scale : 0.f;
-    }
 
   f32x4 L[MT][2];
 #pragma unroll
@@ -170,7 +164,7 @@ __device__ __forceinline__ void chan_attn_mfma_body(float* __restrict__ tout, co
         for (int j = 0; j < 4; ++j) tpart[(((wave - 1) * 4 + mt2 * 2 + nt) * 4 + j) * 64 + lane] = T[mt2][nt][j];
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave > 0) return;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     float den = reds[nt * 16 + lr];
@@ -187,9 +181,6 @@ __device__ __forceinline__ void chan_attn_mfma_body(float* __restrict__ tout, co
         const int tok = mt2 * 16 + kq * 4 + j;
         if (tok < NTOK) tout[((int64_t)b * NTOK + tok) * D + cb * 32 + nt * 16 + lr] = v * inv;
       }
-  }
-  }
-  if (cbi + 1 < ncb) __syncthreads();   // the reduction buffers are re-used by the next column block
   }
 }
 
