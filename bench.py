@@ -275,6 +275,7 @@ def measure(args, world, rank, dev, pipe=None):
     if pipe is None:
         pipe = build_pipeline(dev, args.timesteps, not args.no_sample, None if args.torch_rng else args.seed)
     pipe.act_bf16 = bool(args.act_bf16)
+    pipe.encoder_fp32, pipe.encoder_x3 = args.encoder == "f32", args.encoder == "x3"
     ddpm_module = pipe.diffusion
     if args.sampler == "ddim":
         from vspbfr_amd.ddim import DDIMSampler
@@ -373,6 +374,7 @@ def measure(args, world, rank, dev, pipe=None):
         conv_exec = iso.executed_flops() * args.steps
 
     pipe.diffusion = ddpm_module   # (a DDIM configuration wrapped it)
+    pipe.encoder_fp32 = pipe.encoder_x3 = False
     line = None
     if rank == 0:
         imgs = world * B * args.steps
@@ -500,6 +502,9 @@ def main():
     ap.add_argument("--seed", type=int, default=123, help="seed of the keyed input / noise draws")
     ap.add_argument("--torch-rng", action="store_true", help="draw noise from torch's device RNG stream (one randn per consumer, "
                                                               "as the reference does) instead of the keyed single-launch draws")
+    ap.add_argument("--encoder", choices=["same", "f32", "x3"], default="same",
+                    help="bf16 configurations: the kernels of stage A (e4e encoder) -- same as stages C + D (default), fp32, or the split-precision "
+                         "bf16 kernels (fp32-grade codes for the sampler chain, which amplifies the encoder's rounding)")
     ap.add_argument("--no-extra", action="store_true", help="headline configuration only: skip the extra_configs legs (configs[2], the one-GPU "
                                                              "share of configs[3]) that a default one-GPU run appends to its JSON line")
     ap.add_argument("--launch-check", action="store_true", help="no GPU work: self-launch, rendezvous (gloo), shard + all-gather "

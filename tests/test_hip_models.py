@@ -716,12 +716,16 @@ def test_config_c3_full_size():
         pipe.encoder_fp32 = True                                      # stage A on the fp32 kernels (review r5 weak 1.ii): what does the
         out_encf32 = pipe(lq, image_index0=i0)                        # bf16 encoder cost in accuracy -- the chain amplifies its codes' error
         pipe.encoder_fp32 = False
+        pipe.encoder_x3 = True                                        # stage A on the split-precision bf16 kernels
+        out_encx3 = pipe(lq, image_index0=i0)
+        pipe.encoder_x3 = False
         pipe.act_bf16 = False
         out_f32act = pipe(lq, image_index0=i0)                        # same bf16 kernels, fp32 activations in HBM (round 1's form)
     finally:
         H.BF16_CONV = False
         pipe.act_bf16 = False
         pipe.encoder_fp32 = False
+        pipe.encoder_x3 = False
     assert out["restored"].shape == (B, 3, 512, 512) and torch.isfinite(out["restored"]).all()
     assert out["restored"].dtype == torch.float32 and out["style_sample"].dtype == torch.float32
     d = (out["restored"] - ref["restored"]).float()
@@ -733,6 +737,11 @@ def test_config_c3_full_size():
     rep_enc = {"encoder_fp32_restored_rms": float(de.pow(2).mean().sqrt()), "encoder_fp32_restored_max": float(de.abs().max()),
                "encoder_fp32_pre_latent_max": maxerr(out_encf32["pre_latent"], ref["pre_latent"]), "encoder_fp32_lsb_mean": float(qe.abs().float().mean()),
                "encoder_fp32_lsb_max": int(qe.abs().max())}
+    dx = (out_encx3["restored"] - ref["restored"]).float()
+    qx = OM.save_image_quantize(out_encx3["restored"][:, :, ::4, ::4].cpu()).int() - OM.save_image_quantize(ref["restored"][:, :, ::4, ::4].cpu()).int()
+    rep_enc.update({"encoder_x3_restored_rms": float(dx.pow(2).mean().sqrt()), "encoder_x3_restored_max": float(dx.abs().max()),
+                    "encoder_x3_pre_latent_max": maxerr(out_encx3["pre_latent"], ref["pre_latent"]), "encoder_x3_codes_max": maxerr(out_encx3["latent"], ref["latent"]),
+                    "encoder_x3_lsb_mean": float(qx.abs().float().mean()), "encoder_x3_lsb_max": int(qx.abs().max())})
     rep = {"ddim_chain_vs_oracle": e_chain, "restored_std": std, "bf16_restored_rms": float(d.pow(2).mean().sqrt()),
            "bf16_restored_max": float(d.abs().max()), "bf16_codes_max": maxerr(out["latent"], ref["latent"]),
            "bf16_pre_latent_max": maxerr(out["pre_latent"], ref["pre_latent"]), "lsb_mean": float(q.abs().float().mean()),

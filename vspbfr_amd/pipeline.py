@@ -100,6 +100,7 @@ class RestorationPipeline:
         # stage A on the fp32 kernels in the bf16 configuration too (review r5 weak 1.ii: the sampler chain amplifies the encoder's rounding;
         # stage A runs under C + D of the previous batch on the side stream, so its precision costs little time): measured in DESIGN 5
         self.encoder_fp32 = False
+        self.encoder_x3 = False      # stage A on the split-precision bf16 kernels (vsp_conv2d_bf16x3: fp32-grade results on the bf16 pipe) under the bf16 configuration
         self.overlap_split = "h"     # run_batches: which part of stages A + B runs on the side stream (see there)
 
     def draw_decode_noise(self, B, image_index0, device):
@@ -129,7 +130,9 @@ class RestorationPipeline:
                                      device=low_imgs.device, index_tensor=self._index_tensor)[0]
             owned = True
         mode = hip_ops.BF16_CONV
-        if (mode == "x3" and self.encoder_fp32_under_x3) or (mode and self.encoder_fp32):
+        if mode is True and self.encoder_x3 and not self.encoder_fp32:
+            hip_ops.BF16_CONV = "x3"
+        elif (mode == "x3" and self.encoder_fp32_under_x3) or (mode and self.encoder_fp32):
             # the sampler chain amplifies a perturbation of its condition ~2000x with random weights: the encoder that
             # feeds it keeps the fp32 kernels, the split-precision kernels serve stages C + D (80 % of the FLOPs)
             hip_ops.BF16_CONV = False
