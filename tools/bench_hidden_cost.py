@@ -96,9 +96,14 @@ with torch.no_grad():
         hip_ops.BF16_CONV = False
         pipe.act_bf16 = False
         f32 = pipe(lq, image_index0=0)
+        # (bench.build_pipeline's networks are random-init WITHOUT the fixture's rescale: their images are not unit-scale -- deviations are given
+        #  relative to the fp32 image's standard deviation; the unit-scale figures are test_config_c3_full_size's, profiles/parity_c3_*_r06.json)
+        sigma = float(f32["restored"].float().std())
+        out["restored_sigma_fp32"] = round(sigma, 4)
         for tag, r in (("bf16_all", r_bf), ("bf16_encoder_fp32", r_mix)):
-            out[tag] = {k: round(float((r[k] - f32[k].float()).abs().max()), 5) for k in r}
             d = (r["restored"] - f32["restored"].float())
-            out[tag]["restored_rms"] = round(float(d.pow(2).mean().sqrt()), 5)
-            out[tag]["restored_lsb_max"] = int((((r["restored"].clamp(-1, 1) + 1) * 127.5).round() - ((f32["restored"].float().clamp(-1, 1) + 1) * 127.5).round()).abs().max())
+            out[tag] = {"codes_max": round(float((r["latent"] - f32["latent"].float()).abs().max()), 6),
+                        "pre_latent_max": round(float((r["pre_latent"] - f32["pre_latent"].float()).abs().max()), 6),
+                        "restored_rms_over_sigma": round(float(d.pow(2).mean().sqrt()) / sigma, 5),
+                        "restored_max_over_sigma": round(float(d.abs().max()) / sigma, 5)}
 print(json.dumps(out))
