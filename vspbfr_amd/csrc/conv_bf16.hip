@@ -736,12 +736,16 @@ static BfGeom bf_geom(const ConvK& q, int mode, int co_t, int npix, int erows, i
 template <int MB, int NB, int WM, int WN, int PT, int MODE, bool SPLIT = false, bool IOB = false, bool PAIR = false, bool NOSC = false>
 int launch_bf(ConvK q, const BfGeom& gm, hipStream_t stream) {
   if constexpr (!SPLIT && !IOB) {
-    if (q.io_bf16 && q.w_bs != 0) {   // per-image weights: the copy-only pair staging (the entry checked even rows and the alignment of x)
+    // copy-only pair staging (NOSC): per-image weights (the entry checked even rows and the alignment of x), and every launch WITHOUT an
+    // input scale / shift (plain convolutions: the SMART fusion layers, the encoder's head stages) -- bf16(x * 1 + 0) is x
+    const bool plain = q.bf_isc_s == 0 && q.bf_ish_s == 0 && (q.W & 1) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 3) == 0;
+    if (q.io_bf16 && (q.w_bs != 0 || plain)) {
       if (gm.pt2 <= 1) return launch_bf<MB, NB, WM, WN, 1, MODE, false, true, true, true>(q, gm, stream);
       if (gm.pt2 <= 2) return launch_bf<MB, NB, WM, WN, 2, MODE, false, true, true, true>(q, gm, stream);
       if (gm.pt2 <= 3) return launch_bf<MB, NB, WM, WN, 3, MODE, false, true, true, true>(q, gm, stream);
       if (gm.pt2 <= 5) return launch_bf<MB, NB, WM, WN, 5, MODE, false, true, true, true>(q, gm, stream);
-      return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: per-image weights: the patch plane of this tile needs more than five pair tasks per thread");
+      if (q.w_bs != 0)
+        return vsp::fail(VSP_ENOTSUP, "conv2d_bf16: per-image weights: the patch plane of this tile needs more than five pair tasks per thread");
     }
     if (q.io_bf16) {
       // bf16 activations: pixel-pair staging wherever rows are 4-byte multiples (env VSP_BF16_PAIR=0: the one-pixel tasks, for A/B runs)
