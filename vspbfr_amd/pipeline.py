@@ -101,7 +101,7 @@ class RestorationPipeline:
         # stage A runs under C + D of the previous batch on the side stream, so its precision costs little time): measured in DESIGN 5
         self.encoder_fp32 = False
         self.encoder_x3 = False      # stage A on the split-precision bf16 kernels (vsp_conv2d_bf16x3: fp32-grade results on the bf16 pipe) under the bf16 configuration
-        self.overlap_split = "h"     # run_batches: which part of stages A + B runs on the side stream (see there)
+        self.overlap_split = "auto"  # run_batches: which part of stages A + B runs on the side stream (see there); auto = "h" (fp32) / "ab" (bf16 kernels)
 
     def draw_decode_noise(self, B, image_index0, device):
         """z, prior-decoder, encoder and decoder noise maps of one batch in ONE launch (keyed mode)."""
@@ -230,7 +230,11 @@ class RestorationPipeline:
         #        batch; the small-map head stages, the code assembly and the sampler chain on the side stream underneath C + D
         #   "b"  the whole encoder on the main stream, the chain alone on the side stream
         #   "ab" stages A + B on the side stream (rounds 2-5);  "abc": stage C there too (measured slower in round 5)
+        #   "auto" = "h" on the fp32 kernels (same box: 204.2 against 202.2 img/s for "ab"), "ab" in the bf16-kernel configuration, whose stage A
+        #        is shorter and less chip-filling (same box, after the DDIM fix: "ab" 530.3 / 530.8, "h" 524.1 / 526.7, "b" 523.2 img/s)
         split_mode = tune_env("VSP_OVERLAP_SPLIT", self.overlap_split)
+        if split_mode == "auto":
+            split_mode = "ab" if hip_ops.BF16_CONV is True else "h"
         split = split_mode == "abc"
 
         counter = [0]
