@@ -219,6 +219,7 @@ class RestorationPipeline:
         are small-map / latency-bound work that leaves most CUs idle; overlapped with the big convolutions of the previous
         batch they cost almost nothing.  Yields the same dicts as __call__, in order.  An item is a device batch or a pair
         (batch, image_index0) (keyed mode: GLOBAL index of its first image; plain batches count up from 0)."""
+        from . import hip_ops
         main = torch.cuda.current_stream()
         if not hasattr(self, "_side"):
             self._side = _side_stream()
