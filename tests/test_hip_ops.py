@@ -895,42 +895,6 @@ def test_blur_bf16_separable_form_vs_fp64(H):
             assert float((d > 0).float().mean()) < 0.02, (it, sorted(kw), float((d > 0).float().mean()))
 
 
-def test_blur_f32_strip_separable(H):
-    """Round 6: fp32 planes with outer-product taps take the separable strip walk (fir_strip_f32_kernel; the first plane of a launch stays on
-    the tile kernel).  Against float64 and against the 2-D tile form on the same operands: fp32 rounding only; every epilogue operand; planes
-    whose rows are odd-sized (2H + 1) inputs; a launch cut into < 2 GiB image chunks is not needed at these sizes but the chunk loop runs."""
-    kern = cases.fir_kernel("blur4", "f32strip")
-    kd = dev(kern)
-    for it, (B, C_, Hh, Ww, pad) in enumerate([(2, 5, 33, 129, (1, 1)), (1, 3, 67, 515, (1, 1)), (2, 4, 257, 257, (1, 1)), (1, 2, 35, 35, (1, 1)),
-                                               (2, 3, 125, 125, (2, 2)), (3, 2, 17, 21, (1, 1))]):
-        g_ = torch.Generator(device=DEV).manual_seed(500 + it)
-        x = torch.randn(B, C_, Hh, Ww, device=DEV, generator=g_)
-        oh, ow = Hh + 2 * pad[0] - 3, Ww + 2 * pad[0] - 3
-        nz = torch.randn(B, 1, oh, ow, device=DEV, generator=g_)
-        nw, ab = torch.full((1,), 0.3, device=DEV), torch.randn(C_, device=DEV, generator=g_)
-        r1, r2 = torch.randn(B, C_, oh, ow, device=DEV, generator=g_), torch.randn(B, C_, oh, ow, device=DEV, generator=g_)
-        for kw in (dict(noise=nz, noise_w=nw, act_bias=ab, act=True, res1=r1, res2=r2), dict(act_bias=ab, act=True), dict(res1=r1), {}):
-            got = H.blur_fused(x, kd, pad, **kw)
-            H.SEPARABLE_BLUR = False
-            try:
-                tile = H.blur_fused(x, kd, pad, **kw)
-            finally:
-                H.SEPARABLE_BLUR = True
-            ref = F.conv2d(F.pad(x.double().cpu(), (pad[0], pad[1], pad[0], pad[1])).view(B * C_, 1, Hh + 2 * pad[0], -1),
-                           kern.double().flip(0, 1).view(1, 1, 4, 4)).view(B, C_, oh, ow)
-            if "noise" in kw:
-                ref = ref + 0.3 * nz.double().cpu()
-            if kw.get("act"):
-                ref = F.leaky_relu(ref + ab.double().cpu().view(1, -1, 1, 1), 0.2) * math.sqrt(2.0)
-            for r_ in (kw.get("res1"), kw.get("res2")):
-                if r_ is not None:
-                    ref = ref + r_.double().cpu()
-            scale = float(ref.abs().max()) + 1.0
-            assert got.dtype == torch.float32 and got.shape == (B, C_, oh, ow)
-            assert float((got.double().cpu() - ref).abs().max()) < 2e-6 * scale, (it, sorted(kw))
-            assert float((got - tile).abs().max()) < 2e-6 * scale, (it, sorted(kw))
-
-
 def test_blur_bf16_strip_kernel_bit_identical_many_draws(H, blur_2d):
     """The column-strip bf16 blur (round 5: planes 1 .. N-1 of every 4x4 blur whose rows are whole 16-byte segments) against the fp32
     tile kernel rounded once, over many draws: a fused-multiply-add contraction that differed between the two kernels showed as ONE

@@ -468,138 +468,6 @@ __global__ __launch_bounds__(256, VSP_STRIP_OCC) void fir_strip_bf16_kernel(vsp:
   }
 }
 
-// fp32 planes, 4 x 4 OUTER-PRODUCT taps, up = down = 1 (round 6): the same strip walk for the parity path's blurs.  The 2-D form of this walk
-// measured slower than the tile kernel in round 5 (151 registers, 128 multiply-adds per output row); with the taps as a row pass + a column pass
-// a lane needs 64 multiply-adds per 8 outputs and keeps 4 x 8 row sums instead of 4 x 12 pixels.  A lane owns 8 output columns and walks RC
-// rows: every input row is fetched once per lane as three 16-byte loads (12 columns, 11 used; rows are only dword aligned), rows outside the
-// plane through an out-of-range offset, columns outside a row cleared by per-lane masks.  The first plane of the launch goes to the tile kernel
-// (the left padding of its first row is a negative offset from the descriptor's base).  Arithmetic order differs from the tile kernel's 2-D sum:
-// same result within fp32 rounding (tests/test_hip_ops.py::test_blur_f32_strip_separable).
-template <int RC, bool EN, bool ACT>
-__global__ __launch_bounds__(256, 3) void fir_strip_f32_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ kern,
-                                                             int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int strips_x,
-                                                             int chunks_y, int total, int x_bytes, int out_bytes, Epi epi) {
-  static_assert(RC % 4 == 0, "the row loop is unrolled by the four window slots");
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int sx = gid % strips_x;
-  const int t = gid / strips_x;
-  const int cy = t % chunks_y, plane = 1 + t / chunks_y;
-  const int ox = 8 * sx, oy0 = cy * RC;
-  const int ix0 = ox - pad_x0;
-  float txf[4], tyf[4];   // flipped taps: row factor = first row, column factor = first column / corner
-  {
-    const float c00 = kern[15];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      txf[k] = kern[3 * 4 + (3 - k)];
-      tyf[k] = k == 0 ? 1.f : kern[(3 - k) * 4 + 3] / c00;
-    }
-  }
-  unsigned cm[11];
-#pragma unroll
-  for (int k = 0; k < 11; ++k) cm[k] = (ix0 + k >= 0 && ix0 + k < in_w) ? 0xffffffffu : 0u;
-  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
-  const int c = plane % epi.channels, b = plane / epi.channels;
-  float pscale = 1.f, nw = 0.f, ab = 0.f;
-  if (EN) {
-    if (epi.plane_scale) pscale = epi.plane_scale[plane];
-    if (epi.noise) nw = epi.noise_w[0];
-    if (ACT && epi.act_bias) ab = epi.act_bias[c];
-  }
-  const __amdgpu_buffer_rsrc_t nrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(epi.noise ? epi.noise : kern), 0,
-                                                                       epi.noise ? out_bytes / epi.channels : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(epi.res1 ? epi.res1 : (const void*)kern), 0, epi.res1 ? out_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(epi.res2 ? epi.res2 : (const void*)kern), 0, epi.res2 ? out_bytes : 0, 0x00020000);
-  typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-  u32x4s qa[2], qb[2], qc[2];
-  const int row_b = in_w * 4;
-  const int voff0 = (int)(((int64_t)plane * in_h + (oy0 - pad_y0)) * in_w + ix0) * 4;
-  auto fetch = [&](int r, int slot) {
-    const int iy = oy0 - pad_y0 + r;
-    const int vo = (iy >= 0 && iy < in_h) ? voff0 + r * row_b : 0x7ffffff0;
-    qa[slot] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
-    qb[slot] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 16, 0));
-    qc[slot] = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 32, 0));
-  };
-  float win[4][8];   // row sums of the last four input rows
-  auto hpass = [&](int slot, float (&h)[8]) {
-    float w[11];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      w[k] = __builtin_bit_cast(float, qa[slot][k] & cm[k]);
-      w[4 + k] = __builtin_bit_cast(float, qb[slot][k] & cm[4 + k]);
-      if (k < 3) w[8 + k] = __builtin_bit_cast(float, qc[slot][k] & cm[8 + k]);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = fmaf(txf[3], w[j + 3], fmaf(txf[2], w[j + 2], fmaf(txf[1], w[j + 1], txf[0] * w[j])));
-  };
-  const int orow0 = (int)(((int64_t)plane * out_h + oy0) * out_w + ox);
-  const int nrow0 = (int)(((int64_t)b * out_h + oy0) * out_w + ox);
-  auto emit = [&](int ro, const float (&w0)[8], const float (&w1)[8], const float (&w2)[8], const float (&w3)[8]) {
-    const bool ok = oy0 + ro < out_h;
-    f32x4u nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = nz0, r1a = nz0, r1b = nz0, r2a = nz0, r2b = nz0;
-    if (EN) {
-      const int no = ok ? (nrow0 + ro * out_w) * 4 : 0x7ffffff0;
-      nz0 = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(nrs, no, 0, 0));
-      nz1 = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(nrs, no, 16, 0));
-      const int eo = ok ? (orow0 + ro * out_w) * 4 : 0x7ffffff0;
-      r1a = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(r1rs, eo, 0, 0));
-      r1b = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(r1rs, eo, 16, 0));
-      r2a = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(r2rs, eo, 0, 0));
-      r2b = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(r2rs, eo, 16, 0));
-    }
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaf(tyf[3], w3[j], fmaf(tyf[2], w2[j], fmaf(tyf[1], w1[j], w0[j])));
-    if (EN) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float a = fmaf(j < 4 ? nz0[j & 3] : nz1[j & 3], nw, acc[j] * pscale);
-        if (ACT) {
-          a += ab;
-          a = (a > 0.f ? a : a * epi.slope) * epi.gain;
-        }
-        {
-#pragma clang fp contract(off)
-          a = a + (j < 4 ? r1a[j & 3] : r1b[j & 3]);
-        }
-        a += (j < 4 ? r2a[j & 3] : r2b[j & 3]);
-        acc[j] = a;
-      }
-    }
-    const int so = ok ? (orow0 + ro * out_w) * 4 : 0x7ffffff0;
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4s{__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1]), __builtin_bit_cast(unsigned, acc[2]),
-                                                  __builtin_bit_cast(unsigned, acc[3])}, ors, so, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4s{__builtin_bit_cast(unsigned, acc[4]), __builtin_bit_cast(unsigned, acc[5]), __builtin_bit_cast(unsigned, acc[6]),
-                                                  __builtin_bit_cast(unsigned, acc[7])}, ors, so, 16, 0);
-  };
-  fetch(0, 0);
-  fetch(1, 1);
-  hpass(0, win[0]);
-  fetch(2, 0);
-  hpass(1, win[1]);
-  fetch(3, 1);
-  hpass(0, win[2]);
-  fetch(4, 0);
-#pragma unroll 1
-  for (int r0 = 0; r0 < RC; r0 += 4) {
-    hpass(1, win[3]);
-    fetch(r0 + 5, 1);
-    emit(r0 + 0, win[0], win[1], win[2], win[3]);
-    hpass(0, win[0]);
-    fetch(r0 + 6, 0);
-    emit(r0 + 1, win[1], win[2], win[3], win[0]);
-    hpass(1, win[1]);
-    fetch(r0 + 7, 1);
-    emit(r0 + 2, win[2], win[3], win[0], win[1]);
-    hpass(0, win[2]);
-    fetch(r0 + 8, 0);
-    emit(r0 + 3, win[3], win[0], win[1], win[2]);
-  }
-}
-
 __global__ __launch_bounds__(256) void fir_generic_kernel(float* __restrict__ out, const float* __restrict__ x,
                                                            const float* __restrict__ kern, int major, int in_h,
                                                            int in_w, int minor, int kh, int kw, int up_x, int up_y,
@@ -727,50 +595,6 @@ static int upfirdn2d_impl(T* out, const T* x, const float* kernel, int major, in
         fir_tile_kernel<4, 4, T, 1><<<(unsigned)blocks0, 256, 0, s>>>(out, x, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, blocks0, e);
         return vsp::check_launch("upfirdn2d(strip)");
       }
-    }
-  }
-  if constexpr (!BF) {
-    // fp32 planes with outer-product taps: the separable strip walk (see the kernel), images in chunks of < 2 GiB (32-bit buffer offsets);
-    // the first plane of every chunk on the tile kernel
-    static const int strip32_env = vsp::tune_env("VSP_FIR_STRIP_F32") ? atoi(vsp::tune_env("VSP_FIR_STRIP_F32")) : 1;
-    const int64_t plane_in = (int64_t)in_h * in_w * 4, plane_out = (int64_t)out_h * out_w * 4;
-    const int64_t img_bytes = (plane_in > plane_out ? plane_in : plane_out) * e.channels;
-    if (strip32_env && e.separable && tile_ok && kh == 4 && kw == 4 && out_w % 8 == 0 && out_h >= 4 && in_w >= 12 && img_bytes < 0x7ffffff0ll &&
-        (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
-        (!e.res1 || (reinterpret_cast<uintptr_t>(e.res1) & 15) == 0) && (!e.res2 || (reinterpret_cast<uintptr_t>(e.res2) & 15) == 0) &&
-        (!e.noise || (reinterpret_cast<uintptr_t>(e.noise) & 15) == 0) && (major % e.channels) == 0) {
-      constexpr int RC = 32;
-      const int n_img = major / e.channels;
-      int img_per = (int)(0x7ffffff0ll / img_bytes);
-      img_per = img_per < 1 ? 1 : (img_per > n_img ? n_img : img_per);
-      const int strips_x = out_w / 8, chunks_y = (out_h + RC - 1) / RC;
-      const int tiles_x = (out_w + TOW - 1) / TOW, tiles_y = (out_h + TOH - 1) / TOH;
-      for (int i0 = 0; i0 < n_img; i0 += img_per) {
-        const int ni = n_img - i0 < img_per ? n_img - i0 : img_per;
-        const int planes = ni * e.channels, p0 = i0 * e.channels;
-        const float* xc = reinterpret_cast<const float*>(x) + (int64_t)p0 * in_h * in_w;
-        float* oc = reinterpret_cast<float*>(out) + (int64_t)p0 * out_h * out_w;
-        Epi ec = e;
-        if (e.plane_scale) ec.plane_scale = e.plane_scale + p0;
-        if (e.noise) ec.noise = e.noise + (int64_t)i0 * out_h * out_w;
-        if (e.res1) ec.res1 = static_cast<const float*>(e.res1) + (int64_t)p0 * out_h * out_w;
-        if (e.res2) ec.res2 = static_cast<const float*>(e.res2) + (int64_t)p0 * out_h * out_w;
-        const int64_t total_t = (int64_t)(planes - 1) * chunks_y * strips_x;
-        if (total_t > 0) {
-          const unsigned gridn = (unsigned)((total_t + 255) / 256);
-          const int xb32 = (int)((int64_t)planes * plane_in), ob32 = (int)((int64_t)planes * plane_out);
-#define VSP_STRIP32_LAUNCH(EN_, ACT_)                                                                                                          \
-  fir_strip_f32_kernel<RC, EN_, ACT_><<<gridn, 256, 0, s>>>(oc, xc, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, strips_x, chunks_y, \
-                                                            (int)total_t, xb32, ob32, ec)
-          if (!e.enabled) VSP_STRIP32_LAUNCH(false, false);
-          else if (e.act) VSP_STRIP32_LAUNCH(true, true);
-          else VSP_STRIP32_LAUNCH(true, false);
-#undef VSP_STRIP32_LAUNCH
-        }
-        const int blocks0 = tiles_x * tiles_y;   // the chunk's first plane
-        fir_tile_kernel<4, 4, float, 1><<<(unsigned)blocks0, 256, 0, s>>>(oc, xc, kernel, in_h, in_w, out_h, out_w, pad_x0, pad_y0, tiles_x, tiles_y, blocks0, ec);
-      }
-      return vsp::check_launch("upfirdn2d(strip f32)");
     }
   }
   if (tile_ok && ((kh == 4 && kw == 4) || (kh == 3 && kw == 3) || (kh == 2 && kw == 2))) {
