@@ -140,3 +140,43 @@ def test_tuned_table_winograd_entries_name_eligible_layers():
         seen[val] += 1
     assert seen["winograd4f"] >= 20 and seen["winograd4"] >= 3 and seen["winograd"] >= 10, seen
     assert sum(1 for k, v in table.items() if v == "winograd4f" and k.split(",")[4] == "4") >= 8      # the dilation-group launches of DESIGN 6.6
+
+
+def test_tuning_switches_need_vsp_tune(monkeypatch):
+    """Round 6: a stray VSP_* tuning variable must not change anything unless VSP_TUNE=1 is set as well (library: vsp::tune_env)."""
+    from vspbfr_amd import _lib
+    monkeypatch.delenv("VSP_TUNE", raising=False)
+    monkeypatch.setenv("VSP_SOME_SWITCH", "7")
+    assert _lib.tune_env("VSP_SOME_SWITCH", "1") == "1"
+    monkeypatch.setenv("VSP_TUNE", "0")
+    assert _lib.tune_env("VSP_SOME_SWITCH", "1") == "1"
+    monkeypatch.setenv("VSP_TUNE", "1")
+    assert _lib.tune_env("VSP_SOME_SWITCH", "1") == "7"
+    assert _lib.tune_env("VSP_NOT_SET", "x") == "x"
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vspbfr_amd", "csrc")
+    for name in os.listdir(root):   # no kernel source reads the environment directly any more
+        if name.endswith((".hip", ".h")) and name != "vsp_common.h":
+            src = open(os.path.join(root, name)).read()
+            assert not re.search(r"(?<![_:\w])getenv\(", src), name
+
+
+def test_taps_separable_host_logic():
+    """hip_ops.taps_separable: exact outer products of the FLIPPED taps only; the answer rides on the tensor object and follows in-place edits."""
+    import torch
+    from vspbfr_amd import hip_ops as H
+    from vspbfr_amd.layers import make_kernel
+    k = make_kernel([1, 3, 3, 1]) * 4
+    assert H.taps_separable(k) and k._vsp_separable[1] is True
+    g = torch.Generator().manual_seed(1)
+    assert not H.taps_separable(torch.randn(4, 4, generator=g))
+    u, v = torch.tensor([1.0, 2.0, 4.0, 0.5]), torch.tensor([0.25, 1.0, 3.0, 2.0])
+    assert H.taps_separable(torch.outer(u, v))                      # dyadic factors: exact
+    k2 = k.clone()
+    assert H.taps_separable(k2)
+    k2[1, 2] += 0.125                                                # edited in place: re-decided
+    assert not H.taps_separable(k2)
+    z = k.clone()
+    z[3, 3] = 0.0                                                    # the corner the kernels divide by
+    assert not H.taps_separable(z)
